@@ -1,0 +1,13 @@
+"""elf_amd: MI355X-native (gfx950) implementation of the ELF OpenGo self-play hot path.
+
+The product path is libelf_amd.so (hand-written HIP, elf_amd/csrc) behind the C ABI in
+include/elf_amd.h; this package is the Python host side mirroring the reference's interface.
+Importing never touches oracle/ and never falls back to a CPU implementation.
+"""
+from ._lib import ElfGoError, lib  # noqa: F401
+from .engine import (  # noqa: F401
+    GoEngine, M_PASS, M_RESIGN, M_SKIP, M_INVALID, M_CLEAR, S_EMPTY, S_BLACK, S_WHITE,
+    coord, coord_xy, coord2action, action2coord, d4_transform, d4_inv_transform,
+)
+
+__version__ = "0.1"

@@ -1,0 +1,62 @@
+"""ctypes binding of libelf_amd.so (include/elf_amd.h). There is NO fallback: if the HIP library is
+missing or fails to load, importing the product path raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libelf_amd.so")
+ZOBRIST_BIN = os.path.join(HERE, "data", "zobrist21.bin")
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/elf_amd.h one to one
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    "elfgo_create": (_i, [_i, _i, _i, _vp, C.POINTER(_vp)]),
+    "elfgo_destroy": (_i, [_vp]),
+    "elfgo_board_size": (_i, [_vp]),
+    "elfgo_capacity": (_i, [_vp]),
+    "elfgo_slot_bytes": (_sz, [_vp]),
+    "elfgo_sync": (_i, [_vp, _vp]),
+    "elfgo_reset": (_i, [_vp, _vp, _i, _vp]),
+    "elfgo_copy": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "elfgo_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "elfgo_legal_mask": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "elfgo_extract_agz": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
+    "elfgo_evaluate": (_i, [_vp, _vp, _i, _f, _vp, _vp]),
+    "elfgo_info": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "elfgo_export_board": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "elfgo_playout": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "elfgo_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "elfgo_free": (_i, [_vp]),
+    "elfgo_memcpy_h2d": (_i, [_vp, _vp, _sz]),
+    "elfgo_memcpy_d2h": (_i, [_vp, _vp, _sz]),
+    "elfgo_error_string": (C.c_char_p, [_i]),
+    "elfgo_version": (C.c_char_p, []),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "elf_amd: %s not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C elf_amd/csrc). There is no CPU fallback." % LIB_PATH
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the .so is stale: fail loudly
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class ElfGoError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != 0:
+        raise ElfGoError("libelf_amd status %d: %s" % (status, lib().elfgo_error_string(status).decode()))

@@ -1,0 +1,410 @@
+// libelf_amd.so: HIP kernels (gfx950) + the C ABI declared in include/elf_amd.h.
+// One wave64 = one workgroup = one board; see go_board.cuh for the device engine.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/elf_amd.h"
+#include "go_board.cuh"
+
+using namespace elfgo;
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct Pool {
+  Slot<N>* slots;
+  u64* sk_hash;   // [capacity][MAXMOVE+2]
+  u64* sk_img;    // [capacity][MAXMOVE+2][SKW]
+  const u64* zob; // internal index order
+  __device__ __forceinline__ u64* skh(int b) const { return sk_hash + (size_t)b * (Geo<N>::MAXMOVE + 2); }
+  __device__ __forceinline__ u64* ski(int b) const { return sk_img + (size_t)b * (Geo<N>::MAXMOVE + 2) * Geo<N>::SKW; }
+};
+
+__device__ __forceinline__ int slot_of(const int32_t* ids, int i) { return ids ? ids[i] : i; }
+
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_reset(Pool<N> pool, const int32_t* ids, int n) {
+  __shared__ Slot<N> lds;
+  int b = slot_of(ids, blockIdx.x);
+  Board<N> bd;
+  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.reset();
+  bd.store(&pool.slots[b]);
+}
+
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_copy(Pool<N> pool, const int32_t* dst, const int32_t* src, int n) {
+  using G = Geo<N>;
+  int d = dst[blockIdx.x], s = src[blockIdx.x];
+  if (d == s) return;
+  int lane = threadIdx.x;
+  const uint4* sp = reinterpret_cast<const uint4*>(&pool.slots[s]);
+  uint4* dp = reinterpret_cast<uint4*>(&pool.slots[d]);
+  for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += WAVE) dp[j] = sp[j];
+  int len = pool.slots[s].h.sk_len;
+  const u64* sh = pool.skh(s); u64* dh = pool.skh(d);
+  for (int j = lane; j < len; j += WAVE) dh[j] = sh[j];
+  const u64* si = pool.ski(s); u64* di = pool.ski(d);
+  for (int j = lane; j < len * G::SKW; j += WAVE) di[j] = si[j];
+}
+
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_forward(Pool<N> pool, const int32_t* ids, const int32_t* moves, int n, uint8_t* ok) {
+  __shared__ Slot<N> lds;
+  int b = slot_of(ids, blockIdx.x);
+  int c = moves[blockIdx.x];
+  if (c == M_INVALID || c < 0) {  // go_state.cc:75-77 (reference throws)
+    if (threadIdx.x == 0 && ok) ok[blockIdx.x] = 0xFF;
+    return;
+  }
+  Board<N> bd;
+  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.load(&pool.slots[b]);
+  int r = bd.forward(c);
+  if (r) bd.store(&pool.slots[b]);
+  if (threadIdx.x == 0 && ok) ok[blockIdx.x] = (uint8_t)r;
+}
+
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_legal_mask(Pool<N> pool, const int32_t* ids, int n, uint8_t* mask) {
+  using G = Geo<N>;
+  __shared__ Slot<N> lds;
+  int b = slot_of(ids, blockIdx.x);
+  Board<N> bd;
+  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.load(&pool.slots[b]);
+  u64 legal[G::R], cand[G::R];
+  bd.template legal_moves<false>(legal, cand);
+  uint8_t* out = mask + (size_t)blockIdx.x * G::NA;
+#pragma unroll
+  for (int k = 0; k < G::R; ++k) {
+    int a = k * 64 + bd.lane;
+    if (a < G::NP) out[a] = (uint8_t)((legal[k] >> bd.lane) & 1);
+  }
+  if (bd.lane == 0) out[G::NP] = 1;  // pass is always accepted by TryPlay (board.cc:794-800)
+}
+
+// BoardFeature::extractAGZ (board_feature.cc:247-290) + Transform (board_feature.h:97-113).
+// Output-indexed so that every store instruction is a fully coalesced 256-B segment.
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_extract_agz(Pool<N> pool, const int32_t* ids, const int32_t* d4s, int n,
+                                                       float* dst, int64_t stride) {
+  using G = Geo<N>;
+  __shared__ u64 hist[HIST][2][G::R];
+  const int lane = threadIdx.x;
+  int b = slot_of(ids, blockIdx.x);
+  const Slot<N>* sl = &pool.slots[b];
+  const u64* gh = &sl->hist[0][0][0];
+  for (int j = lane; j < HIST * 2 * G::R; j += WAVE) (&hist[0][0][0])[j] = gh[j];
+  const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
+  const int len = cnt < HIST ? cnt : HIST;
+  const int d4 = d4s ? d4s[blockIdx.x] : 0;
+  const int rot = d4 & 3;
+  const bool flip = ((d4 >> 2) & 1) != 0;
+  __syncthreads();
+  float* out = dst + (size_t)blockIdx.x * stride;
+#pragma unroll
+  for (int k = 0; k < G::R; ++k) {
+    int o = k * 64 + lane;
+    if (o >= G::NP) break;
+    // InvTransform (board_feature.h:115-130): output (x', y') -> board (x, y)
+    int xo = o / N, yo = o % N;
+    if (flip) { int t = xo; xo = yo; yo = t; }
+    int x = xo, y = yo;
+    if (rot == 1) { x = N - 1 - yo; y = xo; }
+    else if (rot == 2) { x = N - 1 - xo; y = N - 1 - yo; }
+    else if (rot == 3) { x = yo; y = N - 1 - xo; }
+    int a = x * N + y, w = a >> 6, sft = a & 63;
+#pragma unroll
+    for (int hk = 0; hk < HIST; ++hk) {
+      int slot = (cnt - 1 - hk) & (HIST - 1);
+      u64 bb = hist[slot][0][w], wb = hist[slot][1][w];
+      bool isb = hk < len && ((bb >> sft) & 1), isw = hk < len && ((wb >> sft) & 1);
+      bool mine = player == S_BLACK ? isb : isw, theirs = player == S_BLACK ? isw : isb;
+      out[(2 * hk) * G::NP + o] = mine ? 1.0f : 0.0f;
+      out[(2 * hk + 1) * G::NP + o] = theirs ? 1.0f : 0.0f;
+    }
+    out[16 * G::NP + o] = player == S_BLACK ? 1.0f : 0.0f;
+    out[17 * G::NP + o] = player == S_BLACK ? 0.0f : 1.0f;
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_evaluate(Pool<N> pool, const int32_t* ids, int n, float komi, float* out) {
+  __shared__ Slot<N> lds;
+  int b = slot_of(ids, blockIdx.x);
+  Board<N> bd;
+  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.load(&pool.slots[b]);
+  float v = bd.evaluate(komi);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+template <int N>
+__global__ void k_info(Pool<N> pool, const int32_t* ids, int n, int32_t* out) {
+  using G = Geo<N>;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Hdr& h = pool.slots[slot_of(ids, i)].h;
+  int32_t* o = out + (size_t)i * ELFGO_INFO_WORDS;
+  bool term = (h.last_move[0] == M_PASS && h.last_move[1] == M_PASS) || h.ply >= G::MAXMOVE || h.superko;
+  o[0] = h.ply; o[1] = h.next_player; o[2] = h.last_move[0]; o[3] = h.last_move[1];
+  o[4] = h.ko_age; o[5] = h.ko_pt; o[6] = h.ko_color; o[7] = h.b_cap; o[8] = h.w_cap;
+  o[9] = term; o[10] = h.superko; o[11] = h.hist_cnt < HIST ? h.hist_cnt : HIST; o[12] = h.sk_len;
+  o[13] = (int32_t)(u32)h.hash; o[14] = (int32_t)(u32)(h.hash >> 32); o[15] = 0;
+}
+
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_export(Pool<N> pool, const int32_t* ids, int n, uint8_t* colour, int16_t* libs) {
+  using G = Geo<N>;
+  const Slot<N>* sl = &pool.slots[slot_of(ids, blockIdx.x)];
+  for (int a = threadIdx.x; a < G::NP; a += WAVE) {
+    u32 v = sl->pt[Board<N>::a2i(a)];
+    colour[(size_t)blockIdx.x * G::NP + a] = v == 0 ? 0 : ((v >> 15) + 1);
+    libs[(size_t)blockIdx.x * G::NP + a] = v == 0 ? 0 : (int16_t)sl->libs[v & 0x7FFF];
+  }
+}
+
+// Whole games inside one launch: position stays in LDS from the first move to the last.
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* ids, const u64* seeds, int n,
+                                                   int max_steps, uint32_t* out) {
+  using G = Geo<N>;
+  __shared__ Slot<N> lds;
+  int b = slot_of(ids, blockIdx.x);
+  Board<N> bd;
+  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.load(&pool.slots[b]);
+  const u64 seed = seeds[blockIdx.x];
+  int steps = 0;
+  while (steps < max_steps && !bd.terminated()) {
+    u64 legal[G::R], cand[G::R];
+    bd.template legal_moves<true>(legal, cand);
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < G::R; ++k) total += __popcll(cand[k]);
+    int pick = M_PASS;
+    if (total > 0) {
+      int r = (int)(playout_rng(seed, (u32)lds.h.ply) % (u32)total);
+      int a = -1;
+#pragma unroll
+      for (int k = 0; k < G::R; ++k) {
+        int c = __popcll(cand[k]);
+        if (a < 0) {
+          if (r < c) {
+            int pre = __builtin_amdgcn_mbcnt_hi((u32)(cand[k] >> 32), __builtin_amdgcn_mbcnt_lo((u32)cand[k], 0));
+            u64 sel = __ballot(((cand[k] >> bd.lane) & 1) && pre == r);
+            a = k * 64 + (int)__builtin_ctzll(sel);
+          } else {
+            r -= c;
+          }
+        }
+      }
+      pick = Board<N>::tr(Board<N>::a2i(a));
+    }
+    if (!bd.forward(pick)) break;
+    ++steps;
+  }
+  bd.store(&pool.slots[b]);
+  if (threadIdx.x == 0) {
+    u64 h = lds.h.hash;
+    uint32_t* o = out + (size_t)blockIdx.x * 4;
+    o[0] = (u32)h; o[1] = (u32)(h >> 32); o[2] = lds.h.ply; o[3] = (u32)steps;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the C ABI
+// ------------------------------------------------------------------------------------------------
+struct ElfGoEngine {
+  int n = 0, capacity = 0, device = 0;
+  void* slots = nullptr;
+  u64* sk_hash = nullptr;
+  u64* sk_img = nullptr;
+  u64* zob = nullptr;
+  size_t slot_bytes = 0;
+};
+
+#define HIPCHK(x)                         \
+  do {                                    \
+    hipError_t _e = (x);                  \
+    if (_e != hipSuccess) return (int)_e; \
+  } while (0)
+
+template <int N>
+static Pool<N> pool_of(const ElfGoEngine* e) {
+  Pool<N> p;
+  p.slots = reinterpret_cast<Slot<N>*>(e->slots);
+  p.sk_hash = e->sk_hash;
+  p.sk_img = e->sk_img;
+  p.zob = e->zob;
+  return p;
+}
+
+template <int N>
+static int create_impl(ElfGoEngine* e, const uint64_t* zob_host) {
+  using G = Geo<N>;
+  e->slot_bytes = sizeof(Slot<N>);
+  HIPCHK(hipMalloc(&e->slots, (size_t)e->capacity * sizeof(Slot<N>)));
+  HIPCHK(hipMalloc((void**)&e->sk_hash, (size_t)e->capacity * (G::MAXMOVE + 2) * sizeof(u64)));
+  HIPCHK(hipMalloc((void**)&e->sk_img, (size_t)e->capacity * (G::MAXMOVE + 2) * G::SKW * sizeof(u64)));
+  HIPCHK(hipMalloc((void**)&e->zob, (size_t)G::PP * sizeof(u64)));
+  // reference Coord order -> internal (transposed) index order
+  std::vector<u64> z(G::PP, 0);
+  for (int i = 0; i < G::P; ++i) z[i] = zob_host[(i % G::S) * G::S + i / G::S];
+  HIPCHK(hipMemcpy(e->zob, z.data(), z.size() * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_reset<N>, dim3(e->capacity), dim3(WAVE), 0, 0, pool_of<N>(e), (const int32_t*)nullptr, e->capacity);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
+#define DISPATCH(e, CALL)                 \
+  do {                                    \
+    if ((e)->n == 19) { constexpr int N = 19; CALL; } \
+    else { constexpr int N = 9; CALL; }   \
+  } while (0)
+
+extern "C" {
+
+int elfgo_create(int board_size, int capacity, int device, const uint64_t* zobrist_host, ElfGoEngine** out) {
+  if (!out || !zobrist_host || capacity <= 0) return ELFGO_E_BADARG;
+  if (board_size != 19 && board_size != 9) return ELFGO_E_BADSIZE;
+  HIPCHK(hipSetDevice(device));
+  ElfGoEngine* e = new (std::nothrow) ElfGoEngine();
+  if (!e) return ELFGO_E_NOMEM;
+  e->n = board_size; e->capacity = capacity; e->device = device;
+  int rc = board_size == 19 ? create_impl<19>(e, zobrist_host) : create_impl<9>(e, zobrist_host);
+  if (rc) { elfgo_destroy(e); return rc; }
+  *out = e;
+  return 0;
+}
+
+int elfgo_destroy(ElfGoEngine* e) {
+  if (!e) return ELFGO_E_BADARG;
+  if (e->slots) (void)hipFree(e->slots);
+  if (e->sk_hash) (void)hipFree(e->sk_hash);
+  if (e->sk_img) (void)hipFree(e->sk_img);
+  if (e->zob) (void)hipFree(e->zob);
+  delete e;
+  return 0;
+}
+
+int elfgo_board_size(const ElfGoEngine* e) { return e ? e->n : ELFGO_E_BADARG; }
+int elfgo_capacity(const ElfGoEngine* e) { return e ? e->capacity : ELFGO_E_BADARG; }
+size_t elfgo_slot_bytes(const ElfGoEngine* e) { return e ? e->slot_bytes : 0; }
+
+int elfgo_sync(ElfGoEngine* e, void* stream) {
+  if (!e) return ELFGO_E_BADARG;
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+#define CHECK_N(e, ids, n)                                             \
+  if (!(e) || (n) < 0) return ELFGO_E_BADARG;                          \
+  if (!(ids) && (n) > (e)->capacity) return ELFGO_E_BADARG;            \
+  if ((n) == 0) return 0;
+
+int elfgo_reset(ElfGoEngine* e, const int32_t* ids, int n, void* stream) {
+  CHECK_N(e, ids, n);
+  DISPATCH(e, hipLaunchKernelGGL(k_reset<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, n));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_copy(ElfGoEngine* e, const int32_t* dst_ids, const int32_t* src_ids, int n, void* stream) {
+  if (!e || n < 0 || !dst_ids || !src_ids) return ELFGO_E_BADARG;
+  if (n == 0) return 0;
+  DISPATCH(e, hipLaunchKernelGGL(k_copy<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), dst_ids, src_ids, n));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_forward(ElfGoEngine* e, const int32_t* ids, const int32_t* moves, int n, uint8_t* ok, void* stream) {
+  CHECK_N(e, ids, n);
+  if (!moves) return ELFGO_E_BADARG;
+  DISPATCH(e, hipLaunchKernelGGL(k_forward<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, moves, n, ok));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_legal_mask(ElfGoEngine* e, const int32_t* ids, int n, uint8_t* mask, void* stream) {
+  CHECK_N(e, ids, n);
+  if (!mask) return ELFGO_E_BADARG;
+  DISPATCH(e, hipLaunchKernelGGL(k_legal_mask<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, n, mask));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_extract_agz(ElfGoEngine* e, const int32_t* ids, const int32_t* d4, int n, float* dst, int64_t stride_floats,
+                      void* stream) {
+  CHECK_N(e, ids, n);
+  if (!dst || stride_floats < (int64_t)18 * e->n * e->n) return ELFGO_E_BADARG;
+  DISPATCH(e, hipLaunchKernelGGL(k_extract_agz<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, d4, n, dst,
+                                 stride_floats));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_evaluate(ElfGoEngine* e, const int32_t* ids, int n, float komi, float* out, void* stream) {
+  CHECK_N(e, ids, n);
+  if (!out) return ELFGO_E_BADARG;
+  DISPATCH(e, hipLaunchKernelGGL(k_evaluate<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, n, komi, out));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_info(ElfGoEngine* e, const int32_t* ids, int n, int32_t* out, void* stream) {
+  CHECK_N(e, ids, n);
+  if (!out) return ELFGO_E_BADARG;
+  DISPATCH(e, hipLaunchKernelGGL(k_info<N>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pool_of<N>(e), ids, n, out));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_export_board(ElfGoEngine* e, const int32_t* ids, int n, uint8_t* colour, int16_t* libs, void* stream) {
+  CHECK_N(e, ids, n);
+  if (!colour || !libs) return ELFGO_E_BADARG;
+  DISPATCH(e, hipLaunchKernelGGL(k_export<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, n, colour, libs));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_playout(ElfGoEngine* e, const int32_t* ids, const uint64_t* seeds, int n, int max_steps, uint32_t* out,
+                  void* stream) {
+  CHECK_N(e, ids, n);
+  if (!seeds || !out) return ELFGO_E_BADARG;
+  DISPATCH(e, hipLaunchKernelGGL(k_playout<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids,
+                                 (const u64*)seeds, n, max_steps, out));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfgo_malloc(void** dptr, size_t bytes) { HIPCHK(hipMalloc(dptr, bytes)); return 0; }
+int elfgo_free(void* dptr) { HIPCHK(hipFree(dptr)); return 0; }
+int elfgo_memcpy_h2d(void* dst, const void* src_host, size_t bytes) {
+  HIPCHK(hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int elfgo_memcpy_d2h(void* dst_host, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+const char* elfgo_error_string(int status) {
+  if (status == 0) return "ok";
+  if (status == ELFGO_E_BADARG) return "elfgo: bad argument";
+  if (status == ELFGO_E_BADSIZE) return "elfgo: unsupported board size (19 or 9)";
+  if (status == ELFGO_E_NOMEM) return "elfgo: out of host memory";
+  return hipGetErrorString((hipError_t)status);
+}
+const char* elfgo_version(void) { return "elf_amd 0.1 (gfx950)"; }
+
+}  // extern "C"
