@@ -98,7 +98,7 @@ __device__ __forceinline__ bool is_stone(u32 v) { return v != 0 && v != PT_BORDE
 __device__ __forceinline__ u64 zob_col(u64 h, int s) { return s == S_BLACK ? h : ((h >> 32) | (h << 32)); }
 __device__ __forceinline__ u16 sk_tag(u64 h) { return (u16)(h ^ (h >> 16) ^ (h >> 32) ^ (h >> 48)); }
 
-// config-2 counter RNG, shared verbatim with oracle/ref_capi.cc and oracle/go_oracle.c
+// config-2 counter RNG, the CPU checkers under oracle/ restate the same function
 __device__ __forceinline__ u32 playout_rng(u64 seed, u32 t) {
   u64 z = seed + (u64)(t + 1) * 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

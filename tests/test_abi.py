@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library builds for gfx950, loads without a GPU and exports every symbol that
+include/elf_amd.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "elf_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(elfgo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    import elf_amd
+    from elf_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "libelf_amd.so lacks %s" % n
+        assert n in _lib.SIGNATURES, "elf_amd/_lib.py lacks a prototype for %s" % n
+    assert set(_lib.SIGNATURES) == set(names)
+    assert elf_amd.lib().elfgo_version().startswith(b"elf_amd")
+
+
+def test_bad_arguments_are_status_codes_not_crashes(built):
+    import elf_amd
+    L = elf_amd.lib()
+    h = ctypes.c_void_p()
+    assert L.elfgo_create(13, 4, 0, None, ctypes.byref(h)) == -1  # null zobrist
+    z = (ctypes.c_uint64 * 441)()
+    assert L.elfgo_create(13, 4, 0, z, ctypes.byref(h)) == -2     # unsupported size
+    assert L.elfgo_destroy(None) == -1
+    assert b"bad argument" in L.elfgo_error_string(-1)
+
+
+def test_product_path_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "elf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "libgo_oracle" not in txt and "libelfref" not in txt, f
+
+
+def test_engine_refuses_to_run_without_gpu(built):
+    import pytest
+    import torch
+    import elf_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        elf_amd.GoEngine(19, 4)
