@@ -81,13 +81,14 @@ __global__ __launch_bounds__(WAVE) void k_legal_mask(Pool<N> pool, const int32_t
   Board<N> bd;
   bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
   bd.load(&pool.slots[b]);
-  u64 legal[G::R], cand[G::R];
+  u64 legal, cand;
   bd.template legal_moves<false>(legal, cand);
   uint8_t* out = mask + (size_t)blockIdx.x * G::NA;
 #pragma unroll
   for (int k = 0; k < G::R; ++k) {
     int a = k * 64 + bd.lane;
-    if (a < G::NP) out[a] = (uint8_t)((legal[k] >> bd.lane) & 1);
+    const u64 wk = rl64(legal, k);
+    if (a < G::NP) out[a] = (uint8_t)((wk >> bd.lane) & 1);
   }
   if (bd.lane == 0) out[G::NP] = 1;  // pass is always accepted by TryPlay (board.cc:794-800)
 }
@@ -186,28 +187,28 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
   const u64 seed = seeds[blockIdx.x];
   int steps = 0;
   while (steps < max_steps && !bd.terminated()) {
-    u64 legal[G::R], cand[G::R];
+    u64 legal, cand;
     bd.template legal_moves<true>(legal, cand);
-    int total = 0;
+    // uniformly random candidate: r-th set bit of the lane-distributed candidate bitboard
+    const int cnt = __popcll(cand);
+    int pre[G::R + 1];
+    pre[0] = 0;
 #pragma unroll
-    for (int k = 0; k < G::R; ++k) total += __popcll(cand[k]);
+    for (int k = 0; k < G::R; ++k) pre[k + 1] = pre[k] + rl(cnt, k);
+    const int total = pre[G::R];
     int pick = M_PASS;
     if (total > 0) {
-      int r = (int)(playout_rng(seed, (u32)lds.h.ply) % (u32)total);
-      int a = -1;
+      const int r = (int)(playout_rng(seed, (u32)bd.ply) % (u32)total);
+      int kw = 0;
 #pragma unroll
-      for (int k = 0; k < G::R; ++k) {
-        int c = __popcll(cand[k]);
-        if (a < 0) {
-          if (r < c) {
-            int pre = __builtin_amdgcn_mbcnt_hi((u32)(cand[k] >> 32), __builtin_amdgcn_mbcnt_lo((u32)cand[k], 0));
-            u64 sel = __ballot(((cand[k] >> bd.lane) & 1) && pre == r);
-            a = k * 64 + (int)__builtin_ctzll(sel);
-          } else {
-            r -= c;
-          }
-        }
-      }
+      for (int k = 1; k < G::R; ++k) kw += r >= pre[k];
+      int base = 0;
+#pragma unroll
+      for (int k = 1; k < G::R; ++k) base = (kw == k) ? pre[k] : base;
+      const u64 wk = rl64(cand, kw);
+      const int rank = __builtin_amdgcn_mbcnt_hi((u32)(wk >> 32), __builtin_amdgcn_mbcnt_lo((u32)wk, 0));
+      const u64 sel = __ballot(lane_bit(wk) && rank == r - base);
+      const int a = kw * 64 + (int)__builtin_ctzll(sel);
       pick = Board<N>::tr(Board<N>::a2i(a));
     }
     if (!bd.forward(pick)) break;
@@ -215,9 +216,9 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
   }
   bd.store(&pool.slots[b]);
   if (threadIdx.x == 0) {
-    u64 h = lds.h.hash;
+    u64 h = bd.hash;
     uint32_t* o = out + (size_t)blockIdx.x * 4;
-    o[0] = (u32)h; o[1] = (u32)(h >> 32); o[2] = lds.h.ply; o[3] = (u32)steps;
+    o[0] = (u32)h; o[1] = (u32)(h >> 32); o[2] = (u32)bd.ply; o[3] = (u32)steps;
   }
 }
 
@@ -256,10 +257,17 @@ static int create_impl(ElfGoEngine* e, const uint64_t* zob_host) {
   HIPCHK(hipMalloc(&e->slots, (size_t)e->capacity * sizeof(Slot<N>)));
   HIPCHK(hipMalloc((void**)&e->sk_hash, (size_t)e->capacity * (G::MAXMOVE + 2) * sizeof(u64)));
   HIPCHK(hipMalloc((void**)&e->sk_img, (size_t)e->capacity * (G::MAXMOVE + 2) * G::SKW * sizeof(u64)));
-  HIPCHK(hipMalloc((void**)&e->zob, (size_t)G::PP * sizeof(u64)));
-  // reference Coord order -> internal (transposed) index order
-  std::vector<u64> z(G::PP, 0);
+  HIPCHK(hipMalloc((void**)&e->zob, (size_t)(G::ZOBW + 3 * G::R) * sizeof(u64)));
+  // reference Coord order -> internal (transposed) index order, followed by the per-word geometry masks
+  std::vector<u64> z(G::ZOBW + 3 * G::R, 0);
   for (int i = 0; i < G::P; ++i) z[i] = zob_host[(i % G::S) * G::S + i / G::S];
+  for (int a = 0; a < G::NP; ++a) {
+    const int k = a >> 6, y = a % N;
+    const u64 bit = 1ull << (a & 63);
+    if (y != 0) z[G::ZOBW + 3 * k + 0] |= bit;
+    if (y != N - 1) z[G::ZOBW + 3 * k + 1] |= bit;
+    z[G::ZOBW + 3 * k + 2] |= bit;
+  }
   HIPCHK(hipMemcpy(e->zob, z.data(), z.size() * sizeof(u64), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_reset<N>, dim3(e->capacity), dim3(WAVE), 0, 0, pool_of<N>(e), (const int32_t*)nullptr, e->capacity);
   HIPCHK(hipGetLastError());

@@ -63,8 +63,9 @@ struct Geo {
   static constexpr int R = (NP + 63) / 64;        // rounds of 64 lanes / u64 words per bitboard
   static constexpr int PP = (P + 7) & ~7;         // u16 arrays padded to 16 B
   static constexpr int MAXMOVE = 2 * NP;          // BOARD_MAX_MOVE (go_common.h:15)
-  static constexpr int TAGS = (MAXMOVE + 2 + 7) & ~7;
   static constexpr int SKW = 2 * R;               // u64 words per superko image (black, white)
+  static constexpr int BLOOM = N > 9 ? 256 : 64;  // u32 words of the superko Bloom filter
+  static constexpr int ZOBW = PP;                 // zobrist table words; geometry masks follow it
 };
 
 // One board slot = the LDS image, also the HBM image (copied 16 B per lane).
@@ -75,19 +76,32 @@ struct alignas(16) Slot {
   u16 pt[G::PP];
   u16 libs[G::PP];
   u64 hist[HIST][2][G::R];
-  u16 tags[G::TAGS];
-  static constexpr int RAW = 64 + 2 * G::PP * 2 + HIST * 2 * G::R * 8 + G::TAGS * 2;
-  unsigned char pad[((RAW + 255) & ~255) - RAW];
+  u32 bloom[G::BLOOM];
+  static constexpr int RAW = 64 + 2 * G::PP * 2 + HIST * 2 * G::R * 8 + G::BLOOM * 4;
+  static constexpr int PADB = ((RAW + 255) & ~255) - RAW;
+  unsigned char pad[PADB > 0 ? PADB : 256];
 };
-static_assert(sizeof(Slot<19>) == 4096, "19x19 slot is 4 KiB");
-static_assert(sizeof(Slot<9>) % 256 == 0, "slot is 256-B granular");
+static_assert(sizeof(Slot<19>) == 3840, "19x19 slot is 3.75 KiB");
+static_assert(sizeof(Slot<19>) % 256 == 0 && sizeof(Slot<9>) % 256 == 0, "slot is 256-B granular");
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ u64 rfl64(u64 v) {
-  u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+__device__ __forceinline__ u64 rl64(u64 v, int lane) {
+  u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
   return ((u64)hi << 32) | lo;
 }
+// lane l receives the value of lane l-1 / l+1 (zero at the ends of a 16-lane row; only lanes < R <= 6 matter)
+__device__ __forceinline__ u64 dpp_prev(u64 v) {
+  u32 lo = __builtin_amdgcn_update_dpp(0u, (u32)v, 0x111, 0xf, 0xf, true);
+  u32 hi = __builtin_amdgcn_update_dpp(0u, (u32)(v >> 32), 0x111, 0xf, 0xf, true);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 dpp_next(u64 v) {
+  u32 lo = __builtin_amdgcn_update_dpp(0u, (u32)v, 0x101, 0xf, 0xf, true);
+  u32 hi = __builtin_amdgcn_update_dpp(0u, (u32)(v >> 32), 0x101, 0xf, 0xf, true);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ bool lane_bit(u64 uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
 __device__ __forceinline__ u64 wave_xor64(u64 v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
@@ -96,9 +110,8 @@ __device__ __forceinline__ u64 wave_xor64(u64 v) {
 __device__ __forceinline__ bool is_stone(u32 v) { return v != 0 && v != PT_BORDER; }
 // base/board.cc:24-36 transform_hash
 __device__ __forceinline__ u64 zob_col(u64 h, int s) { return s == S_BLACK ? h : ((h >> 32) | (h << 32)); }
-__device__ __forceinline__ u16 sk_tag(u64 h) { return (u16)(h ^ (h >> 16) ^ (h >> 32) ^ (h >> 48)); }
 
-// config-2 counter RNG, the CPU checkers under oracle/ restate the same function
+// config-2 counter RNG; the CPU checkers under oracle/ restate the same function
 __device__ __forceinline__ u32 playout_rng(u64 seed, u32 t) {
   u64 z = seed + (u64)(t + 1) * 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -113,15 +126,27 @@ struct Board {
   static constexpr int S = G::S, NP = G::NP, R = G::R;
 
   Slot<N>* L;          // LDS image of this wave's board
-  const u64* zob;      // Zobrist constants in INTERNAL index order (global memory)
+  const u64* zob;      // Zobrist constants in INTERNAL index order (global memory) + geometry masks
   u64* sk_hash;        // this board's superko hashes   [MAXMOVE+2]        (HBM)
   u64* sk_img;         // this board's superko images   [MAXMOVE+2][SKW]   (HBM)
   int lane;
   int idx[R];          // LDS index of this lane's point in round k (clamped for invalid lanes)
-  bool valid[R];
+  // lane-distributed bitboards in NN action order: lane k < R holds bits [64k, 64k+64); other lanes 0
+  u64 Bw, Ww;          // black / white stones of the current position
+  u64 mTop, mBot, mValid;  // per-lane geometry masks: y != 0, y != N-1, a < N*N
+  // wave-uniform copy of the header (SGPRs); LDS/HBM copy is refreshed by store_hdr()
+  u64 hash;
+  int ply, next_player, ko_pt, ko_age, ko_color, lm0, lm1, lm2, lm3, b_cap, w_cap, hist_cnt, sk_len, superko;
 
   __device__ __forceinline__ static int a2i(int a) { return a + S + 1 + 2 * (a / N); }
   __device__ __forceinline__ static int tr(int i) { return (i % S) * S + i / S; }  // idx <-> reference Coord
+  __device__ __forceinline__ static int i2a(int i) { return (i / S - 1) * N + (i % S - 1); }
+  // reference delta4 order L,T,R,B = x-1,y-1,x+1,y+1 (board.h:220) -> internal -S,-1,+S,+1
+  __device__ __forceinline__ static int dir4(int q) { return (q & 1) ? ((q & 2) ? 1 : -1) : ((q & 2) ? S : -S); }
+  // single-wave workgroup: LDS ops of one wave execute in order, so a wavefront-scope fence (no
+  // instructions, compiler ordering only) is all the synchronisation the engine needs -- in particular
+  // no s_waitcnt vmcnt(0) behind the fire-and-forget superko stores to HBM.
+  __device__ __forceinline__ static void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
   __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skh, u64* ski) {
     L = lds; zob = z; sk_hash = skh; sk_img = ski;
@@ -129,9 +154,48 @@ struct Board {
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       int a = k * 64 + lane;
-      valid[k] = a < NP;
-      idx[k] = a2i(valid[k] ? a : 0);
+      idx[k] = a2i(a < NP ? a : 0);
     }
+    const u64* geo = z + G::ZOBW;
+    mTop = lane < R ? geo[lane * 3 + 0] : 0ull;
+    mBot = lane < R ? geo[lane * 3 + 1] : 0ull;
+    mValid = lane < R ? geo[lane * 3 + 2] : 0ull;
+    Bw = Ww = 0;
+  }
+
+  // points adjacent to X (4-neighbourhood), X lane-distributed
+  __device__ __forceinline__ u64 dilate(u64 X) const {
+    const u64 p = dpp_prev(X), n = dpp_next(X);
+    u64 d = ((X << 1) | (p >> 63)) & mTop;          // a-1 in X (same column run)
+    d |= ((X >> 1) | (n << 63)) & mBot;             // a+1 in X
+    d |= (X << N) | (p >> (64 - N));                // a-N in X
+    d |= (X >> N) | (n << (64 - N));                // a+N in X
+    return d & mValid;
+  }
+
+  __device__ __forceinline__ void load_hdr() {
+    u32 w = lane < 16 ? reinterpret_cast<const u32*>(&L->h)[lane] : 0u;
+    u32 w0 = rl(w, 0), w1 = rl(w, 1), w2 = rl(w, 2), w3 = rl(w, 3), w4 = rl(w, 4), w5 = rl(w, 5), w6 = rl(w, 6),
+        w7 = rl(w, 7), w8 = rl(w, 8);
+    hash = ((u64)w1 << 32) | w0;
+    ply = w2 & 0xFFFF; ko_pt = w2 >> 16;
+    ko_age = w3 & 0xFFFF; lm0 = w3 >> 16;
+    lm1 = w4 & 0xFFFF; lm2 = w4 >> 16;
+    lm3 = w5 & 0xFFFF; b_cap = w5 >> 16;
+    w_cap = w6 & 0xFFFF; hist_cnt = w6 >> 16;
+    sk_len = w7 & 0xFFFF; next_player = (w7 >> 16) & 0xFF; ko_color = w7 >> 24;
+    superko = w8 & 0xFF;
+  }
+  __device__ __forceinline__ void store_hdr() {
+    if (lane == 0) {
+      Hdr& h = L->h;
+      h.hash = hash; h.ply = (u16)ply; h.ko_pt = (u16)ko_pt; h.ko_age = (u16)ko_age;
+      h.last_move[0] = (u16)lm0; h.last_move[1] = (u16)lm1; h.last_move[2] = (u16)lm2; h.last_move[3] = (u16)lm3;
+      h.b_cap = (u16)b_cap; h.w_cap = (u16)w_cap; h.hist_cnt = (u16)hist_cnt; h.sk_len = (u16)sk_len;
+      h.next_player = (unsigned char)next_player; h.ko_color = (unsigned char)ko_color;
+      h.superko = (unsigned char)superko;
+    }
+    wsync();
   }
 
   // ---- slot <-> HBM, 16 B per lane, fully coalesced ------------------------------------------
@@ -140,10 +204,14 @@ struct Board {
     uint4* d = reinterpret_cast<uint4*>(L);
 #pragma unroll
     for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += 64) d[j] = s[j];
-    __syncthreads();
+    wsync();
+    load_hdr();
+    const int newest = (hist_cnt + HIST - 1) & (HIST - 1);
+    Bw = (lane < R && hist_cnt != 0) ? L->hist[newest][0][lane] : 0ull;
+    Ww = (lane < R && hist_cnt != 0) ? L->hist[newest][1][lane] : 0ull;
   }
-  __device__ __forceinline__ void store(Slot<N>* g) const {
-    __syncthreads();
+  __device__ __forceinline__ void store(Slot<N>* g) {
+    store_hdr();
     const uint4* s = reinterpret_cast<const uint4*>(L);
     uint4* d = reinterpret_cast<uint4*>(g);
 #pragma unroll
@@ -154,150 +222,162 @@ struct Board {
   __device__ __forceinline__ void reset() {
     u32* w = reinterpret_cast<u32*>(L);
     for (int j = lane; j < (int)(sizeof(Slot<N>) / 4); j += 64) w[j] = 0;
-    __syncthreads();
+    wsync();
     for (int j = lane; j < G::PP; j += 64) {
       int a = j / S, b = j % S;
       bool on = j < G::P && a >= 1 && a <= N && b >= 1 && b <= N;
       L->pt[j] = on ? 0 : PT_BORDER;
     }
-    if (lane == 0) {
-      L->h.ply = 1;
-      L->h.next_player = S_BLACK;
-      for (int j = 0; j < 4; ++j) L->h.last_move[j] = M_INVALID;
-    }
-    __syncthreads();
-  }
-
-  // current position as bitboards = newest history entry (zeros for a fresh board)
-  __device__ __forceinline__ const u64* cur_bits() const {
-    int cnt = L->h.hist_cnt;
-    return &L->hist[(cnt + HIST - 1) & (HIST - 1)][0][0];
+    hash = 0; ply = 1; next_player = S_BLACK; ko_pt = 0; ko_age = 0; ko_color = 0;
+    lm0 = lm1 = lm2 = lm3 = M_INVALID; b_cap = w_cap = 0; hist_cnt = 0; sk_len = 0; superko = 0;
+    Bw = Ww = 0;
+    wsync();
   }
 
   // base/go_state.h:141-147 terminated()
   __device__ __forceinline__ bool terminated() const {
-    const Hdr& h = L->h;
-    return (h.last_move[0] == M_PASS && h.last_move[1] == M_PASS) || h.ply >= G::MAXMOVE || h.superko;
+    return (lm0 == M_PASS && lm1 == M_PASS) || ply >= G::MAXMOVE || superko;
+  }
+
+  __device__ __forceinline__ static void atomic_inc_u16(u16* p) {
+    // LDS has no 16-bit atomic add: add into the containing dword (never carries: liberties < 2^15)
+    size_t a = reinterpret_cast<size_t>(p);
+    u32* w = reinterpret_cast<u32*>(a & ~size_t(3));
+    atomicAdd(w, (a & 2) ? 0x10000u : 1u);
+  }
+  __device__ __forceinline__ int popc_lanes(u64 X) const {   // population of a lane-distributed bitboard
+    int c = __popcll(X), t = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) t += rl(c, k);
+    return t;
   }
 
   // ---- GoState::forward (go_state.cc:74-94). c = reference Coord, wave-uniform. ---------------
-  // returns 1 played, 0 refused (terminated / illegal). M_INVALID is rejected by the host (-1).
+  // returns 1 played, 0 refused (terminated / illegal). M_INVALID is rejected by the caller.
   __device__ int forward(int c) {
     c = rfl(c);
-    Hdr& h = L->h;
     if (terminated()) return 0;
-    const int player = h.next_player, opp = S_BLACK + S_WHITE - player;
+    const int player = next_player, opp = S_BLACK + S_WHITE - player;
     const bool is_move = !(c == M_PASS || c == M_RESIGN);
-    int i = 0;
-    u32 nv = 0, nl = 0;
-    int n[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
-    // reference delta4 order L,T,R,B = x-1,y-1,x+1,y+1 (board.h:220) -> internal -S,-1,+S,+1
-    const int dl = (lane & 1) ? ((lane & 2) ? 1 : -1) : ((lane & 2) ? S : -S);
+    int i = 0, ka = 0;
+    u64 abit = 0;
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    const int dl = dir4(lane & 3);
     if (is_move) {
       // ---- TryPlay, board.cc:788-827
       if (c >= G::P) return 0;
       int x = c % S - 1, y = c / S - 1;
       if (x < 0 || x >= N || y < 0 || y >= N) return 0;                       // :803
       i = (x + 1) * S + (y + 1);
-      if (L->pt[i] != 0) return 0;                                            // :808
-      if (h.ko_pt == c && h.ko_age == 0 && h.ko_color == player) return 0;    // :234-240
+      const int a = x * N + y;
+      ka = a >> 6; abit = 1ull << (a & 63);
+      if (rl64(Bw | Ww, ka) & abit) return 0;                                 // :808 occupied
+      if (ko_pt == c && ko_age == 0 && ko_color == player) return 0;          // :234-240
+      u32 nv = 0, nl = 0;
       if (lane < 4) {                                                         // StoneLibertyAnalysis :161-199
         nv = L->pt[i + dl];
         nl = is_stone(nv) ? L->libs[nv & 0x7FFF] : 0;
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { n[k] = rl((int)nv, k); l[k] = rl((int)nl, k); }
-      int nempty = 0, own_safe = 0, enemy_atari = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (n[k] == 0) { ++nempty; continue; }
-        if (n[k] == PT_BORDER) continue;
-        bool own = ((n[k] >> 15) + 1) == player;
-        if (own) own_safe += l[k] > 1; else enemy_atari += l[k] == 1;
+      n0 = rl((int)nv, 0); n1 = rl((int)nv, 1); n2 = rl((int)nv, 2); n3 = rl((int)nv, 3);
+      l0 = rl((int)nl, 0); l1 = rl((int)nl, 1); l2 = rl((int)nl, 2); l3 = rl((int)nl, 3);
+      int nempty = (n0 == 0) + (n1 == 0) + (n2 == 0) + (n3 == 0);
+      if (nempty == 0) {                                                      // isSuicideMove :201-232
+        const int pb = player == S_WHITE ? 0x8000 : 0;
+        auto saves = [&](int n, int l) { return n != PT_BORDER && (((n & 0x8000) == pb) ? l > 1 : l == 1); };
+        if (!(saves(n0, l0) || saves(n1, l1) || saves(n2, l2) || saves(n3, l3))) return 0;
       }
-      if (nempty == 0 && own_safe == 0 && enemy_atari == 0) return 0;         // isSuicideMove :201-232
     }
     // ---- _add_board_hash (go_state.cc:113-121): record the PRE-move position, skipped for pass
     if (c != M_PASS) {
-      int t = h.sk_len;
-      const u64* cb = cur_bits();
-      bool have = h.hist_cnt != 0;
-      if (lane < G::SKW) sk_img[(size_t)t * G::SKW + lane] = have ? cb[lane] : 0ull;
-      if (lane == 0) { sk_hash[t] = h.hash; L->tags[t] = sk_tag(h.hash); }
+      if (lane < R) {
+        sk_img[(size_t)sk_len * G::SKW + lane] = Bw;
+        sk_img[(size_t)sk_len * G::SKW + R + lane] = Ww;
+      }
+      if (lane == 0) {
+        sk_hash[sk_len] = hash;
+        const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
+        L->bloom[h1 >> 5] |= 1u << (h1 & 31);
+        L->bloom[h2 >> 5] |= 1u << (h2 & 31);
+      }
     }
-    __syncthreads();
-    u64 hash = h.hash;
     int total_cap = 0, ko_c = 0;
     bool new_ko = false;
     if (is_move) {
       // ---- Play, board.cc:1297-1401
-      const u32 ownbit = player == S_WHITE ? 0x8000u : 0u;
-      int own[4], m = 0, cap[4], nc = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        own[k] = -1; cap[k] = -1;
+      const int ownbit = player == S_WHITE ? 0x8000 : 0;
+      // classify the <=4 distinct neighbour groups (first occurrence wins, like GroupId4 slots)
+      auto stone = [](int n) { return n != 0 && n != PT_BORDER; };
+      const bool f0 = stone(n0), f1 = stone(n1) && n1 != n0, f2 = stone(n2) && n2 != n0 && n2 != n1,
+                 f3 = stone(n3) && n3 != n0 && n3 != n1 && n3 != n2;
+      auto isown = [&](int n) { return (n & 0x8000) == ownbit; };
+      const int o0 = (f0 && isown(n0)) ? n0 : -1, o1 = (f1 && isown(n1)) ? n1 : -1, o2 = (f2 && isown(n2)) ? n2 : -1,
+                o3 = (f3 && isown(n3)) ? n3 : -1;
+      const int c0 = (f0 && !isown(n0) && l0 == 1) ? n0 : -1, c1 = (f1 && !isown(n1) && l1 == 1) ? n1 : -1,
+                c2 = (f2 && !isown(n2) && l2 == 1) ? n2 : -1, c3 = (f3 && !isown(n3) && l3 == 1) ? n3 : -1;
+      const int m = (o0 >= 0) + (o1 >= 0) + (o2 >= 0) + (o3 >= 0);
+      const bool anycap = (c0 >= 0) | (c1 >= 0) | (c2 >= 0) | (c3 >= 0);
+      // enemy groups that survive lose the liberty at i (:1327)
+      if (lane < 4) {
+        int n = lane == 0 ? n0 : lane == 1 ? n1 : lane == 2 ? n2 : n3;
+        int l = lane == 0 ? l0 : lane == 1 ? l1 : lane == 2 ? l2 : l3;
+        bool f = lane == 0 ? f0 : lane == 1 ? f1 : lane == 2 ? f2 : f3;
+        if (f && !isown(n) && l != 1) L->libs[n & 0x7FFF] = (u16)(l - 1);
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (n[k] == 0 || n[k] == PT_BORDER) continue;
-        bool dup = false;
-#pragma unroll
-        for (int j = 0; j < k; ++j) dup |= n[j] == n[k];
-        if (dup) continue;
-        if ((u32)(n[k] & 0x8000) == ownbit) {
-          own[m++] = n[k];
-        } else if (l[k] == 1) {
-          cap[nc++] = n[k];                                                   // :1346 liberties hit 0
-        } else if (lane == 0) {
-          L->libs[n[k] & 0x7FFF] = (u16)(l[k] - 1);                           // :1327 --g->liberties
-        }
-      }
-      // final representative of the mover's group
-      const u32 newv = m > 0 ? (u32)own[0] : (ownbit | (u32)i);
-      bool capf[R];
-#pragma unroll
-      for (int k = 0; k < R; ++k) capf[k] = false;
-      if (nc > 0) {
+      const int first_own = o0 >= 0 ? o0 : o1 >= 0 ? o1 : o2 >= 0 ? o2 : o3;
+      const u32 newv = m > 0 ? (u32)first_own : (u32)(ownbit | i);
+      u64 capw = 0;   // lane-distributed bitboard of the stones captured by this move
+      if (anycap) {
         // EmptyGroup / RemoveStoneAndAddLiberty (:526-572): wave-parallel removal
         u64 xh = 0;
-        u64 capbal = 0; int capk = 0;
+        u32 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-          u32 v = valid[k] ? L->pt[idx[k]] : 0;
-          bool isc = v != 0 && ((int)v == cap[0] || (int)v == cap[1] || (int)v == cap[2] || (int)v == cap[3]);
-          u64 bal = __ballot(isc);
-          if (bal) { capbal = bal; capk = k; }
-          total_cap += __popcll(bal);
-          capf[k] = isc;
-          if (isc) { L->pt[idx[k]] = 0; xh ^= zob_col(zob[idx[k]], opp); }
+          int vv = (int)v[k];
+          bool isc = vv == c0 || vv == c1 || vv == c2 || vv == c3;   // c* are stones: never matches pad/border
+          u64 bal = __ballot(isc) & rl64(mValid, k);
+          if (bal) {
+            if (lane == k) capw = bal;
+            total_cap += __popcll(bal);
+            if (lane_bit(bal)) { L->pt[idx[k]] = 0; xh ^= zob_col(zob[idx[k]], opp); }
+            if (total_cap == 1 && ko_c == 0) ko_c = tr(a2i(k * 64 + (int)__builtin_ctzll(bal)));   // :1355 capture_c
+          }
         }
         hash ^= wave_xor64(xh);
-        if (total_cap == 1) ko_c = tr(a2i(capk * 64 + (int)__builtin_ctzll(capbal)));   // :1355 capture_c
+        if (player == S_BLACK) Ww &= ~capw; else Bw &= ~capw;
       }
       // place the stone with its final label; fold further own groups into it (MergeGroups :712-752)
       if (lane == 0) L->pt[i] = (u16)newv;
+      if (lane == ka) { if (player == S_BLACK) Bw |= abit; else Ww |= abit; }
       if (m >= 2) {
+        u32 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-          u32 v = valid[k] ? L->pt[idx[k]] : 0;
-          if (v != 0 && ((int)v == own[1] || (int)v == own[2] || (int)v == own[3])) L->pt[idx[k]] = (u16)newv;
+          int vv = (int)v[k];
+          if (vv != (int)newv && (vv == o0 || vv == o1 || vv == o2 || vv == o3)) L->pt[idx[k]] = (u16)newv;
         }
       }
-      __syncthreads();
-      if (nc > 0) {
+      wsync();
+      if (anycap) {
         // liberty give-back: every removed stone returns one liberty to each DISTINCT adjacent group (:533-538)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-          if (capf[k]) {
-            int p = idx[k];
-            u32 a0 = L->pt[p - 1], a1 = L->pt[p + 1], a2 = L->pt[p - S], a3 = L->pt[p + S];
-            if (is_stone(a0)) atomicAdd_u16(&L->libs[a0 & 0x7FFF]);
-            if (is_stone(a1) && a1 != a0) atomicAdd_u16(&L->libs[a1 & 0x7FFF]);
-            if (is_stone(a2) && a2 != a0 && a2 != a1) atomicAdd_u16(&L->libs[a2 & 0x7FFF]);
-            if (is_stone(a3) && a3 != a0 && a3 != a1 && a3 != a2) atomicAdd_u16(&L->libs[a3 & 0x7FFF]);
+          const u64 ck = rl64(capw, k);
+          if (ck) {
+            if (lane_bit(ck)) {
+              int p = idx[k];
+              u32 a0 = L->pt[p - 1], a1 = L->pt[p + 1], a2 = L->pt[p - S], a3 = L->pt[p + S];
+              if (is_stone(a0)) atomic_inc_u16(&L->libs[a0 & 0x7FFF]);
+              if (is_stone(a1) && a1 != a0) atomic_inc_u16(&L->libs[a1 & 0x7FFF]);
+              if (is_stone(a2) && a2 != a0 && a2 != a1) atomic_inc_u16(&L->libs[a2 & 0x7FFF]);
+              if (is_stone(a3) && a3 != a0 && a3 != a1 && a3 != a2) atomic_inc_u16(&L->libs[a3 & 0x7FFF]);
+            }
           }
         }
-        __syncthreads();
+        wsync();
       }
       // liberties of the mover's group
       int newlibs;
@@ -308,180 +388,153 @@ struct Board {
         newlibs = __popcll(__ballot(e == 0));
       } else if (m == 1) {
         // MergeToGroup (:677-708) restated: the played point stops being a liberty; each previously
-        // empty neighbour counts only if no other stone of the group already touches it.
-        int kk = lane / 3, jj = lane % 3;          // lanes 0..11: neighbour kk, its j-th other side
-        bool fresh = false;
-        if (lane < 12) {
-          int dk = (kk & 1) ? ((kk & 2) ? 1 : -1) : ((kk & 2) ? S : -S);
-          // the three directions from e that do not lead back to i
-          int dj;
-          {
-            int cand0 = -S, cand1 = -1, cand2 = S, cand3 = 1;
-            int back = -dk;
-            int arr[3]; int q = 0;
-            if (cand0 != back) arr[q++] = cand0;
-            if (cand1 != back) arr[q++] = cand1;
-            if (cand2 != back) arr[q++] = cand2;
-            if (cand3 != back) arr[q++] = cand3;
-            dj = arr[jj];
-          }
-          u32 nk = kk == 0 ? (u32)n[0] : kk == 1 ? (u32)n[1] : kk == 2 ? (u32)n[2] : (u32)n[3];
-          if (nk == 0) fresh = L->pt[i + dk + dj] == newv;   // another stone of the group touches e
-          else fresh = true;                                  // not an (originally) empty point: ignore
-        }
-        u64 touched = __ballot(fresh);
-        int add = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) add += (n[k] == 0) && (((touched >> (3 * k)) & 7ull) == 0);
+        // empty neighbour e counts only if no other stone of the group already touches it.
+        const int kk = lane / 3, jj = lane - 3 * kk;   // lanes 0..11: neighbour kk, its jj-th side not facing i
+        const int nk = kk == 0 ? n0 : kk == 1 ? n1 : kk == 2 ? n2 : n3;
+        bool touch = false;
+        if (lane < 12 && nk == 0) touch = L->pt[i + dir4(kk) + dir4((kk + 3 + jj) & 3)] == newv;
+        const u64 t = __ballot(touch);
+        const int add = ((n0 == 0) && ((t & 7ull) == 0)) + ((n1 == 0) && (((t >> 3) & 7ull) == 0)) +
+                        ((n2 == 0) && (((t >> 6) & 7ull) == 0)) + ((n3 == 0) && (((t >> 9) & 7ull) == 0));
         newlibs = (int)L->libs[root] - 1 + add;
       } else {
-        // RecomputeGroupLiberties (:754-782): count empty points touching the merged group
-        newlibs = 0;
+        // RecomputeGroupLiberties (:754-782): |dilate(group) & empty| on bitboards
+        u64 gw = 0;
+        u32 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-          bool lib = false;
-          if (valid[k]) {
-            int p = idx[k];
-            if (L->pt[p] == 0)
-              lib = L->pt[p - 1] == newv || L->pt[p + 1] == newv || L->pt[p - S] == newv || L->pt[p + S] == newv;
-          }
-          newlibs += __popcll(__ballot(lib));
+          u64 bal = __ballot(v[k] == newv);
+          if (lane == k) gw = bal;
         }
+        gw &= mValid;
+        newlibs = popc_lanes(dilate(gw) & ~(Bw | Ww));
       }
+      newlibs = rfl(newlibs);
       if (lane == 0) L->libs[root] = (u16)newlibs;
       hash ^= zob_col(zob[i], player);
       new_ko = (m == 0 && total_cap == 1 && newlibs == 1);                    // :1386
     }
     // ---- history push (go_state.cc:90-92; BoardHistory(board) board_feature.h:45-56) as bitboards
     {
-      const int slot = h.hist_cnt & (HIST - 1);
-      if (is_move) {
-        u64 myb = 0, myw = 0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          u32 v = valid[k] ? L->pt[idx[k]] : 0;
-          bool st = v != 0;   // valid points are never border
-          u64 bb = __ballot(st && !(v & 0x8000)), wb = __ballot(st && (v & 0x8000));
-          if (lane == k) { myb = bb; myw = wb; }
-        }
-        if (lane < R) { L->hist[slot][0][lane] = myb; L->hist[slot][1][lane] = myw; }
-      } else {
-        const u64* cb = cur_bits();
-        bool have = h.hist_cnt != 0;
-        if (lane < 2 * R) (&L->hist[slot][0][0])[lane] = have ? cb[lane] : 0ull;
-      }
+      const int slot = hist_cnt & (HIST - 1);
+      if (lane < R) { L->hist[slot][0][lane] = Bw; L->hist[slot][1][lane] = Ww; }
     }
     // ---- header update: caps :1348-1351, ko :1384-1393, update_next_move :1225-1238
-    if (lane == 0) {
-      h.hash = hash;
-      if (is_move) {
-        if (player == S_BLACK) h.b_cap += total_cap; else h.w_cap += total_cap;
-        if (new_ko) { h.ko_pt = (u16)ko_c; h.ko_color = (unsigned char)opp; h.ko_age = 0; }
-        else h.ko_age++;
-      }
-      h.next_player = (unsigned char)opp;
-      h.last_move[3] = h.last_move[2]; h.last_move[2] = h.last_move[1]; h.last_move[1] = h.last_move[0];
-      h.last_move[0] = (u16)c;
-      h.ply++;
-      h.hist_cnt++;
-      if (c != M_PASS) h.sk_len++;
-      h.superko = 0;
+    if (is_move) {
+      if (player == S_BLACK) b_cap += total_cap; else w_cap += total_cap;
+      if (new_ko) { ko_pt = ko_c; ko_color = opp; ko_age = 0; }
+      else ko_age = (ko_age + 1) & 0xFFFF;
     }
-    __syncthreads();
-    // ---- _check_superko (go_state.cc:96-111) for the new position, cached in the header
+    next_player = opp;
+    lm3 = lm2; lm2 = lm1; lm1 = lm0; lm0 = c;
+    ply++;
+    hist_cnt = (hist_cnt + 1) & 0xFFFF;
+    if (c != M_PASS) sk_len++;
+    superko = 0;
+    wsync();
+    // ---- _check_superko (go_state.cc:96-111) for the new position, cached in the header.
+    // Bloom filter in LDS first (two probes); the exact (hash, image) records in HBM only on a hit.
     if (c != M_PASS) {
-      const int len = h.sk_len;
-      const u16 tag = sk_tag(hash);
-      bool hit = false;
-      for (int base = 0; base < len; base += 64) {
-        int t = base + lane;
-        bool cand = t < len && L->tags[t] == tag;
-        u64 bal = __ballot(cand);
-        while (bal) {                       // rare: 16-bit tag match -> full hash, then full image
-          int tl = (int)__builtin_ctzll(bal);
-          bal &= bal - 1;
-          int tt = base + tl;
-          if (sk_hash[tt] == hash) {
-            const u64* cb = cur_bits();
-            bool same = lane < G::SKW ? sk_img[(size_t)tt * G::SKW + lane] == cb[lane] : true;
+      const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
+      const u32 b1 = L->bloom[h1 >> 5], b2 = L->bloom[h2 >> 5];
+      if (rfl((int)((b1 >> (h1 & 31)) & (b2 >> (h2 & 31)) & 1u))) {
+        bool hit = false;
+        for (int base = 0; base < sk_len; base += 64) {
+          int t = base + lane;
+          u64 bal = __ballot(t < sk_len && sk_hash[t] == hash);
+          while (bal) {
+            int tt = base + (int)__builtin_ctzll(bal);
+            bal &= bal - 1;
+            bool same = true;
+            if (lane < R) same = sk_img[(size_t)tt * G::SKW + lane] == Bw && sk_img[(size_t)tt * G::SKW + R + lane] == Ww;
             if (__all(same)) hit = true;
           }
         }
+        if (hit) superko = 1;
       }
-      if (hit && lane == 0) h.superko = 1;
-      __syncthreads();
     }
     return 1;
   }
 
-  __device__ __forceinline__ static void atomicAdd_u16(u16* p) {
-    // LDS has no 16-bit atomic add: add into the containing dword (never carries: liberties < 2^15)
-    size_t a = reinterpret_cast<size_t>(p);
-    u32* w = reinterpret_cast<u32*>(a & ~size_t(3));
-    atomicAdd(w, (a & 2) ? 0x10000u : 1u);
-  }
-
   // ---- legal moves for the side to move (TryPlay :788-827 over every point) --------------------
-  // legal[k] bit l = action 64k+l is playable; optionally also the "not own true eye" candidate set
-  // used by the config-2 playout policy (isTrueEye, board.cc:1850-1914).
+  // Results are lane-distributed bitboards (lane k holds actions [64k, 64k+64)).  Points with an empty
+  // neighbour are settled on bitboards (a handful of 64-bit VALU ops); only the surrounded empty points
+  // touch the LDS group tables, one predicated round per non-empty 64-point word.
+  // cand = legal minus the mover's own true eyes (isTrueEye, board.cc:1850-1914), for the config-2 policy.
   template <bool WITH_EYES>
-  __device__ __forceinline__ void legal_moves(u64 (&legal)[R], u64 (&cand)[R]) const {
-    const Hdr& h = L->h;
-    const int player = h.next_player;
+  __device__ __forceinline__ void legal_moves(u64& legal, u64& cand) const {
+    const int player = next_player;
     const u32 ownbit = player == S_WHITE ? 0x8000u : 0u;
-    const int ko_i = (h.ko_age == 0 && h.ko_color == player) ? tr(h.ko_pt) : -1;
+    const u64 E = ~(Bw | Ww) & mValid;
+    const u64 open = E & dilate(E);
+    const u64 need = E & ~open;
+    u64 okw = open, eyew = 0;
+    if (__ballot(need != 0)) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      bool ok = false, eye = false;
-      if (valid[k]) {
-        const int p = idx[k];
-        if (L->pt[p] == 0) {
+      for (int k = 0; k < R; ++k) {
+        const u64 nk = rl64(need, k);
+        if (nk == 0) continue;
+        bool good = false, eye = false;
+        if (lane_bit(nk)) {
+          const int p = idx[k];
           u32 a[4] = {L->pt[p - S], L->pt[p - 1], L->pt[p + S], L->pt[p + 1]};
-          ok = a[0] == 0 || a[1] == 0 || a[2] == 0 || a[3] == 0;
-          if (!ok) {
-            bool allown = true;
+          u32 lb[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lb[j] = L->libs[a[j] == PT_BORDER ? 0 : (a[j] & 0x7FFF)];
+          bool allown = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bool border = a[j] == PT_BORDER;
+            bool own = (a[j] & 0x8000) == ownbit;
+            good |= !border && (own ? lb[j] > 1 : lb[j] == 1);
+            allown &= border || own;
+          }
+          if (WITH_EYES && allown && good) {
+            // isEye holds (board.cc:1850-1860); isFakeEye :1887-1906 on the diagonals
+            u32 d[4] = {L->pt[p - S - 1], L->pt[p - S + 1], L->pt[p + S - 1], L->pt[p + S + 1]};
+            int nopp = 0, nb = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              if (a[j] == PT_BORDER) continue;
-              int lb = L->libs[a[j] & 0x7FFF];
-              bool own = (a[j] & 0x8000) == ownbit;
-              ok |= own ? lb > 1 : lb == 1;
-              allown &= own;
+              nb += d[j] == PT_BORDER;
+              nopp += d[j] != PT_BORDER && d[j] != 0 && (d[j] & 0x8000) != ownbit;
             }
-            if (WITH_EYES && allown) {
-              // isEye holds; isFakeEye :1887-1906 on the diagonals
-              u32 d[4] = {L->pt[p - S - 1], L->pt[p - S + 1], L->pt[p + S - 1], L->pt[p + S + 1]};
-              int nopp = 0, nb = 0;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (d[j] == PT_BORDER) ++nb;
-                else if (d[j] != 0 && (d[j] & 0x8000) != ownbit) ++nopp;
-              }
-              bool fake = (nb > 0 && nopp >= 1) || (nb == 0 && nopp >= 2);
-              eye = !fake;
-            }
+            bool fake = (nb > 0 && nopp >= 1) || (nb == 0 && nopp >= 2);
+            eye = !fake;
           }
-          if (p == ko_i) ok = false;
         }
+        const u64 gb = __ballot(good), eb = __ballot(eye);
+        if (lane == k) { okw |= gb; eyew = eb; }
       }
-      legal[k] = __ballot(ok);
-      if (WITH_EYES) cand[k] = __ballot(ok && !eye);
     }
+    if (ko_age == 0 && ko_color == player && ko_pt != 0) {
+      const int a = i2a(tr(ko_pt));
+      if (lane == (a >> 6)) okw &= ~(1ull << (a & 63));
+    }
+    legal = okw;
+    cand = okw & ~eyew;
   }
 
   // ---- Tromp-Taylor area score (go_state.h:32-93 simple_flood_fill x2 + simple_tt_scoring) ----
   // Row-bitboard flood fill in registers: lane x holds column-bits y of row x.
   __device__ int tt_area() const {
-    const u64* cb = cur_bits();
-    const bool have = L->h.hist_cnt != 0;
-    u32 B = 0, Wt = 0;
+    // re-slice the action-order bitboards into rows: row x = bits [x*N, x*N+N)
+    const int bit0 = (lane < N ? lane : 0) * N, w = bit0 >> 6, s = bit0 & 63;
+    const u64 b0 = rl64(Bw, 0), b1 = R > 1 ? rl64(Bw, 1 % R) : 0, b2 = R > 2 ? rl64(Bw, 2 % R) : 0, b3 = R > 3 ? rl64(Bw, 3 % R) : 0,
+              b4 = R > 4 ? rl64(Bw, 4 % R) : 0, b5 = R > 5 ? rl64(Bw, 5 % R) : 0;
+    const u64 w0 = rl64(Ww, 0), w1 = R > 1 ? rl64(Ww, 1 % R) : 0, w2 = R > 2 ? rl64(Ww, 2 % R) : 0, w3 = R > 3 ? rl64(Ww, 3 % R) : 0,
+              w4 = R > 4 ? rl64(Ww, 4 % R) : 0, w5 = R > 5 ? rl64(Ww, 5 % R) : 0;
+    auto sel = [&](int q, u64 x0, u64 x1, u64 x2, u64 x3, u64 x4, u64 x5) -> u64 {
+      return q == 0 ? x0 : q == 1 ? x1 : q == 2 ? x2 : q == 3 ? x3 : q == 4 ? x4 : q == 5 ? x5 : 0ull;
+    };
+    const u64 bl = sel(w, b0, b1, b2, b3, b4, b5), bh = sel(w + 1, b0, b1, b2, b3, b4, b5);
+    const u64 wl = sel(w, w0, w1, w2, w3, w4, w5), wh = sel(w + 1, w0, w1, w2, w3, w4, w5);
     const u32 rowmask = (1u << N) - 1;
-    if (lane < N && have) {
-      int bit0 = lane * N, w = bit0 >> 6, s = bit0 & 63;
-      u64 b0 = cb[w], w0 = cb[R + w];
-      u64 b1 = (w + 1 < R) ? cb[w + 1] : 0ull, w1 = (w + 1 < R) ? cb[R + w + 1] : 0ull;
-      u64 bb = s ? ((b0 >> s) | (b1 << (64 - s))) : b0;
-      u64 ww = s ? ((w0 >> s) | (w1 << (64 - s))) : w0;
+    u32 B = 0, Wt = 0;
+    if (lane < N) {
+      u64 bb = s ? ((bl >> s) | (bh << (64 - s))) : bl;
+      u64 ww = s ? ((wl >> s) | (wh << (64 - s))) : wl;
       B = (u32)bb & rowmask;
       Wt = (u32)ww & rowmask;
     }
@@ -512,7 +565,7 @@ struct Board {
 
   // GoState::evaluate (go_state.h:194-203)
   __device__ __forceinline__ float evaluate(float komi) const {
-    if (L->h.superko) return L->h.next_player == S_BLACK ? 1.0f : -1.0f;
+    if (superko) return next_player == S_BLACK ? 1.0f : -1.0f;
     return (float)tt_area() - komi;
   }
 };
