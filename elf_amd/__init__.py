@@ -11,3 +11,4 @@ from .engine import (  # noqa: F401
 )
 
 __version__ = "0.1"
+from .selfplay import SelfPlay, MctsOptions, SpOptions  # noqa: F401,E402

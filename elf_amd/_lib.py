@@ -27,6 +27,29 @@ SIGNATURES = {
     "elfgo_info": (_i, [_vp, _vp, _i, _vp, _vp]),
     "elfgo_export_board": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "elfgo_playout": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "elfmcts_create": (_i, [_vp, _i, _i, _i, _vp, C.POINTER(_vp)]),
+    "elfmcts_destroy": (_i, [_vp]),
+    "elfmcts_set_options": (_i, [_vp, _vp]),
+    "elfmcts_num_games": (_i, [_vp]),
+    "elfmcts_edge_stride": (_i, [_vp]),
+    "elfmcts_node_bytes": (_sz, [_vp]),
+    "elfmcts_clear": (_i, [_vp, _vp, _i, _vp]),
+    "elfmcts_set_root": (_i, [_vp, _vp, _vp]),
+    "elfmcts_set_d4": (_i, [_vp, _vp, _vp]),
+    "elfmcts_dirichlet": (_i, [_vp, _vp, _vp, _f, _vp]),
+    "elfmcts_select": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "elfmcts_expand": (_i, [_vp, _vp, _i64, _vp, _i, _vp]),
+    "elfmcts_root": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "elfmcts_advance": (_i, [_vp, _vp, _vp]),
+    "elfsp_create": (_i, [_vp, _i, _vp, C.POINTER(_vp)]),
+    "elfsp_destroy": (_i, [_vp]),
+    "elfsp_engine": (_vp, [_vp]),
+    "elfsp_mcts": (_vp, [_vp]),
+    "elfsp_max_rows": (_i, [_vp]),
+    "elfsp_begin_step": (_i, [_vp, _vp, _i64, C.POINTER(_i), _vp]),
+    "elfsp_end_step": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "elfsp_stats": (_i, [_vp, _vp]),
+    "elfsp_search_log": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "elfgo_malloc": (_i, [C.POINTER(_vp), _sz]),
     "elfgo_free": (_i, [_vp]),
     "elfgo_memcpy_h2d": (_i, [_vp, _vp, _sz]),

@@ -10,6 +10,7 @@
 
 #include "../../include/elf_amd.h"
 #include "go_board.cuh"
+#include "engine_host.h"
 
 using namespace elfgo;
 
@@ -18,16 +19,6 @@ using namespace elfgo;
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <int N>
-struct Pool {
-  Slot<N>* slots;
-  u64* sk_hash;   // [capacity][MAXMOVE+2]
-  u64* sk_img;    // [capacity][MAXMOVE+2][SKW]
-  const u64* zob; // internal index order
-  __device__ __forceinline__ u64* skh(int b) const { return sk_hash + (size_t)b * (Geo<N>::MAXMOVE + 2); }
-  __device__ __forceinline__ u64* ski(int b) const { return sk_img + (size_t)b * (Geo<N>::MAXMOVE + 2) * Geo<N>::SKW; }
-};
-
 __device__ __forceinline__ int slot_of(const int32_t* ids, int i) { return ids ? ids[i] : i; }
 
 template <int N>
@@ -106,36 +97,9 @@ __global__ __launch_bounds__(WAVE) void k_extract_agz(Pool<N> pool, const int32_
   const u64* gh = &sl->hist[0][0][0];
   for (int j = lane; j < HIST * 2 * G::R; j += WAVE) (&hist[0][0][0])[j] = gh[j];
   const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
-  const int len = cnt < HIST ? cnt : HIST;
   const int d4 = d4s ? d4s[blockIdx.x] : 0;
-  const int rot = d4 & 3;
-  const bool flip = ((d4 >> 2) & 1) != 0;
   __syncthreads();
-  float* out = dst + (size_t)blockIdx.x * stride;
-#pragma unroll
-  for (int k = 0; k < G::R; ++k) {
-    int o = k * 64 + lane;
-    if (o >= G::NP) break;
-    // InvTransform (board_feature.h:115-130): output (x', y') -> board (x, y)
-    int xo = o / N, yo = o % N;
-    if (flip) { int t = xo; xo = yo; yo = t; }
-    int x = xo, y = yo;
-    if (rot == 1) { x = N - 1 - yo; y = xo; }
-    else if (rot == 2) { x = N - 1 - xo; y = N - 1 - yo; }
-    else if (rot == 3) { x = yo; y = N - 1 - xo; }
-    int a = x * N + y, w = a >> 6, sft = a & 63;
-#pragma unroll
-    for (int hk = 0; hk < HIST; ++hk) {
-      int slot = (cnt - 1 - hk) & (HIST - 1);
-      u64 bb = hist[slot][0][w], wb = hist[slot][1][w];
-      bool isb = hk < len && ((bb >> sft) & 1), isw = hk < len && ((wb >> sft) & 1);
-      bool mine = player == S_BLACK ? isb : isw, theirs = player == S_BLACK ? isw : isb;
-      out[(2 * hk) * G::NP + o] = mine ? 1.0f : 0.0f;
-      out[(2 * hk + 1) * G::NP + o] = theirs ? 1.0f : 0.0f;
-    }
-    out[16 * G::NP + o] = player == S_BLACK ? 1.0f : 0.0f;
-    out[17 * G::NP + o] = player == S_BLACK ? 0.0f : 1.0f;
-  }
+  extract_agz_planes<N>(hist, cnt, player, d4, dst + (size_t)blockIdx.x * stride, lane);
 }
 
 template <int N>
@@ -225,31 +189,6 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
 // ------------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------------
-struct ElfGoEngine {
-  int n = 0, capacity = 0, device = 0;
-  void* slots = nullptr;
-  u64* sk_hash = nullptr;
-  u64* sk_img = nullptr;
-  u64* zob = nullptr;
-  size_t slot_bytes = 0;
-};
-
-#define HIPCHK(x)                         \
-  do {                                    \
-    hipError_t _e = (x);                  \
-    if (_e != hipSuccess) return (int)_e; \
-  } while (0)
-
-template <int N>
-static Pool<N> pool_of(const ElfGoEngine* e) {
-  Pool<N> p;
-  p.slots = reinterpret_cast<Slot<N>*>(e->slots);
-  p.sk_hash = e->sk_hash;
-  p.sk_img = e->sk_img;
-  p.zob = e->zob;
-  return p;
-}
-
 template <int N>
 static int create_impl(ElfGoEngine* e, const uint64_t* zob_host) {
   using G = Geo<N>;
@@ -274,12 +213,6 @@ static int create_impl(ElfGoEngine* e, const uint64_t* zob_host) {
   HIPCHK(hipDeviceSynchronize());
   return 0;
 }
-
-#define DISPATCH(e, CALL)                 \
-  do {                                    \
-    if ((e)->n == 19) { constexpr int N = 19; CALL; } \
-    else { constexpr int N = 9; CALL; }   \
-  } while (0)
 
 extern "C" {
 

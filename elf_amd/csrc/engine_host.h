@@ -1,0 +1,51 @@
+// Host-side engine object shared by the translation units of libelf_amd.so (board engine, MCTS, self-play).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/elf_amd.h"
+#include "go_board.cuh"
+
+using namespace elfgo;
+
+template <int N>
+struct Pool {
+  Slot<N>* slots;
+  u64* sk_hash;   // [capacity][MAXMOVE+2]
+  u64* sk_img;    // [capacity][MAXMOVE+2][SKW]
+  const u64* zob; // internal index order
+  __device__ __forceinline__ u64* skh(int b) const { return sk_hash + (size_t)b * (Geo<N>::MAXMOVE + 2); }
+  __device__ __forceinline__ u64* ski(int b) const { return sk_img + (size_t)b * (Geo<N>::MAXMOVE + 2) * Geo<N>::SKW; }
+};
+
+struct ElfGoEngine {
+  int n = 0, capacity = 0, device = 0;
+  void* slots = nullptr;
+  u64* sk_hash = nullptr;
+  u64* sk_img = nullptr;
+  u64* zob = nullptr;
+  size_t slot_bytes = 0;
+};
+
+#define HIPCHK(x)                         \
+  do {                                    \
+    hipError_t _e = (x);                  \
+    if (_e != hipSuccess) return (int)_e; \
+  } while (0)
+
+template <int N>
+static Pool<N> pool_of(const ElfGoEngine* e) {
+  Pool<N> p;
+  p.slots = reinterpret_cast<Slot<N>*>(e->slots);
+  p.sk_hash = e->sk_hash;
+  p.sk_img = e->sk_img;
+  p.zob = e->zob;
+  return p;
+}
+
+#define DISPATCH(e, CALL)                 \
+  do {                                    \
+    if ((e)->n == 19) { constexpr int N = 19; CALL; } \
+    else { constexpr int N = 9; CALL; }   \
+  } while (0)
+

@@ -120,6 +120,38 @@ __device__ __forceinline__ u32 playout_rng(u64 seed, u32 t) {
   return (u32)(z >> 32);
 }
 
+// Superko record store of a GAME board (GoState::_board_hashes, go_state.h:218): every pre-move position
+// of the game so far, (hash, black/white bitboards) per record, in HBM.
+template <int N>
+struct GameSK {
+  using G = Geo<N>;
+  u64* sk_hash;   // [MAXMOVE+2]
+  u64* sk_img;    // [MAXMOVE+2][SKW]
+  __device__ __forceinline__ void record(int sk_len, u64 hash, u64 Bw, u64 Ww, int lane) const {
+    if (lane < G::R) {
+      sk_img[(size_t)sk_len * G::SKW + lane] = Bw;
+      sk_img[(size_t)sk_len * G::SKW + G::R + lane] = Ww;
+    }
+    if (lane == 0) sk_hash[sk_len] = hash;
+  }
+  // go_state.cc:96-111: hash match, then full image compare, over records [0, sk_len)
+  __device__ __forceinline__ bool exact_hit(int sk_len, u64 hash, u64 Bw, u64 Ww, int lane) const {
+    bool hit = false;
+    for (int base = 0; base < sk_len; base += 64) {
+      int t = base + lane;
+      u64 bal = __ballot(t < sk_len && sk_hash[t] == hash);
+      while (bal) {
+        int tt = base + (int)__builtin_ctzll(bal);
+        bal &= bal - 1;
+        bool same = true;
+        if (lane < G::R) same = sk_img[(size_t)tt * G::SKW + lane] == Bw && sk_img[(size_t)tt * G::SKW + G::R + lane] == Ww;
+        if (__all(same)) hit = true;
+      }
+    }
+    return hit;
+  }
+};
+
 template <int N>
 struct Board {
   using G = Geo<N>;
@@ -255,6 +287,11 @@ struct Board {
   // ---- GoState::forward (go_state.cc:74-94). c = reference Coord, wave-uniform. ---------------
   // returns 1 played, 0 refused (terminated / illegal). M_INVALID is rejected by the caller.
   __device__ int forward(int c) {
+    GameSK<N> sk{sk_hash, sk_img};
+    return forward(c, sk);
+  }
+  template <class SK>
+  __device__ int forward(int c, const SK& sk) {
     c = rfl(c);
     if (terminated()) return 0;
     const int player = next_player, opp = S_BLACK + S_WHITE - player;
@@ -289,12 +326,8 @@ struct Board {
     }
     // ---- _add_board_hash (go_state.cc:113-121): record the PRE-move position, skipped for pass
     if (c != M_PASS) {
-      if (lane < R) {
-        sk_img[(size_t)sk_len * G::SKW + lane] = Bw;
-        sk_img[(size_t)sk_len * G::SKW + R + lane] = Ww;
-      }
+      sk.record(sk_len, hash, Bw, Ww, lane);
       if (lane == 0) {
-        sk_hash[sk_len] = hash;
         const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
         L->bloom[h1 >> 5] |= 1u << (h1 & 31);
         L->bloom[h2 >> 5] |= 1u << (h2 & 31);
@@ -440,19 +473,7 @@ struct Board {
       const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
       const u32 b1 = L->bloom[h1 >> 5], b2 = L->bloom[h2 >> 5];
       if (rfl((int)((b1 >> (h1 & 31)) & (b2 >> (h2 & 31)) & 1u))) {
-        bool hit = false;
-        for (int base = 0; base < sk_len; base += 64) {
-          int t = base + lane;
-          u64 bal = __ballot(t < sk_len && sk_hash[t] == hash);
-          while (bal) {
-            int tt = base + (int)__builtin_ctzll(bal);
-            bal &= bal - 1;
-            bool same = true;
-            if (lane < R) same = sk_img[(size_t)tt * G::SKW + lane] == Bw && sk_img[(size_t)tt * G::SKW + R + lane] == Ww;
-            if (__all(same)) hit = true;
-          }
-        }
-        if (hit) superko = 1;
+        if (sk.exact_hit(sk_len, hash, Bw, Ww, lane)) superko = 1;
       }
     }
     return 1;
@@ -569,5 +590,56 @@ struct Board {
     return (float)tt_area() - komi;
   }
 };
+
+// BoardFeature::extractAGZ (board_feature.cc:247-290) + InvTransform (board_feature.h:115-130).
+// hist = LDS copy of a slot's history ring; output-indexed so every store instruction of the wave is one
+// fully coalesced 256-B segment of a plane.
+template <int N>
+__device__ __forceinline__ void extract_agz_planes(const u64 (*hist)[2][Geo<N>::R], int cnt, int player, int d4,
+                                                   float* __restrict__ out, int lane) {
+  using G = Geo<N>;
+  const int len = cnt < HIST ? cnt : HIST;
+  const int rot = d4 & 3;
+  const bool flip = ((d4 >> 2) & 1) != 0;
+#pragma unroll
+  for (int k = 0; k < G::R; ++k) {
+    int o = k * 64 + lane;
+    if (o >= G::NP) break;
+    int xo = o / N, yo = o % N;
+    if (flip) { int t = xo; xo = yo; yo = t; }
+    int x = xo, y = yo;
+    if (rot == 1) { x = N - 1 - yo; y = xo; }
+    else if (rot == 2) { x = N - 1 - xo; y = N - 1 - yo; }
+    else if (rot == 3) { x = yo; y = N - 1 - xo; }
+    int a = x * N + y, w = a >> 6, sft = a & 63;
+#pragma unroll
+    for (int hk = 0; hk < HIST; ++hk) {
+      int slot = (cnt - 1 - hk) & (HIST - 1);
+      u64 bb = hist[slot][0][w], wb = hist[slot][1][w];
+      bool isb = hk < len && ((bb >> sft) & 1), isw = hk < len && ((wb >> sft) & 1);
+      bool mine = player == S_BLACK ? isb : isw, theirs = player == S_BLACK ? isw : isb;
+      out[(2 * hk) * G::NP + o] = mine ? 1.0f : 0.0f;
+      out[(2 * hk + 1) * G::NP + o] = theirs ? 1.0f : 0.0f;
+    }
+    out[16 * G::NP + o] = player == S_BLACK ? 1.0f : 0.0f;
+    out[17 * G::NP + o] = player == S_BLACK ? 0.0f : 1.0f;
+  }
+}
+
+// BoardFeature::action2Coord (board_feature.h:139-144): NN action id under D4 code d4 -> (reference Coord, D4-0 action id)
+template <int N>
+__device__ __forceinline__ void action_to_coord(int i, int d4, int& coord, int& a0) {
+  constexpr int S = N + 2;
+  if (i >= N * N) { coord = M_PASS; a0 = N * N; return; }
+  int xo = i / N, yo = i % N;
+  if ((d4 >> 2) & 1) { int t = xo; xo = yo; yo = t; }
+  const int rot = d4 & 3;
+  int x = xo, y = yo;
+  if (rot == 1) { x = N - 1 - yo; y = xo; }
+  else if (rot == 2) { x = N - 1 - xo; y = N - 1 - yo; }
+  else if (rot == 3) { x = yo; y = N - 1 - xo; }
+  coord = (y + 1) * S + (x + 1);
+  a0 = x * N + y;
+}
 
 }  // namespace elfgo

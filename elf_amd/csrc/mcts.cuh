@@ -1,0 +1,803 @@
+// Device-resident MCTS for gfx950 (CDNA4): one search tree per game, one wave64 per game (select / backup)
+// or per leaf (feature write, expansion).  Replaces, for the self-play hot path, the reference's CPU search
+//   src_cpp/elf/ai/tree_search/tree_search_node.h   NodeT: UCT :361-397, findMove :205-231, addVirtualLoss :233-251,
+//                                                   updateEdgeStats :253-278, followEdge :280-302, setEvaluation :176-203,
+//                                                   enhanceExploration :132-155; SearchTreeT::treeAdvance :420-436
+//   src_cpp/elf/ai/tree_search/tree_search_base.h   EdgeInfo::getScore :132-157, MCTSResultT::addActions :237-294
+//   src_cpp/elf/ai/tree_search/tree_search.h        single_rollout :264-322, batch_rollouts :200-262
+//   src_cpp/elfgames/go/mcts/mcts.h                 MCTSActor: pre_evaluate :185-207, get_extractor :175-183,
+//                                                   post_nn_result :209-230, remove_pass_if_dangerous :232-242, pi2response :256-332
+// Semantics reproduced bit-for-bit (single search thread): edge iteration order of the
+// reference's std::unordered_map (edges are STORED in that order, so "first in iteration order" is "lowest
+// index"), std::sort order of the priors, the float/double promotion sequence of the PUCT score, the
+// sequential fp32 sums (FPU running mean, prior normalisation), virtual loss, duplicate-leaf handling.
+// One documented canonicalisation: leaves of a batch are backed up in first-occurrence order (the reference
+// iterates an unordered_map keyed by heap addresses, tree_search.h:216,245).
+//
+// HBM layout (sized for 288 GB): per game a pool of C fixed-size node records (12 KiB at 19x19):
+//   [64 B header][368 x 16 B edge stats {prior, reward, visits, vloss}][368 x i32 child][368 x u16 coord][board slot 3840 B]
+// The board slot is the same LDS image the board engine uses, so "allocateState" (tree_search.h:174-190)
+// is: 16-B/lane coalesced load of the parent's slot -> Board::forward in LDS -> coalesced store.
+#pragma once
+#include "go_board.cuh"
+#include "stl_emul.h"
+
+namespace elfgo {
+
+enum { NS_NOT_VISITED = 0, NS_EVAL_REQUESTED = 1, NS_VISITED = 2 };   // NodeT::VisitType
+enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2 };
+enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8 };
+constexpr int MCTS_KMAX = 64;   // max rollouts per batch (one lane per unique leaf)
+
+struct NodeHdr {          // 64 B
+  int parent;             // node id, -1 for the root
+  int parent_edge;        // index of the edge in the parent's arrays
+  int n_edges;            // stateActions_.size()
+  int num_visits;         // numVisits_
+  float V;                // V_
+  float unsigned_mean_q;  // unsignedMeanQ_
+  float unsigned_parent_q;
+  int status;             // NS_*
+  int flip;               // flipQSign_
+  int has_state;          // stateType_ == NODE_STATE_SET
+  int alive;
+  int mark;
+  int pad[4];
+};
+static_assert(sizeof(NodeHdr) == 64, "NodeHdr must be 64 bytes");
+
+template <int N>
+struct alignas(256) NodeRec {
+  static constexpr int NE = (N * N + 1 + 15) & ~15;
+  NodeHdr h;
+  float4 stat[NE];   // x prior_probability, y reward, z num_visits (int bits), w virtual_loss  (EdgeInfo, tree_search_base.h:102-124)
+  int child[NE];
+  u16 coord[NE];
+  Slot<N> board;
+};
+static_assert(sizeof(NodeRec<19>) == 12032, "19x19 node record");
+
+struct TreeCfg {          // TSOptions / SearchAlgoOptions (tree_search_options.h:23-229) + MCTSActorParams (go/mcts/mcts.h:17-37)
+  int rollouts_per_batch;
+  int virtual_loss;
+  int use_prior;
+  int unexplored_q_zero;
+  int root_unexplored_q_zero;
+  float c_puct;
+  float komi;
+  int ply_pass_enabled;
+  int remove_pass_if_dangerous;
+  int rotation_flip;
+};
+
+struct GameState {        // 64 B per game
+  int root;
+  int free_top;           // number of ids on the free stack
+  int err;
+  int rng_pos;            // D4 draws consumed from d4buf this move
+  int n_unique;           // leaves of the current batch
+  int n_nn;               // ... of which need the net
+  int row_base;
+  int rollouts_done;
+  int pad[8];
+};
+
+struct LeafRec {          // 32 B
+  int node;
+  int count;
+  int kind;
+  int d4;
+  float value;
+  int nn_index;
+  int pad[2];
+};
+
+struct RowRec { int game, node, d4, pad; };
+
+template <int N>
+struct TreePool {
+  NodeRec<N>* nodes;      // [G][C]
+  int* free_stack;        // [G][C]
+  GameState* gs;          // [G]
+  LeafRec* leaves;        // [G][MCTS_KMAX]
+  unsigned char* d4buf;   // [G][W]  pre-drawn rng() % 8 of the actor's mt19937 (go/mcts/mcts.h:175-183)
+  const double* sqrt_tab; // [sqrt_n] host libm sqrt((double)k): the reference's std::sqrt(int) (tree_search_base.h:153)
+  int sqrt_n;
+  int C, W, G;
+  __device__ __forceinline__ NodeRec<N>* game_nodes(int g) const { return nodes + (size_t)g * C; }
+};
+
+__device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ void mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// wave-uniform copy of a node header
+struct HdrU {
+  int parent, parent_edge, n_edges, num_visits, status, flip, has_state;
+  float V, umq, upq;
+  __device__ __forceinline__ void load(const NodeHdr* h, int lane) {
+    int w = lane < 16 ? reinterpret_cast<const int*>(h)[lane] : 0;
+    parent = rl(w, 0); parent_edge = rl(w, 1); n_edges = rl(w, 2); num_visits = rl(w, 3);
+    V = __int_as_float(rl(w, 4)); umq = __int_as_float(rl(w, 5)); upq = __int_as_float(rl(w, 6));
+    status = rl(w, 7); flip = rl(w, 8); has_state = rl(w, 9);
+  }
+};
+
+// Superko records of a TREE node: the reference copies the whole record map into every
+// GoState (go_state.h:117-124); here the records of a node are its ancestors' positions (parent-linked
+// chain up to the root) followed by the game's own records.  Same hit rule: hash, then full image.
+template <int N>
+struct TreeSK {
+  using G = Geo<N>;
+  const NodeRec<N>* nodes;
+  int from;            // node whose state is being forwarded (the new child's parent)
+  int move_out;        // the move being played from `from`
+  GameSK<N> game;      // records of the game board the root was copied from
+  int root_sk_len;     // records that precede the root position
+  __device__ __forceinline__ void record(int, u64, u64, u64, int) const {}
+  __device__ __forceinline__ bool exact_hit(int, u64 hash, u64 Bw, u64 Ww, int lane) const {
+    int a = from, mv = move_out;
+    bool hit = false;
+    for (;;) {
+      const NodeRec<N>& nd = nodes[a];
+      if (mv != M_PASS) {
+        const u64 h = nd.board.h.hash;
+        if (rfl((int)(h == hash))) {
+          const int cnt = nd.board.h.hist_cnt;
+          const int newest = (cnt + HIST - 1) & (HIST - 1);
+          bool same = true;
+          if (lane < G::R) {
+            const u64 b = cnt ? nd.board.hist[newest][0][lane] : 0ull, w = cnt ? nd.board.hist[newest][1][lane] : 0ull;
+            same = b == Bw && w == Ww;
+          }
+          if (__all(same)) hit = true;
+        }
+      }
+      const int p = rfl(nd.h.parent);
+      if (p < 0) break;
+      mv = rfl((int)nodes[p].coord[rfl(nd.h.parent_edge)]);
+      a = p;
+    }
+    if (hit) return true;
+    return game.exact_hit(root_sk_len, hash, Bw, Ww, lane);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// tree bookkeeping
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void node_init(NodeRec<N>* nd, int parent, int parent_edge, float parent_q, int lane) {
+  if (lane < 16) {
+    int v = 0;
+    if (lane == 0) v = parent;
+    else if (lane == 1) v = parent_edge;
+    else if (lane == 5 || lane == 6) v = __float_as_int(parent_q);   // NodeT ctor: unsignedMeanQ_ = unsignedParentQ_ (:99-103)
+    else if (lane == 10) v = 1;                                        // alive
+    reinterpret_cast<int*>(&nd->h)[lane] = v;
+  }
+}
+
+// SearchTreeT::clear (:411-416): every id free, then allocateRoot -> addNode(0.0)
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_clear(TreePool<N> tp) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  NodeRec<N>* nodes = tp.game_nodes(g);
+  int* fs = tp.free_stack + (size_t)g * tp.C;
+  for (int i = lane; i < tp.C; i += 64) {
+    fs[i] = tp.C - 1 - i;   // pops hand out 0, 1, 2, ...
+    nodes[i].h.alive = 0;
+  }
+  mem_sync();
+  node_init(&nodes[0], -1, -1, 0.0f, lane);
+  if (lane == 0) {
+    GameState& s = tp.gs[g];
+    s.root = 0; s.free_top = tp.C - 1; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
+  }
+}
+
+// TreeSearchT::setRootNodeState (tree_search.h:478-493): give the root a copy of the game's state if it
+// has none; otherwise check hash equality (StateTrait::equals, go/mcts/ai.h:40-42).
+template <int N, class PoolT>
+__global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool, const int32_t* board_ids) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  NodeRec<N>* nodes = tp.game_nodes(g);
+  GameState& s = tp.gs[g];
+  const int root = rfl(s.root);
+  const Slot<N>* src = &pool.slots[board_ids ? board_ids[g] : g];
+  NodeRec<N>& r = nodes[root];
+  if (rfl(r.h.has_state) == 0) {
+    const uint4* sp = reinterpret_cast<const uint4*>(src);
+    uint4* dp = reinterpret_cast<uint4*>(&r.board);
+    for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += 64) dp[j] = sp[j];
+    if (lane == 0) r.h.has_state = 1;
+  } else if (lane == 0 && r.board.h.hash != src->h.hash) {
+    s.err |= MCTS_ERR_ROOT_HASH;
+  }
+  if (lane == 0) { s.rng_pos = 0; s.rollouts_done = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// select: rollouts_per_batch sequential descents per game (TreeSearchSingleThreadT::batch_rollouts, first half)
+// ------------------------------------------------------------------------------------------------
+template <int N, class PoolT>
+__global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
+  using G = Geo<N>;
+  using NR = NodeRec<N>;
+  constexpr int R = (N * N + 1 + 63) / 64;
+  __shared__ Slot<N> lds;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  NR* nodes = tp.game_nodes(g);
+  int* fs = tp.free_stack + (size_t)g * tp.C;
+  GameState& gs = tp.gs[g];
+  const int bslot = board_ids ? board_ids[g] : g;
+  const int root = rfl(gs.root);
+  int free_top = rfl(gs.free_top), rng_pos = rfl(gs.rng_pos), err = 0;
+  const int root_sk_len = rfl((int)nodes[root].board.h.sk_len);
+  Board<N> bd;
+  bd.init(&lds, pool.zob, nullptr, nullptr);
+
+  // lane u holds the u-th unique leaf of this batch
+  int my_leaf = -1, my_count = 0, my_kind = 0, my_d4 = 0, my_nn = 0;
+  float my_value = 0.0f;
+  int n_unique = 0, n_nn = 0;
+  const float vl_f = (float)cfg.virtual_loss;
+
+  for (int j = 0; j < cfg.rollouts_per_batch; ++j) {
+    int node = root, depth = 0;
+    bool board_in_lds = false;   // LDS holds the state of `node`
+    HdrU h;
+    for (;;) {                   // single_rollout, tree_search.h:264-322
+      h.load(&nodes[node].h, lane);
+      if (h.status != NS_VISITED || h.n_edges == 0) break;
+      NR& nd = nodes[node];
+      // ---- findMove :205-231 + UCT :361-397 + EdgeInfo::getScore (tree_search_base.h:132-157)
+      float umq = h.umq;
+      if (cfg.unexplored_q_zero || (cfg.root_unexplored_q_zero && depth == 0)) umq = 0.0f;
+      const int all_visits = h.num_visits + 1;
+      const double sq = all_visits < tp.sqrt_n ? tp.sqrt_tab[all_visits] : sqrt((double)all_visits);
+      float4 st[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int e = k * 64 + lane;
+        st[k] = e < h.n_edges ? nd.stat[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float best_s = -__builtin_huge_valf();
+      int best_e = 0x7FFFFFFF;
+      float uq[R];
+      u64 vmask[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int e = k * 64 + lane;
+        const bool valid = e < h.n_edges;
+        const float prior = st[k].x, reward = st[k].y, vl = st[k].w;
+        const int nv = __float_as_int(st[k].z);
+        float r = h.flip ? -reward : reward;
+        r = __fsub_rn(r, vl);
+        const int nvl = (int)__fadd_rn((float)nv, vl);                       // int + float -> float -> int
+        const float q = nvl > 0 ? __fdiv_rn(r, (float)nvl) : (h.flip ? -umq : umq);
+        uq[k] = nv > 0 ? __fdiv_rn(reward, (float)nv) : umq;
+        const float pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);   // float / int, then * double sqrt, stored to float
+        const float score = cfg.use_prior ? __fadd_rn(__fmul_rn(pp, cfg.c_puct), q) : q;
+        vmask[k] = __ballot(valid && nvl != 0);                              // !first_visit
+        if (valid && score > best_s) { best_s = score; best_e = e; }         // strict >: first in iteration order wins
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float os = __shfl_xor(best_s, o, 64);
+        const int oe = __shfl_xor(best_e, o, 64);
+        if (os > best_s || (os == best_s && oe < best_e)) { best_s = os; best_e = oe; }
+      }
+      best_e = rfl(best_e);
+      if (best_e == 0x7FFFFFFF) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
+      // BestAction::addAction :333-347: sequential fp32 sum of unsigned_q over edges that are not first visits
+      float tq = 0.0f;
+      int tv = 0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        u64 m = vmask[k];
+        while (m) {
+          const int l = (int)__builtin_ctzll(m);
+          m &= m - 1;
+          tq = __fadd_rn(tq, rlf(uq[k], l));
+          ++tv;
+        }
+      }
+      const float new_umq = __fdiv_rn(__fadd_rn(h.upq, tq), (float)(tv + 1));   // :227-228
+      // ---- addVirtualLoss :233-251
+      const int bk = best_e >> 6, bl = best_e & 63;
+      float cur_vl = 0.0f;
+#pragma unroll
+      for (int k = 0; k < R; ++k) if (k == bk) cur_vl = st[k].w;
+      cur_vl = rlf(cur_vl, bl);
+      int child = 0, mv = 0;
+      if (lane == 0) {
+        nd.h.unsigned_mean_q = new_umq;
+        if (cfg.virtual_loss > 0) nd.stat[best_e].w = __fadd_rn(cur_vl, vl_f);
+        child = nd.child[best_e];
+        mv = nd.coord[best_e];
+      }
+      child = rfl(child); mv = rfl(mv);
+      // ---- followEdge :280-302 -> SearchTreeT::addNode(unsignedMeanQ_) :439-443
+      if (child < 0) {
+        if (free_top <= 0) { err |= MCTS_ERR_POOL; break; }
+        child = rfl(fs[free_top - 1]);
+        --free_top;
+        node_init(&nodes[child], node, best_e, new_umq, lane);
+        if (lane == 0) nd.child[best_e] = child;
+      }
+      // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
+      HdrU ch;
+      ch.load(&nodes[child].h, lane);
+      if (!ch.has_state) {
+        if (!board_in_lds) bd.load(&nd.board);
+        TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skh(bslot), pool.ski(bslot)}, root_sk_len};
+        if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; board_in_lds = false; break; }
+        bd.store(&nodes[child].board);
+        if (lane == 0) nodes[child].h.has_state = 1;
+        board_in_lds = true;
+      } else {
+        board_in_lds = false;
+      }
+      mem_sync();
+      node = child;
+      ++depth;
+    }
+    // ---- leaf bookkeeping: batch_rollouts :211-233 (requestEvaluation, duplicate leaves)
+    const u64 dup = __ballot(lane < n_unique && my_leaf == node);
+    if (dup) {
+      if (lane == (int)__builtin_ctzll(dup)) ++my_count;
+    } else {
+      int kind = LK_REVISIT, d4 = 0;
+      float value = 0.0f;
+      if (h.status == NS_NOT_VISITED) {
+        if (!board_in_lds) bd.load(&nodes[node].board);   // only the root can get here without a fresh state
+        if (bd.terminated()) {                             // MCTSActor::pre_evaluate :185-207
+          kind = LK_TERMINAL;
+          value = bd.evaluate(cfg.komi) > 0.0f ? 1.0f : -1.0f;
+        } else {
+          kind = LK_NN;
+          if (cfg.rotation_flip) {                         // get_extractor :175-183: rng() % 8, one draw per NN leaf
+            if (rng_pos >= tp.W) err |= MCTS_ERR_RNG;
+            else d4 = rfl((int)tp.d4buf[(size_t)g * tp.W + rng_pos]);
+            ++rng_pos;
+          }
+        }
+        if (lane == 0) nodes[node].h.status = NS_EVAL_REQUESTED;
+      }
+      if (lane == n_unique) {
+        my_leaf = node; my_count = 1; my_kind = kind; my_d4 = d4; my_value = value; my_nn = n_nn;
+      }
+      ++n_unique;
+      if (kind == LK_NN) ++n_nn;
+    }
+    mem_sync();
+  }
+  if (lane < n_unique) {
+    LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + lane];
+    lr.node = my_leaf; lr.count = my_count; lr.kind = my_kind; lr.d4 = my_d4; lr.value = my_value; lr.nn_index = my_nn;
+  }
+  if (lane == 0) {
+    gs.free_top = free_top; gs.rng_pos = rng_pos; gs.n_unique = n_unique; gs.n_nn = n_nn;
+    gs.rollouts_done += cfg.rollouts_per_batch;
+    if (err) gs.err |= err;
+  }
+}
+
+// rows of the net batch: game-major, leaf order within a game; row_base = exclusive prefix over games.
+// One wave per (game, unique leaf); the wave of (G-1, 0) also publishes the total row count.
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, float* __restrict__ s_out, int64_t stride, RowRec* rowmap,
+                                                       int32_t* counts /* [0]=rows [1]=err-or */) {
+  using G = Geo<N>;
+  __shared__ u64 hist[HIST][2][G::R];
+  const int g = blockIdx.x / K, u = blockIdx.x % K, lane = threadIdx.x;
+  const GameState& gs = tp.gs[g];
+  const bool last = (g == tp.G - 1 && u == 0);
+  if (u >= rfl(gs.n_unique) && !last) return;
+  int base = 0, eor = 0;
+  for (int i = lane; i < tp.G; i += 64) {
+    if (i < g) base += tp.gs[i].n_nn;
+    eor |= tp.gs[i].err;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { base += __shfl_xor(base, o, 64); eor |= __shfl_xor(eor, o, 64); }
+  if (last && lane == 0) { counts[0] = base + gs.n_nn; counts[1] = eor; }
+  if (u == 0 && lane == 0) tp.gs[g].row_base = base;
+  if (u >= rfl(gs.n_unique)) return;
+  const LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + u];
+  if (rfl(lr.kind) != LK_NN) return;
+  const int row = base + rfl(lr.nn_index), node = rfl(lr.node), d4 = rfl(lr.d4);
+  const Slot<N>* sl = &tp.game_nodes(g)[node].board;
+  const u64* gh = &sl->hist[0][0][0];
+  for (int j = lane; j < HIST * 2 * G::R; j += 64) (&hist[0][0][0])[j] = gh[j];
+  const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
+  __syncthreads();
+  extract_agz_planes<N>(hist, cnt, player, d4, s_out + (size_t)row * stride, lane);
+  if (lane == 0) { rowmap[row].game = g; rowmap[row].node = node; rowmap[row].d4 = d4; rowmap[row].pad = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// expand: MCTSActor::post_nn_result / pi2response + NodeT::setEvaluation, one wave per net row
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct ExpandLds {
+  static constexpr int NA = N * N + 1;
+  static constexpr int NE = NodeRec<N>::NE;
+  static constexpr int PP = Geo<N>::PP;
+  Slot<N> board;
+  float prob[NE];     // candidate priors (insertion order once sorted)
+  u16 key[NE];        // candidate coords
+  float sprob[NE];    // sorted
+  u16 skey[NE];
+  u16 seq[NE];        // epoch insertion sequence (indices into skey)
+  u16 nseq[NE];
+  u16 tkey[PP];       // time of key in the current epoch, 0xFFFF = absent
+  u16 sx[NE];         // exclusive prefix of group sizes at group-first times
+  u64 legalw[8];      // legal-move bitboard words (D4-0 action order)
+};
+
+// iteration order of the reference's unordered_map after inserting skey[0..n) (see stl_emul.h); result in L.seq
+template <int N>
+__device__ __forceinline__ void umap_order_wave(ExpandLds<N>& L, int n, int lane) {
+  constexpr int P = Geo<N>::P;     // coords are < (N+2)^2
+  constexpr int NE = NodeRec<N>::NE;
+  int have = 0, done = 0;
+  for (int ep = 0; ep < stl_emul::kNumEpochs && done < n; ++ep) {
+    const int nb = stl_emul::epoch_buckets(ep);
+    const int take = (n < nb ? n : nb) - done;
+    const int m = have + take;
+    for (int t = have + lane; t < m; t += 64) L.seq[t] = (u16)(done + (t - have));
+    done += take;
+    Board<N>::wsync();
+    if (nb >= P) {
+      // every key has its own bucket: the epoch iterates as the plain reverse of its insertion sequence
+      for (int t = lane; t < m; t += 64) L.nseq[m - 1 - t] = L.seq[t];
+    } else {
+      for (int i = lane; i < ExpandLds<N>::PP; i += 64) L.tkey[i] = 0xFFFF;
+      Board<N>::wsync();
+      for (int t = lane; t < m; t += 64) L.tkey[L.skey[L.seq[t]]] = (u16)t;
+      Board<N>::wsync();
+      // per element: first time / size of its bucket and its rank inside the bucket, by scanning the
+      // (at most ceil(P/nb)) coords of its residue class; group sizes are prefix-summed over first times
+      constexpr int RR = (NE + 63) / 64;
+      int ftv[RR], rkv[RR];
+      int carry = 0;
+#pragma unroll
+      for (int k = 0; k < RR; ++k) {
+        const int t = k * 64 + lane;
+        int ft = 0xFFFF, cnt = 0, rk = 0;
+        if (t < m) {
+          const int kk = L.skey[L.seq[t]];
+          for (int c = kk % nb; c < P; c += nb) {
+            const int tt = L.tkey[c];
+            if (tt != 0xFFFF) { ++cnt; ft = tt < ft ? tt : ft; rk += tt < t; }
+          }
+        }
+        ftv[k] = ft; rkv[k] = rk;
+        const int hv = (t < m && ft == t) ? cnt : 0;   // group size, placed at the group's first time
+        int inc = hv;                                   // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int y = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += y;
+        }
+        if (t < m) L.sx[t] = (u16)(carry + inc - hv);
+        carry += rl(inc, 63);
+      }
+      Board<N>::wsync();
+#pragma unroll
+      for (int k = 0; k < RR; ++k) {
+        const int t = k * 64 + lane;
+        if (t < m) L.nseq[m - 1 - ((int)L.sx[ftv[k]] + rkv[k])] = L.seq[t];
+      }
+    }
+    Board<N>::wsync();
+    for (int t = lane; t < m; t += 64) L.seq[t] = L.nseq[t];
+    have = m;
+    Board<N>::wsync();
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* zob, const RowRec* rowmap, const float* __restrict__ pi,
+                                                     int64_t pi_stride, const float* __restrict__ value, int n_rows, TreeCfg cfg) {
+  using G = Geo<N>;
+  using NR = NodeRec<N>;
+  constexpr int NA = N * N + 1, R = (NA + 63) / 64;
+  __shared__ ExpandLds<N> L;
+  const int row = blockIdx.x, lane = threadIdx.x;
+  if (row >= n_rows) return;
+  const int g = rowmap[row].game, node = rowmap[row].node, d4 = rowmap[row].d4;
+  NR& nd = tp.game_nodes(g)[node];
+  Board<N> bd;
+  bd.init(&L.board, zob, nullptr, nullptr);
+  bd.load(&nd.board);
+  // ---- post_nn_result :209-230
+  bool pass_enabled = bd.ply >= cfg.ply_pass_enabled;
+  if (cfg.remove_pass_if_dangerous && pass_enabled && bd.lm0 != M_PASS) {   // :232-242
+    const bool black_win = bd.evaluate(cfg.komi) > 0.0f;
+    if ((black_win && bd.next_player == S_WHITE) || (!black_win && bd.next_player == S_BLACK)) pass_enabled = false;
+  }
+  u64 legal, cand;
+  bd.template legal_moves<false>(legal, cand);
+  // ---- pi2response :256-332.  Candidates in NN action order; valid ones compacted in that order.
+  const float* prow = pi + (size_t)row * pi_stride;
+  int nvalid = 0;
+  bool anyvalid_tie = false;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int i = k * 64 + lane;
+    if (i < NA) {
+      int coord, a0;
+      action_to_coord<N>(i, d4, coord, a0);
+      L.prob[i] = prow[i];
+      L.key[i] = (u16)coord;
+    }
+  }
+  if (lane < G::R) L.legalw[lane] = legal;
+  Board<N>::wsync();
+  u64 vbal[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int i = k * 64 + lane;
+    bool valid = false;
+    if (i < NA) {
+      int coord, a0;
+      action_to_coord<N>(i, d4, coord, a0);
+      if (coord == M_PASS) valid = pass_enabled;
+      else valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;
+    }
+    vbal[k] = __ballot(valid);
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) nvalid += __popcll(vbal[k]);
+  Board<N>::wsync();
+  int n = 0;   // number of edges
+  if (nvalid == 0) {
+    // "Add pass if there is no valid move" :321-324 (only reachable with pass disabled)
+    if (lane == 0) { L.skey[0] = M_PASS; L.sprob[0] = 1.0f; }
+    n = 1;
+  } else {
+    // compact the valid candidates (action order) into sprob/skey[0..nvalid)
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int i = k * 64 + lane;
+      const bool v = (vbal[k] >> lane) & 1;
+      const int r = off + __popcll(vbal[k] & ((1ull << lane) - 1));
+      if (v) { L.sprob[r] = L.prob[i]; L.skey[r] = L.key[i]; }
+      off += __popcll(vbal[k]);
+    }
+    Board<N>::wsync();
+    n = nvalid;
+    // rank sort by (prob desc, position asc); equal priors among VALID candidates -> exact std::sort replay below
+    int rank[R];
+    bool tie = false;
+#pragma unroll
+    for (int k = 0; k < R; ++k) rank[k] = 0;
+    float pme[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { const int i = k * 64 + lane; pme[k] = i < n ? L.sprob[i] : 0.0f; }
+    for (int jn = 0; jn < n; ++jn) {
+      const float pj = L.sprob[jn];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int i = k * 64 + lane;
+        if (i < n) {
+          rank[k] += (pj > pme[k]) || (pj == pme[k] && jn < i);
+          tie |= (pj == pme[k] && jn != i);
+        }
+      }
+    }
+    anyvalid_tie = __any(tie);
+    if (!anyvalid_tie) {
+      float pv[R];
+      u16 kv[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) { const int i = k * 64 + lane; pv[k] = i < n ? L.sprob[i] : 0.f; kv[k] = i < n ? L.skey[i] : 0; }
+      Board<N>::wsync();
+#pragma unroll
+      for (int k = 0; k < R; ++k) { const int i = k * 64 + lane; if (i < n) { L.sprob[rank[k]] = pv[k]; L.skey[rank[k]] = kv[k]; } }
+    } else {
+      // the reference sorts ALL 362 pairs with an unstable std::sort and filters afterwards: replay it exactly
+      Board<N>::wsync();
+      if (lane == 0) {
+        stl_emul::sort_desc<u16>(L.key, L.prob, NA);
+        int w = 0;
+        for (int i = 0; i < NA; ++i) {
+          const int coord = L.key[i];
+          bool valid;
+          if (coord == M_PASS) valid = pass_enabled;
+          else {
+            const int x = coord % G::S - 1, y = coord / G::S - 1, a0 = x * N + y;
+            valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;
+          }
+          if (valid) { L.sprob[w] = L.prob[i]; L.skey[w] = (u16)coord; ++w; }
+        }
+      }
+    }
+    Board<N>::wsync();
+    // normalize :244-254: total = 1e-10 + sequential fp32 sum in sorted order
+    float total = 1e-10f;
+    if (lane == 0) {
+      for (int i = 0; i < n; ++i) total = __fadd_rn(total, L.sprob[i]);
+    }
+    total = rlf(total, 0);
+    for (int i = lane; i < n; i += 64) L.sprob[i] = __fdiv_rn(L.sprob[i], total);
+  }
+  Board<N>::wsync();
+  if (nvalid == 0) {
+    // normalize of the single (PASS, 1.0) entry
+    if (lane == 0) L.sprob[0] = __fdiv_rn(1.0f, __fadd_rn(1e-10f, 1.0f));
+    Board<N>::wsync();
+  }
+  // ---- setEvaluation :176-203: insert in this order; store edges in the map's ITERATION order
+  umap_order_wave<N>(L, n, lane);
+  for (int jn = lane; jn < n; jn += 64) {
+    const int src = L.seq[jn];
+    nd.stat[jn] = make_float4(L.sprob[src], 0.0f, __int_as_float(0), 0.0f);
+    nd.child[jn] = -1;
+    nd.coord[jn] = L.skey[src];
+  }
+  if (lane == 0) {
+    nd.h.n_edges = n;
+    nd.h.V = value[row];                                  // resp->value = reply.value :222
+    nd.h.flip = bd.next_player == S_WHITE;                // pre_evaluate :186
+    nd.h.status = NS_VISITED;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backup: batch_rollouts :245-259, one wave per game, leaves in first-occurrence order
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg) {
+  using NR = NodeRec<N>;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  NR* nodes = tp.game_nodes(g);
+  const GameState& gs = tp.gs[g];
+  const int nu = rfl(gs.n_unique);
+  if (lane != 0) return;   // pointer chase: serial by nature; edge statistics are 16-B records
+  for (int u = 0; u < nu; ++u) {
+    const LeafRec lr = tp.leaves[(size_t)g * MCTS_KMAX + u];
+    NR& leaf = nodes[lr.node];
+    if (lr.kind == LK_TERMINAL) {            // pre_evaluate result -> setEvaluation with an empty pi
+      leaf.h.V = lr.value;
+      leaf.h.flip = leaf.board.h.next_player == S_WHITE;
+      leaf.h.n_edges = 0;
+      leaf.h.status = NS_VISITED;
+    }
+    const float reward = leaf.h.V;           // MCTSActor::reward (go/mcts/mcts.h:163-165)
+    const float vsub = (float)(cfg.virtual_loss * lr.count);
+    int c = lr.node;
+    for (;;) {                               // updateEdgeStats :253-278 along the trajectory
+      const int p = nodes[c].h.parent;
+      if (p < 0) break;
+      const int e = nodes[c].h.parent_edge;
+      NR& pn = nodes[p];
+      pn.h.num_visits += 1;
+      float4 s = pn.stat[e];
+      s.y = __fadd_rn(s.y, reward);
+      s.z = __int_as_float(__float_as_int(s.z) + 1);
+      s.w = __fsub_rn(s.w, vsub);
+      pn.stat[e] = s;
+      c = p;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// root services
+// ------------------------------------------------------------------------------------------------
+// NodeT::enhanceExploration :132-155; etas/Z drawn on the host with libstdc++'s gamma_distribution
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const float* etas, const float* Z, float epsilon) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  NodeRec<N>& r = tp.game_nodes(g)[rfl(tp.gs[g].root)];
+  const int n = rfl(r.h.n_edges);
+  if (rfl(r.h.status) != NS_VISITED) return;
+  const float z = Z[g], ome = __fsub_rn(1.0f, epsilon);
+  for (int i = lane; i < n; i += 64) {
+    const float p = r.stat[i].x;
+    // (1 - epsilon) * p + epsilon * etas[i] / Z, left to right, no contraction
+    r.stat[i].x = __fadd_rn(__fmul_rn(ome, p), __fdiv_rn(__fmul_rn(epsilon, etas[(size_t)g * NodeRec<N>::NE + i]), z));
+  }
+}
+
+struct RootInfo {   // 32 B per game
+  int n_edges, num_visits, status, root;
+  float V;
+  int rng_pos, err, free_top;
+};
+
+// root edges in iteration order (MCTSResultT::addActions walks exactly this, tree_search_base.h:248-292)
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_root(TreePool<N> tp, RootInfo* info, int32_t* coord, int32_t* visits, float* prior,
+                                                   float* reward, int32_t* child) {
+  constexpr int NE = NodeRec<N>::NE;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const GameState& gs = tp.gs[g];
+  const NodeRec<N>& r = tp.game_nodes(g)[rfl(gs.root)];
+  const int n = rfl(r.h.n_edges);
+  if (lane == 0) {
+    RootInfo ri;
+    ri.n_edges = n; ri.num_visits = r.h.num_visits; ri.status = r.h.status; ri.root = gs.root; ri.V = r.h.V;
+    ri.rng_pos = gs.rng_pos; ri.err = gs.err; ri.free_top = gs.free_top;
+    info[g] = ri;
+  }
+  for (int i = lane; i < NE; i += 64) {
+    const size_t o = (size_t)g * NE + i;
+    if (i < n) {
+      const float4 s = r.stat[i];
+      if (coord) coord[o] = r.coord[i];
+      if (visits) visits[o] = __float_as_int(s.z);
+      if (prior) prior[o] = s.x;
+      if (reward) reward[o] = s.y;
+      if (child) child[o] = r.child[i];
+    } else {
+      if (coord) coord[o] = -1;
+      if (visits) visits[o] = 0;
+      if (prior) prior[o] = 0.f;
+      if (reward) reward[o] = 0.f;
+      if (child) child[o] = -1;
+    }
+  }
+}
+
+// SearchTreeT::treeAdvance :420-436: the child reached by `move` becomes the root, everything else is freed.
+// Reachability by walking parent links (depth-bounded), then a sweep that pushes dead ids on the free stack.
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_advance(TreePool<N> tp, const int32_t* moves) {
+  using NR = NodeRec<N>;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  NR* nodes = tp.game_nodes(g);
+  int* fs = tp.free_stack + (size_t)g * tp.C;
+  GameState& gs = tp.gs[g];
+  const int old_root = rfl(gs.root), mv = moves[g];
+  const NR& r = nodes[old_root];
+  const int n = rfl(r.h.n_edges);
+  int next_root = -1;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const u64 b = __ballot(i < n && r.coord[i] == mv);
+    if (b) next_root = rfl(r.child[base + (int)__builtin_ctzll(b)]);
+  }
+  // keep[id]: alive and the parent chain reaches next_root
+  for (int base = 0; base < tp.C; base += 64) {
+    const int id = base + lane;
+    int keep = 0;
+    if (nodes[id].h.alive) {
+      int a = id;
+      for (;;) {
+        if (a == next_root) { keep = 1; break; }
+        a = nodes[a].h.parent;
+        if (a < 0) break;
+      }
+      nodes[id].h.mark = keep;
+    }
+  }
+  mem_sync();
+  int free_top = rfl(gs.free_top);
+  for (int base = 0; base < tp.C; base += 64) {
+    const int id = base + lane;
+    const bool dead = nodes[id].h.alive && !nodes[id].h.mark;
+    const u64 b = __ballot(dead);
+    if (dead) {
+      nodes[id].h.alive = 0;
+      fs[free_top + __popcll(b & ((1ull << lane) - 1))] = id;
+    }
+    free_top += __popcll(b);
+  }
+  mem_sync();
+  if (next_root < 0) {                       // allocateRoot -> addNode(0.0)
+    next_root = rfl(fs[free_top - 1]);
+    --free_top;
+    node_init(&nodes[next_root], -1, -1, 0.0f, lane);
+  } else if (lane == 0) {
+    nodes[next_root].h.parent = -1;
+    nodes[next_root].h.parent_edge = -1;
+  }
+  if (lane == 0) { gs.root = next_root; gs.free_top = free_top; }
+}
+
+}  // namespace elfgo

@@ -1,0 +1,213 @@
+// C ABI of the device-resident MCTS (include/elf_amd.h, elfmcts_*): host side of mcts.cuh.
+#include <math.h>
+
+#include <new>
+#include <vector>
+
+#include "engine_host.h"
+#include "mcts.cuh"
+
+struct ElfMcts {
+  ElfGoEngine* eng = nullptr;
+  int G = 0, C = 0, W = 0, NE = 0;
+  void* nodes = nullptr;
+  int* free_stack = nullptr;
+  GameState* gs = nullptr;
+  LeafRec* leaves = nullptr;
+  unsigned char* d4buf = nullptr;
+  double* sqrt_tab = nullptr;
+  int sqrt_n = 0;
+  RowRec* rowmap = nullptr;
+  int32_t* all_games = nullptr;
+  TreeCfg cfg;
+  size_t node_bytes = 0;
+};
+
+template <int N>
+static TreePool<N> tree_of(const ElfMcts* m) {
+  TreePool<N> t;
+  t.nodes = reinterpret_cast<NodeRec<N>*>(m->nodes);
+  t.free_stack = m->free_stack;
+  t.gs = m->gs;
+  t.leaves = m->leaves;
+  t.d4buf = m->d4buf;
+  t.sqrt_tab = m->sqrt_tab;
+  t.sqrt_n = m->sqrt_n;
+  t.C = m->C; t.W = m->W; t.G = m->G;
+  return t;
+}
+
+// per-game variant of k_mcts_clear for a list of games
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_clear_list(TreePool<N> tp, const int32_t* games) {
+  const int g = games[blockIdx.x], lane = threadIdx.x;
+  NodeRec<N>* nodes = tp.game_nodes(g);
+  int* fs = tp.free_stack + (size_t)g * tp.C;
+  for (int i = lane; i < tp.C; i += 64) {
+    fs[i] = tp.C - 1 - i;
+    nodes[i].h.alive = 0;
+  }
+  mem_sync();
+  node_init(&nodes[0], -1, -1, 0.0f, lane);
+  if (lane == 0) {
+    GameState& s = tp.gs[g];
+    s.root = 0; s.free_top = tp.C - 1; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
+  }
+}
+
+static int cfg_from(const ElfMctsOptions* o, TreeCfg* c) {
+  if (!o || o->num_rollouts_per_batch <= 0 || o->num_rollouts_per_batch > MCTS_KMAX) return ELFGO_E_BADARG;
+  c->rollouts_per_batch = o->num_rollouts_per_batch;
+  c->virtual_loss = o->virtual_loss;
+  c->use_prior = o->use_prior;
+  c->unexplored_q_zero = o->unexplored_q_zero;
+  c->root_unexplored_q_zero = o->root_unexplored_q_zero;
+  c->c_puct = o->c_puct;
+  c->komi = o->komi;
+  c->ply_pass_enabled = o->ply_pass_enabled;
+  c->remove_pass_if_dangerous = o->remove_pass_if_dangerous;
+  c->rotation_flip = o->rotation_flip;
+  return 0;
+}
+
+extern "C" {
+
+int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_window, const ElfMctsOptions* opt, ElfMcts** out) {
+  if (!e || !out || num_games <= 0 || num_games > e->capacity || nodes_per_game < 64 || (nodes_per_game & 63) || d4_window <= 0)
+    return ELFGO_E_BADARG;
+  ElfMcts* m = new (std::nothrow) ElfMcts();
+  if (!m) return ELFGO_E_NOMEM;
+  int rc = cfg_from(opt, &m->cfg);
+  if (rc) { delete m; return rc; }
+  HIPCHK(hipSetDevice(e->device));
+  m->eng = e; m->G = num_games; m->C = nodes_per_game; m->W = d4_window;
+  m->node_bytes = e->n == 19 ? sizeof(NodeRec<19>) : sizeof(NodeRec<9>);
+  m->NE = e->n == 19 ? NodeRec<19>::NE : NodeRec<9>::NE;
+  const size_t G = num_games, C = nodes_per_game;
+#define MCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { elfmcts_destroy(m); return (int)_e; } } while (0)
+  MCHK(hipMalloc(&m->nodes, G * C * m->node_bytes));
+  MCHK(hipMalloc((void**)&m->free_stack, G * C * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->gs, G * sizeof(GameState)));
+  MCHK(hipMalloc((void**)&m->leaves, G * MCTS_KMAX * sizeof(LeafRec)));
+  MCHK(hipMalloc((void**)&m->d4buf, G * (size_t)d4_window));
+  MCHK(hipMemset(m->d4buf, 0, G * (size_t)d4_window));
+  MCHK(hipMalloc((void**)&m->rowmap, G * MCTS_KMAX * sizeof(RowRec)));
+  MCHK(hipMalloc((void**)&m->all_games, G * sizeof(int32_t)));
+  {
+    std::vector<int32_t> ids(G);
+    for (size_t i = 0; i < G; ++i) ids[i] = (int32_t)i;
+    MCHK(hipMemcpy(m->all_games, ids.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  // std::sqrt(int) of the reference (tree_search_base.h:153) tabulated with the host libm
+  m->sqrt_n = 1 << 17;
+  {
+    std::vector<double> t(m->sqrt_n);
+    for (int i = 0; i < m->sqrt_n; ++i) t[i] = std::sqrt((double)i);
+    MCHK(hipMalloc((void**)&m->sqrt_tab, t.size() * sizeof(double)));
+    MCHK(hipMemcpy(m->sqrt_tab, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  rc = elfmcts_clear(m, nullptr, num_games, nullptr);
+  if (rc) { elfmcts_destroy(m); return rc; }
+  MCHK(hipDeviceSynchronize());
+#undef MCHK
+  *out = m;
+  return 0;
+}
+
+int elfmcts_destroy(ElfMcts* m) {
+  if (!m) return ELFGO_E_BADARG;
+  if (m->nodes) (void)hipFree(m->nodes);
+  if (m->free_stack) (void)hipFree(m->free_stack);
+  if (m->gs) (void)hipFree(m->gs);
+  if (m->leaves) (void)hipFree(m->leaves);
+  if (m->d4buf) (void)hipFree(m->d4buf);
+  if (m->sqrt_tab) (void)hipFree(m->sqrt_tab);
+  if (m->rowmap) (void)hipFree(m->rowmap);
+  if (m->all_games) (void)hipFree(m->all_games);
+  delete m;
+  return 0;
+}
+
+int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt) {
+  if (!m) return ELFGO_E_BADARG;
+  return cfg_from(opt, &m->cfg);
+}
+int elfmcts_num_games(const ElfMcts* m) { return m ? m->G : ELFGO_E_BADARG; }
+int elfmcts_edge_stride(const ElfMcts* m) { return m ? m->NE : ELFGO_E_BADARG; }
+size_t elfmcts_node_bytes(const ElfMcts* m) { return m ? m->node_bytes : 0; }
+
+int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream) {
+  if (!m || n < 0 || n > m->G) return ELFGO_E_BADARG;
+  if (n == 0) return 0;
+  const int32_t* list = games ? games : m->all_games;
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_clear_list<N>, dim3(n), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), list));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfmcts_set_root(ElfMcts* m, const int32_t* board_ids, void* stream) {
+  if (!m) return ELFGO_E_BADARG;
+  DISPATCH(m->eng, {
+    hipLaunchKernelGGL((k_mcts_set_root<N, Pool<N>>), dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
+                       board_ids);
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfmcts_set_d4(ElfMcts* m, const uint8_t* d4_host, void* stream) {
+  if (!m || !d4_host) return ELFGO_E_BADARG;
+  HIPCHK(hipMemcpyAsync(m->d4buf, d4_host, (size_t)m->G * m->W, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int elfmcts_dirichlet(ElfMcts* m, const float* etas, const float* Z, float epsilon, void* stream) {
+  if (!m || !etas || !Z) return ELFGO_E_BADARG;
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_dirichlet<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), etas, Z, epsilon));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfmcts_select(ElfMcts* m, const int32_t* board_ids, float* s_dst, int64_t stride_floats, int32_t* counts, void* stream) {
+  if (!m || !s_dst || !counts || stride_floats < (int64_t)18 * m->eng->n * m->eng->n) return ELFGO_E_BADARG;
+  const int K = m->cfg.rollouts_per_batch;
+  DISPATCH(m->eng, {
+    hipLaunchKernelGGL((k_mcts_select<N, Pool<N>>), dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
+                       board_ids, m->cfg);
+    hipLaunchKernelGGL(k_mcts_features<N>, dim3(m->G * K), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), K, s_dst, stride_floats,
+                       m->rowmap, counts);
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const float* value, int n_rows, void* stream) {
+  if (!m || n_rows < 0 || n_rows > m->G * MCTS_KMAX) return ELFGO_E_BADARG;
+  if (n_rows > 0 && (!pi || !value || pi_stride_floats < (int64_t)m->eng->n * m->eng->n + 1)) return ELFGO_E_BADARG;
+  DISPATCH(m->eng, {
+    if (n_rows > 0)
+      hipLaunchKernelGGL(k_mcts_expand<N>, dim3(n_rows), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (const u64*)m->eng->zob,
+                         (const RowRec*)m->rowmap, pi, pi_stride_floats, value, n_rows, m->cfg);
+    hipLaunchKernelGGL(k_mcts_backup<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), m->cfg);
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, float* prior, float* reward, int32_t* child, void* stream) {
+  if (!m || !info) return ELFGO_E_BADARG;
+  static_assert(sizeof(RootInfo) == ELFMCTS_ROOT_WORDS * 4, "RootInfo layout");
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_root<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (RootInfo*)info, coord,
+                                      visits, prior, reward, child));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfmcts_advance(ElfMcts* m, const int32_t* moves, void* stream) {
+  if (!m || !moves) return ELFGO_E_BADARG;
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_advance<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), moves));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,346 @@
+// Host side of the self-play loop over the device engines (include/elf_amd.h, elfsp_*).
+//
+// Mirrors, for G games advanced in lock-step on one GPU, what the reference does on one std::thread per game:
+//   src_cpp/elfgames/go/common/game_selfplay.cc   GoGameSelfPlay::act :272-430, init_ai :30-78,
+//                                                  mcts_make_diverse_move :80-95, mcts_update_info :97-119, finish_game :121-149
+//   src_cpp/elf/ai/tree_search/mcts.h             MCTSAI_T::act / align_state / advanceMoves :59-81,141-167
+//   src_cpp/elf/ai/tree_search/tree_search.h      TreeSearchT::run :410-426, chooseAction :495-528
+//   src_cpp/elfgames/go/mcts/mcts.h               MCTSGoAI::getValue / getMCTSPolicy :358-372
+//   src_cpp/elfgames/go/common/game_utils.h       ResignCheck :14-54
+// Everything that depends on libstdc++'s implementation-defined distributions stays on the host and uses the
+// very same library: std::gamma_distribution (Dirichlet noise), std::uniform_real_distribution (move sampling,
+// never-resign draw), std::mt19937 streams per game and per actor.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <random>
+#include <utility>
+#include <vector>
+
+#include "engine_host.h"
+
+struct ElfSpSearchRec {   // == ElfSpSearch in include/elf_amd.h
+  int32_t game, move_played, best_action, total_visits, n_edges;
+  float root_value, max_score, predicted_value;
+};
+
+struct SpGame {
+  std::mt19937 rng;        // GoGameBase::_rng (game_base.h:32-38)
+  std::mt19937 actor_rng;  // MCTSActor::rng_ (go/mcts/mcts.h:52), seeded with params.seed = _rng() (game_selfplay.cc:47)
+  // ResignCheck (game_utils.h:14-54)
+  bool never_resign = false, has_calculated_never_resign = false;
+  float last_predicted = 0.0f;
+  int ply = 1;             // GoState::getPly of the game board
+  int seq = 0;             // games finished by this slot
+};
+
+struct ElfSelfPlay {
+  ElfSpOptions opt;
+  ElfGoEngine* eng = nullptr;
+  ElfMcts* mcts = nullptr;
+  int G = 0, NE = 0, NA = 0, K = 0, steps_per_move = 0, step_in_move = 0, W = 0;
+  hipStream_t stream = nullptr;
+  std::vector<SpGame> games;
+  // device scratch
+  int32_t* d_counts = nullptr;   // [2]
+  int32_t* d_info = nullptr;     // [G][8]
+  int32_t *d_coord = nullptr, *d_visits = nullptr, *d_moves = nullptr, *d_ids = nullptr, *d_binfo = nullptr;
+  float *d_prior = nullptr, *d_reward = nullptr, *d_etas = nullptr, *d_Z = nullptr, *d_val = nullptr;
+  uint8_t* d_ok = nullptr;
+  // host mirrors
+  std::vector<int32_t> h_info, h_coord, h_visits, h_moves, h_binfo;
+  std::vector<float> h_prior, h_reward, h_etas, h_Z, h_val;
+  std::vector<uint8_t> h_d4, h_ok;
+  int32_t h_counts[2] = {0, 0};
+  int last_rows = 0;
+  bool search_open = false;
+  // statistics / capture
+  int64_t n_moves = 0, n_games = 0, n_rollouts = 0, n_rows = 0, n_steps = 0;
+  double sum_final = 0.0;
+  std::vector<ElfSpSearchRec> log_search;
+  std::vector<int32_t> log_coord, log_visits;
+  std::vector<float> log_prior, log_reward;
+  int log_cap = 0;
+};
+
+#define SPCHK(x)                  \
+  do {                            \
+    int _rc = (x);                \
+    if (_rc != 0) return _rc;     \
+  } while (0)
+
+static int sp_begin_search(ElfSelfPlay* sp) {
+  // MCTSAI_T::act -> align_state (mcts.h:141-167) happened at the end of the previous move (treeAdvance) or is a
+  // clear when the tree is not persistent; then TreeSearchT::run :410-417
+  const int G = sp->G;
+  if (!sp->opt.persistent_tree) SPCHK(elfmcts_clear(sp->mcts, nullptr, G, sp->stream));
+  SPCHK(elfmcts_set_root(sp->mcts, nullptr, sp->stream));
+  SPCHK(elfmcts_root(sp->mcts, sp->d_info, nullptr, nullptr, nullptr, nullptr, nullptr, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_info.data(), sp->d_info, sizeof(int32_t) * G * ELFMCTS_ROOT_WORDS, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  for (int g = 0; g < G; ++g)
+    if (sp->h_info[g * ELFMCTS_ROOT_WORDS + 6]) return ELFGO_E_MCTS_BASE - sp->h_info[g * ELFMCTS_ROOT_WORDS + 6];
+  if (sp->opt.root_epsilon > 0.0f) {
+    // NodeT::enhanceExploration (tree_search_node.h:132-155), draws from actors_[0]->rng()
+    for (int g = 0; g < G; ++g) {
+      const int n = sp->h_info[g * ELFMCTS_ROOT_WORDS + 0];
+      std::gamma_distribution<> dis(sp->opt.root_alpha);
+      float Z = 1e-10;
+      float* et = &sp->h_etas[(size_t)g * sp->NE];
+      for (int i = 0; i < n; ++i) {
+        et[i] = dis(sp->games[g].actor_rng);
+        Z += et[i];
+      }
+      sp->h_Z[g] = Z;
+    }
+    HIPCHK(hipMemcpyAsync(sp->d_etas, sp->h_etas.data(), sizeof(float) * (size_t)G * sp->NE, hipMemcpyHostToDevice, sp->stream));
+    HIPCHK(hipMemcpyAsync(sp->d_Z, sp->h_Z.data(), sizeof(float) * G, hipMemcpyHostToDevice, sp->stream));
+    SPCHK(elfmcts_dirichlet(sp->mcts, sp->d_etas, sp->d_Z, sp->opt.root_epsilon, sp->stream));
+  }
+  // BoardFeature::RandomShuffle draws of this move (go/mcts/mcts.h:175-183), from a copy of the actor stream
+  for (int g = 0; g < G; ++g) {
+    std::mt19937 c = sp->games[g].actor_rng;
+    uint8_t* d = &sp->h_d4[(size_t)g * sp->W];
+    for (int i = 0; i < sp->W; ++i) d[i] = (uint8_t)(c() % 8);
+  }
+  SPCHK(elfmcts_set_d4(sp->mcts, sp->h_d4.data(), sp->stream));
+  sp->step_in_move = 0;
+  sp->search_open = true;
+  return 0;
+}
+
+static int sp_finish_move(ElfSelfPlay* sp) {
+  const int G = sp->G, NE = sp->NE;
+  SPCHK(elfmcts_root(sp->mcts, sp->d_info, sp->d_coord, sp->d_visits, sp->d_prior, sp->d_reward, nullptr, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_info.data(), sp->d_info, sizeof(int32_t) * G * ELFMCTS_ROOT_WORDS, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_coord.data(), sp->d_coord, sizeof(int32_t) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_visits.data(), sp->d_visits, sizeof(int32_t) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_prior.data(), sp->d_prior, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_reward.data(), sp->d_reward, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  std::vector<int> finished;
+  for (int g = 0; g < G; ++g) {
+    SpGame& gm = sp->games[g];
+    const int32_t* info = &sp->h_info[g * ELFMCTS_ROOT_WORDS];
+    if (info[6]) return ELFGO_E_MCTS_BASE - info[6];
+    gm.actor_rng.discard((unsigned long long)info[5]);   // D4 draws the search consumed
+    const int n = info[0];
+    const int32_t* coord = &sp->h_coord[(size_t)g * NE];
+    const int32_t* visits = &sp->h_visits[(size_t)g * NE];
+    const float* reward = &sp->h_reward[(size_t)g * NE];
+    float root_value;
+    memcpy(&root_value, &info[4], 4);
+    // chooseAction :495-528 with MCTSResultT::addActions (tree_search_base.h:237-294), MOST_VISITED
+    int best_action = M_INVALID, total_visits = 0, best_i = -1;
+    float max_score = -3.402823466e+38f;
+    for (int i = 0; i < n; ++i) {
+      const float score = (float)visits[i];
+      total_visits += visits[i];
+      if (score > max_score) { max_score = score; best_action = coord[i]; best_i = i; }
+    }
+    int c = best_action;
+    // mcts_make_diverse_move (game_selfplay.cc:80-95): MCTSPolicy::normalize (tree_search_base.h:190-203) + sampleAction
+    if (gm.ply <= sp->opt.policy_distri_cutoff && n > 0) {
+      std::vector<std::pair<int, float>> policy(n);
+      float exp_sum = 0;
+      for (int i = 0; i < n; ++i) {
+        float e = std::pow((float)visits[i], 1.0 / 1.0f);
+        policy[i] = std::make_pair(coord[i], e);
+        exp_sum += e;
+      }
+      for (auto& p : policy) p.second /= exp_sum;
+      // elf_utils::sample_multinomial (elf/utils/utils.h:159-182)
+      float Z = 0.0;
+      for (const auto& p : policy) Z += p.second;
+      std::uniform_real_distribution<> dis(0, Z);
+      float rd = dis(gm.rng);
+      std::vector<float> accu(n + 1);
+      accu[0] = 0;
+      size_t pick = n - 1;
+      for (size_t i = 1; i < accu.size(); i++) {
+        accu[i] = policy[i - 1].second + accu[i - 1];
+        if (rd < accu[i]) { pick = i - 1; break; }
+      }
+      c = policy[pick].first;
+    }
+    // mcts_update_info :97-119 with MCTSGoAI::getValue (go/mcts/mcts.h:358-365)
+    float predicted = root_value;
+    if (total_visits != 0 && best_i >= 0) predicted = reward[best_i] / visits[best_i];
+    gm.last_predicted = predicted;
+    if (sp->log_cap > 0 && (int)sp->log_search.size() < sp->log_cap) {
+      ElfSpSearchRec r;
+      r.game = g; r.move_played = c; r.best_action = best_action; r.total_visits = total_visits; r.n_edges = n;
+      r.root_value = root_value; r.max_score = max_score; r.predicted_value = predicted;
+      sp->log_search.push_back(r);
+      sp->log_coord.insert(sp->log_coord.end(), coord, coord + NE);
+      sp->log_visits.insert(sp->log_visits.end(), visits, visits + NE);
+      sp->log_prior.insert(sp->log_prior.end(), &sp->h_prior[(size_t)g * NE], &sp->h_prior[(size_t)g * NE] + NE);
+      sp->log_reward.insert(sp->log_reward.end(), reward, reward + NE);
+    }
+    // shouldResign (go_state_ext.h:207-214) -> ResignCheck::check (game_utils.h:24-40); side to move = parity of ply
+    bool resign = false;
+    {
+      const bool black = (gm.ply & 1) == 1;   // ply 1 = Black to move
+      const float value = black ? predicted : -predicted;
+      if (!gm.has_calculated_never_resign) {
+        std::uniform_real_distribution<> dis(0.0, 1.0);
+        gm.never_resign = (dis(gm.rng) < sp->opt.never_resign_prob);
+        gm.has_calculated_never_resign = true;
+      }
+      if (!gm.never_resign && !(value >= -1.0 + sp->opt.resign_thres)) resign = true;
+    }
+    if (resign && gm.ply >= 50) {
+      finished.push_back(g);
+      sp->h_moves[g] = M_PASS;       // placeholder; the board is reset below
+      sp->sum_final += ((gm.ply & 1) == 1) ? -1.0 : 1.0;   // setFinalValue FR_RESIGN (go_state_ext.h:83-85)
+      gm.ply = -1;                   // marks "finished by resignation"
+    } else {
+      sp->h_moves[g] = c;
+    }
+  }
+  sp->n_moves += G;
+  // GoStateExt::forward(c) (game_selfplay.cc:408) on the real game boards; tree follows (advanceMoves -> treeAdvance)
+  HIPCHK(hipMemcpyAsync(sp->d_moves, sp->h_moves.data(), sizeof(int32_t) * G, hipMemcpyHostToDevice, sp->stream));
+  SPCHK(elfgo_forward(sp->eng, nullptr, sp->d_moves, G, sp->d_ok, sp->stream));
+  if (sp->opt.persistent_tree) SPCHK(elfmcts_advance(sp->mcts, sp->d_moves, sp->stream));
+  SPCHK(elfgo_info(sp->eng, nullptr, G, sp->d_binfo, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_binfo.data(), sp->d_binfo, sizeof(int32_t) * G * ELFGO_INFO_WORDS, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_ok.data(), sp->d_ok, G, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  std::vector<int> by_end;
+  for (int g = 0; g < G; ++g) {
+    SpGame& gm = sp->games[g];
+    if (gm.ply < 0) continue;   // resigned
+    if (sp->h_ok[g] != 1) return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD;   // "Something is wrong! Move cannot be applied" :409-418
+    const int32_t* bi = &sp->h_binfo[g * ELFGO_INFO_WORDS];
+    gm.ply = bi[0];
+    const bool terminated = bi[9] != 0;
+    if (terminated || (sp->opt.move_cutoff > 0 && gm.ply >= sp->opt.move_cutoff)) by_end.push_back(g);   // :420-429
+  }
+  if (!by_end.empty()) {
+    // finish_game -> setFinalValue: GoState::evaluate(komi) (go_state_ext.h:100-102)
+    std::vector<int32_t> ids(by_end.begin(), by_end.end());
+    HIPCHK(hipMemcpyAsync(sp->d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, sp->stream));
+    SPCHK(elfgo_evaluate(sp->eng, sp->d_ids, (int)ids.size(), sp->opt.mcts.komi, sp->d_val, sp->stream));
+    HIPCHK(hipMemcpyAsync(sp->h_val.data(), sp->d_val, sizeof(float) * ids.size(), hipMemcpyDeviceToHost, sp->stream));
+    HIPCHK(hipStreamSynchronize(sp->stream));
+    for (size_t i = 0; i < ids.size(); ++i) sp->sum_final += sp->h_val[i];
+    finished.insert(finished.end(), by_end.begin(), by_end.end());
+  }
+  if (!finished.empty()) {
+    // finish_game :121-149: _ai->endGame (resetTree), _state_ext.restart() (state reset, resign check reset)
+    std::vector<int32_t> ids(finished.begin(), finished.end());
+    HIPCHK(hipMemcpyAsync(sp->d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, sp->stream));
+    SPCHK(elfgo_reset(sp->eng, sp->d_ids, (int)ids.size(), sp->stream));
+    SPCHK(elfmcts_clear(sp->mcts, sp->d_ids, (int)ids.size(), sp->stream));
+    HIPCHK(hipStreamSynchronize(sp->stream));   // ids is a stack vector
+    for (int g : finished) {
+      SpGame& gm = sp->games[g];
+      gm.ply = 1; gm.never_resign = false; gm.has_calculated_never_resign = false; gm.last_predicted = 0.0f;
+      gm.seq++;
+    }
+    sp->n_games += (int64_t)finished.size();
+  }
+  sp->search_open = false;
+  return 0;
+}
+
+extern "C" {
+
+int elfsp_create(const ElfSpOptions* o, int device, const uint64_t* zobrist_host, ElfSelfPlay** out) {
+  if (!o || !out || !zobrist_host || o->num_games <= 0 || o->num_rollouts_per_thread <= 0) return ELFGO_E_BADARG;
+  ElfSelfPlay* sp = new (std::nothrow) ElfSelfPlay();
+  if (!sp) return ELFGO_E_NOMEM;
+  sp->opt = *o;
+  const int G = o->num_games;
+  int rc = elfgo_create(o->board_size, G, device, zobrist_host, &sp->eng);
+  if (rc) { delete sp; return rc; }
+  sp->K = o->mcts.num_rollouts_per_batch;
+  sp->steps_per_move = (o->num_rollouts_per_thread + sp->K - 1) / sp->K;   // for (idx = 0; idx < num_rollout; idx += batch) tree_search.h:112-117
+  sp->W = sp->steps_per_move * sp->K;
+  rc = elfmcts_create(sp->eng, G, o->nodes_per_game, sp->W, &o->mcts, &sp->mcts);
+  if (rc) { elfgo_destroy(sp->eng); delete sp; return rc; }
+  sp->G = G; sp->NE = elfmcts_edge_stride(sp->mcts); sp->NA = o->board_size * o->board_size + 1;
+  sp->games.resize(G);
+  for (int g = 0; g < G; ++g) {
+    // GoGameBase ctor: _rng.seed(options.seed) (game_base.h:32-38); restart() -> init_ai: params.seed = _rng() (game_selfplay.cc:47)
+    const uint32_t seed = o->seed + (G > 1 ? (uint32_t)g : 0u);
+    sp->games[g].rng.seed(seed);
+    const uint64_t aseed = sp->games[g].rng();
+    sp->games[g].actor_rng.seed(aseed);
+  }
+#define A(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { elfsp_destroy(sp); return (int)_e; } } while (0)
+  const size_t GE = (size_t)G * sp->NE;
+  A(sp->d_counts, 8); A(sp->d_info, sizeof(int32_t) * G * ELFMCTS_ROOT_WORDS);
+  A(sp->d_coord, 4 * GE); A(sp->d_visits, 4 * GE); A(sp->d_prior, 4 * GE); A(sp->d_reward, 4 * GE); A(sp->d_etas, 4 * GE);
+  A(sp->d_Z, 4 * G); A(sp->d_moves, 4 * G); A(sp->d_ids, 4 * G); A(sp->d_val, 4 * G); A(sp->d_ok, G);
+  A(sp->d_binfo, sizeof(int32_t) * G * ELFGO_INFO_WORDS);
+#undef A
+  sp->h_info.resize(G * ELFMCTS_ROOT_WORDS); sp->h_coord.resize(GE); sp->h_visits.resize(GE); sp->h_prior.resize(GE);
+  sp->h_reward.resize(GE); sp->h_etas.assign(GE, 0.f); sp->h_Z.resize(G); sp->h_moves.resize(G); sp->h_val.resize(G);
+  sp->h_ok.resize(G); sp->h_binfo.resize(G * ELFGO_INFO_WORDS); sp->h_d4.resize((size_t)G * sp->W);
+  sp->log_cap = o->log_searches;
+  *out = sp;
+  return 0;
+}
+
+int elfsp_destroy(ElfSelfPlay* sp) {
+  if (!sp) return ELFGO_E_BADARG;
+  void* ptrs[] = {sp->d_counts, sp->d_info, sp->d_coord, sp->d_visits, sp->d_prior, sp->d_reward, sp->d_etas, sp->d_Z,
+                  sp->d_moves, sp->d_ids, sp->d_val, sp->d_ok, sp->d_binfo};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (sp->mcts) elfmcts_destroy(sp->mcts);
+  if (sp->eng) elfgo_destroy(sp->eng);
+  delete sp;
+  return 0;
+}
+
+ElfGoEngine* elfsp_engine(ElfSelfPlay* sp) { return sp ? sp->eng : nullptr; }
+ElfMcts* elfsp_mcts(ElfSelfPlay* sp) { return sp ? sp->mcts : nullptr; }
+int elfsp_max_rows(const ElfSelfPlay* sp) { return sp ? sp->G * sp->K : ELFGO_E_BADARG; }
+
+int elfsp_begin_step(ElfSelfPlay* sp, float* s_dst, int64_t stride_floats, int* n_rows, void* stream) {
+  if (!sp || !s_dst || !n_rows) return ELFGO_E_BADARG;
+  sp->stream = (hipStream_t)stream;
+  if (!sp->search_open) SPCHK(sp_begin_search(sp));
+  SPCHK(elfmcts_select(sp->mcts, nullptr, s_dst, stride_floats, sp->d_counts, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_counts, sp->d_counts, 8, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  if (sp->h_counts[1]) return ELFGO_E_MCTS_BASE - sp->h_counts[1];
+  sp->last_rows = sp->h_counts[0];
+  *n_rows = sp->last_rows;
+  return 0;
+}
+
+int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, void* stream) {
+  if (!sp || !sp->search_open) return ELFGO_E_BADARG;
+  sp->stream = (hipStream_t)stream;
+  SPCHK(elfmcts_expand(sp->mcts, pi, pi_stride_floats, value, sp->last_rows, sp->stream));
+  sp->n_rows += sp->last_rows;
+  sp->n_rollouts += (int64_t)sp->G * sp->K;
+  sp->n_steps++;
+  if (++sp->step_in_move >= sp->steps_per_move) SPCHK(sp_finish_move(sp));
+  return 0;
+}
+
+int elfsp_stats(const ElfSelfPlay* sp, int64_t* out) {
+  if (!sp || !out) return ELFGO_E_BADARG;
+  out[0] = sp->n_moves; out[1] = sp->n_games; out[2] = sp->n_rollouts; out[3] = sp->n_rows; out[4] = sp->n_steps;
+  out[5] = (int64_t)sp->log_search.size(); out[6] = sp->steps_per_move; out[7] = sp->step_in_move;
+  return 0;
+}
+
+int elfsp_search_log(const ElfSelfPlay* sp, int first, int n, ElfSpSearch* rec, int32_t* coord, int32_t* visits, float* prior, float* reward) {
+  if (!sp || first < 0 || n < 0 || first + n > (int)sp->log_search.size()) return ELFGO_E_BADARG;
+  static_assert(sizeof(ElfSpSearch) == sizeof(ElfSpSearchRec), "ElfSpSearch layout");
+  const size_t NE = sp->NE;
+  if (rec) memcpy(rec, sp->log_search.data() + first, sizeof(ElfSpSearchRec) * n);
+  if (coord) memcpy(coord, sp->log_coord.data() + first * NE, 4 * NE * n);
+  if (visits) memcpy(visits, sp->log_visits.data() + first * NE, 4 * NE * n);
+  if (prior) memcpy(prior, sp->log_prior.data() + first * NE, 4 * NE * n);
+  if (reward) memcpy(reward, sp->log_reward.data() + first * NE, 4 * NE * n);
+  return 0;
+}
+
+}  // extern "C"

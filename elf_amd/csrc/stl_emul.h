@@ -1,0 +1,206 @@
+// Exact emulation of two libstdc++ behaviours that are semantically visible in the reference's MCTS.
+//
+// (1) Iteration order of std::unordered_map<Coord, EdgeInfo> (NodeT::stateActions_,
+//     elf/ai/tree_search/tree_search_node.h:310) after the insertions of NodeT::setEvaluation (:186-189).
+//     PUCT tie-breaks (:338-341,:370-385), the assignment of Dirichlet draws to edges (:149-154) and
+//     MCTSResultT::addActions (tree_search_base.h:248-292) all follow that order.
+//     libstdc++ (GCC 11) facts used, all checked against the real container by tests/test_stl_emul.py:
+//       * std::hash<unsigned short> is the identity, bucket = key % bucket_count;
+//       * a default-constructed map grows 1 -> 13 -> 29 -> 59 -> 127 -> 257 -> 541 buckets, rehashing
+//         BEFORE the insert that would exceed load factor 1;
+//       * an insert into an empty bucket puts the node at the head of the global list, an insert into a
+//         non-empty bucket puts it at the front of that bucket's run; a rehash re-inserts the nodes in
+//         their current iteration order under the same two rules.
+//     Hence one "epoch" (a sequence inserted into an empty table of nb buckets) iterates as the REVERSE
+//     of: buckets in order of first appearance, each bucket's keys in insertion order.
+// (2) std::sort with comparator a.second > b.second (go/mcts/mcts.h:292-297): introsort + final insertion
+//     sort; not stable, so the order of equal priors is whatever this exact algorithm produces.
+//
+// Host and device (gfx950) compile the same code; the device uses the serial forms only on rare paths.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define STL_HD __host__ __device__ __forceinline__
+#else
+#define STL_HD static inline
+#endif
+
+namespace stl_emul {
+
+// bucket counts of successive rehashes and the element count each can hold before the next one
+constexpr int kNumEpochs = 6;
+STL_HD int epoch_buckets(int e) {
+  return e == 0 ? 13 : e == 1 ? 29 : e == 2 ? 59 : e == 3 ? 127 : e == 4 ? 257 : 541;
+}
+
+// Serial reference form. keys[0..n) = insertion order (distinct, < 65536), n <= 541.
+// order[i] = index into keys of the i-th element in iteration order. tmp: 2*n ints of scratch.
+template <typename K>
+STL_HD void umap_iteration_order(const K* keys, int n, int* order, int* tmp) {
+  int* cur = tmp;        // current iteration order (indices into keys)
+  int* seq = tmp + n;    // insertion sequence of this epoch
+  int have = 0, done = 0;
+  for (int e = 0; e < kNumEpochs && done < n; ++e) {
+    const int nb = epoch_buckets(e);
+    const int take = (n < nb ? n : nb) - done;
+    int m = 0;
+    for (int i = 0; i < have; ++i) seq[m++] = cur[i];
+    for (int i = 0; i < take; ++i) seq[m++] = done + i;
+    done += take;
+    // groups in order of first appearance, members in insertion order; then reverse
+    int w = 0;
+    for (int i = 0; i < m; ++i) {
+      const int b = (int)keys[seq[i]] % nb;
+      bool first = true;
+      for (int j = 0; j < i; ++j)
+        if ((int)keys[seq[j]] % nb == b) { first = false; break; }
+      if (!first) continue;
+      for (int j = i; j < m; ++j)
+        if ((int)keys[seq[j]] % nb == b) cur[m - 1 - w++] = seq[j];
+    }
+    have = m;
+  }
+  for (int i = 0; i < n; ++i) order[i] = cur[i];
+}
+
+// ---- std::sort (libstdc++ bits/stl_algo.h: __introsort_loop, __final_insertion_sort) -------------
+// Elements are (key, val) pairs held in two parallel arrays; comp(a, b) = val[a] > val[b].
+template <typename K>
+struct PairRef {
+  K* k;
+  float* v;
+};
+
+template <typename K>
+STL_HD void pr_swap(PairRef<K> p, int a, int b) {
+  K tk = p.k[a]; p.k[a] = p.k[b]; p.k[b] = tk;
+  float tv = p.v[a]; p.v[a] = p.v[b]; p.v[b] = tv;
+}
+
+template <typename K>
+STL_HD void unguarded_linear_insert(PairRef<K> p, int last) {
+  const K vk = p.k[last];
+  const float vv = p.v[last];
+  int next = last - 1;
+  while (vv > p.v[next]) {
+    p.k[last] = p.k[next]; p.v[last] = p.v[next];
+    last = next;
+    --next;
+  }
+  p.k[last] = vk; p.v[last] = vv;
+}
+
+template <typename K>
+STL_HD void insertion_sort(PairRef<K> p, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (p.v[i] > p.v[first]) {
+      const K vk = p.k[i];
+      const float vv = p.v[i];
+      for (int j = i; j > first; --j) { p.k[j] = p.k[j - 1]; p.v[j] = p.v[j - 1]; }
+      p.k[first] = vk; p.v[first] = vv;
+    } else {
+      unguarded_linear_insert(p, i);
+    }
+  }
+}
+
+template <typename K>
+STL_HD void adjust_heap(PairRef<K> p, int first, int hole, int len, K vk, float vv) {
+  const int top = hole;
+  int second = hole;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (p.v[first + second] > p.v[first + (second - 1)]) second--;
+    p.k[first + hole] = p.k[first + second]; p.v[first + hole] = p.v[first + second];
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    p.k[first + hole] = p.k[first + (second - 1)]; p.v[first + hole] = p.v[first + (second - 1)];
+    hole = second - 1;
+  }
+  int parent = (hole - 1) / 2;   // __push_heap
+  while (hole > top && p.v[first + parent] > vv) {
+    p.k[first + hole] = p.k[first + parent]; p.v[first + hole] = p.v[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  p.k[first + hole] = vk; p.v[first + hole] = vv;
+}
+
+template <typename K>
+STL_HD void heap_sort(PairRef<K> p, int first, int last) {   // __partial_sort(first, last, last)
+  const int len = last - first;
+  if (len >= 2) {                                             // __make_heap
+    int parent = (len - 2) / 2;
+    for (;;) {
+      adjust_heap(p, first, parent, len, p.k[first + parent], p.v[first + parent]);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {                                  // __sort_heap / __pop_heap
+    --last;
+    const K vk = p.k[last];
+    const float vv = p.v[last];
+    p.k[last] = p.k[first]; p.v[last] = p.v[first];
+    adjust_heap(p, first, 0, last - first, vk, vv);
+  }
+}
+
+template <typename K>
+STL_HD int partition_pivot(PairRef<K> p, int first, int last) {   // __unguarded_partition_pivot
+  const int mid = first + (last - first) / 2;
+  const int a = first + 1, b = mid, c = last - 1;                 // __move_median_to_first(first, a, b, c)
+  if (p.v[a] > p.v[b]) {
+    if (p.v[b] > p.v[c]) pr_swap(p, first, b);
+    else if (p.v[a] > p.v[c]) pr_swap(p, first, c);
+    else pr_swap(p, first, a);
+  } else if (p.v[a] > p.v[c]) pr_swap(p, first, a);
+  else if (p.v[b] > p.v[c]) pr_swap(p, first, c);
+  else pr_swap(p, first, b);
+  int lo = first + 1, hi = last;                                  // __unguarded_partition(first+1, last, first)
+  for (;;) {
+    while (p.v[lo] > p.v[first]) ++lo;
+    --hi;
+    while (p.v[first] > p.v[hi]) --hi;
+    if (!(lo < hi)) return lo;
+    pr_swap(p, lo, hi);
+    ++lo;
+  }
+}
+
+// std::sort(v.begin(), v.end(), [](a, b){ return a.second > b.second; }) on n <= 1024 pairs
+template <typename K>
+STL_HD void sort_desc(K* keys, float* vals, int n) {
+  if (n <= 0) return;
+  PairRef<K> p{keys, vals};
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  // __introsort_loop with an explicit stack (recursion on the right part, loop on the left)
+  int stk_first[64], stk_last[64], stk_depth[64], sp = 0;
+  stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    while (last - first > 16) {
+      if (depth == 0) { heap_sort(p, first, last); break; }
+      --depth;
+      const int cut = partition_pivot(p, first, last);
+      // the recursive call on [cut, last) runs to completion BEFORE the loop continues on [first, cut);
+      // the two ranges are disjoint, so deferring the left part (stack) and continuing right is equivalent
+      stk_first[sp] = first; stk_last[sp] = cut; stk_depth[sp] = depth; ++sp;
+      first = cut;
+    }
+  }
+  if (n > 16) {                                                   // __final_insertion_sort
+    insertion_sort(p, 0, 16);
+    for (int i = 16; i < n; ++i) unguarded_linear_insert(p, i);
+  } else {
+    insertion_sort(p, 0, n);
+  }
+}
+
+}  // namespace stl_emul

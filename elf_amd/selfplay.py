@@ -1,0 +1,146 @@
+"""Host side of MCTS self-play over the C ABI (include/elf_amd.h, elfsp_* / elfmcts_*).
+
+Mirrors the reference's option structs and batch interface:
+  TSOptions / SearchAlgoOptions      src_cpp/elf/ai/tree_search/tree_search_options.h:23-229
+  GameOptions (subset)               src_cpp/elfgames/go/common/go_game_specific.h:16-268
+  GCWrapper.reg_callback / run       src_py/elf/utils_elf.py:340-359,426-437
+The policy/value net stays a PyTorch module called through the callback with batch["s"]; it returns
+"pi" [B, N*N+1] and "V" [B] exactly as Evaluator.actor does (src_py/rlpytorch/trainer/trainer.py:73-116).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class MctsOptions(C.Structure):
+    """ElfMctsOptions"""
+    _fields_ = [("num_rollouts_per_batch", C.c_int32), ("virtual_loss", C.c_int32), ("use_prior", C.c_int32),
+                ("unexplored_q_zero", C.c_int32), ("root_unexplored_q_zero", C.c_int32), ("c_puct", C.c_float),
+                ("komi", C.c_float), ("ply_pass_enabled", C.c_int32), ("remove_pass_if_dangerous", C.c_int32),
+                ("rotation_flip", C.c_int32)]
+
+
+class SpOptions(C.Structure):
+    """ElfSpOptions"""
+    _fields_ = [("board_size", C.c_int32), ("num_games", C.c_int32), ("nodes_per_game", C.c_int32),
+                ("num_rollouts_per_thread", C.c_int32), ("persistent_tree", C.c_int32), ("root_epsilon", C.c_float),
+                ("root_alpha", C.c_float), ("seed", C.c_uint32), ("policy_distri_cutoff", C.c_int32),
+                ("move_cutoff", C.c_int32), ("resign_thres", C.c_float), ("never_resign_prob", C.c_float),
+                ("log_searches", C.c_int32), ("mcts", MctsOptions)]
+
+
+class SpSearch(C.Structure):
+    """ElfSpSearch"""
+    _fields_ = [("game", C.c_int32), ("move_played", C.c_int32), ("best_action", C.c_int32), ("total_visits", C.c_int32),
+                ("n_edges", C.c_int32), ("root_value", C.c_float), ("max_score", C.c_float), ("predicted_value", C.c_float)]
+
+
+STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_per_move", "step_in_move")
+
+
+class SelfPlay:
+    """G self-play games in lock-step on one GPU; trees, boards and leaf features live in HBM."""
+
+    def __init__(self, board_size=19, num_games=16, device=0, mcts_rollout_per_thread=8192, mcts_rollout_per_batch=16,
+                 mcts_puct=1.5, mcts_virtual_loss=1, mcts_use_prior=True, mcts_persistent_tree=True, mcts_epsilon=0.0,
+                 mcts_alpha=0.0, mcts_unexplored_q_zero=False, mcts_root_unexplored_q_zero=False, komi=7.5,
+                 ply_pass_enabled=0, policy_distri_cutoff=0, move_cutoff=-1, resign_thres=0.0, never_resign_prob=0.0,
+                 seed=0, nodes_per_game=None, log_searches=0, rotation_flip=True, remove_pass_if_dangerous=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("elf_amd.SelfPlay needs a ROCm GPU (no CPU fallback exists)")
+        self.L = _lib.lib()
+        self.n = int(board_size)
+        self.num_games = int(num_games)
+        self.device = torch.device("cuda", device)
+        self.num_action = self.n * self.n + 1
+        if nodes_per_game is None:
+            # one node per rollout of the current search + the subtree kept from the previous ones
+            nodes_per_game = 4 * mcts_rollout_per_thread + 1024
+        nodes_per_game = (int(nodes_per_game) + 63) // 64 * 64
+        mo = MctsOptions(mcts_rollout_per_batch, mcts_virtual_loss, int(mcts_use_prior), int(mcts_unexplored_q_zero),
+                         int(mcts_root_unexplored_q_zero), mcts_puct, komi, ply_pass_enabled, int(remove_pass_if_dangerous),
+                         int(rotation_flip))
+        self.opt = SpOptions(self.n, self.num_games, nodes_per_game, mcts_rollout_per_thread, int(mcts_persistent_tree),
+                             mcts_epsilon, mcts_alpha, seed, policy_distri_cutoff, move_cutoff, resign_thres, never_resign_prob,
+                             log_searches, mo)
+        z = np.fromfile(_lib.ZOBRIST_BIN, dtype="<u8")
+        zz = np.ascontiguousarray(z[: (self.n + 2) ** 2])
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        check(self.L.elfsp_create(C.byref(self.opt), device, zz.ctypes.data, C.byref(h)))
+        self._h = h
+        self.max_rows = self.L.elfsp_max_rows(self._h)
+        self.edge_stride = self.L.elfmcts_edge_stride(self.L.elfsp_mcts(self._h))
+        # the batcher's "s" tensor (common/game_feature.h:159-163): [B, 18, N, N] f32 -- resident in HBM
+        self.s = torch.zeros((self.max_rows, 18, self.n, self.n), dtype=torch.float32, device=self.device)
+        self._rows = C.c_int(0)
+        self._cb = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.elfsp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- batch interface
+    def begin_step(self):
+        check(self.L.elfsp_begin_step(self._h, C.c_void_p(self.s.data_ptr()), 18 * self.n * self.n, C.byref(self._rows),
+                                      self._stream()))
+        return self._rows.value
+
+    def end_step(self, pi, v):
+        rows = self._rows.value
+        if rows:
+            if pi.dtype != torch.float32 or not pi.is_contiguous():
+                pi = pi.float().contiguous()
+            if v.dtype != torch.float32 or not v.is_contiguous():
+                v = v.float().contiguous()
+            v = v.reshape(-1)
+            if pi.shape[0] < rows or pi.shape[1] != self.num_action or v.shape[0] < rows:
+                raise ValueError("reply shapes do not match the batch")
+            check(self.L.elfsp_end_step(self._h, C.c_void_p(pi.data_ptr()), pi.stride(0), C.c_void_p(v.data_ptr()), self._stream()))
+        else:
+            check(self.L.elfsp_end_step(self._h, None, 0, None, self._stream()))
+
+    def reg_callback(self, key, cb):
+        """GCWrapper.reg_callback (utils_elf.py:340-359): cb(batch) -> dict(pi=..., V=...)"""
+        self._cb[key] = cb
+
+    def run(self):
+        """GCWrapper.run (utils_elf.py:426-437): serve one batch."""
+        rows = self.begin_step()
+        reply = {"pi": None, "V": None}
+        if rows:
+            cb = self._cb.get("actor_black") or self._cb.get("actor")
+            reply = cb({"s": self.s[:rows]})
+        self.end_step(reply["pi"], reply["V"])
+        return rows
+
+    # ---- results
+    def stats(self):
+        out = (C.c_int64 * 8)()
+        check(self.L.elfsp_stats(self._h, out))
+        return dict(zip(STAT_FIELDS, [int(x) for x in out]))
+
+    def search_log(self):
+        n = self.stats()["logged"]
+        rec = (SpSearch * n)()
+        ne = self.edge_stride
+        coord = np.zeros((n, ne), np.int32); visits = np.zeros((n, ne), np.int32)
+        prior = np.zeros((n, ne), np.float32); reward = np.zeros((n, ne), np.float32)
+        if n:
+            check(self.L.elfsp_search_log(self._h, 0, n, rec, coord.ctypes.data, visits.ctypes.data, prior.ctypes.data,
+                                          reward.ctypes.data))
+        return list(rec), coord, visits, prior, reward

@@ -72,6 +72,117 @@ int elfgo_export_board(ElfGoEngine* e, const int32_t* ids, int n, uint8_t* colou
 int elfgo_playout(ElfGoEngine* e, const int32_t* ids, const uint64_t* seeds, int n, int max_steps,
                   uint32_t* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident MCTS (one tree per game) -- replaces, behind the same seams, the reference's
+ *   elf/ai/tree_search/tree_search.h        TreeSearchT / TreeSearchSingleThreadT::batch_rollouts (:200-262)
+ *   elf/ai/tree_search/tree_search_node.h   NodeT / SearchTreeT
+ *   elfgames/go/mcts/mcts.h                 MCTSActor::evaluate / pi2response (:73-121, :256-332)
+ * The net stays outside: elfmcts_select() writes the leaf features of every game into the caller's
+ * "s" tensor (the write GoFeature::extractStateAGZ does into the batcher's tensor, common/game_feature.h:38-40)
+ * and elfmcts_expand() consumes the caller's "pi"/"V" reply tensors (ReplyPolicy/ReplyValue, :42-71).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ElfMcts ElfMcts;
+
+/* TSOptions + SearchAlgoOptions (elf/ai/tree_search/tree_search_options.h:23-229), MCTSActorParams (go/mcts/mcts.h:17-37) */
+typedef struct ElfMctsOptions {
+  int32_t num_rollouts_per_batch;   /* TSOptions.num_rollouts_per_batch, <= 64 */
+  int32_t virtual_loss;             /* TSOptions.virtual_loss */
+  int32_t use_prior;                /* alg_opt.use_prior */
+  int32_t unexplored_q_zero;        /* alg_opt.unexplored_q_zero */
+  int32_t root_unexplored_q_zero;   /* alg_opt.root_unexplored_q_zero */
+  float c_puct;                     /* alg_opt.c_puct */
+  float komi;                       /* MCTSActorParams.komi */
+  int32_t ply_pass_enabled;         /* MCTSActorParams.ply_pass_enabled */
+  int32_t remove_pass_if_dangerous; /* MCTSActorParams.remove_pass_if_dangerous */
+  int32_t rotation_flip;            /* MCTSActorParams.rotation_flip */
+} ElfMctsOptions;
+
+#define ELFMCTS_E_POOL 1      /* node pool of some game exhausted (raise nodes_per_game) */
+#define ELFMCTS_E_ROOT_HASH 2 /* TreeSearch::Root state is not the same as the input state (tree_search.h:488-492) */
+#define ELFMCTS_E_FORWARD 4   /* a tree edge could not be played */
+#define ELFMCTS_E_RNG 8       /* more D4 draws requested than uploaded with elfmcts_set_d4 */
+
+#define ELFMCTS_ROOT_WORDS 8
+/* per-game record of elfmcts_root (int32 words): 0 n_edges 1 num_visits 2 status 3 root id 4 V (float bits)
+ * 5 d4 draws consumed this move 6 error bits 7 free node ids */
+
+/* `num_games` trees over boards of engine `e` (game g searches from board slot board_ids[g]);
+ * nodes_per_game (multiple of 64) fixed-size node records each; d4_window = max D4 draws per move. */
+int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_window, const ElfMctsOptions* opt, ElfMcts** out);
+int elfmcts_destroy(ElfMcts* m);
+int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt);
+int elfmcts_num_games(const ElfMcts* m);
+int elfmcts_edge_stride(const ElfMcts* m);   /* row length of the per-edge arrays (368 at 19x19, 96 at 9x9) */
+size_t elfmcts_node_bytes(const ElfMcts* m);
+/* SearchTreeT::clear (tree_search_node.h:411-416) for games[0..n) (device int32, NULL = all games) */
+int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream);
+/* TreeSearchT::setRootNodeState (tree_search.h:478-493) for every game; board_ids device int32 or NULL (slot g) */
+int elfmcts_set_root(ElfMcts* m, const int32_t* board_ids, void* stream);
+/* rng() % 8 draws of the actor's mt19937 (BoardFeature::RandomShuffle, board_feature.h:74-78), host uint8 [num_games][d4_window] */
+int elfmcts_set_d4(ElfMcts* m, const uint8_t* d4_host, void* stream);
+/* NodeT::enhanceExploration (tree_search_node.h:132-155): etas device f32 [num_games][edge_stride] in edge
+ * iteration order, Z device f32 [num_games] (= 1e-10 + sum of etas, accumulated in fp32 on the host) */
+int elfmcts_dirichlet(ElfMcts* m, const float* etas, const float* Z, float epsilon, void* stream);
+/* first half of batch_rollouts (:205-233): num_rollouts_per_batch descents per game, then the features of
+ * every leaf that needs the net into s_dst (row r at s_dst + r*stride_floats, rows game-major);
+ * counts (device int32[2]) <- {rows, OR of error bits}. */
+int elfmcts_select(ElfMcts* m, const int32_t* board_ids, float* s_dst, int64_t stride_floats, int32_t* counts, void* stream);
+/* second half (:235-259): pi2response + setEvaluation for the n_rows leaves of the last select, then backup */
+int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const float* value, int n_rows, void* stream);
+/* root edges in the reference's iteration order (what MCTSResultT::addActions walks, tree_search_base.h:237-294);
+ * info device int32 [num_games][ELFMCTS_ROOT_WORDS]; the per-edge outputs ([num_games][edge_stride]) may be NULL */
+int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, float* prior, float* reward, int32_t* child, void* stream);
+/* SearchTreeT::treeAdvance (tree_search_node.h:420-436), moves device int32 [num_games] (reference Coords) */
+int elfmcts_advance(ElfMcts* m, const int32_t* moves, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-play driver: G games advanced in lock-step on one GPU -- the host half of
+ *   elfgames/go/common/game_selfplay.cc  GoGameSelfPlay::act (:272-430) and
+ *   elf/ai/tree_search/mcts.h            MCTSAI_T::act (:59-81)
+ * One elfsp_begin_step / elfsp_end_step pair is one batch of the reference's batch interface
+ * (GCWrapper._call, src_py/elf/utils_elf.py:368-414): begin fills "s" rows [0, n_rows), the caller runs the
+ * net, end consumes "pi" and "V".  Moves, Dirichlet noise, move sampling, resignation and game restarts
+ * happen inside end_step when a search completes.
+ * ------------------------------------------------------------------------------------------------ */
+#define ELFGO_E_MCTS_BASE (-100) /* status = ELFGO_E_MCTS_BASE - (OR of ELFMCTS_E_* bits) */
+typedef struct ElfSelfPlay ElfSelfPlay;
+
+typedef struct ElfSpOptions {
+  int32_t board_size;               /* 19 or 9 */
+  int32_t num_games;                /* ContextOptions.num_games (games per GPU) */
+  int32_t nodes_per_game;           /* node records per tree (multiple of 64) */
+  int32_t num_rollouts_per_thread;  /* TSOptions.num_rollouts_per_thread; one search thread per game */
+  int32_t persistent_tree;          /* TSOptions.persistent_tree */
+  float root_epsilon, root_alpha;   /* TSOptions.root_epsilon / root_alpha */
+  uint32_t seed;                    /* GameOptions.seed; game g uses seed + g when num_games > 1 */
+  int32_t policy_distri_cutoff;     /* GameOptions.policy_distri_cutoff */
+  int32_t move_cutoff;              /* GameOptions.move_cutoff */
+  float resign_thres;               /* ClientCtrl.{black,white}_resign_thres */
+  float never_resign_prob;          /* ClientCtrl.never_resign_prob */
+  int32_t log_searches;             /* keep the first N search results for elfsp_search_log (tests) */
+  ElfMctsOptions mcts;
+} ElfSpOptions;
+
+/* what GameNotifierBase::OnMCTSResult (common/notifier.h:13) sees after one search */
+typedef struct ElfSpSearch {
+  int32_t game, move_played, best_action, total_visits, n_edges;
+  float root_value, max_score, predicted_value;
+} ElfSpSearch;
+
+int elfsp_create(const ElfSpOptions* opt, int device, const uint64_t* zobrist_host, ElfSelfPlay** out);
+int elfsp_destroy(ElfSelfPlay* sp);
+ElfGoEngine* elfsp_engine(ElfSelfPlay* sp);
+ElfMcts* elfsp_mcts(ElfSelfPlay* sp);
+int elfsp_max_rows(const ElfSelfPlay* sp);   /* num_games * num_rollouts_per_batch */
+/* s_dst device f32, rows stride_floats apart; *n_rows (host) <- rows that need the net this step */
+int elfsp_begin_step(ElfSelfPlay* sp, float* s_dst, int64_t stride_floats, int* n_rows, void* stream);
+int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, void* stream);
+/* out[8]: moves played, games finished, rollouts, net rows, steps, searches logged, steps per move, step in move */
+int elfsp_stats(const ElfSelfPlay* sp, int64_t* out);
+/* logged searches [first, first+n): records and root edges (host arrays, [n][edge_stride], may be NULL) */
+int elfsp_search_log(const ElfSelfPlay* sp, int first, int n, ElfSpSearch* rec, int32_t* coord, int32_t* visits, float* prior,
+                     float* reward);
+
 /* convenience for callers without a HIP runtime of their own (tests, cgo/ctypes stubs) */
 int elfgo_malloc(void** dptr, size_t bytes);
 int elfgo_free(void* dptr);

@@ -1,0 +1,59 @@
+"""Generates tests/golden/mcts_*.npz from the REAL reference self-play stack (oracle/_ref/libelfsp*.so =
+elf::Context + GoGameSelfPlay + MCTSGoAI/MCTSActor + tree_search/*.h compiled in place from /root/reference),
+fed by the deterministic stub net of oracle/stub_net.h.  Run in the build container only:
+    python oracle/gen_golden_mcts.py
+Per search (= per move) the fixture holds what GameNotifierBase::OnMCTSResult reports: the move played, the
+most-visited action, root value, and the root edges IN THE REFERENCE'S ITERATION ORDER with prior, visit
+count and accumulated reward.  One search thread (deterministic); V is a multiple of 1/256 so
+the backup order cannot matter (H2).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from pyoracle import MCTS_DEFAULTS, RefSelfPlay  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+CASES = {
+    # name: (board size, overrides)
+    "mcts_19_r8192": (19, dict(rollouts_per_thread=8192, max_searches=3)),                      # BASELINE config 3 search settings
+    "mcts_19_r256_dir": (19, dict(rollouts_per_thread=256, max_searches=24, policy_distri_cutoff=10)),
+    "mcts_19_r256_ties": (19, dict(rollouts_per_thread=256, max_searches=12, net_tie_levels=5, root_epsilon=0.0)),
+    "mcts_19_r512_client": (19, dict(rollouts_per_thread=512, rollouts_per_batch=8, virtual_loss=5, c_puct=0.85, max_searches=10,
+                                     ply_pass_enabled=3, policy_distri_cutoff=30, net_salt=11)),   # start_client.sh flavour
+    "mcts_19_r128_fresh": (19, dict(rollouts_per_thread=128, persistent_tree=0, max_searches=10, root_epsilon=0.0,
+                                    unexplored_q_zero=1)),
+    "mcts_9_r512": (9, dict(rollouts_per_thread=512, max_searches=70, policy_distri_cutoff=6, net_salt=3)),   # plays to game end
+    "mcts_9_r64_ties": (9, dict(rollouts_per_thread=64, max_searches=60, net_tie_levels=3, root_epsilon=0.1, root_alpha=0.5)),
+}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, (n, kw) in CASES.items():
+        R = RefSelfPlay(n)
+        cfg = dict(MCTS_DEFAULTS)
+        cfg.update(kw)
+        r = R.run(**cfg)
+        r2 = R.run(**cfg)
+        assert all(np.array_equal(r[k], r2[k]) for k in ("coord", "visits", "prior", "reward")), "reference not deterministic"
+        S = r["search"]
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            board_size=np.int32(n),
+            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], np.float64),
+            move_played=np.array([s.move_played for s in S], np.int32),
+            best_action=np.array([s.best_action for s in S], np.int32),
+            total_visits=np.array([s.total_visits for s in S], np.int32),
+            n_edges=np.array([s.n_edges for s in S], np.int32),
+            root_value=np.array([s.root_value for s in S], np.float32),
+            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"])
+        print(name, "searches", len(S), "moves", [s.move_played for s in S][:12], "rows", r["rows"], "ref search s", r["usec"] / 1e6)
+
+
+if __name__ == "__main__":
+    main()

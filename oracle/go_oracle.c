@@ -407,3 +407,9 @@ int orc_playout_moves(OrcState* st, uint64_t seed, int max_steps, int32_t* moves
   }
   return steps;
 }
+
+/* ---- deterministic stub net shared with oracle/ref_selfplay.cc (oracle/stub_net.h) ---- */
+#include "stub_net.h"
+void orc_stub_net(const float* s, int batch, uint32_t salt, int tie_levels, float* pi, float* v) {
+  stubnet_eval(s, batch, ORC_N, salt, tie_levels, pi, v);
+}

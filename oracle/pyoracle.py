@@ -194,3 +194,83 @@ class Ref(_Engine):
         self.L.ref_zobrist.argtypes = [C.c_void_p]
         self.L.ref_zobrist(z.ctypes.data)
         return z
+
+
+# ---- MCTS / self-play: the real reference stack (oracle/ref_selfplay.cc) and the stub net ----------------
+class RefSpConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_games", "batchsize", "mcts_threads", "rollouts_per_thread", "rollouts_per_batch",
+                                         "virtual_loss", "persistent_tree", "use_prior", "unexplored_q_zero",
+                                         "root_unexplored_q_zero")] + \
+        [("c_puct", C.c_float), ("root_epsilon", C.c_float), ("root_alpha", C.c_float), ("seed", C.c_uint32), ("komi", C.c_float),
+         ("ply_pass_enabled", C.c_int32), ("policy_distri_cutoff", C.c_int32), ("move_cutoff", C.c_int32),
+         ("resign_thres", C.c_float), ("never_resign_prob", C.c_float), ("net_salt", C.c_uint32), ("net_tie_levels", C.c_int32),
+         ("max_searches", C.c_int32), ("timeout_usec", C.c_int32)]
+
+
+class RefSpSearch(C.Structure):
+    _fields_ = [("game", C.c_int32), ("move_played", C.c_int32), ("best_action", C.c_int32), ("total_visits", C.c_int32),
+                ("n_edges", C.c_int32), ("root_value", C.c_float), ("max_score", C.c_float), ("pad", C.c_int32)]
+
+
+MCTS_DEFAULTS = dict(num_games=1, batchsize=16, mcts_threads=1, rollouts_per_thread=8192, rollouts_per_batch=16, virtual_loss=1,
+                     persistent_tree=1, use_prior=1, unexplored_q_zero=0, root_unexplored_q_zero=0, c_puct=1.5, root_epsilon=0.25,
+                     root_alpha=0.03, seed=1234, komi=7.5, ply_pass_enabled=0, policy_distri_cutoff=0, move_cutoff=-1,
+                     resign_thres=0.0, never_resign_prob=0.0, net_salt=7, net_tie_levels=0, max_searches=4, timeout_usec=10)
+
+
+class RefSelfPlay:
+    """The reference's own Context + GoGameSelfPlay + MCTSGoAI, net = stub (or a Python callback)."""
+
+    @staticmethod
+    def path(n):
+        return os.path.join(HERE, "_ref", "libelfsp%d.so" % n)
+
+    @classmethod
+    def available(cls, n):
+        return os.path.exists(cls.path(n))
+
+    def __init__(self, n):
+        self.n = n
+        self.na = n * n + 1
+        self.L = C.CDLL(self.path(n))
+        self.L.refsp_run.restype = C.c_int
+
+    def run(self, net=None, **kw):
+        """-> dict(search=list[RefSpSearch], coord, visits, prior, reward [k, NA], stats)"""
+        cfg = dict(MCTS_DEFAULTS)
+        cfg.update(kw)
+        c = RefSpConfig(**cfg)
+        m, na = c.max_searches, self.na
+        S = (RefSpSearch * m)()
+        coord = np.full((m, na), -1, np.int32); visits = np.zeros((m, na), np.int32)
+        prior = np.zeros((m, na), np.float32); reward = np.zeros((m, na), np.float32)
+        stats = (C.c_int64 * 3)()
+        cb = None
+        if net is not None:
+            NETFN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+            n = self.n
+
+            def _net(sp, b, pip, vp, _u):
+                s = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_float)), shape=(b, 18, n, n))
+                pi, v = net(s)
+                np.ctypeslib.as_array(C.cast(pip, C.POINTER(C.c_float)), shape=(b, na))[:] = pi
+                np.ctypeslib.as_array(C.cast(vp, C.POINTER(C.c_float)), shape=(b,))[:] = v
+            cb = NETFN(_net)
+        k = self.L.refsp_run(C.byref(c), cb, None, S, coord.ctypes.data_as(C.c_void_p), visits.ctypes.data_as(C.c_void_p),
+                             prior.ctypes.data_as(C.c_void_p), reward.ctypes.data_as(C.c_void_p), stats)
+        if k < 0:
+            raise RuntimeError("refsp_run failed")
+        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
+                    batches=int(stats[0]), rows=int(stats[1]), usec=int(stats[2]))
+
+
+def stub_net(n, s, salt=7, tie_levels=0):
+    """oracle/stub_net.h through the port library: s [B,18,n,n] f32 -> (pi [B,n*n+1], v [B])"""
+    L = C.CDLL(os.path.join(HERE, "libgo_oracle%d.so" % n))
+    s = np.ascontiguousarray(s, dtype=np.float32)
+    b = s.shape[0]
+    pi = np.zeros((b, n * n + 1), np.float32)
+    v = np.zeros((b,), np.float32)
+    L.orc_stub_net(s.ctypes.data_as(C.c_void_p), C.c_int(b), C.c_uint32(salt), C.c_int(tie_levels), pi.ctypes.data_as(C.c_void_p),
+                   v.ctypes.data_as(C.c_void_p))
+    return pi, v

@@ -1,0 +1,279 @@
+// TEST INFRASTRUCTURE ONLY -- not part of the product path.
+//
+// The REAL reference self-play stack, compiled in place from /root/reference by oracle/Makefile into
+// oracle/_ref/libelfsp{19,9}.so:  elf::Context batcher (elf/base/context.h) + ThreadedDispatcher +
+// GoGameSelfPlay (elfgames/go/common/game_selfplay.cc) + MCTSGoAI / MCTSActor (elfgames/go/mcts/mcts.h)
+// + the generic tree search (elf/ai/tree_search/*.h).  This file only plays the role of the Python
+// half (GCWrapper, src_py/elf/utils_elf.py:291-437, and GameContext, inference/game_context.h:31-69):
+// it allocates the batch buffers, serves "actor_black"/"actor_white" batches with a net function, and
+// records what GameNotifierBase::OnMCTSResult (common/notifier.h:13) reports after every search.
+// Nothing from the reference is copied into this repository.
+//
+// Used (a) to generate tests/golden/mcts_*.npz (oracle/gen_golden_mcts.py), (b) as the CPU baseline of
+// kind "reference" for MCTS rollouts/s in bench.py.
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "elf/base/context.h"
+#include "elf/base/dispatcher.h"
+#include "elfgames/go/common/dispatcher_callback.h"
+#include "elfgames/go/common/game_feature.h"
+#include "elfgames/go/common/game_selfplay.h"
+#include "elfgames/go/common/go_game_specific.h"
+
+#include "stub_net.h"
+
+extern "C" {
+
+// Mirrors the option structs the reference exposes to Python (TSOptions tree_search_options.h:77-229,
+// GameOptions go_game_specific.h:16-268); plain C so ctypes can fill it.
+struct RefSpConfig {
+  int32_t num_games;            // ContextOptions.num_games
+  int32_t batchsize;            // ContextOptions.batchsize
+  int32_t mcts_threads;         // TSOptions.num_threads
+  int32_t rollouts_per_thread;  // TSOptions.num_rollouts_per_thread
+  int32_t rollouts_per_batch;   // TSOptions.num_rollouts_per_batch
+  int32_t virtual_loss;         // TSOptions.virtual_loss
+  int32_t persistent_tree;      // TSOptions.persistent_tree
+  int32_t use_prior;            // alg_opt.use_prior
+  int32_t unexplored_q_zero, root_unexplored_q_zero;
+  float c_puct, root_epsilon, root_alpha;
+  uint32_t seed;                // GameOptions.seed (game idx i uses seed + i when num_games > 1: see below)
+  float komi;
+  int32_t ply_pass_enabled, policy_distri_cutoff, move_cutoff;
+  float resign_thres;           // ClientCtrl black/white_resign_thres (setRequest)
+  float never_resign_prob;      // ClientCtrl.never_resign_prob
+  // stub net
+  uint32_t net_salt;
+  int32_t net_tie_levels;
+  // stop after this many searches (summed over games) have been recorded
+  int32_t max_searches;
+  int32_t timeout_usec;         // batch collector timeout (game.py:365-402 --gpu path uses 10)
+};
+
+// One record per finished search (MCTSAI_T::act), in completion order.
+struct RefSpSearch {
+  int32_t game;          // game index (thread)
+  int32_t move_played;   // Coord passed to OnMCTSResult: after mcts_make_diverse_move / mcts_update_info
+  int32_t best_action;   // MCTSResult.best_action (most visited)
+  int32_t total_visits;  // MCTSResult.total_visits
+  int32_t n_edges;
+  float root_value;      // MCTSResult.root_value
+  float max_score;
+  int32_t pad;
+};
+
+typedef void (*refsp_net_fn)(const float* s, int batch, float* pi, float* v, void* user);
+
+}  // extern "C"
+
+namespace {
+
+struct Capture : public GameNotifierBase {
+  std::mutex m;
+  int max_searches = 0;
+  std::vector<RefSpSearch> searches;
+  std::vector<int32_t> coord, visits, child;   // [search][BOARD_NUM_ACTION], root edges in ITERATION order
+  std::vector<float> prior, reward;
+  std::atomic<int> count{0};
+  int game_of_thread(const std::thread::id&) { return 0; }
+
+  void OnMCTSResult(Coord c, const MCTSResult& r) override {
+    std::lock_guard<std::mutex> l(m);
+    if ((int)searches.size() >= max_searches) return;
+    RefSpSearch s;
+    memset(&s, 0, sizeof(s));
+    s.game = current_game;
+    s.move_played = c;
+    s.best_action = r.best_action;
+    s.total_visits = r.total_visits;
+    s.n_edges = (int)r.action_edge_pairs.size();
+    s.root_value = r.root_value;
+    s.max_score = r.max_score;
+    searches.push_back(s);
+    const size_t base = coord.size();
+    coord.resize(base + BOARD_NUM_ACTION, -1);
+    visits.resize(base + BOARD_NUM_ACTION, 0);
+    child.resize(base + BOARD_NUM_ACTION, -1);
+    prior.resize(base + BOARD_NUM_ACTION, 0.f);
+    reward.resize(base + BOARD_NUM_ACTION, 0.f);
+    for (size_t i = 0; i < r.action_edge_pairs.size(); ++i) {
+      coord[base + i] = r.action_edge_pairs[i].first;
+      visits[base + i] = r.action_edge_pairs[i].second.num_visits;
+      child[base + i] = r.action_edge_pairs[i].second.child_node;
+      prior[base + i] = r.action_edge_pairs[i].second.prior_probability;
+      reward[base + i] = r.action_edge_pairs[i].second.reward;
+    }
+    count++;
+  }
+  int current_game = 0;   // parity runs use num_games == 1
+};
+
+struct Buffers {
+  std::vector<float> s, pi, V;
+  std::vector<int64_t> a, rv, black_ver, white_ver;
+};
+
+}  // namespace
+
+extern "C" {
+
+int refsp_board_size() { return BOARD_SIZE; }
+
+// Runs reference self-play until cfg->max_searches searches have been captured.
+// out arrays sized [max_searches] / [max_searches][BOARD_NUM_ACTION]. Returns the number captured
+// (<0 on error).  stats[0] = batches served, stats[1] = rows served, stats[2] = wall seconds * 1e6.
+int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSearch* out_search, int32_t* out_coord,
+              int32_t* out_visits, float* out_prior, float* out_reward, int64_t* stats) {
+  try {
+    ContextOptions co;
+    co.num_games = cfg->num_games;
+    co.batchsize = cfg->batchsize;
+    auto& ts = co.mcts_options;
+    ts.num_threads = cfg->mcts_threads;
+    ts.num_rollouts_per_thread = cfg->rollouts_per_thread;
+    ts.num_rollouts_per_batch = cfg->rollouts_per_batch;
+    ts.virtual_loss = cfg->virtual_loss;
+    ts.persistent_tree = cfg->persistent_tree != 0;
+    ts.root_epsilon = cfg->root_epsilon;
+    ts.root_alpha = cfg->root_alpha;
+    ts.alg_opt.use_prior = cfg->use_prior != 0;
+    ts.alg_opt.c_puct = cfg->c_puct;
+    ts.alg_opt.unexplored_q_zero = cfg->unexplored_q_zero != 0;
+    ts.alg_opt.root_unexplored_q_zero = cfg->root_unexplored_q_zero != 0;
+    ts.pick_method = "most_visited";
+
+    GameOptions opt;
+    opt.mode = "selfplay";
+    opt.seed = cfg->seed;
+    opt.komi = cfg->komi;
+    opt.ply_pass_enabled = cfg->ply_pass_enabled;
+    opt.policy_distri_cutoff = cfg->policy_distri_cutoff;
+    opt.move_cutoff = cfg->move_cutoff;
+    opt.use_mcts = true;
+    opt.port = 0;
+
+    const int n = cfg->num_games, B = cfg->batchsize;
+    elf::Context ctx;
+    GoFeature gf(opt);
+    gf.registerExtractor(B, ctx.getExtractor());
+
+    using ThreadedDispatcher = GoGameSelfPlay::ThreadedDispatcher;
+    Ctrl ctrl;
+    ThreadedDispatcher disp(ctrl, n);
+    DispatcherCallback dcb(&disp, ctx.getClient());
+
+    Capture cap;
+    cap.max_searches = cfg->max_searches;
+    std::vector<std::unique_ptr<GoGameSelfPlay>> games;
+    for (int i = 0; i < n; ++i) {
+      GameOptions gopt = opt;
+      if (n > 1 && cfg->seed != 0) gopt.seed = cfg->seed + i;   // distinct games in throughput runs
+      games.emplace_back(new GoGameSelfPlay(i, ctx.getClient(), co, gopt, &disp, &cap));
+    }
+    ctx.setStartCallback(n, [&](int i, elf::GameClient*) {
+      disp.RegGame(i);
+      games[i]->mainLoop();
+    });
+
+    // what Allocator.spec2batches does (utils_elf.py:59-99) with the desc of game.py:365-402, num_recv = 2
+    struct Group { const char* name; std::vector<std::string> keys; int bs; int timeout; };
+    std::vector<Group> groups = {
+        {"actor_black", {"s", "pi", "V", "a", "rv"}, B, cfg->timeout_usec},
+        {"actor_white", {"s", "pi", "V", "a", "rv"}, B, cfg->timeout_usec},
+        {"game_start", {"black_ver", "white_ver"}, 1, 0},
+        {"game_end", {}, 1, 0},
+    };
+    std::vector<Buffers> bufs;
+    bufs.reserve(groups.size() * 2 + 1);
+    std::vector<int> idx2buf;
+    for (auto& g : groups) {
+      for (int r = 0; r < 2; ++r) {
+        auto smo = ctx.createSharedMemOptions(g.name, g.bs);
+        smo.setTimeout(g.timeout);
+        elf::SharedMem& sm = ctx.allocateSharedMem(smo, g.keys);
+        bufs.emplace_back();
+        Buffers& b = bufs.back();
+        const int idx = sm.getSharedMemOptions().getIdx();
+        if ((int)idx2buf.size() <= idx) idx2buf.resize(idx + 1, -1);
+        idx2buf[idx] = (int)bufs.size() - 1;
+        for (const auto& k : g.keys) {
+          elf::AnyP* p = sm[k];
+          const auto& f = p->field();
+          const size_t ne = f.getSize().nelement();
+          void* addr = nullptr;
+          if (k == "s") { b.s.assign(ne, 0.f); addr = b.s.data(); }
+          else if (k == "pi") { b.pi.assign(ne, 0.f); addr = b.pi.data(); }
+          else if (k == "V") { b.V.assign(ne, 0.f); addr = b.V.data(); }
+          else if (k == "a") { b.a.assign(ne, 0); addr = b.a.data(); }
+          else if (k == "rv") { b.rv.assign(ne, 0); addr = b.rv.data(); }
+          else if (k == "black_ver") { b.black_ver.assign(ne, 0); addr = b.black_ver.data(); }
+          else if (k == "white_ver") { b.white_ver.assign(ne, 0); addr = b.white_ver.data(); }
+          p->setAddress((uint64_t)addr, f.getSize().getContinuousStrides(f.getSizeOfType()).vec());
+        }
+      }
+    }
+
+    ctx.start();
+    {
+      // Client::setRequest (train/distri_client.h:318-331) / GameContext::setRequest (inference/game_context.h:76-88)
+      MsgRequest req;
+      req.vers.black_ver = 0;
+      req.vers.white_ver = -1;   // self-play: one AI plays both colours
+      req.vers.mcts_opt = co.mcts_options;
+      req.client_ctrl.black_resign_thres = cfg->resign_thres;
+      req.client_ctrl.white_resign_thres = cfg->resign_thres;
+      req.client_ctrl.never_resign_prob = cfg->never_resign_prob;
+      req.client_ctrl.num_game_thread_used = n;
+      disp.sendToThread(req);
+    }
+
+    int64_t batches = 0, rows = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int NA = BOARD_NUM_ACTION;
+    while (cap.count.load() < cfg->max_searches) {
+      const elf::SharedMem* sm = ctx.wait(100000);
+      if (sm == nullptr) { continue; }
+      const int eb = sm->getEffectiveBatchSize();
+      const auto& smo = sm->getSharedMemOptions();
+      Buffers& b = bufs[idx2buf[smo.getIdx()]];
+      const std::string& label = smo.getLabel();
+      if (label == "actor_black" || label == "actor_white") {
+        if (net) net(b.s.data(), eb, b.pi.data(), b.V.data(), net_user);
+        else stubnet_eval(b.s.data(), eb, BOARD_SIZE, cfg->net_salt, cfg->net_tie_levels, b.pi.data(), b.V.data());
+        for (int i = 0; i < eb; ++i) { b.rv[i] = 0; b.a[i] = 0; }
+        (void)NA;
+        batches++; rows += eb;
+      }
+      ctx.step();
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (stats) {
+      stats[0] = batches; stats[1] = rows;
+      stats[2] = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+    }
+    ctx.stop();
+
+    const int k = (int)cap.searches.size();
+    for (int i = 0; i < k; ++i) out_search[i] = cap.searches[i];
+    if (out_coord) memcpy(out_coord, cap.coord.data(), sizeof(int32_t) * (size_t)k * BOARD_NUM_ACTION);
+    if (out_visits) memcpy(out_visits, cap.visits.data(), sizeof(int32_t) * (size_t)k * BOARD_NUM_ACTION);
+    if (out_prior) memcpy(out_prior, cap.prior.data(), sizeof(float) * (size_t)k * BOARD_NUM_ACTION);
+    if (out_reward) memcpy(out_reward, cap.reward.data(), sizeof(float) * (size_t)k * BOARD_NUM_ACTION);
+    return k;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "refsp_run: %s\n", e.what());
+    return -1;
+  }
+}
+
+void refsp_stub_net(const float* s, int batch, uint32_t salt, int tie_levels, float* pi, float* v) {
+  stubnet_eval(s, batch, BOARD_SIZE, salt, tie_levels, pi, v);
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// Host check of elf_amd/csrc/stl_emul.h against the real libstdc++ containers/algorithms.
+// Built and run by tests/test_stl_emul.py (CPU only).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../elf_amd/csrc/stl_emul.h"
+
+typedef unsigned short Coord;
+
+static int check_umap(std::mt19937& rng, int n, int universe) {
+  std::vector<Coord> all(universe);
+  for (int i = 0; i < universe; ++i) all[i] = (Coord)i;
+  std::shuffle(all.begin(), all.end(), rng);
+  std::vector<Coord> keys(all.begin(), all.begin() + n);
+  std::unordered_map<Coord, int> m;
+  for (int i = 0; i < n; ++i) m.insert(std::make_pair(keys[i], i));
+  std::vector<int> order(n), tmp(2 * n + 2);
+  stl_emul::umap_iteration_order(keys.data(), n, order.data(), tmp.data());
+  int i = 0;
+  for (const auto& p : m) {
+    if (p.second != order[i]) return 1;
+    ++i;
+  }
+  return 0;
+}
+
+static int check_sort(std::vector<float> vals) {
+  const int n = (int)vals.size();
+  std::vector<std::pair<Coord, float>> ref(n);
+  std::vector<Coord> k(n);
+  std::vector<float> v(n);
+  for (int i = 0; i < n; ++i) { ref[i] = std::make_pair((Coord)i, vals[i]); k[i] = (Coord)i; v[i] = vals[i]; }
+  using T = std::pair<Coord, float>;
+  std::sort(ref.begin(), ref.end(), [](const T& a, const T& b) { return a.second > b.second; });
+  stl_emul::sort_desc(k.data(), v.data(), n);
+  for (int i = 0; i < n; ++i)
+    if (ref[i].first != k[i] || ref[i].second != v[i]) return 1;
+  return 0;
+}
+
+int main() {
+  std::mt19937 rng(12345);
+  int bad = 0, cases = 0;
+  for (int n = 0; n <= 362; ++n)
+    for (int rep = 0; rep < 6; ++rep) { bad += check_umap(rng, n, 441); ++cases; }
+  for (int n = 0; n <= 82; ++n)
+    for (int rep = 0; rep < 6; ++rep) { bad += check_umap(rng, n, 121); ++cases; }
+  for (int n = 363; n <= 441; n += 7) { bad += check_umap(rng, n, 441); ++cases; }
+  printf("umap cases %d bad %d\n", cases, bad);
+  int sbad = 0, scases = 0;
+  for (int n : {0, 1, 2, 3, 15, 16, 17, 18, 31, 33, 64, 82, 100, 200, 361, 362, 500, 1000}) {
+    for (int levels : {1, 2, 3, 5, 17, 1000, 1 << 20}) {
+      for (int rep = 0; rep < 8; ++rep) {
+        std::vector<float> v(n);
+        for (auto& x : v) x = (float)(rng() % (unsigned)levels) / (float)levels;
+        sbad += check_sort(v); ++scases;
+      }
+    }
+    std::vector<float> v(n);
+    for (int i = 0; i < n; ++i) v[i] = (float)i;                 sbad += check_sort(v); ++scases;   // ascending
+    for (int i = 0; i < n; ++i) v[i] = (float)(n - i);           sbad += check_sort(v); ++scases;   // descending
+    for (int i = 0; i < n; ++i) v[i] = (float)(i < n / 2 ? i : n - i);  sbad += check_sort(v); ++scases;  // organ pipe
+    for (int i = 0; i < n; ++i) v[i] = (float)(i % 2 ? i : -i);  sbad += check_sort(v); ++scases;
+  }
+  // median-of-3 killer (forces the heapsort fallback of introsort) for the descending comparator
+  for (int n : {362, 512, 1000}) {
+    std::vector<float> v(n);
+    int k = n / 2;
+    for (int i = 1; i <= k; ++i) {
+      if (i % 2 == 1) { v[i - 1] = (float)-i; v[i] = (float)-(k + i); }
+      v[k + i - 1] = (float)-(2 * i);
+    }
+    sbad += check_sort(v); ++scases;
+  }
+  printf("sort cases %d bad %d\n", scases, sbad);
+  return (bad || sbad) ? 1 : 0;
+}

@@ -1,0 +1,75 @@
+"""GPU: device-resident MCTS + self-play host loop vs golden fixtures produced by the REAL reference stack
+(oracle/gen_golden_mcts.py: elf::Context + GoGameSelfPlay + MCTSGoAI + tree_search/*.h), same stub net.
+Bar: bit-exact -- root edge ORDER (unordered_map iteration order), priors (after Dirichlet), visit counts,
+accumulated rewards, most-visited action, sampled move, root value, for every search of the fixture."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pyoracle import stub_net
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(elf_amd, name, max_searches=None):
+    import torch
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    n = int(g["board_size"])
+    m = len(g["move_played"]) if max_searches is None else min(max_searches, len(g["move_played"]))
+    sp = elf_amd.SelfPlay(
+        board_size=n, num_games=1, device=0, mcts_rollout_per_thread=int(cfg["rollouts_per_thread"]),
+        mcts_rollout_per_batch=int(cfg["rollouts_per_batch"]), mcts_puct=float(np.float32(cfg["c_puct"])),
+        mcts_virtual_loss=int(cfg["virtual_loss"]), mcts_use_prior=bool(cfg["use_prior"]),
+        mcts_persistent_tree=bool(cfg["persistent_tree"]), mcts_epsilon=float(np.float32(cfg["root_epsilon"])),
+        mcts_alpha=float(np.float32(cfg["root_alpha"])), mcts_unexplored_q_zero=bool(cfg["unexplored_q_zero"]),
+        mcts_root_unexplored_q_zero=bool(cfg["root_unexplored_q_zero"]), komi=float(np.float32(cfg["komi"])),
+        ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
+        move_cutoff=int(cfg["move_cutoff"]), resign_thres=float(np.float32(cfg["resign_thres"])),
+        never_resign_prob=float(np.float32(cfg["never_resign_prob"])), seed=int(cfg["seed"]), log_searches=m)
+    salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
+    rows_total = 0
+    while sp.stats()["logged"] < m:
+        rows = sp.begin_step()
+        rows_total += rows
+        if rows:
+            pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), salt, ties)
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        else:
+            sp.end_step(None, None)
+    rec, coord, visits, prior, reward = sp.search_log()
+    na = n * n + 1
+    for i in range(m):
+        ne = int(g["n_edges"][i])
+        ctx = "%s search %d" % (name, i)
+        assert rec[i].n_edges == ne, ctx
+        assert np.array_equal(coord[i, :ne], g["coord"][i, :ne].astype(np.int32)), ctx + ": edge iteration order"
+        assert np.array_equal(prior[i, :ne].view(np.uint32), g["prior"][i, :ne].view(np.uint32)), ctx + ": priors"
+        assert np.array_equal(visits[i, :ne], g["visits"][i, :ne]), ctx + ": visit counts"
+        assert np.array_equal(reward[i, :ne].view(np.uint32), g["reward"][i, :ne].view(np.uint32)), ctx + ": rewards"
+        assert rec[i].best_action == int(g["best_action"][i]), ctx
+        assert rec[i].total_visits == int(g["total_visits"][i]), ctx
+        assert np.float32(rec[i].root_value) == g["root_value"][i], ctx
+        assert rec[i].move_played == int(g["move_played"][i]), ctx + ": move played"
+    assert na <= coord.shape[1]
+    sp.close()
+    return rows_total
+
+
+@pytest.fixture(scope="module")
+def elf(built):
+    import elf_amd
+    return elf_amd
+
+
+@pytest.mark.parametrize("name", ["mcts_19_r128_fresh", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512_client",
+                                  "mcts_9_r512", "mcts_9_r64_ties"])
+def test_search_matches_reference(elf, name):
+    run_case(elf, name)
+
+
+def test_config3_8192_rollouts(elf):
+    """BASELINE config 3 search settings: bs 16, 8192 rollouts/move, puct 1.5, vloss 1, eps 0.25 / alpha 0.03."""
+    run_case(elf, "mcts_19_r8192")
