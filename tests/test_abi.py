@@ -10,7 +10,7 @@ from conftest import ROOT
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "elf_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(elfgo_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(elf(?:go|mcts|sp)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(built):
@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(built):
     from elf_amd import _lib
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = declared_symbols()
-    assert len(names) >= 20
+    assert len(names) >= 40
     for n in names:
         assert hasattr(L, n), "libelf_amd.so lacks %s" % n
         assert n in _lib.SIGNATURES, "elf_amd/_lib.py lacks a prototype for %s" % n
@@ -43,6 +43,27 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "libgo_oracle" not in txt and "libelfref" not in txt, f
+
+
+def test_mcts_bad_arguments_are_status_codes(built):
+    import elf_amd
+    L = elf_amd.lib()
+    h = ctypes.c_void_p()
+    assert L.elfmcts_create(None, 1, 64, 16, None, ctypes.byref(h)) == -1
+    assert L.elfmcts_destroy(None) == -1
+    assert L.elfsp_create(None, 0, None, ctypes.byref(h)) == -1
+    assert L.elfsp_destroy(None) == -1
+    assert L.elfsp_begin_step(None, None, 0, None, None) == -1
+
+
+def test_selfplay_refuses_to_run_without_gpu(built):
+    import pytest
+    import torch
+    import elf_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        elf_amd.SelfPlay(19, 2)
 
 
 def test_engine_refuses_to_run_without_gpu(built):

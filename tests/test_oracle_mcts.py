@@ -1,0 +1,62 @@
+"""CPU: the MCTS oracle side.  (a) stub net properties the parity argument rests on; (b) the committed MCTS
+golden fixtures are internally consistent with the reference's own invariants (tree_search.h:200-262:
+visits sum, one visit per unique leaf); (c) where oracle/_ref is present, the REAL reference self-play stack
+reproduces the committed fixture (the generating script is oracle/gen_golden_mcts.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pyoracle import MCTS_DEFAULTS, RefSelfPlay, stub_net
+
+CASES = ["mcts_19_r8192", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512_client", "mcts_19_r128_fresh", "mcts_9_r512",
+         "mcts_9_r64_ties"]
+
+
+@pytest.mark.parametrize("n", [19, 9])
+def test_stub_net_is_a_quantised_distribution(built, n):
+    rng = np.random.default_rng(0)
+    s = (rng.random((5, 18, n, n)) < 0.3).astype(np.float32)
+    pi, v = stub_net(n, s)
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-5) and (pi > 0).all()
+    assert np.array_equal(v * 256, np.round(v * 256)) and (np.abs(v) <= 1).all()   # multiples of 1/256: exact fp32 sums
+    pi2, v2 = stub_net(n, s)
+    assert np.array_equal(pi, pi2) and np.array_equal(v, v2)
+    pit, _ = stub_net(n, s, tie_levels=3)
+    assert len(np.unique(pit[0])) <= 3   # forced equal priors
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fixture_invariants(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    n = int(g["board_size"])
+    for i in range(len(g["move_played"])):
+        ne = int(g["n_edges"][i])
+        c = g["coord"][i, :ne]
+        assert len(set(c.tolist())) == ne and (g["coord"][i, ne:] == -1).all()
+        assert g["visits"][i, :ne].sum() == g["total_visits"][i]
+        assert abs(g["prior"][i, :ne].sum() - 1.0) < 1e-3
+        # most_visited with strict '>' in iteration order (tree_search_base.h:276-281)
+        assert g["best_action"][i] == c[int(np.argmax(g["visits"][i, :ne]))]
+        if cfg["persistent_tree"] == 0:   # a fresh tree: the all-at-root first batch adds no visit
+            per_batch = int(cfg["rollouts_per_batch"])
+            assert g["total_visits"][i] <= cfg["rollouts_per_thread"] - per_batch
+        assert ne <= n * n + 1
+
+
+@pytest.mark.parametrize("name", ["mcts_19_r128_fresh", "mcts_9_r64_ties"])
+def test_reference_reproduces_fixture(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = int(g["board_size"])
+    if not RefSelfPlay.available(n):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    kw = {k: (float(np.float32(v)) if isinstance(MCTS_DEFAULTS[k], float) else int(v)) for k, v in cfg.items()}
+    r = RefSelfPlay(n).run(**kw)
+    assert np.array_equal(r["coord"].astype(np.int16), g["coord"])
+    assert np.array_equal(r["visits"], g["visits"])
+    assert np.array_equal(r["prior"].view(np.uint32), g["prior"].view(np.uint32))
+    assert np.array_equal(r["reward"].view(np.uint32), g["reward"].view(np.uint32))
+    assert [s.move_played for s in r["search"]] == g["move_played"].tolist()
