@@ -1,13 +1,20 @@
 #!/usr/bin/env python
-"""bench.py -- driver contract. One "step" = one pass of the hot path over one batch:
-4096 concurrent 19x19 boards (per GPU) played from the empty board to game end by the config-2
-policy (BASELINE.json configs[1]), whole games inside one k_playout launch.
+"""bench.py -- driver contract.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload mcts|board]
   (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Prints ONE JSON line on rank 0.  value = board steps/s summed over all ranks (weak scaling:
-independent boards per GPU, no data-path collective -- SURVEY.md 8e).
+Default workload "mcts" = BASELINE.json configs[2], the configuration the headline metric is quoted on:
+MCTS self-play, 16 rollouts per batch per game, 8192 rollouts per move, puct 1.5, virtual loss 1, Dirichlet
+0.25/0.03, random-init 20-block/256-channel policy/value net on PyTorch-ROCm (fp16, channels_last), G games per
+GPU in lock-step.  One "step" = one batch of the reference's batch interface for every game: G*16 rollouts
+(select -> leaf features -> net -> expand -> backup).  value = rollouts/s summed over ranks.
+
+Workload "board" = configs[1]: 4096 concurrent 19x19 boards per GPU played to game end by the config-2 policy,
+whole games inside one k_playout launch; value = board steps/s.  The default run also measures it and reports
+it under "board_step" in the same JSON line.
+
+Weak scaling: every rank owns independent games/boards, no data-path collective.
 """
 import argparse
 import json
@@ -23,6 +30,10 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 STEP_BYTES = {19: 8730, 9: 4450}  # reference state in + out + legal mask, per board step
+# SURVEY.md 8d, algorithmic bytes of one MCTS rollout: per visited node 362 x 20 B edge read + 12 B vloss write + 12 B
+# backup write; per expansion 8368 B state copy + 7240 B edge init + 26728 B features + 1468 B reply read + 8730 B legality
+ROLLOUT_NODE_BYTES = 362 * 20 + 12 + 12
+ROLLOUT_EXPAND_BYTES = 8368 + 7240 + 26728 + 1468 + 8730
 
 
 def seeds_for(rank, boards, rep):
@@ -31,7 +42,7 @@ def seeds_for(rank, boards, rep):
     return b * np.uint64(0x9E3779B9) + np.uint64(1)
 
 
-def cpu_baseline(n, budget_s=12.0):
+def cpu_baseline_board(n, budget_s=12.0):
     """Reference (oracle/_ref, the real ELF board engine) or port timed on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
@@ -44,7 +55,7 @@ def cpu_baseline(n, budget_s=12.0):
         t0 = time.time()
         tot, _ = R.playout(playout_seeds(cores * 2), threads=cores)  # calibration
         rate = tot / max(time.time() - t0, 1e-6)
-        games = int(max(cores * 4, min(4096, rate * budget_s / 455.0)))
+        games = int(max(cores * 4, min(65536, rate * budget_s / 455.0)))
         games -= games % cores
         t0 = time.time()
         tot, _ = R.playout(playout_seeds(games), threads=cores)
@@ -64,16 +75,29 @@ def cpu_baseline(n, budget_s=12.0):
             "sample": "%d config-2 games (%d board steps), single thread, %.1f s" % (games, tot, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--boards", type=int, default=4096)
-    ap.add_argument("--board-size", type=int, default=19)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline_mcts(n, rollouts_per_batch):
+    """The REAL reference self-play stack (oracle/_ref/libelfsp: Context batcher + GoGameSelfPlay + MCTSGoAI) on the host
+    cores, one game thread + one search thread per core, net replaced by the stub (host-side ceiling of the reference:
+    its net time is excluded, ours is included)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        from pyoracle import RefSelfPlay
+    except Exception as e:
+        return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
+    if not RefSelfPlay.available(n):
+        return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": "oracle/_ref/libelfsp%d.so not built" % n}
+    cores = max(1, min(len(os.sched_getaffinity(0)) // 2, 32))
+    rollouts, moves = 2048, 2
+    r = RefSelfPlay(n).run(num_games=cores, mcts_threads=1, rollouts_per_thread=rollouts, rollouts_per_batch=rollouts_per_batch,
+                           batchsize=rollouts_per_batch, max_searches=cores * moves, seed=1234)
+    dt = r["usec"] / 1e6
+    done = len(r["search"]) * rollouts
+    return {"value": done / dt, "unit": "rollouts/s", "cores": cores * 2, "kind": "reference",
+            "sample": "%d searches of %d rollouts (bs %d) by %d reference game threads + %d search threads, stub net (net time "
+                      "excluded), %.1f s" % (len(r["search"]), rollouts, rollouts_per_batch, cores, cores, dt)}
 
+
+def init_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,15 +108,26 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    return rank, local_rank, world, dist
 
+
+def reduce_max_sum(dist, dev, dt, count):
+    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+    s_all = torch.tensor([count], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(s_all, op=dist.ReduceOp.SUM)
+    return float(t_all.item()), int(s_all.item())
+
+
+def run_board(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     import elf_amd
     n, boards = args.board_size, args.boards
     eng = elf_amd.GoEngine(n, boards, local_rank)
     dev = eng.device
     out = torch.empty((boards, 4), dtype=torch.int32, device=dev)
-    total = args.warmup + args.steps
-    # inputs resident in HBM before the timed region
-    seeds = [torch.from_numpy(seeds_for(rank, boards, r).view(np.int64)).to(dev) for r in range(total)]
+    total = warmup + steps
+    seeds = [torch.from_numpy(seeds_for(rank, boards, r).view(np.int64)).to(dev) for r in range(total)]  # resident in HBM
     step_counts = torch.zeros(total, dtype=torch.int64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(total)]
 
@@ -108,56 +143,184 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for r in range(args.warmup):
+    for r in range(warmup):
         one(r)
     barrier()
     t0 = time.perf_counter()
-    for r in range(args.warmup, total):
+    for r in range(warmup, total):
         one(r)
     barrier()
     dt = time.perf_counter() - t0
-
     counts = step_counts.cpu().numpy()
-    my_steps = int(counts[args.warmup:].sum())
-    kern_ms = [ev[r][0].elapsed_time(ev[r][1]) for r in range(args.warmup, total)]
-    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
-    s_all = torch.tensor([my_steps], dtype=torch.int64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        dist.all_reduce(s_all, op=dist.ReduceOp.SUM)
-    dt_max, steps_all = float(t_all.item()), int(s_all.item())
+    my_steps = int(counts[warmup:].sum())
+    kern_ms = [ev[r][0].elapsed_time(ev[r][1]) for r in range(warmup, total)]
+    dt_max, steps_all = reduce_max_sum(dist, dev, dt, my_steps)
+    eng.close()
+    if rank != 0:
+        return None
+    avg_kernel_s = float(np.mean(kern_ms)) / 1e3
+    steps_per_launch = my_steps / steps
+    achieved = steps_per_launch * STEP_BYTES[n] / avg_kernel_s / 1e9
+    traffic = load_traffic("k_playout<%d>" % n)
+    res = {
+        "metric": "board_steps_per_sec (%dx%d GoState::forward + legal-move mask, random legal play to game end)" % (n, n),
+        "value": steps_all / dt_max, "unit": "board_steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d concurrent %dx%d boards per GPU, config-2 random legal non-eye play "
+                               "to game end, board-step kernel only (no net)" % (boards, n, n),
+                   "boards_per_gpu": boards, "board_size": n, "board_steps_per_pass": steps_per_launch,
+                   "parallelism": "independent boards per GPU, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "k_playout<%d>" % n, "avg_kernel_ms": avg_kernel_s * 1e3,
+                     "algorithmic_bytes_per_step": STEP_BYTES[n],
+                     "note": "algorithmic bytes = reference Board in+out + legal mask per step (SURVEY.md 8d); the kernel "
+                             "keeps the position in LDS for the whole game, so this is a rate against the HBM roof; "
+                             "traffic = PMC HBM bytes per launch from profiles/ (FETCH_SIZE x2 + WRITE_SIZE, KiB)"},
+    }
+    res["cpu_baseline"] = cpu_baseline_board(n) if with_cpu else None
+    return res
 
+
+def load_traffic(kernel):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/gpu_round.sh), committed under profiles/."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(p)).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
+    import elf_amd
+    from elf_amd.net import make_net
+    n, G, K = args.board_size, args.games, args.rollouts_per_batch
+    dev = torch.device("cuda", local_rank)
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.net_dtype]
+    net = None
+    if args.net != "null":
+        torch.backends.cudnn.benchmark = True
+        net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0)
+    sp = elf_amd.SelfPlay(board_size=n, num_games=G, device=local_rank, mcts_rollout_per_thread=args.rollouts,
+                          mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1, mcts_persistent_tree=True,
+                          mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0, policy_distri_cutoff=30,
+                          seed=1234 + 1000 * rank, nodes_per_game=args.nodes_per_game)
+    na = n * n + 1
+    uni_pi = torch.full((sp.max_rows, na), 1.0 / na, dtype=torch.float32, device=dev)
+    zero_v = torch.zeros(sp.max_rows, dtype=torch.float32, device=dev)
+    rows_log = []
+    t_sel = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(warmup + steps)]
+    t_exp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(warmup + steps)]
+
+    def one(i):
+        t_sel[i][0].record()
+        rows = sp.begin_step()           # select + leaf features into sp.s (HBM), one host sync for the row count
+        t_sel[i][1].record()
+        if net is not None and rows:
+            with torch.no_grad():
+                out = net({"s": sp.s})   # fixed shape [G*K, 18, N, N]: rows >= `rows` are stale and ignored (no MIOpen re-tuning)
+            pi, v = out["pi"], out["V"]
+        else:
+            pi, v = uni_pi, zero_v
+        t_exp[i][0].record()
+        sp.end_step(pi, v)               # expand + backup
+        t_exp[i][1].record()
+        rows_log.append(rows)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        one(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        one(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    my_rollouts = G * K * steps
+    my_rows = int(sum(rows_log[warmup:]))
+    sel_ms = float(np.mean([a.elapsed_time(b) for a, b in t_sel[warmup:]]))
+    exp_ms = float(np.mean([a.elapsed_time(b) for a, b in t_exp[warmup:]]))
+    dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
+    st = sp.stats()
+    sp.close()
+    if rank != 0:
+        return None
+    step_ms = dt_max / steps * 1e3
+    # roofline of the search kernels (select+features / expand+backup), SURVEY.md 8d bytes with a depth estimate
+    depth = st["node_visits"] / max(st["rollouts"], 1)   # measured mean descent depth (select kernel counter)
+    bytes_per_step = G * K * depth * ROLLOUT_NODE_BYTES + my_rows / steps * ROLLOUT_EXPAND_BYTES
+    search_s = (sel_ms + exp_ms) / 1e3
+    achieved = bytes_per_step / search_s / 1e9
+    res = {
+        "metric": "mcts_rollouts_per_sec (self-play, %dx%d Go, %d rollouts/move, bs %d)" % (n, n, args.rollouts, K),
+        "value": roll_all / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 search statistics; net %s" % args.net_dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
+                               "persistent tree, %s, %d games per GPU in lock-step"
+                               % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last)"
+                                  % (args.net_blocks, args.net_dim, args.net_dtype) if net is not None else "null net (uniform prior, V=0)", G),
+                   "games_per_gpu": G, "board_size": n, "rollouts_per_step": G * K, "net_rows_per_step": my_rows / steps,
+                   "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
+                   "net_ms_per_step": step_ms - sel_ms - exp_ms,
+                   "moves_per_sec": roll_all / dt_max / args.rollouts,
+                   "games_per_sec_est": roll_all / dt_max / args.rollouts / 250.0,
+                   "games_per_sec_note": "rollouts/s / (rollouts per move x 250 moves per game); a full game does not fit a bench run",
+                   "parallelism": "independent games per GPU, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": load_traffic("k_mcts_select<%d>" % n),
+                     "kernel": "k_mcts_select+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
+                     "algorithmic_bytes_per_rollout": bytes_per_step / (G * K),
+                     "note": "search kernels only (HIP events around begin_step/end_step on the launch stream); bytes per rollout = "
+                             "depth x (362x20 B edge read + 24 B writes) + per expansion 52534 B (SURVEY.md 8d) with depth %.1f; "
+                             "the path is latency-bound (pointer chasing down the tree), not HBM-bound -- see DESIGN.md" % depth,
+                     "mean_depth": depth},
+        "selfplay_stats": st,
+    }
+    res["cpu_baseline"] = cpu_baseline_mcts(n, K) if with_cpu else None
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["mcts", "board", "both"], default="both")
+    ap.add_argument("--boards", type=int, default=4096)
+    ap.add_argument("--board-size", type=int, default=19)
+    ap.add_argument("--games", type=int, default=128)
+    ap.add_argument("--rollouts", type=int, default=8192)
+    ap.add_argument("--rollouts-per-batch", type=int, default=16)
+    ap.add_argument("--nodes-per-game", type=int, default=None)
+    ap.add_argument("--net", choices=["resnet", "null"], default="resnet")
+    ap.add_argument("--net-blocks", type=int, default=20)
+    ap.add_argument("--net-dim", type=int, default=256)
+    ap.add_argument("--net-dtype", choices=["fp16", "bf16", "fp32"], default="fp16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world, dist = init_dist(args)
+    with_cpu = (not args.no_cpu_baseline) and world == 1
+    res = None
+    if args.workload in ("mcts", "both"):
+        steps = args.steps if args.steps is not None else 40
+        warmup = args.warmup if args.warmup is not None else 8
+        res = run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu)
+    if args.workload in ("board", "both"):
+        bsteps = args.steps if (args.steps is not None and args.workload == "board") else 20
+        bwarm = args.warmup if (args.warmup is not None and args.workload == "board") else 3
+        b = run_board(args, rank, local_rank, world, dist, bsteps, bwarm, with_cpu)
+        if args.workload == "board":
+            res = b
+        elif rank == 0:
+            res["board_step"] = b
     if rank == 0:
-        avg_kernel_s = float(np.mean(kern_ms)) / 1e3
-        steps_per_launch = my_steps / args.steps
-        achieved = steps_per_launch * STEP_BYTES[n] / avg_kernel_s / 1e9
-        res = {
-            "metric": "board_steps_per_sec (19x19 GoState::forward + legal-move mask, random legal play to game end)"
-            if n == 19 else "board_steps_per_sec (9x9)",
-            "value": steps_all / dt_max,
-            "unit": "board_steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u16",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d concurrent %dx%d boards per GPU, config-2 random legal non-eye play "
-                                   "to game end, board-step kernel only (no net)" % (boards, n, n),
-                       "boards_per_gpu": boards, "board_size": n, "board_steps_per_pass": steps_per_launch,
-                       "parallelism": "independent boards per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_playout<%d>" % n, "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_step": STEP_BYTES[n],
-                         "note": "algorithmic bytes = reference Board in+out + legal mask per step (SURVEY.md 8d); the kernel "
-                                 "keeps the position in LDS for the whole game, so this is a rate against the HBM roof, not "
-                                 "HBM traffic (PMC traffic in profiles/)"},
-        }
-        res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

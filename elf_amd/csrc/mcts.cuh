@@ -79,8 +79,10 @@ struct GameState {        // 64 B per game
   int n_nn;               // ... of which need the net
   int row_base;
   int rollouts_done;
-  int pad[8];
+  long long node_visits;  // sum over rollouts of the number of visited (selected-at) nodes: mean depth = node_visits / rollouts
+  int pad[6];
 };
+static_assert(sizeof(GameState) == 64, "GameState must be 64 bytes");
 
 struct LeafRec {          // 32 B
   int node;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(64) void k_mcts_clear(TreePool<N> tp) {
   if (lane == 0) {
     GameState& s = tp.gs[g];
     s.root = 0; s.free_top = tp.C - 1; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
+    s.node_visits = 0;
   }
 }
 
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   float my_value = 0.0f;
   int n_unique = 0, n_nn = 0;
   const float vl_f = (float)cfg.virtual_loss;
+  int visited_nodes = 0;
 
   for (int j = 0; j < cfg.rollouts_per_batch; ++j) {
     int node = root, depth = 0;
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       node = child;
       ++depth;
     }
+    visited_nodes += depth;
     // ---- leaf bookkeeping: batch_rollouts :211-233 (requestEvaluation, duplicate leaves)
     const u64 dup = __ballot(lane < n_unique && my_leaf == node);
     if (dup) {
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   if (lane == 0) {
     gs.free_top = free_top; gs.rng_pos = rng_pos; gs.n_unique = n_unique; gs.n_nn = n_nn;
     gs.rollouts_done += cfg.rollouts_per_batch;
+    gs.node_visits += visited_nodes;
     if (err) gs.err |= err;
   }
 }

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(64) void k_mcts_clear_list(TreePool<N> tp, const in
   if (lane == 0) {
     GameState& s = tp.gs[g];
     s.root = 0; s.free_top = tp.C - 1; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
+    // node_visits is a lifetime counter (statistics): not reset with the tree
   }
 }
 
@@ -88,6 +89,7 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
   MCHK(hipMalloc(&m->nodes, G * C * m->node_bytes));
   MCHK(hipMalloc((void**)&m->free_stack, G * C * sizeof(int)));
   MCHK(hipMalloc((void**)&m->gs, G * sizeof(GameState)));
+  MCHK(hipMemset(m->gs, 0, G * sizeof(GameState)));
   MCHK(hipMalloc((void**)&m->leaves, G * MCTS_KMAX * sizeof(LeafRec)));
   MCHK(hipMalloc((void**)&m->d4buf, G * (size_t)d4_window));
   MCHK(hipMemset(m->d4buf, 0, G * (size_t)d4_window));
@@ -200,6 +202,16 @@ int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, flo
   DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_root<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (RootInfo*)info, coord,
                                       visits, prior, reward, child));
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int elfmcts_node_visits(ElfMcts* m, int64_t* out_host) {
+  if (!m || !out_host) return ELFGO_E_BADARG;
+  std::vector<GameState> gs(m->G);
+  HIPCHK(hipMemcpy(gs.data(), m->gs, sizeof(GameState) * m->G, hipMemcpyDeviceToHost));
+  long long t = 0;
+  for (auto& g : gs) t += g.node_visits;
+  *out_host = t;
   return 0;
 }
 

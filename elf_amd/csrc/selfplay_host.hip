@@ -324,8 +324,9 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
   return 0;
 }
 
-int elfsp_stats(const ElfSelfPlay* sp, int64_t* out) {
+int elfsp_stats(ElfSelfPlay* sp, int64_t* out) {
   if (!sp || !out) return ELFGO_E_BADARG;
+  SPCHK(elfmcts_node_visits(sp->mcts, &out[8]));
   out[0] = sp->n_moves; out[1] = sp->n_games; out[2] = sp->n_rollouts; out[3] = sp->n_rows; out[4] = sp->n_steps;
   out[5] = (int64_t)sp->log_search.size(); out[6] = sp->steps_per_move; out[7] = sp->step_in_move;
   return 0;

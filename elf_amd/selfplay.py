@@ -39,7 +39,7 @@ class SpSearch(C.Structure):
                 ("n_edges", C.c_int32), ("root_value", C.c_float), ("max_score", C.c_float), ("predicted_value", C.c_float)]
 
 
-STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_per_move", "step_in_move")
+STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_per_move", "step_in_move", "node_visits")
 
 
 class SelfPlay:
@@ -130,7 +130,7 @@ class SelfPlay:
 
     # ---- results
     def stats(self):
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 9)()
         check(self.L.elfsp_stats(self._h, out))
         return dict(zip(STAT_FIELDS, [int(x) for x in out]))
 

@@ -132,6 +132,8 @@ int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const 
 /* root edges in the reference's iteration order (what MCTSResultT::addActions walks, tree_search_base.h:237-294);
  * info device int32 [num_games][ELFMCTS_ROOT_WORDS]; the per-edge outputs ([num_games][edge_stride]) may be NULL */
 int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, float* prior, float* reward, int32_t* child, void* stream);
+/* statistics: total number of tree nodes descended through by all rollouts so far (mean depth = this / rollouts); synchronous */
+int elfmcts_node_visits(ElfMcts* m, int64_t* out_host);
 /* SearchTreeT::treeAdvance (tree_search_node.h:420-436), moves device int32 [num_games] (reference Coords) */
 int elfmcts_advance(ElfMcts* m, const int32_t* moves, void* stream);
 
@@ -177,8 +179,9 @@ int elfsp_max_rows(const ElfSelfPlay* sp);   /* num_games * num_rollouts_per_bat
 /* s_dst device f32, rows stride_floats apart; *n_rows (host) <- rows that need the net this step */
 int elfsp_begin_step(ElfSelfPlay* sp, float* s_dst, int64_t stride_floats, int* n_rows, void* stream);
 int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, void* stream);
-/* out[8]: moves played, games finished, rollouts, net rows, steps, searches logged, steps per move, step in move */
-int elfsp_stats(const ElfSelfPlay* sp, int64_t* out);
+/* out[9]: moves played, games finished, rollouts, net rows, steps, searches logged, steps per move, step in move,
+ * tree nodes descended through (synchronises the device) */
+int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
 /* logged searches [first, first+n): records and root edges (host arrays, [n][edge_stride], may be NULL) */
 int elfsp_search_log(const ElfSelfPlay* sp, int first, int n, ElfSpSearch* rec, int32_t* coord, int32_t* visits, float* prior,
                      float* reward);

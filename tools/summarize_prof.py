@@ -7,6 +7,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else ""
+sfx = ("_" + tag) if tag else ""
 
 
 def find(pattern):
@@ -14,16 +16,16 @@ def find(pattern):
 
 
 print("# rocprofv3 --kernel-trace --stats (kernel_stats)")
-for f in find("stats/**/*kernel_stats.csv"):
+for f in find("stats%s/**/*kernel_stats.csv" % sfx):
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
-    for r in rows[:12]:
+    for r in rows[:16]:
         print("%-60s calls=%s total_ns=%s avg_ns=%s pct=%s" % (
             r.get("Name", "")[:60], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 
 print("\n# PMC counters: per kernel, mean per dispatch")
 for d in ("pmc_fetch", "pmc_write", "pmc_lds", "pmc_sq"):
-    for f in find(d + "/**/*counter_collection.csv"):
+    for f in find(d + sfx + "/**/*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:
             for r in csv.DictReader(fh):
