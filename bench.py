@@ -53,7 +53,7 @@ def cpu_baseline_board(n, budget_s=12.0):
     if Ref.available(n):
         R = Ref(n)
         t0 = time.time()
-        tot, _ = R.playout(playout_seeds(cores * 2), threads=cores)  # calibration
+        tot, _ = R.playout(playout_seeds(cores * 8), threads=cores)  # calibration
         rate = tot / max(time.time() - t0, 1e-6)
         games = int(max(cores * 4, min(65536, rate * budget_s / 455.0)))
         games -= games % cores
@@ -199,14 +199,18 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     dev = torch.device("cuda", local_rank)
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.net_dtype]
     net = None
-    if args.net != "null":
+    if args.net == "resnet":
         torch.backends.cudnn.benchmark = True
-        net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0)
+        net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0, fold_bn=not args.no_fold_bn)
     sp = elf_amd.SelfPlay(board_size=n, num_games=G, device=local_rank, mcts_rollout_per_thread=args.rollouts,
                           mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1, mcts_persistent_tree=True,
                           mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0, policy_distri_cutoff=30,
                           seed=1234 + 1000 * rank, nodes_per_game=args.nodes_per_game)
     na = n * n + 1
+    # --net random: a peaky pseudo-random policy and a random value drawn on the GPU by torch (no conv net): isolates the
+    # search kernels while still growing deep, narrow trees like a trained net does.  --net null: uniform prior, V = 0.
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
     uni_pi = torch.full((sp.max_rows, na), 1.0 / na, dtype=torch.float32, device=dev)
     zero_v = torch.zeros(sp.max_rows, dtype=torch.float32, device=dev)
     rows_log = []
@@ -221,6 +225,9 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
             with torch.no_grad():
                 out = net({"s": sp.s})   # fixed shape [G*K, 18, N, N]: rows >= `rows` are stale and ignored (no MIOpen re-tuning)
             pi, v = out["pi"], out["V"]
+        elif args.net == "random" and rows:
+            pi = torch.softmax(4.0 * torch.randn((sp.max_rows, na), device=dev, generator=gen), dim=1)
+            v = torch.tanh(0.5 * torch.randn((sp.max_rows,), device=dev, generator=gen))
         else:
             pi, v = uni_pi, zero_v
         t_exp[i][0].record()
@@ -263,8 +270,9 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "dtype": "f32 search statistics; net %s" % args.net_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
                                "persistent tree, %s, %d games per GPU in lock-step"
-                               % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last)"
-                                  % (args.net_blocks, args.net_dim, args.net_dtype) if net is not None else "null net (uniform prior, V=0)", G),
+                               % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s)"
+                                  % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs")
+                                  if net is not None else "NO conv net (--net %s: search kernels only)" % args.net, G),
                    "games_per_gpu": G, "board_size": n, "rollouts_per_step": G * K, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
                    "net_ms_per_step": step_ms - sel_ms - exp_ms,
@@ -298,7 +306,8 @@ def main():
     ap.add_argument("--rollouts", type=int, default=8192)
     ap.add_argument("--rollouts-per-batch", type=int, default=16)
     ap.add_argument("--nodes-per-game", type=int, default=None)
-    ap.add_argument("--net", choices=["resnet", "null"], default="resnet")
+    ap.add_argument("--net", choices=["resnet", "random", "null"], default="resnet")
+    ap.add_argument("--no-fold-bn", action="store_true")
     ap.add_argument("--net-blocks", type=int, default=20)
     ap.add_argument("--net-dim", type=int, default=256)
     ap.add_argument("--net-dtype", choices=["fp16", "bf16", "fp32"], default="fp16")
