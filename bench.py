@@ -192,6 +192,15 @@ def load_traffic(kernel):
         return None
 
 
+def mcts_traffic(n, rollouts_per_step):
+    """PMC HBM bytes of the four search kernels per step, scaled per rollout from the profiled run (profiles/pmc_traffic.json)."""
+    try:
+        per = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["k_mcts_search<%d>" % n]["hbm_bytes_per_rollout"]
+        return per * rollouts_per_step
+    except Exception:
+        return None
+
+
 def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     import elf_amd
     from elf_amd.net import make_net
@@ -281,7 +290,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "games_per_sec_note": "rollouts/s / (rollouts per move x 250 moves per game); a full game does not fit a bench run",
                    "parallelism": "independent games per GPU, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": load_traffic("k_mcts_select<%d>" % n),
+                     "traffic": mcts_traffic(n, G * K),
                      "kernel": "k_mcts_select+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
                      "algorithmic_bytes_per_rollout": bytes_per_step / (G * K),
                      "note": "search kernels only (HIP events around begin_step/end_step on the launch stream); bytes per rollout = "
