@@ -1,0 +1,33 @@
+"""CPU: bench.py's multi-process path (one process per GPU, independent units per rank, max-over-ranks time,
+sum-over-ranks count) with world_size 2 over gloo.  The data path has no collective."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_world_size_2_gloo():
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    rep = json.loads([l for l in outs[0][0].strip().splitlines() if l.startswith("{")][-1])
+    assert rep["world"] == 2 and rep["total"] == 2001 and abs(rep["dt_max"] - 0.1) < 1e-9
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 reports
