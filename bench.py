@@ -216,38 +216,36 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     if args.net == "resnet":
         torch.backends.cudnn.benchmark = True
         net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0, fold_bn=not args.no_fold_bn)
-    sp = elf_amd.SelfPlay(board_size=n, num_games=G, device=local_rank, mcts_rollout_per_thread=args.rollouts,
-                          mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1, mcts_persistent_tree=True,
-                          mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0, policy_distri_cutoff=30,
-                          seed=1234 + 1000 * rank, nodes_per_game=args.nodes_per_game)
+    from elf_amd.pipeline import PipelinedSelfPlay
+    groups = max(1, args.groups)
+    Gg = G // groups
+    G = Gg * groups
+    sp = PipelinedSelfPlay(groups=groups, seed=1234 + 1000 * rank, board_size=n, num_games=Gg, device=local_rank,
+                           mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1,
+                           mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0,
+                           policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game)
     na = n * n + 1
+    rows_max = sp.groups[0].max_rows
     # --net random: a peaky pseudo-random policy and a random value drawn on the GPU by torch (no conv net): isolates the
     # search kernels while still growing deep, narrow trees like a trained net does.  --net null: uniform prior, V = 0.
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
-    uni_pi = torch.full((sp.max_rows, na), 1.0 / na, dtype=torch.float32, device=dev)
-    zero_v = torch.zeros(sp.max_rows, dtype=torch.float32, device=dev)
+    uni_pi = torch.full((rows_max, na), 1.0 / na, dtype=torch.float32, device=dev)
+    zero_v = torch.zeros(rows_max, dtype=torch.float32, device=dev)
     rows_log = []
-    t_sel = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(warmup + steps)]
-    t_exp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(warmup + steps)]
+
+    def net_fn(s, rows):
+        if net is not None:
+            with torch.no_grad():
+                out = net({"s": s})   # fixed shape [Gg*K, 18, N, N]: rows >= `rows` are stale and ignored (no MIOpen re-tuning)
+            return out["pi"], out["V"]
+        if args.net == "random":
+            return (torch.softmax(4.0 * torch.randn((rows_max, na), device=dev, generator=gen), dim=1),
+                    torch.tanh(0.5 * torch.randn((rows_max,), device=dev, generator=gen)))
+        return uni_pi, zero_v
 
     def one(i):
-        t_sel[i][0].record()
-        rows = sp.begin_step()           # select + leaf features into sp.s (HBM), one host sync for the row count
-        t_sel[i][1].record()
-        if net is not None and rows:
-            with torch.no_grad():
-                out = net({"s": sp.s})   # fixed shape [G*K, 18, N, N]: rows >= `rows` are stale and ignored (no MIOpen re-tuning)
-            pi, v = out["pi"], out["V"]
-        elif args.net == "random" and rows:
-            pi = torch.softmax(4.0 * torch.randn((sp.max_rows, na), device=dev, generator=gen), dim=1)
-            v = torch.tanh(0.5 * torch.randn((sp.max_rows,), device=dev, generator=gen))
-        else:
-            pi, v = uni_pi, zero_v
-        t_exp[i][0].record()
-        sp.end_step(pi, v)               # expand + backup
-        t_exp[i][1].record()
-        rows_log.append(rows)
+        rows_log.append(sp.step(net_fn))   # every group: select -> leaf features -> net -> expand -> backup
 
     def barrier():
         if dist is not None:
@@ -257,15 +255,17 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     for i in range(warmup):
         one(i)
     barrier()
+    sp.timing = True
     t0 = time.perf_counter()
     for i in range(warmup, warmup + steps):
         one(i)
     barrier()
     dt = time.perf_counter() - t0
+    sp.timing = False
     my_rollouts = G * K * steps
     my_rows = int(sum(rows_log[warmup:]))
-    sel_ms = float(np.mean([a.elapsed_time(b) for a, b in t_sel[warmup:]]))
-    exp_ms = float(np.mean([a.elapsed_time(b) for a, b in t_exp[warmup:]]))
+    sel_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_select])) / steps
+    exp_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_expand])) / steps
     dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
     st = sp.stats()
     sp.close()
@@ -283,13 +283,13 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 search statistics; net %s" % args.net_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
-                               "persistent tree, %s, %d games per GPU in lock-step"
+                               "persistent tree, %s, %d games per GPU in %d lock-step group(s) pipelined against the net"
                                % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s)"
                                   % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs")
-                                  if net is not None else "NO conv net (--net %s: search kernels only)" % args.net, G),
+                                  if net is not None else "NO conv net (--net %s: search kernels only)" % args.net, G, groups),
                    "games_per_gpu": G, "board_size": n, "rollouts_per_step": G * K, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
-                   "net_ms_per_step": step_ms - sel_ms - exp_ms,
+                   "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups,
                    "moves_per_sec": roll_all / dt_max / args.rollouts,
                    "games_per_sec_est": roll_all / dt_max / args.rollouts / 250.0,
                    "games_per_sec_note": "rollouts/s / (rollouts per move x 250 moves per game); a full game does not fit a bench run",
@@ -316,7 +316,8 @@ def main():
     ap.add_argument("--workload", choices=["mcts", "board", "both"], default="both")
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--board-size", type=int, default=19)
-    ap.add_argument("--games", type=int, default=128)
+    ap.add_argument("--games", type=int, default=256, help="games per GPU (split over --groups)")
+    ap.add_argument("--groups", type=int, default=2, help="lock-step game groups pipelined against the net (1 = serial)")
     ap.add_argument("--rollouts", type=int, default=8192)
     ap.add_argument("--rollouts-per-batch", type=int, default=16)
     ap.add_argument("--nodes-per-game", type=int, default=None)

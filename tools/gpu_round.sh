@@ -15,11 +15,11 @@ echo "== bench (default: mcts + board)"
 timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cat $OUT/bench.json
 echo "== bench mcts null net (search kernels only)"
-timeout 600 python bench.py --workload mcts --net random --games 1024 --nodes-per-game 8192 --rollouts 2048 --warmup 88 --steps 32 --no-cpu-baseline > $OUT/bench_nullnet.json 2> $OUT/bench_nullnet.err; echo "rc=$?"
+timeout 600 python bench.py --workload mcts --net random --games 1024 --groups 1 --nodes-per-game 8192 --rollouts 2048 --warmup 88 --steps 32 --no-cpu-baseline > $OUT/bench_nullnet.json 2> $OUT/bench_nullnet.err; echo "rc=$?"
 cat $OUT/bench_nullnet.json
 [ "$2" = "quick" ] && exit 0
 PROF_BOARD="python bench.py --workload board --steps 5 --warmup 1 --no-cpu-baseline"
-PROF_MCTS="python bench.py --workload mcts --net random --games 1024 --nodes-per-game 8192 --rollouts 2048 --warmup 88 --steps 32 --no-cpu-baseline"
+PROF_MCTS="python bench.py --workload mcts --net random --games 1024 --groups 1 --nodes-per-game 8192 --rollouts 2048 --warmup 88 --steps 32 --no-cpu-baseline"
 for W in board mcts; do
   if [ $W = board ]; then CMD="$PROF_BOARD"; else CMD="$PROF_MCTS"; fi
   echo "== rocprofv3 stats $W"
