@@ -12,3 +12,4 @@ from .engine import (  # noqa: F401
 
 __version__ = "0.1"
 from .selfplay import SelfPlay, MctsOptions, SpOptions  # noqa: F401,E402
+from . import compat  # noqa: F401,E402

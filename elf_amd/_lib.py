@@ -50,6 +50,7 @@ SIGNATURES = {
     "elfsp_begin_step": (_i, [_vp, _vp, _i64, C.POINTER(_i), _vp]),
     "elfsp_end_step": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "elfsp_stats": (_i, [_vp, _vp]),
+    "elfsp_games_finished": (_i64, [_vp]),
     "elfsp_search_log": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "elfgo_malloc": (_i, [C.POINTER(_vp), _sz]),
     "elfgo_free": (_i, [_vp]),

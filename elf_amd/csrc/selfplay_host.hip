@@ -324,6 +324,8 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
   return 0;
 }
 
+int64_t elfsp_games_finished(const ElfSelfPlay* sp) { return sp ? sp->n_games : -1; }
+
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out) {
   if (!sp || !out) return ELFGO_E_BADARG;
   SPCHK(elfmcts_node_visits(sp->mcts, &out[8]));

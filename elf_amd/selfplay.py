@@ -134,6 +134,9 @@ class SelfPlay:
         check(self.L.elfsp_stats(self._h, out))
         return dict(zip(STAT_FIELDS, [int(x) for x in out]))
 
+    def games_finished(self):
+        return int(self.L.elfsp_games_finished(self._h))
+
     def search_log(self):
         n = self.stats()["logged"]
         rec = (SpSearch * n)()

@@ -182,6 +182,8 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
 /* out[9]: moves played, games finished, rollouts, net rows, steps, searches logged, steps per move, step in move,
  * tree nodes descended through (synchronises the device) */
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
+/* games finished so far (host counter, no device synchronisation) */
+int64_t elfsp_games_finished(const ElfSelfPlay* sp);
 /* logged searches [first, first+n): records and root edges (host arrays, [n][edge_stride], may be NULL) */
 int elfsp_search_log(const ElfSelfPlay* sp, int first, int n, ElfSpSearch* rec, int32_t* coord, int32_t* visits, float* prior,
                      float* reward);

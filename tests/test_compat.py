@@ -1,0 +1,93 @@
+"""The reference-named Python surface (elf_amd.compat): option structs, GameContext, GCWrapper, Batch.
+CPU part: names, defaults and error behaviour of the reference (utils_elf.py:340-359,406-414; game_context.h:38-40).
+GPU part: a reference-style self-play loop through GCWrapper reproduces a reference fixture."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def test_option_structs_carry_the_reference_field_names():
+    from elf_amd import compat
+    ts = compat.TSOptions()
+    for f in ("max_num_moves", "num_threads", "num_rollouts_per_thread", "num_rollouts_per_batch", "verbose", "verbose_time", "seed",
+              "persistent_tree", "root_epsilon", "root_alpha", "log_prefix", "pick_method", "alg_opt", "virtual_loss"):
+        assert hasattr(ts, f)                      # tree_search_options.h:215-228
+    for f in ("use_prior", "c_puct", "unexplored_q_zero", "root_unexplored_q_zero"):
+        assert hasattr(ts.alg_opt, f)              # tree_search_options.h:70-74
+    assert (ts.num_threads, ts.num_rollouts_per_thread, ts.num_rollouts_per_batch, ts.alg_opt.c_puct) == (16, 100, 8, 5.0)
+    co = compat.ContextOptions()
+    for f in ("job_id", "batchsize", "num_games", "T", "mcts_options"):
+        assert hasattr(co, f)                      # python_options_utils_cpp.h:46
+    go = compat.GameOptions()
+    assert (go.komi, go.policy_distri_cutoff, go.resign_thres, go.move_cutoff) == (7.5, 20, 0.05, -1)
+
+
+def test_error_behaviour_matches_the_reference():
+    from elf_amd import compat
+    go = compat.GameOptions()
+    go.mode = "bogus"
+    with pytest.raises(ValueError):
+        compat.GameContext(compat.ContextOptions(), go)
+    go.mode = "selfplay"
+    gc = compat.GameContext(compat.ContextOptions(), go)
+    params = gc.getParams()
+    assert params["num_action"] == 362 and params["ACTION_PASS"] == -99 and params["num_planes"] == 18
+    w = compat.GCWrapper(gc, 16, {"actor_black": dict(input=["s"], reply=["pi", "V", "a", "rv"]), "game_end": dict(batchsize=1)})
+    with pytest.raises(ValueError):
+        w.reg_callback("no_such_key", lambda b: None)
+    assert w.reg_callback_if_exists("nope", None) is False
+    assert w.reg_callback("actor_black", lambda b: None)
+    with pytest.raises(ValueError):
+        w.start()                                  # game_end has no callback yet (utils_elf.py:416-424)
+    b = compat.Batch(s=np.zeros((4, 2)), last_r=np.arange(5))
+    assert b.first_k(2)["s"].shape == (2, 2) and "r" in b and len(b["r"]) == 4
+    with pytest.raises(KeyError):
+        b["zzz"]
+
+
+@pytest.mark.gpu
+def test_reference_style_loop_reproduces_fixture(built):
+    import torch
+    from elf_amd import compat
+    from pyoracle import stub_net
+    g = np.load(os.path.join(GOLDEN, "mcts_19_r256_dir.npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    co, opt = compat.ContextOptions(), compat.GameOptions()
+    co.num_games, co.batchsize = 1, 16
+    ts = co.mcts_options
+    ts.num_threads, ts.num_rollouts_per_thread, ts.num_rollouts_per_batch = 1, int(cfg["rollouts_per_thread"]), int(cfg["rollouts_per_batch"])
+    ts.virtual_loss, ts.persistent_tree = int(cfg["virtual_loss"]), bool(cfg["persistent_tree"])
+    ts.root_epsilon, ts.root_alpha = float(np.float32(cfg["root_epsilon"])), float(np.float32(cfg["root_alpha"]))
+    ts.alg_opt.c_puct = float(np.float32(cfg["c_puct"]))
+    opt.seed, opt.komi, opt.policy_distri_cutoff, opt.ply_pass_enabled = int(cfg["seed"]), 7.5, int(cfg["policy_distri_cutoff"]), 0
+    m = 8
+    opt.log_searches = m
+    GC = compat.GameContext(co, opt)
+    desc = {"actor_black": dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=16, timeout_usec=10),
+            "game_end": dict(batchsize=1)}
+    gcw = compat.GCWrapper(GC, co.batchsize, desc, num_recv=2, gpu=0, params=GC.getParams())
+    calls = []
+
+    def actor(batch):                              # Evaluator.actor-shaped callback
+        s = batch["s"]
+        calls.append(batch.batchsize)
+        pi, v = stub_net(19, s.cpu().numpy(), int(cfg["net_salt"]), int(cfg["net_tie_levels"]))
+        return dict(pi=torch.from_numpy(pi).to(s.device), V=torch.from_numpy(v).to(s.device), rv=0)
+
+    gcw.reg_callback("actor_black", actor)
+    gcw.reg_callback("game_end", lambda batch: None)
+    gcw.start()
+    GC.getClient().setRequest(0, -1, 0.0, -1)
+    while GC._sp.stats()["logged"] < m:
+        gcw.run()
+    gcw.stop()
+    rec, coord, visits, _, _ = GC._sp.search_log()
+    for i in range(m):
+        ne = int(g["n_edges"][i])
+        assert np.array_equal(coord[i, :ne], g["coord"][i, :ne].astype(np.int32))
+        assert np.array_equal(visits[i, :ne], g["visits"][i, :ne])
+        assert rec[i].move_played == int(g["move_played"][i])
+    assert max(calls) <= 16
