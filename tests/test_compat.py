@@ -81,7 +81,7 @@ def test_reference_style_loop_reproduces_fixture(built):
     gcw.reg_callback("game_end", lambda batch: None)
     gcw.start()
     GC.getClient().setRequest(0, -1, 0.0, -1)
-    while GC._sp.stats()["logged"] < m:
+    while GC._sp is None or GC._sp.stats()["logged"] < m:
         gcw.run()
     gcw.stop()
     rec, coord, visits, _, _ = GC._sp.search_log()
