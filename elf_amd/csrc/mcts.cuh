@@ -117,7 +117,9 @@ struct HdrU {
   int parent, parent_edge, n_edges, num_visits, status, flip, has_state;
   float V, umq, upq;
   __device__ __forceinline__ void load(const NodeHdr* h, int lane) {
-    int w = lane < 16 ? reinterpret_cast<const int*>(h)[lane] : 0;
+    set(lane < 16 ? reinterpret_cast<const int*>(h)[lane] : 0);
+  }
+  __device__ __forceinline__ void set(int w) {
     parent = rl(w, 0); parent_edge = rl(w, 1); n_edges = rl(w, 2); num_visits = rl(w, 3);
     V = __int_as_float(rl(w, 4)); umq = __int_as_float(rl(w, 5)); upq = __int_as_float(rl(w, 6));
     status = rl(w, 7); flip = rl(w, 8); has_state = rl(w, 9);
@@ -250,8 +252,27 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     int node = root, depth = 0;
     bool board_in_lds = false;   // LDS holds the state of `node`
     HdrU h;
+    // One memory round trip per tree level: the header, the edge statistics, the child ids and the coords of a node are
+    // requested together (speculatively: a leaf's edge arrays are never used), so the only dependent load of a level is
+    // the one of the chosen child.
+    int hw;
+    float4 st[R];
+    int chv[R];
+    u32 cdv[R];
+    auto request = [&](int nid) {
+      const NR& q = nodes[nid];
+      hw = lane < 16 ? reinterpret_cast<const int*>(&q.h)[lane] : 0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int e = k * 64 + lane, ec = e < NR::NE ? e : NR::NE - 1;
+        st[k] = q.stat[ec];
+        chv[k] = q.child[ec];
+        cdv[k] = q.coord[ec];
+      }
+    };
+    request(node);
     for (;;) {                   // single_rollout, tree_search.h:264-322
-      h.load(&nodes[node].h, lane);
+      h.set(hw);
       if (h.status != NS_VISITED || h.n_edges == 0) break;
       NR& nd = nodes[node];
       // ---- findMove :205-231 + UCT :361-397 + EdgeInfo::getScore (tree_search_base.h:132-157)
@@ -259,12 +280,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       if (cfg.unexplored_q_zero || (cfg.root_unexplored_q_zero && depth == 0)) umq = 0.0f;
       const int all_visits = h.num_visits + 1;
       const double sq = all_visits < tp.sqrt_n ? tp.sqrt_tab[all_visits] : sqrt((double)all_visits);
-      float4 st[R];
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const int e = k * 64 + lane;
-        st[k] = e < h.n_edges ? nd.stat[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
       float best_s = -__builtin_huge_valf();
       int best_e = 0x7FFFFFFF;
       float uq[R];
@@ -307,44 +322,39 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         }
       }
       const float new_umq = __fdiv_rn(__fadd_rn(h.upq, tq), (float)(tv + 1));   // :227-228
-      // ---- addVirtualLoss :233-251
+      // ---- addVirtualLoss :233-251; chosen edge's child / coord straight from the registers
       const int bk = best_e >> 6, bl = best_e & 63;
       float cur_vl = 0.0f;
-#pragma unroll
-      for (int k = 0; k < R; ++k) if (k == bk) cur_vl = st[k].w;
-      cur_vl = rlf(cur_vl, bl);
       int child = 0, mv = 0;
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if (k == bk) { cur_vl = st[k].w; child = chv[k]; mv = (int)cdv[k]; }
+      cur_vl = rlf(cur_vl, bl); child = rl(child, bl); mv = rl(mv, bl);
       if (lane == 0) {
         nd.h.unsigned_mean_q = new_umq;
         if (cfg.virtual_loss > 0) nd.stat[best_e].w = __fadd_rn(cur_vl, vl_f);
-        child = nd.child[best_e];
-        mv = nd.coord[best_e];
       }
-      child = rfl(child); mv = rfl(mv);
-      // ---- followEdge :280-302 -> SearchTreeT::addNode(unsignedMeanQ_) :439-443
+      ++depth;
       if (child < 0) {
-        if (free_top <= 0) { err |= MCTS_ERR_POOL; break; }
+        // ---- followEdge :280-302 -> SearchTreeT::addNode(unsignedMeanQ_) :439-443
+        if (free_top <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
         child = rfl(fs[free_top - 1]);
         --free_top;
         node_init(&nodes[child], node, best_e, new_umq, lane);
         if (lane == 0) nd.child[best_e] = child;
-      }
-      // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
-      HdrU ch;
-      ch.load(&nodes[child].h, lane);
-      if (!ch.has_state) {
-        if (!board_in_lds) bd.load(&nd.board);
+        // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
+        bd.load(&nd.board);
         TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skh(bslot), pool.ski(bslot)}, root_sk_len};
-        if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; board_in_lds = false; break; }
+        if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; --depth; break; }
         bd.store(&nodes[child].board);
         if (lane == 0) nodes[child].h.has_state = 1;
         board_in_lds = true;
-      } else {
-        board_in_lds = false;
+        node = child;
+        h.status = NS_NOT_VISITED; h.n_edges = 0;   // the fresh node is this rollout's leaf: no need to read it back
+        break;
       }
-      mem_sync();
       node = child;
-      ++depth;
+      request(node);             // existing children always own a state (created together with the node)
     }
     visited_nodes += depth;
     // ---- leaf bookkeeping: batch_rollouts :211-233 (requestEvaluation, duplicate leaves)
@@ -526,87 +536,93 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
   }
   u64 legal, cand;
   bd.template legal_moves<false>(legal, cand);
-  // ---- pi2response :256-332.  Candidates in NN action order; valid ones compacted in that order.
+  // ---- pi2response :256-332.  The reference sorts all N*N+1 (coord, prior) pairs by prior (descending) and then keeps
+  // the valid ones in that order.  If no two VALID candidates share a prior the result is the unique descending order
+  // of the valid ones: a register bitonic sort of 512 slots (8 per lane), invalid candidates keyed last.
   const float* prow = pi + (size_t)row * pi_stride;
-  int nvalid = 0;
-  bool anyvalid_tie = false;
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    const int i = k * 64 + lane;
-    if (i < NA) {
-      int coord, a0;
-      action_to_coord<N>(i, d4, coord, a0);
-      L.prob[i] = prow[i];
-      L.key[i] = (u16)coord;
-    }
-  }
   if (lane < G::R) L.legalw[lane] = legal;
   Board<N>::wsync();
-  u64 vbal[R];
+  constexpr int SK = 8;   // 512 sort slots: element e = k*64 + lane
+  u64 sx[SK];
+  int nvalid = 0;
 #pragma unroll
-  for (int k = 0; k < R; ++k) {
+  for (int k = 0; k < SK; ++k) {
     const int i = k * 64 + lane;
     bool valid = false;
+    int coord = 0;
+    float p = 0.0f;
     if (i < NA) {
-      int coord, a0;
+      int a0;
       action_to_coord<N>(i, d4, coord, a0);
+      p = prow[i];
+      L.prob[i] = p;            // kept in action order for the exact std::sort replay
+      L.key[i] = (u16)coord;
       if (coord == M_PASS) valid = pass_enabled;
-      else valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;
+      else valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;      // s.checkMove(v.first) :308-309
     }
-    vbal[k] = __ballot(valid);
+    nvalid += __popcll(__ballot(valid));
+    // monotone float -> uint key (ascending with the value), inverted for a descending sort; coord as payload
+    const u32 bits = __float_as_uint(p);
+    const u32 ukey = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    sx[k] = valid ? (((u64)(~ukey) << 32) | (u32)coord) : ~0ull;
   }
-#pragma unroll
-  for (int k = 0; k < R; ++k) nvalid += __popcll(vbal[k]);
-  Board<N>::wsync();
   int n = 0;   // number of edges
+  bool tie = false;
+  float sp[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) sp[k] = 0.0f;
   if (nvalid == 0) {
-    // "Add pass if there is no valid move" :321-324 (only reachable with pass disabled)
-    if (lane == 0) { L.skey[0] = M_PASS; L.sprob[0] = 1.0f; }
+    // "Add pass if there is no valid move" :321-324 (only reachable with pass disabled); normalize: 1 / (1e-10 + 1)
+    if (lane == 0) { L.skey[0] = M_PASS; L.sprob[0] = __fdiv_rn(1.0f, __fadd_rn(1e-10f, 1.0f)); }
     n = 1;
   } else {
-    // compact the valid candidates (action order) into sprob/skey[0..nvalid)
-    int off = 0;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int i = k * 64 + lane;
-      const bool v = (vbal[k] >> lane) & 1;
-      const int r = off + __popcll(vbal[k] & ((1ull << lane) - 1));
-      if (v) { L.sprob[r] = L.prob[i]; L.skey[r] = L.key[i]; }
-      off += __popcll(vbal[k]);
-    }
-    Board<N>::wsync();
     n = nvalid;
-    // rank sort by (prob desc, position asc); equal priors among VALID candidates -> exact std::sort replay below
-    int rank[R];
-    bool tie = false;
 #pragma unroll
-    for (int k = 0; k < R; ++k) rank[k] = 0;
-    float pme[R];
+    for (int size = 2; size <= 64 * SK; size <<= 1) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) { const int i = k * 64 + lane; pme[k] = i < n ? L.sprob[i] : 0.0f; }
-    for (int jn = 0; jn < n; ++jn) {
-      const float pj = L.sprob[jn];
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        if (stride >= 64) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const int i = k * 64 + lane;
-        if (i < n) {
-          rank[k] += (pj > pme[k]) || (pj == pme[k] && jn < i);
-          tie |= (pj == pme[k] && jn != i);
+          for (int k = 0; k < SK; ++k) {
+            const int kp = k ^ (stride >> 6);
+            if (kp > k) {
+              const bool up = ((k * 64) & size) == 0;
+              const u64 a = sx[k], b = sx[kp];
+              const bool sw = up ? (a > b) : (a < b);
+              sx[k] = sw ? b : a;
+              sx[kp] = sw ? a : b;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < SK; ++k) {
+            const u64 y = __shfl_xor(sx[k], stride, 64);
+            const bool up = (((k * 64 + lane) & size) == 0);
+            const bool keep_min = (((lane & stride) == 0) == up);
+            const bool less = sx[k] < y;
+            sx[k] = (keep_min == less) ? sx[k] : y;
+          }
         }
       }
     }
-    anyvalid_tie = __any(tie);
-    if (!anyvalid_tie) {
-      float pv[R];
-      u16 kv[R];
+    // sorted element e = k*64 + lane (e < n <= N*N+1 <= 6*64): prior back from the key, coord from the payload
 #pragma unroll
-      for (int k = 0; k < R; ++k) { const int i = k * 64 + lane; pv[k] = i < n ? L.sprob[i] : 0.f; kv[k] = i < n ? L.skey[i] : 0; }
-      Board<N>::wsync();
+    for (int k = 0; k < R; ++k) {
+      const int e = k * 64 + lane;
+      const u32 ukey = ~(u32)(sx[k] >> 32);
+      const u32 bits = (ukey & 0x80000000u) ? (ukey & 0x7FFFFFFFu) : ~ukey;
+      sp[k] = __uint_as_float(bits);
+      if (e < n) { L.sprob[e] = sp[k]; L.skey[e] = (u16)(sx[k] & 0xFFFFu); }
+    }
+    Board<N>::wsync();
 #pragma unroll
-      for (int k = 0; k < R; ++k) { const int i = k * 64 + lane; if (i < n) { L.sprob[rank[k]] = pv[k]; L.skey[rank[k]] = kv[k]; } }
-    } else {
-      // the reference sorts ALL 362 pairs with an unstable std::sort and filters afterwards: replay it exactly
-      Board<N>::wsync();
+    for (int k = 0; k < R; ++k) {
+      const int e = k * 64 + lane;
+      if (e + 1 < n) tie |= (sp[k] == L.sprob[e + 1]);
+    }
+    if (__any(tie)) {
+      // equal priors among valid candidates: the order is whatever libstdc++'s unstable std::sort makes of ALL pairs
+      // (go/mcts/mcts.h:292-297): replay it exactly, then filter
       if (lane == 0) {
         stl_emul::sort_desc<u16>(L.key, L.prob, NA);
         int w = 0;
@@ -621,22 +637,24 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
           if (valid) { L.sprob[w] = L.prob[i]; L.skey[w] = (u16)coord; ++w; }
         }
       }
+      Board<N>::wsync();
+#pragma unroll
+      for (int k = 0; k < R; ++k) { const int e = k * 64 + lane; sp[k] = e < n ? L.sprob[e] : 0.0f; }
     }
-    Board<N>::wsync();
-    // normalize :244-254: total = 1e-10 + sequential fp32 sum in sorted order
+    // normalize :244-254: total = 1e-10 + sequential fp32 sum in sorted order (readlane chain, no LDS round trips)
     float total = 1e-10f;
-    if (lane == 0) {
-      for (int i = 0; i < n; ++i) total = __fadd_rn(total, L.sprob[i]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int cnt = n - k * 64 < 64 ? n - k * 64 : 64;
+      for (int l = 0; l < cnt; ++l) total = __fadd_rn(total, rlf(sp[k], l));
     }
-    total = rlf(total, 0);
-    for (int i = lane; i < n; i += 64) L.sprob[i] = __fdiv_rn(L.sprob[i], total);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int e = k * 64 + lane;
+      if (e < n) L.sprob[e] = __fdiv_rn(sp[k], total);
+    }
   }
   Board<N>::wsync();
-  if (nvalid == 0) {
-    // normalize of the single (PASS, 1.0) entry
-    if (lane == 0) L.sprob[0] = __fdiv_rn(1.0f, __fadd_rn(1e-10f, 1.0f));
-    Board<N>::wsync();
-  }
   // ---- setEvaluation :176-203: insert in this order; store edges in the map's ITERATION order
   umap_order_wave<N>(L, n, lane);
   for (int jn = lane; jn < n; jn += 64) {
