@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Refresh profiles/pmc_traffic.json from the PMC summaries of one tools/gpu_round.sh visit.
+usage: python tools/update_traffic.py gpurun_out/<tag> <tag>   (FETCH_SIZE doubled: MI355X_MICROARCH.md, gfx950 counts 128-B requests as 64 B)"""
+import json, os, re, sys
+out, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def counters(path):
+    acc = {}
+    for line in open(path):
+        m = re.match(r"(.{48}) (\S+)\s+n=(\d+) mean=(\S+)", line.rstrip("\n"))
+        if m and m.group(2) in ("FETCH_SIZE", "WRITE_SIZE"):
+            acc.setdefault(m.group(1).strip(), {})[m.group(2)] = (float(m.group(4)), int(m.group(3)))
+    return acc
+def hbm(c):  # KiB counters -> bytes
+    return (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
+p = os.path.join(root, "profiles", "pmc_traffic.json")
+res = json.load(open(p)) if os.path.exists(p) else {}
+b = counters(os.path.join(out, "summary_board.txt"))
+for k, c in b.items():
+    if "k_playout<19>" in k:
+        res["k_playout<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
+                                "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over %d launches of bench.py --workload board "
+                                        "(4096 boards, 1.865M board steps per launch); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_board_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
+m = counters(os.path.join(out, "summary_mcts.txt"))
+per, n = {}, 0
+for k, c in m.items():
+    for name in ("k_mcts_select", "k_mcts_features", "k_mcts_expand", "k_mcts_backup"):
+        if name in k:
+            per[name] = hbm(c); n = c["FETCH_SIZE"][1]
+if per:
+    roll = 16384
+    res["k_mcts_search<19>"] = {"hbm_bytes_per_rollout": sum(per.values()) / roll, "per_kernel_bytes_per_launch": per, "rollouts_per_launch": roll,
+                                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d steps of bench.py --workload mcts --net random --games 1024 "
+                                        "--rollouts 2048 (16384 rollouts per step); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_mcts_search_only_rocprofv3.txt" % (n, tag)}
+json.dump(res, open(p, "w"), indent=1)
+print(json.dumps(res, indent=1))
