@@ -216,6 +216,12 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     if args.net == "resnet":
         torch.backends.cudnn.benchmark = True
         net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0, fold_bn=not args.no_fold_bn)
+        if args.no_fold_bn or dtype != torch.float16:
+            args.net_impl = "eager"   # the fused epilogue is an fp16, BN-folded inference path
+        if args.net_impl != "eager":
+            from elf_amd.net import FusedInferenceNet
+            net = FusedInferenceNet(net)
+    feat_fmt = "f16_nhwc" if (args.features == "f16" or (args.features == "auto" and net is not None and dtype == torch.float16)) else "f32_nchw"
     from elf_amd.pipeline import PipelinedSelfPlay
     groups = max(1, args.groups)
     Gg = G // groups
@@ -223,7 +229,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     sp = PipelinedSelfPlay(groups=groups, seed=1234 + 1000 * rank, board_size=n, num_games=Gg, device=local_rank,
                            mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1,
                            mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0,
-                           policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game)
+                           policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt)
     na = n * n + 1
     rows_max = sp.groups[0].max_rows
     # --net random: a peaky pseudo-random policy and a random value drawn on the GPU by torch (no conv net): isolates the
@@ -284,8 +290,10 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "dtype": "f32 search statistics; net %s" % args.net_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
                                "persistent tree, %s, %d games per GPU in %d lock-step group(s) pipelined against the net"
-                               % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s)"
-                                  % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs")
+                               % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s%s; leaf features %s)"
+                                  % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs",
+                                     {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl],
+                                     feat_fmt)
                                   if net is not None else "NO conv net (--net %s: search kernels only)" % args.net, G, groups),
                    "games_per_gpu": G, "board_size": n, "rollouts_per_step": G * K, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
@@ -326,6 +334,10 @@ def main():
     ap.add_argument("--net-blocks", type=int, default=20)
     ap.add_argument("--net-dim", type=int, default=256)
     ap.add_argument("--net-dtype", choices=["fp16", "bf16", "fp32"], default="fp16")
+    ap.add_argument("--net-impl", choices=["eager", "fused"], default="fused",
+                    help="eager: plain PyTorch modules; fused: PyTorch convs + one HIP epilogue pass per conv (elfnet_bias_act_f16)")
+    ap.add_argument("--features", choices=["auto", "f32", "f16"], default="auto",
+                    help="leaf feature rows: f32 NCHW (reference layout) or f16 channels_last (auto: f16 when the net is fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

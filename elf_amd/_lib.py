@@ -23,6 +23,7 @@ SIGNATURES = {
     "elfgo_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "elfgo_legal_mask": (_i, [_vp, _vp, _i, _vp, _vp]),
     "elfgo_extract_agz": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
+    "elfgo_extract_agz_fmt": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _vp]),
     "elfgo_evaluate": (_i, [_vp, _vp, _i, _f, _vp, _vp]),
     "elfgo_info": (_i, [_vp, _vp, _i, _vp, _vp]),
     "elfgo_export_board": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -30,6 +31,7 @@ SIGNATURES = {
     "elfmcts_create": (_i, [_vp, _i, _i, _i, _vp, C.POINTER(_vp)]),
     "elfmcts_destroy": (_i, [_vp]),
     "elfmcts_set_options": (_i, [_vp, _vp]),
+    "elfmcts_set_feature_format": (_i, [_vp, _i]),
     "elfmcts_num_games": (_i, [_vp]),
     "elfmcts_edge_stride": (_i, [_vp]),
     "elfmcts_node_bytes": (_sz, [_vp]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     "elfsp_stats": (_i, [_vp, _vp]),
     "elfsp_games_finished": (_i64, [_vp]),
     "elfsp_search_log": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "elfnet_bias_act_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfgo_malloc": (_i, [C.POINTER(_vp), _sz]),
     "elfgo_free": (_i, [_vp]),
     "elfgo_memcpy_h2d": (_i, [_vp, _vp, _sz]),

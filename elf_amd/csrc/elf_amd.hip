@@ -84,13 +84,14 @@ __global__ __launch_bounds__(WAVE) void k_legal_mask(Pool<N> pool, const int32_t
   if (bd.lane == 0) out[G::NP] = 1;  // pass is always accepted by TryPlay (board.cc:794-800)
 }
 
-// BoardFeature::extractAGZ (board_feature.cc:247-290) + Transform (board_feature.h:97-113).
-// Output-indexed so that every store instruction is a fully coalesced 256-B segment.
+// BoardFeature::extractAGZ (board_feature.cc:247-290) + Transform (board_feature.h:97-113): bit planes in output order
+// via ballots, then one flat vectorised store of the row (go_board.cuh: agz_bitplanes / agz_store).
 template <int N>
 __global__ __launch_bounds__(WAVE) void k_extract_agz(Pool<N> pool, const int32_t* ids, const int32_t* d4s, int n,
-                                                       float* dst, int64_t stride) {
+                                                       void* dst, int64_t stride, int fmt) {
   using G = Geo<N>;
   __shared__ u64 hist[HIST][2][G::R];
+  __shared__ u64 tpl[18][G::R];
   const int lane = threadIdx.x;
   int b = slot_of(ids, blockIdx.x);
   const Slot<N>* sl = &pool.slots[b];
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(WAVE) void k_extract_agz(Pool<N> pool, const int32_
   const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
   const int d4 = d4s ? d4s[blockIdx.x] : 0;
   __syncthreads();
-  extract_agz_planes<N>(hist, cnt, player, d4, dst + (size_t)blockIdx.x * stride, lane);
+  char* row = (char*)dst + (size_t)blockIdx.x * stride * (fmt == FEAT_F16_NHWC ? 2 : 4);
+  extract_agz_row<N>(hist, tpl, cnt, player, d4, row, fmt, lane);
 }
 
 template <int N>
@@ -285,14 +287,20 @@ int elfgo_legal_mask(ElfGoEngine* e, const int32_t* ids, int n, uint8_t* mask, v
   return 0;
 }
 
-int elfgo_extract_agz(ElfGoEngine* e, const int32_t* ids, const int32_t* d4, int n, float* dst, int64_t stride_floats,
-                      void* stream) {
+int elfgo_extract_agz_fmt(ElfGoEngine* e, const int32_t* ids, const int32_t* d4, int n, void* dst, int64_t stride_elems, int fmt,
+                          void* stream) {
   CHECK_N(e, ids, n);
-  if (!dst || stride_floats < (int64_t)18 * e->n * e->n) return ELFGO_E_BADARG;
+  if (!dst || stride_elems < (int64_t)18 * e->n * e->n || (fmt != ELFGO_FEAT_F32_NCHW && fmt != ELFGO_FEAT_F16_NHWC)) return ELFGO_E_BADARG;
+  if (((uintptr_t)dst & (fmt == ELFGO_FEAT_F16_NHWC ? 1 : 3)) != 0) return ELFGO_E_BADARG;
   DISPATCH(e, hipLaunchKernelGGL(k_extract_agz<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, d4, n, dst,
-                                 stride_floats));
+                                 stride_elems, fmt));
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int elfgo_extract_agz(ElfGoEngine* e, const int32_t* ids, const int32_t* d4, int n, float* dst, int64_t stride_floats,
+                      void* stream) {
+  return elfgo_extract_agz_fmt(e, ids, d4, n, dst, stride_floats, ELFGO_FEAT_F32_NCHW, stream);
 }
 
 int elfgo_evaluate(ElfGoEngine* e, const int32_t* ids, int n, float komi, float* out, void* stream) {

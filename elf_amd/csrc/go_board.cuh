@@ -591,39 +591,107 @@ struct Board {
   }
 };
 
-// BoardFeature::extractAGZ (board_feature.cc:247-290) + InvTransform (board_feature.h:115-130).
-// hist = LDS copy of a slot's history ring; output-indexed so every store instruction of the wave is one
-// fully coalesced 256-B segment of a plane.
+// BoardFeature::extractAGZ (board_feature.cc:247-290) under Transform (board_feature.h:97-113), two stages:
+//  1. agz_bitplanes: the 18 planes as bit rows in OUTPUT order (bit o of plane p = value at transformed point o).  Lane l
+//     looks up the source bit of output points 64k+l in the history ring; one ballot per (plane, k) is the output word.
+//  2. agz_store: the row is one flat array (fp32 [18][N][N], the reference's layout, or fp16 [N][N][18] = channels_last
+//     for an fp16 net); lanes own 16 consecutive BYTES of it, so every store instruction of the body is one
+//     contiguous 1-KiB segment (global_store_dwordx4) whatever the alignment of the row (head/tail peeled per element).
+enum { FEAT_F32_NCHW = 0, FEAT_F16_NHWC = 1 };
+
 template <int N>
-__device__ __forceinline__ void extract_agz_planes(const u64 (*hist)[2][Geo<N>::R], int cnt, int player, int d4,
-                                                   float* __restrict__ out, int lane) {
+__device__ __forceinline__ void agz_bitplanes(const u64 (*hist)[2][Geo<N>::R], int cnt, int player, int d4,
+                                              u64 (*tpl)[Geo<N>::R], int lane) {
   using G = Geo<N>;
   const int len = cnt < HIST ? cnt : HIST;
   const int rot = d4 & 3;
   const bool flip = ((d4 >> 2) & 1) != 0;
+  const bool blk = player == S_BLACK;
 #pragma unroll
   for (int k = 0; k < G::R; ++k) {
     int o = k * 64 + lane;
-    if (o >= G::NP) break;
+    const bool valid = o < G::NP;
+    if (!valid) o = 0;
     int xo = o / N, yo = o % N;
     if (flip) { int t = xo; xo = yo; yo = t; }
     int x = xo, y = yo;
     if (rot == 1) { x = N - 1 - yo; y = xo; }
     else if (rot == 2) { x = N - 1 - xo; y = N - 1 - yo; }
     else if (rot == 3) { x = yo; y = N - 1 - xo; }
-    int a = x * N + y, w = a >> 6, sft = a & 63;
+    const int a = x * N + y, w = a >> 6, sft = a & 63;
 #pragma unroll
     for (int hk = 0; hk < HIST; ++hk) {
-      int slot = (cnt - 1 - hk) & (HIST - 1);
-      u64 bb = hist[slot][0][w], wb = hist[slot][1][w];
-      bool isb = hk < len && ((bb >> sft) & 1), isw = hk < len && ((wb >> sft) & 1);
-      bool mine = player == S_BLACK ? isb : isw, theirs = player == S_BLACK ? isw : isb;
-      out[(2 * hk) * G::NP + o] = mine ? 1.0f : 0.0f;
-      out[(2 * hk + 1) * G::NP + o] = theirs ? 1.0f : 0.0f;
+      const int slot = (cnt - 1 - hk) & (HIST - 1);
+      const bool on = valid && hk < len;
+      const u64 mb = __ballot(on && ((hist[slot][0][w] >> sft) & 1));
+      const u64 mw = __ballot(on && ((hist[slot][1][w] >> sft) & 1));
+      if (lane == 0) { tpl[2 * hk][k] = blk ? mb : mw; tpl[2 * hk + 1][k] = blk ? mw : mb; }
     }
-    out[16 * G::NP + o] = player == S_BLACK ? 1.0f : 0.0f;
-    out[17 * G::NP + o] = player == S_BLACK ? 0.0f : 1.0f;
+    const u64 full = __ballot(valid);
+    if (lane == 0) { tpl[16][k] = blk ? full : 0; tpl[17][k] = blk ? 0 : full; }
   }
+}
+
+template <int N>
+__device__ __forceinline__ u32 agz_bit(const u64 (*tpl)[Geo<N>::R], int p, int o) { return (u32)(tpl[p][o >> 6] >> (o & 63)) & 1u; }
+
+template <int N, int FMT>
+__device__ __forceinline__ void agz_store(const u64 (*tpl)[Geo<N>::R], void* __restrict__ row, int lane) {
+  using G = Geo<N>;
+  constexpr int TOTAL = 18 * G::NP;
+  const uintptr_t addr = (uintptr_t)row;
+  if (FMT == FEAT_F32_NCHW) {
+    float* out = (float*)row;
+    const int head = (int)(((16 - (addr & 15)) & 15) >> 2);     // floats up to the first 16-B boundary
+    if (lane < head) out[lane] = agz_bit<N>(tpl, lane / G::NP, lane % G::NP) ? 1.0f : 0.0f;
+    const int body = (TOTAL - head) >> 2;
+    float4* o4 = (float4*)(out + head);
+    for (int j = lane; j < body; j += 64) {
+      const int f = head + 4 * j;
+      int p = f / G::NP, o = f - p * G::NP;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = agz_bit<N>(tpl, p, o) ? 1.0f : 0.0f;
+        if (++o == G::NP) { o = 0; ++p; }
+      }
+      o4[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const int f = head + 4 * body + lane;
+    if (f < TOTAL) out[f] = agz_bit<N>(tpl, f / G::NP, f % G::NP) ? 1.0f : 0.0f;
+  } else {
+    u16* out = (u16*)row;                                       // IEEE half bits: 1.0 = 0x3C00
+    const int head = (int)(((16 - (addr & 15)) & 15) >> 1);
+    if (lane < head) out[lane] = agz_bit<N>(tpl, lane % 18, lane / 18) ? 0x3C00 : 0;
+    const int body = (TOTAL - head) >> 3;
+    uint4* o4 = (uint4*)(out + head);
+    for (int j = lane; j < body; j += 64) {
+      const int f = head + 8 * j;
+      int o = f / 18, p = f - o * 18;
+      u32 v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u32 lo = agz_bit<N>(tpl, p, o) ? 0x3C00u : 0u;
+        if (++p == 18) { p = 0; ++o; }
+        u32 hi = agz_bit<N>(tpl, p, o) ? 0x3C00u : 0u;
+        if (++p == 18) { p = 0; ++o; }
+        v[e] = lo | (hi << 16);
+      }
+      o4[j] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    const int f = head + 8 * body + lane;
+    if (f < TOTAL) out[f] = agz_bit<N>(tpl, f % 18, f / 18) ? 0x3C00 : 0;
+  }
+}
+
+// whole extraction of one position by one wave; `hist` and `tpl` are LDS
+template <int N>
+__device__ __forceinline__ void extract_agz_row(const u64 (*hist)[2][Geo<N>::R], u64 (*tpl)[Geo<N>::R], int cnt, int player, int d4,
+                                                void* __restrict__ row, int fmt, int lane) {
+  agz_bitplanes<N>(hist, cnt, player, d4, tpl, lane);
+  __syncthreads();
+  if (fmt == FEAT_F16_NHWC) agz_store<N, FEAT_F16_NHWC>(tpl, row, lane);
+  else agz_store<N, FEAT_F32_NCHW>(tpl, row, lane);
 }
 
 // BoardFeature::action2Coord (board_feature.h:139-144): NN action id under D4 code d4 -> (reference Coord, D4-0 action id)

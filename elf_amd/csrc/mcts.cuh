@@ -402,10 +402,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
 // rows of the net batch: game-major, leaf order within a game; row_base = exclusive prefix over games.
 // One wave per (game, unique leaf); the wave of (G-1, 0) also publishes the total row count.
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, float* __restrict__ s_out, int64_t stride, RowRec* rowmap,
+__global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, void* __restrict__ s_out, int64_t stride, int fmt, RowRec* rowmap,
                                                        int32_t* counts /* [0]=rows [1]=err-or */) {
   using G = Geo<N>;
   __shared__ u64 hist[HIST][2][G::R];
+  __shared__ u64 tpl[18][G::R];
   const int g = blockIdx.x / K, u = blockIdx.x % K, lane = threadIdx.x;
   const GameState& gs = tp.gs[g];
   const bool last = (g == tp.G - 1 && u == 0);
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, flo
   for (int j = lane; j < HIST * 2 * G::R; j += 64) (&hist[0][0][0])[j] = gh[j];
   const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
   __syncthreads();
-  extract_agz_planes<N>(hist, cnt, player, d4, s_out + (size_t)row * stride, lane);
+  extract_agz_row<N>(hist, tpl, cnt, player, d4, (char*)s_out + (size_t)row * stride * (fmt == FEAT_F16_NHWC ? 2 : 4), fmt, lane);
   if (lane == 0) { rowmap[row].game = g; rowmap[row].node = node; rowmap[row].d4 = d4; rowmap[row].pad = 0; }
 }
 

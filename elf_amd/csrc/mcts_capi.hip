@@ -21,6 +21,7 @@ struct ElfMcts {
   int32_t* all_games = nullptr;
   TreeCfg cfg;
   size_t node_bytes = 0;
+  int feat_fmt = ELFGO_FEAT_F32_NCHW;
 };
 
 template <int N>
@@ -134,6 +135,11 @@ int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt) {
   if (!m) return ELFGO_E_BADARG;
   return cfg_from(opt, &m->cfg);
 }
+int elfmcts_set_feature_format(ElfMcts* m, int fmt) {
+  if (!m || (fmt != ELFGO_FEAT_F32_NCHW && fmt != ELFGO_FEAT_F16_NHWC)) return ELFGO_E_BADARG;
+  m->feat_fmt = fmt;
+  return 0;
+}
 int elfmcts_num_games(const ElfMcts* m) { return m ? m->G : ELFGO_E_BADARG; }
 int elfmcts_edge_stride(const ElfMcts* m) { return m ? m->NE : ELFGO_E_BADARG; }
 size_t elfmcts_node_bytes(const ElfMcts* m) { return m ? m->node_bytes : 0; }
@@ -177,7 +183,7 @@ int elfmcts_select(ElfMcts* m, const int32_t* board_ids, float* s_dst, int64_t s
     hipLaunchKernelGGL((k_mcts_select<N, Pool<N>>), dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
                        board_ids, m->cfg);
     hipLaunchKernelGGL(k_mcts_features<N>, dim3(m->G * K), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), K, s_dst, stride_floats,
-                       m->rowmap, counts);
+                       m->feat_fmt, m->rowmap, counts);
   });
   HIPCHK(hipGetLastError());
   return 0;

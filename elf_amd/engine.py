@@ -155,16 +155,26 @@ class GoEngine:
         check(self.L.elfgo_legal_mask(self._h, p, k, C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
-    def extract_agz(self, ids=None, d4=None, out=None, n=None):
-        """BoardFeature::extractAGZ into `out` [k,18,N,N] fp32 (allocated if None): the batcher's "s" tensor."""
+    def extract_agz(self, ids=None, d4=None, out=None, n=None, fmt="f32_nchw"):
+        """BoardFeature::extractAGZ into `out` [k,18,N,N] (allocated if None): the batcher's "s" tensor.
+        fmt "f32_nchw": fp32 contiguous rows (the reference's layout); "f16_nhwc": fp16 channels_last rows, i.e. what
+        an fp16 channels_last net reads without a cast/permute pass."""
         t, p, k = self._ids(ids, n)
         d, dp = self._i32(d4, k)
+        f16 = fmt == "f16_nhwc"
+        if not f16 and fmt != "f32_nchw":
+            raise ValueError("fmt must be 'f32_nchw' or 'f16_nhwc'")
+        row = NUM_AGZ_PLANES * self.n * self.n
         if out is None:
-            out = torch.empty((k, NUM_AGZ_PLANES, self.n, self.n), dtype=torch.float32, device=self.device)
-        assert out.dtype == torch.float32 and out.is_cuda and out.shape[0] >= k
-        assert out[0].is_contiguous()
-        stride = out.stride(0) if out.shape[0] > 1 else NUM_AGZ_PLANES * self.n * self.n
-        check(self.L.elfgo_extract_agz(self._h, p, dp, k, C.c_void_p(out.data_ptr()), stride, self._stream()))
+            if f16:
+                out = torch.empty((k, self.n, self.n, NUM_AGZ_PLANES), dtype=torch.float16, device=self.device).permute(0, 3, 1, 2)
+            else:
+                out = torch.empty((k, NUM_AGZ_PLANES, self.n, self.n), dtype=torch.float32, device=self.device)
+        assert out.is_cuda and out.shape[0] >= k and out.dtype == (torch.float16 if f16 else torch.float32)
+        inner = (1, self.n * NUM_AGZ_PLANES, NUM_AGZ_PLANES) if f16 else (self.n * self.n, self.n, 1)
+        assert tuple(out.stride()[1:]) == inner, "rows must be %s" % ("channels_last" if f16 else "contiguous [18,N,N]")
+        stride = out.stride(0) if out.shape[0] > 1 else row
+        check(self.L.elfgo_extract_agz_fmt(self._h, p, dp, k, C.c_void_p(out.data_ptr()), stride, 1 if f16 else 0, self._stream()))
         return out
 
     def evaluate(self, ids=None, komi=7.5, n=None):

@@ -98,3 +98,60 @@ def make_net(board_size=19, num_block=20, dim=256, device="cuda", dtype=torch.fl
     for p in net.parameters():
         p.requires_grad_(False)
     return net
+
+
+class FusedInferenceNet:
+    """Inference-only execution of a BN-folded fp16 channels_last PolicyValueNet with ONE epilogue pass per convolution.
+
+    The convolutions stay PyTorch-ROCm ops (MIOpen / CK implicit GEMM); what changes is what runs between them.  Eager PyTorch
+    issues conv -> bias add -> ReLU (-> residual add -> ReLU) as separate elementwise kernels, i.e. five HBM round trips of the
+    [B,256,N,N] activation per residual block; here each conv is bias-free and is followed by one in-place pass
+    (`elfnet_bias_act_f16`, elf_amd/csrc/net_epilogue.hip): relu(x + b) after the lower conv, relu(x + b + skip) after the upper.
+    (PyTorch's own fused MIOpen ops, miopen_convolution_relu / miopen_convolution_add_relu, were measured and rejected: for
+    fp16 channels_last MIOpen's fusion plan falls back to naive kernels, > 10x slower.)
+    Same function as PolicyValueNet.forward (src_py/elfgames/go/df_model3.py:62-110,224-313) up to fp16 rounding: the fused
+    epilogue rounds once where the eager sequence rounds after every kernel."""
+
+    def __init__(self, net):
+        import ctypes as C
+        from . import _lib
+        p = next(net.parameters())
+        if p.dtype != torch.float16:
+            raise ValueError("FusedInferenceNet needs an fp16 net")
+        if any(isinstance(m, nn.BatchNorm2d) for m in net.modules()):
+            raise ValueError("fold BatchNorm first (make_net(fold_bn=True))")
+        self.net, self.C = net, C
+        self.L = _lib.lib()   # raises if libelf_amd.so is missing: no silent fallback
+        self.check = _lib.check
+        conv = lambda seq: seq[0]
+        self.first = conv(net.init_conv)
+        self.blocks = [(conv(b.lower), conv(b.upper)) for b in net.resnet]
+
+    def _ep(self, x, bias, res, relu=True):
+        rows = x.numel() // x.shape[1]
+        C = self.C
+        self.check(self.L.elfnet_bias_act_f16(C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                             C.c_void_p(res.data_ptr()) if res is not None else None, rows, x.shape[1], int(relu),
+                                             C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return x
+
+    def _conv(self, x, c, res=None):
+        y = torch.nn.functional.conv2d(x, c.weight, None, c.stride, c.padding)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        return self._ep(y, c.bias, res)
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        net = self.net
+        s = batch["s"] if isinstance(batch, dict) else batch
+        if s.dtype != torch.float16:
+            s = s.to(torch.float16)
+        s = s.contiguous(memory_format=torch.channels_last)   # no-op for SelfPlay(feature_format="f16_nhwc")
+        h = self._conv(s, self.first)
+        for lo, up in self.blocks:
+            h = self._conv(self._conv(h, lo), up, res=h)
+        pi = net.pi_linear(net.pi_final_conv(h).reshape(-1, 2 * net.d))
+        pi = torch.softmax(pi.float(), dim=1)
+        v = torch.relu(net.value_linear1(net.value_final_conv(h).reshape(-1, net.d)))
+        v = torch.tanh(net.value_linear2(v)).float().reshape(-1)
+        return dict(pi=pi, V=v)

@@ -49,7 +49,8 @@ class SelfPlay:
                  mcts_puct=1.5, mcts_virtual_loss=1, mcts_use_prior=True, mcts_persistent_tree=True, mcts_epsilon=0.0,
                  mcts_alpha=0.0, mcts_unexplored_q_zero=False, mcts_root_unexplored_q_zero=False, komi=7.5,
                  ply_pass_enabled=0, policy_distri_cutoff=0, move_cutoff=-1, resign_thres=0.0, never_resign_prob=0.0,
-                 seed=0, nodes_per_game=None, log_searches=0, rotation_flip=True, remove_pass_if_dangerous=True):
+                 seed=0, nodes_per_game=None, log_searches=0, rotation_flip=True, remove_pass_if_dangerous=True,
+                 feature_format="f32_nchw"):
         if not torch.cuda.is_available():
             raise RuntimeError("elf_amd.SelfPlay needs a ROCm GPU (no CPU fallback exists)")
         self.L = _lib.lib()
@@ -75,8 +76,17 @@ class SelfPlay:
         self._h = h
         self.max_rows = self.L.elfsp_max_rows(self._h)
         self.edge_stride = self.L.elfmcts_edge_stride(self.L.elfsp_mcts(self._h))
-        # the batcher's "s" tensor (common/game_feature.h:159-163): [B, 18, N, N] f32 -- resident in HBM
-        self.s = torch.zeros((self.max_rows, 18, self.n, self.n), dtype=torch.float32, device=self.device)
+        # the batcher's "s" tensor (common/game_feature.h:159-163): [B, 18, N, N] -- resident in HBM.  "f32_nchw" is the
+        # reference's layout; "f16_nhwc" is the same logical tensor as fp16 channels_last, written directly by the select
+        # kernel for an fp16 channels_last net
+        if feature_format == "f16_nhwc":
+            self.s = torch.zeros((self.max_rows, self.n, self.n, 18), dtype=torch.float16, device=self.device).permute(0, 3, 1, 2)
+            check(self.L.elfmcts_set_feature_format(self.L.elfsp_mcts(self._h), 1))
+        elif feature_format == "f32_nchw":
+            self.s = torch.zeros((self.max_rows, 18, self.n, self.n), dtype=torch.float32, device=self.device)
+        else:
+            raise ValueError("feature_format must be 'f32_nchw' or 'f16_nhwc'")
+        self.feature_format = feature_format
         self._rows = C.c_int(0)
         self._cb = {}
 

@@ -60,6 +60,15 @@ int elfgo_legal_mask(ElfGoEngine* e, const int32_t* ids, int n, uint8_t* mask, v
  * This is the write into the batcher's "s" tensor (common/game_feature.h:38-40). d4 NULL = code 0. */
 int elfgo_extract_agz(ElfGoEngine* e, const int32_t* ids, const int32_t* d4, int n, float* dst,
                       int64_t stride_floats, void* stream);
+/* The same extraction with a selectable row format (emit what an fp16 channels_last net reads, so the
+ * fp32->fp16 cast and the NCHW->NHWC permute of the reference's trainer.py/model path disappear):
+ *   ELFGO_FEAT_F32_NCHW  fp32 [18][N][N]  (the reference's "s" row, what elfgo_extract_agz writes)
+ *   ELFGO_FEAT_F16_NHWC  fp16 [N][N][18]  (= torch channels_last of a [18,N,N] half tensor)
+ * stride_elems counts elements of the chosen type between consecutive rows (>= 18*N*N). */
+#define ELFGO_FEAT_F32_NCHW 0
+#define ELFGO_FEAT_F16_NHWC 1
+int elfgo_extract_agz_fmt(ElfGoEngine* e, const int32_t* ids, const int32_t* d4, int n, void* dst, int64_t stride_elems,
+                          int fmt, void* stream);
 /* GoState::evaluate (go_state.h:194-203): Tromp-Taylor area(black) - area(white) - komi; superko -> +-1 */
 int elfgo_evaluate(ElfGoEngine* e, const int32_t* ids, int n, float komi, float* out, void* stream);
 /* per-board info records (ELFGO_INFO_WORDS int32 each) */
@@ -111,6 +120,9 @@ typedef struct ElfMctsOptions {
 int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_window, const ElfMctsOptions* opt, ElfMcts** out);
 int elfmcts_destroy(ElfMcts* m);
 int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt);
+/* row format elfmcts_select / elfsp_begin_step write into s_dst (ELFGO_FEAT_*; default fp32 NCHW). With
+ * ELFGO_FEAT_F16_NHWC s_dst points to halfs and the stride argument counts halfs. */
+int elfmcts_set_feature_format(ElfMcts* m, int fmt);
 int elfmcts_num_games(const ElfMcts* m);
 int elfmcts_edge_stride(const ElfMcts* m);   /* row length of the per-edge arrays (368 at 19x19, 96 at 9x9) */
 size_t elfmcts_node_bytes(const ElfMcts* m);
@@ -187,6 +199,16 @@ int64_t elfsp_games_finished(const ElfSelfPlay* sp);
 /* logged searches [first, first+n): records and root edges (host arrays, [n][edge_stride], may be NULL) */
 int elfsp_search_log(const ElfSelfPlay* sp, int first, int n, ElfSpSearch* rec, int32_t* coord, int32_t* visits, float* prior,
                      float* reward);
+
+/* ------------------------------------------------------------------------------------------------
+ * Glue for the PyTorch-ROCm policy/value net (the net itself stays on PyTorch, BASELINE.json north_star): the
+ * convolution's epilogue as ONE pass over the fp16 channels_last activation instead of PyTorch's separate
+ * bias-add, residual-add and ReLU kernels (src_py/elfgames/go/df_model3.py:62-110 Block.forward:
+ * relu(bn(conv(x))) and relu(bn(conv(h)) + x) with eval BatchNorm folded into the conv).
+ *   x[r][c] <- act(x[r][c] + bias[c] + (res ? res[r][c] : 0)),  x/res fp16 [rows][channels] contiguous
+ *   (channels % 8 == 0, 16-B aligned), bias fp16 [channels] or NULL, relu != 0 applies max(.,0).
+ * fp32 arithmetic, one rounding to fp16. */
+int elfnet_bias_act_f16(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream);
 
 /* convenience for callers without a HIP runtime of their own (tests, cgo/ctypes stubs) */
 int elfgo_malloc(void** dptr, size_t bytes);
