@@ -54,6 +54,20 @@ SIGNATURES = {
     "elfsp_stats": (_i, [_vp, _vp]),
     "elfsp_games_finished": (_i64, [_vp]),
     "elfsp_search_log": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "elfsp_records_pending": (_i, [_vp]),
+    "elfsp_pop_record": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "elftrain_create": (_i, [_vp, _i, _i, _i, C.c_uint32, C.POINTER(_vp)]),
+    "elftrain_destroy": (_i, [_vp]),
+    "elftrain_capacity": (_i, [_vp]),
+    "elftrain_max_moves": (_i, [_vp]),
+    "elftrain_num_records": (_i, [_vp]),
+    "elftrain_put": (_i, [_vp, _i, _vp, _i, _f, _i64, _vp, _i, _vp, _i]),
+    "elftrain_draw": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "elftrain_extract": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "elfrec_coords_to_sgfstr": (_i, [_i, _vp, _i, _vp, _sz]),
+    "elfrec_sgfstr_to_coords": (_i, [_i, C.c_char_p, _vp, _i]),
+    "elfrec_record_to_json": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _i, _i, C.c_uint64, C.c_uint64, _vp, _sz]),
+    "elfrec_quantise_policy": (_i, [_i, _vp, _vp, _i, _vp]),
     "elfnet_bias_act_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfgo_malloc": (_i, [C.POINTER(_vp), _sz]),
     "elfgo_free": (_i, [_vp]),

@@ -1,0 +1,226 @@
+// Self-play record format, host side: what the reference's GoStateExt::dumpRecord (go_state_ext.h:131-148),
+// MsgResult/Record::setJsonFields (record.h:203-262), GoStateExt::addMCTSPolicy (go_state_ext.h:158-181) and the SGF string
+// helpers coords2sgfstr / sgfstr2coords / str2coord / coord2str (sgf/sgf.h:21-57,87-125) produce and consume.  The JSON text
+// follows nlohmann::json::dump() of the reference (compact separators, object keys in std::map order, floats widened to double
+// and printed with the shortest round-trip digits in nlohmann's fixed/exponent layout), so that the reference's
+// Record::createFromJson reads it back field for field.
+#include "record_host.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <charconv>
+
+#include "../../include/elf_amd.h"
+
+namespace {
+
+// nlohmann 3.1 dtoa: to_chars / format_buffer with min_exp = -4, max_exp = 15 (digits10 of double)
+void put_double(std::string& o, double v) {
+  if (!std::isfinite(v)) { o += "null"; return; }
+  if (std::signbit(v)) { o += '-'; v = -v; }
+  if (v == 0) { o += "0.0"; return; }
+  char sci[64];
+  auto res = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);   // shortest round-trip digits
+  std::string t(sci, res.ptr);
+  const size_t e = t.find('e');
+  std::string digits;
+  for (size_t i = 0; i < e; ++i) if (t[i] != '.') digits += t[i];
+  const int exp10 = atoi(t.c_str() + e + 1);
+  const int k = (int)digits.size();
+  const int n = exp10 + 1;              // decimal point position: value = 0.digits * 10^n
+  if (k <= n && n <= 15) { o += digits; o.append((size_t)(n - k), '0'); o += ".0"; return; }
+  if (0 < n && n <= 15) { o.append(digits, 0, (size_t)n); o += '.'; o.append(digits, (size_t)n, std::string::npos); return; }
+  if (-4 < n && n <= 0) { o += "0."; o.append((size_t)(-n), '0'); o += digits; return; }
+  o += digits[0];
+  if (k > 1) { o += '.'; o.append(digits, 1, std::string::npos); }
+  o += 'e';
+  int ex = n - 1;
+  if (ex < 0) { o += '-'; ex = -ex; } else { o += '+'; }
+  if (ex < 10) o += '0';
+  o += std::to_string(ex);
+}
+void put_float(std::string& o, float v) { put_double(o, (double)v); }
+void put_bool(std::string& o, bool b) { o += b ? "true" : "false"; }
+
+inline int X(int c, int S) { return c % S - 1; }
+inline int Y(int c, int S) { return c / S - 1; }
+
+}  // namespace
+
+SpRecordMeta elfrec_meta_from_options(const ElfSpOptions& o) {
+  SpRecordMeta m{};
+  m.board_size = o.board_size; m.black_ver = o.model_ver; m.white_ver = -1;   // self-play: one AI plays both colours
+  m.num_threads = 1; m.num_rollouts_per_thread = o.num_rollouts_per_thread; m.num_rollouts_per_batch = o.mcts.num_rollouts_per_batch;
+  m.virtual_loss = o.mcts.virtual_loss; m.persistent_tree = o.persistent_tree != 0; m.use_prior = o.mcts.use_prior != 0;
+  m.unexplored_q_zero = o.mcts.unexplored_q_zero != 0; m.root_unexplored_q_zero = o.mcts.root_unexplored_q_zero != 0;
+  m.c_puct = o.mcts.c_puct; m.root_epsilon = o.root_epsilon; m.root_alpha = o.root_alpha;
+  m.black_resign_thres = o.resign_thres; m.white_resign_thres = o.resign_thres; m.never_resign_prob = o.never_resign_prob;
+  m.num_game_thread_used = o.num_games;
+  return m;
+}
+
+std::string elfrec_record_json(const SpRecordMeta& m, const SpRecord& r) {
+  std::string o;
+  o.reserve(4096 + r.policies.size() * 3);
+  const int P = (m.board_size + 2) * (m.board_size + 2);
+  o += "{\"offline\":false,\"pri\":0.0,\"request\":{\"client_ctrl\":{\"async\":false,\"black_resign_thres\":";
+  put_float(o, m.black_resign_thres);
+  o += ",\"client_type\":1,\"never_resign_prob\":"; put_float(o, m.never_resign_prob);
+  o += ",\"num_game_thread_used\":" + std::to_string(m.num_game_thread_used);
+  o += ",\"player_swap\":false,\"white_resign_thres\":"; put_float(o, m.white_resign_thres);
+  o += "},\"vers\":{\"black_ver\":" + std::to_string(m.black_ver) + ",\"mcts_opt\":{\"alg_opt\":{\"c_puct\":"; put_float(o, m.c_puct);
+  o += ",\"root_unexplored_q_zero\":"; put_bool(o, m.root_unexplored_q_zero);
+  o += ",\"unexplored_q_zero\":"; put_bool(o, m.unexplored_q_zero);
+  o += ",\"use_prior\":"; put_bool(o, m.use_prior);
+  o += "},\"log_prefix\":\"\",\"max_num_moves\":0,\"num_rollouts_per_batch\":" + std::to_string(m.num_rollouts_per_batch);
+  o += ",\"num_rollouts_per_thread\":" + std::to_string(m.num_rollouts_per_thread);
+  o += ",\"num_threads\":" + std::to_string(m.num_threads) + ",\"persistent_tree\":"; put_bool(o, m.persistent_tree);
+  o += ",\"pick_method\":\"most_visited\",\"root_alpha\":"; put_float(o, m.root_alpha);
+  o += ",\"root_epsilon\":"; put_float(o, m.root_epsilon);
+  o += ",\"seed\":0,\"verbose\":false,\"verbose_time\":false,\"virtual_loss\":" + std::to_string(m.virtual_loss);
+  o += "},\"white_ver\":" + std::to_string(m.white_ver) + "}},\"result\":{\"black_never_resign\":"; put_bool(o, r.never_resign);
+  o += ",\"content\":\"";
+  {
+    std::vector<char> buf(r.moves.size() * 6 + 8);
+    const int len = elfrec_coords_to_sgfstr(m.board_size, r.moves.data(), (int)r.moves.size(), buf.data(), buf.size());
+    for (int i = 0; i < len; ++i) {   // coord2str of an off-board Coord can emit '`' or '\\'-range bytes; escape as nlohmann does
+      const unsigned char ch = (unsigned char)buf[i];
+      if (ch == '"') o += "\\\"";
+      else if (ch == '\\') o += "\\\\";
+      else if (ch < 0x20) { char t[8]; snprintf(t, sizeof(t), "\\u%04x", ch); o += t; }
+      else o += (char)ch;
+    }
+  }
+  o += "\",\"num_move\":" + std::to_string(r.num_move);
+  const size_t np = r.policies.size() / (size_t)P;
+  if (np) {   // MsgResult::setJsonFields only creates the key when there is at least one policy (record.h:212-218)
+    o += ",\"policies\":[";
+    for (size_t i = 0; i < np; ++i) {
+      o += i ? ",[" : "[";
+      for (int k = 0; k < P; ++k) { if (k) o += ','; o += std::to_string((int)r.policies[i * P + k]); }
+      o += ']';
+    }
+    o += ']';
+  }
+  o += ",\"reward\":"; put_float(o, r.reward);
+  o += ",\"using_models\":[";
+  {
+    bool first = true;   // std::set<int64_t>: ascending, without negatives (addCurrentModel, go_state_ext.h:69-74)
+    int64_t a = m.black_ver, b = m.white_ver;
+    if (a > b) { int64_t t = a; a = b; b = t; }
+    if (a >= 0) { o += std::to_string(a); first = false; }
+    if (b >= 0 && b != a) { if (!first) o += ','; o += std::to_string(b); }
+  }
+  o += "],\"values\":[";
+  for (size_t i = 0; i < r.values.size(); ++i) { if (i) o += ','; put_float(o, r.values[i]); }
+  o += "],\"white_never_resign\":"; put_bool(o, r.never_resign);
+  o += "},\"seq\":" + std::to_string(r.seq) + ",\"thread_id\":" + std::to_string(r.thread_id) + ",\"timestamp\":" + std::to_string(r.timestamp) + "}";
+  return o;
+}
+
+void elfrec_append_policy(int board_size, const int32_t* coord, const float* prob, int n, std::vector<uint8_t>* policies) {
+  const size_t P = (size_t)(board_size + 2) * (board_size + 2);
+  const size_t base = policies->size();
+  policies->resize(base + P, 0);
+  (void)elfrec_quantise_policy(board_size, coord, prob, n, policies->data() + base);
+}
+
+extern "C" {
+
+// coords2sgfstr (sgf/sgf.h:87-95) with coord2str (:48-57): "(;B[xy];W[xy]...)", pass = "[]"
+int elfrec_coords_to_sgfstr(int board_size, const uint16_t* coords, int n, char* out, size_t cap) {
+  if (board_size < 1 || n < 0 || (n > 0 && !coords)) return ELFGO_E_BADARG;
+  const int S = board_size + 2;
+  size_t len = 0;
+  auto put = [&](char c) { if (out && len < cap) out[len] = c; ++len; };
+  put('(');
+  for (int i = 0; i < n; ++i) {
+    put(';'); put(i % 2 == 0 ? 'B' : 'W'); put('[');
+    const int c = coords[i];
+    if (c != 0 /* M_PASS */) { put((char)('a' + X(c, S))); put((char)('a' + Y(c, S))); }
+    put(']');
+  }
+  put(')');
+  if (out && len < cap) out[len] = 0;
+  if (out && len >= cap) return ELFGO_E_BADSIZE;
+  return (int)len;
+}
+
+// sgfstr2coords (sgf/sgf.h:97-125) with str2coord (:21-46); returns the number of moves (all of them are counted, the
+// first `cap` are stored)
+int elfrec_sgfstr_to_coords(int board_size, const char* sgf, uint16_t* out, int cap) {
+  if (board_size < 1 || !sgf || cap < 0 || (cap > 0 && !out)) return ELFGO_E_BADARG;
+  const int N = board_size, S = N + 2;
+  const size_t L = strlen(sgf);
+  if (L == 0 || sgf[0] != '(') return 0;
+  int cnt = 0;
+  size_t i = 1;
+  while (true) {
+    if (i >= L || sgf[i] != ';') break;
+    while (i < L && sgf[i] != '[') i++;
+    if (i == L) break;
+    i++;
+    size_t j = i;
+    while (j < L && sgf[j] != ']') j++;
+    if (j == L) break;
+    // str2coord(sgf.substr(i, j - i))
+    int coord;
+    const size_t sl = j - i;
+    const char* s = sgf + i;
+    if (sl < 2) coord = 0;   // M_PASS
+    else {
+      size_t k = 0;
+      while (k < sl && (s[k] == '\n' || s[k] == ' ')) k++;
+      if (k == sl) coord = 3;   // M_INVALID
+      else {
+        const int x = s[k] - 'a';
+        k++;
+        while (k < sl && (s[k] == '\n' || s[k] == ' ')) k++;
+        if (k == sl) coord = 3;
+        else {
+          const int y = s[k] - 'a';
+          coord = (x >= 0 && x < N && y >= 0 && y < N) ? (y + 1) * S + (x + 1) : 3;   // ON_BOARD, OFFSETXY (board.h:183-186)
+        }
+      }
+    }
+    if (cnt < cap) out[cnt] = (uint16_t)coord;
+    cnt++;
+    i = j + 1;
+  }
+  return cnt;
+}
+
+// Record JSON from plain arrays (what elfsp_pop_record returns for a finished game); usable without a GPU
+int elfrec_record_to_json(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const uint8_t* policies, int num_policies,
+                          const float* values, int num_values, float reward, int never_resign, int seq, uint64_t thread_id,
+                          uint64_t timestamp, char* out, size_t cap) {
+  if (!opt || num_moves < 0 || num_policies < 0 || num_values < 0 || (num_moves && !moves) || (num_policies && !policies) ||
+      (num_values && !values)) return ELFGO_E_BADARG;
+  SpRecord r;
+  const size_t P = (size_t)(opt->board_size + 2) * (opt->board_size + 2);
+  r.moves.assign(moves, moves + num_moves);
+  r.policies.assign(policies, policies + (size_t)num_policies * P);
+  r.values.assign(values, values + num_values);
+  r.reward = reward; r.never_resign = never_resign != 0; r.num_move = num_moves; r.seq = seq; r.thread_id = thread_id; r.timestamp = timestamp;
+  const std::string t = elfrec_record_json(elfrec_meta_from_options(*opt), r);
+  if (out && cap > t.size()) { memcpy(out, t.data(), t.size()); out[t.size()] = 0; }
+  else if (out) return ELFGO_E_BADSIZE;
+  return (int)t.size();
+}
+
+// GoStateExt::addMCTSPolicy (go_state_ext.h:158-181): out[(N+2)^2] <- 0; out[coord[k]] = (unsigned char)(prob[k] / max * 255)
+int elfrec_quantise_policy(int board_size, const int32_t* coord, const float* prob, int n, uint8_t* out) {
+  if (board_size < 1 || n < 0 || !out || (n > 0 && (!coord || !prob))) return ELFGO_E_BADARG;
+  const int P = (board_size + 2) * (board_size + 2);
+  float max_val = 0.0;
+  for (int k = 0; k < n; ++k) max_val = prob[k] > max_val ? prob[k] : max_val;   // std::max(max_val, entry.second)
+  memset(out, 0, (size_t)P);
+  for (int k = 0; k < n; ++k) {
+    if (coord[k] < 0 || coord[k] >= P) return ELFGO_E_BADARG;
+    out[coord[k]] = static_cast<unsigned char>(prob[k] / max_val * 255);
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -18,7 +18,12 @@
 #include <utility>
 #include <vector>
 
+#include <chrono>
+#include <deque>
+#include <string>
+
 #include "engine_host.h"
+#include "record_host.h"
 
 struct ElfSpSearchRec {   // == ElfSpSearch in include/elf_amd.h
   int32_t game, move_played, best_action, total_visits, n_edges;
@@ -33,6 +38,7 @@ struct SpGame {
   float last_predicted = 0.0f;
   int ply = 1;             // GoState::getPly of the game board
   int seq = 0;             // games finished by this slot
+  SpRecord rec;            // GoStateExt::_mcts_policies / _predicted_values / the game's moves (go_state_ext.h:131-148)
 };
 
 struct ElfSelfPlay {
@@ -62,7 +68,26 @@ struct ElfSelfPlay {
   std::vector<int32_t> log_coord, log_visits;
   std::vector<float> log_prior, log_reward;
   int log_cap = 0;
+  // finished-game records (GameNotifier::OnGameEnd -> GoStateExt::dumpRecord), newest at the back
+  std::deque<std::string> records;
+  SpRecordMeta meta{};
 };
+
+static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int final_ply) {
+  SpGame& gm = sp->games[g];
+  if (sp->opt.keep_records > 0) {
+    SpRecord& r = gm.rec;
+    r.reward = final_value;                      // _state.getFinalValue()
+    r.never_resign = gm.never_resign;
+    r.num_move = final_ply - 1;                  // _state.getPly() - 1
+    r.thread_id = (uint64_t)g;
+    r.seq = gm.seq + 2;                          // _seq: ctor restart() -> 1, first request restart() -> 2, then +1 per game
+    r.timestamp = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    if ((int)sp->records.size() >= sp->opt.keep_records) sp->records.pop_front();
+    sp->records.push_back(elfrec_record_json(sp->meta, r));
+  }
+  gm.rec = SpRecord();                           // GoStateExt::restart(): _mcts_policies.clear(), _predicted_values.clear()
+}
 
 #define SPCHK(x)                  \
   do {                            \
@@ -141,8 +166,11 @@ static int sp_finish_move(ElfSelfPlay* sp) {
     }
     int c = best_action;
     // mcts_make_diverse_move (game_selfplay.cc:80-95): MCTSPolicy::normalize (tree_search_base.h:190-203) + sampleAction
-    if (gm.ply <= sp->opt.policy_distri_cutoff && n > 0) {
-      std::vector<std::pair<int, float>> policy(n);
+    const bool diverse = gm.ply <= sp->opt.policy_distri_cutoff;
+    const bool keep_policy = sp->opt.keep_records > 0 && (diverse || sp->opt.policy_distri_training_for_all);
+    std::vector<std::pair<int, float>> policy;
+    if ((diverse && n > 0) || keep_policy) {
+      policy.resize(n);
       float exp_sum = 0;
       for (int i = 0; i < n; ++i) {
         float e = std::pow((float)visits[i], 1.0 / 1.0f);
@@ -150,6 +178,8 @@ static int sp_finish_move(ElfSelfPlay* sp) {
         exp_sum += e;
       }
       for (auto& p : policy) p.second /= exp_sum;
+    }
+    if (diverse && n > 0) {
       // elf_utils::sample_multinomial (elf/utils/utils.h:159-182)
       float Z = 0.0;
       for (const auto& p : policy) Z += p.second;
@@ -164,10 +194,17 @@ static int sp_finish_move(ElfSelfPlay* sp) {
       }
       c = policy[pick].first;
     }
+    if (keep_policy) {   // _state_ext.addMCTSPolicy(policy) :89-92
+      std::vector<int32_t> pc(n);
+      std::vector<float> pp(n);
+      for (int i = 0; i < n; ++i) { pc[i] = policy[i].first; pp[i] = policy[i].second; }
+      elfrec_append_policy(sp->opt.board_size, pc.data(), pp.data(), n, &gm.rec.policies);
+    }
     // mcts_update_info :97-119 with MCTSGoAI::getValue (go/mcts/mcts.h:358-365)
     float predicted = root_value;
     if (total_visits != 0 && best_i >= 0) predicted = reward[best_i] / visits[best_i];
     gm.last_predicted = predicted;
+    if (sp->opt.keep_records > 0) gm.rec.values.push_back(predicted);   // addPredictedValue, mcts_update_info :98-100
     if (sp->log_cap > 0 && (int)sp->log_search.size() < sp->log_cap) {
       ElfSpSearchRec r;
       r.game = g; r.move_played = c; r.best_action = best_action; r.total_visits = total_visits; r.n_edges = n;
@@ -193,7 +230,9 @@ static int sp_finish_move(ElfSelfPlay* sp) {
     if (resign && gm.ply >= 50) {
       finished.push_back(g);
       sp->h_moves[g] = M_PASS;       // placeholder; the board is reset below
-      sp->sum_final += ((gm.ply & 1) == 1) ? -1.0 : 1.0;   // setFinalValue FR_RESIGN (go_state_ext.h:83-85)
+      const float fv = ((gm.ply & 1) == 1) ? -1.0f : 1.0f;   // setFinalValue FR_RESIGN (go_state_ext.h:83-85)
+      sp->sum_final += fv;
+      sp_finish_record(sp, g, fv, gm.ply);
       gm.ply = -1;                   // marks "finished by resignation"
     } else {
       sp->h_moves[g] = c;
@@ -215,6 +254,7 @@ static int sp_finish_move(ElfSelfPlay* sp) {
     if (sp->h_ok[g] != 1) return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD;   // "Something is wrong! Move cannot be applied" :409-418
     const int32_t* bi = &sp->h_binfo[g * ELFGO_INFO_WORDS];
     gm.ply = bi[0];
+    if (sp->opt.keep_records > 0) gm.rec.moves.push_back((uint16_t)sp->h_moves[g]);   // GoState::_moves
     const bool terminated = bi[9] != 0;
     if (terminated || (sp->opt.move_cutoff > 0 && gm.ply >= sp->opt.move_cutoff)) by_end.push_back(g);   // :420-429
   }
@@ -225,7 +265,10 @@ static int sp_finish_move(ElfSelfPlay* sp) {
     SPCHK(elfgo_evaluate(sp->eng, sp->d_ids, (int)ids.size(), sp->opt.mcts.komi, sp->d_val, sp->stream));
     HIPCHK(hipMemcpyAsync(sp->h_val.data(), sp->d_val, sizeof(float) * ids.size(), hipMemcpyDeviceToHost, sp->stream));
     HIPCHK(hipStreamSynchronize(sp->stream));
-    for (size_t i = 0; i < ids.size(); ++i) sp->sum_final += sp->h_val[i];
+    for (size_t i = 0; i < ids.size(); ++i) {
+      sp->sum_final += sp->h_val[i];
+      sp_finish_record(sp, ids[i], sp->h_val[i], sp->games[ids[i]].ply);
+    }
     finished.insert(finished.end(), by_end.begin(), by_end.end());
   }
   if (!finished.empty()) {
@@ -281,6 +324,7 @@ int elfsp_create(const ElfSpOptions* o, int device, const uint64_t* zobrist_host
   sp->h_reward.resize(GE); sp->h_etas.assign(GE, 0.f); sp->h_Z.resize(G); sp->h_moves.resize(G); sp->h_val.resize(G);
   sp->h_ok.resize(G); sp->h_binfo.resize(G * ELFGO_INFO_WORDS); sp->h_d4.resize((size_t)G * sp->W);
   sp->log_cap = o->log_searches;
+  sp->meta = elfrec_meta_from_options(*o);
   *out = sp;
   return 0;
 }
@@ -321,6 +365,20 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
   sp->n_rollouts += (int64_t)sp->G * sp->K;
   sp->n_steps++;
   if (++sp->step_in_move >= sp->steps_per_move) SPCHK(sp_finish_move(sp));
+  return 0;
+}
+
+int elfsp_records_pending(const ElfSelfPlay* sp) { return sp ? (int)sp->records.size() : ELFGO_E_BADARG; }
+
+int elfsp_pop_record(ElfSelfPlay* sp, char* buf, size_t cap, size_t* len) {
+  if (!sp || !len) return ELFGO_E_BADARG;
+  if (sp->records.empty()) { *len = 0; return 0; }
+  const std::string& r = sp->records.front();
+  *len = r.size();
+  if (!buf || cap < r.size() + 1) return ELFGO_E_BADSIZE;   // *len tells the caller what to allocate; nothing is consumed
+  memcpy(buf, r.data(), r.size());
+  buf[r.size()] = 0;
+  sp->records.pop_front();
   return 0;
 }
 

@@ -1,0 +1,126 @@
+// Training-side replay loader on the device: one wave per training sample replays a recorded game up to a
+// sampled ply with the board engine of go_board.cuh (position in LDS for the whole replay) and emits every field of the
+// reference's "train" batch in one launch.
+//
+// Replaces, for a batch of n samples, what one reference game thread does per sample:
+//   src_cpp/elfgames/go/train/game_train.cc          GoGameTrain::act :23-58
+//   src_cpp/elfgames/go/common/go_state_ext.h        GoStateExtOffline::fromRecord :248-258, switchBeforeMove :283-290
+//   src_cpp/elfgames/go/common/game_feature.h        extractMoveIdx/NumMove/PredictedValue/AugCode/Winner :73-96,
+//                                                    extractStateExtAGZ :103-106, extractMCTSPi :107-127,
+//                                                    extractOfflineAction :129-139, extractStateSelfplayVersion :141-145
+#pragma once
+#include "go_board.cuh"
+
+namespace elfgo {
+
+// Replay store in HBM: `capacity` record slots padded to max_moves plies each (sized for 288 GB: 19x19 records with full
+// 441-byte policies are 318 KB, i.e. 100 k games = 32 GB).
+struct ReplayStore {
+  u16* moves;            // [capacity][max_moves] reference Coords of Record.result.content (sgfstr2coords)
+  int32_t* num_moves;    // [capacity] _offline_all_moves.size()
+  float* winner;         // [capacity] reward > 0 ? 1 : -1 (go_state_ext.h:250)
+  int64_t* black_ver;    // [capacity] Record.request.vers.black_ver
+  unsigned char* pol;    // [capacity][max_moves][P] CoordRecord.prob (record.h:180-182), P = (N+2)^2; may be NULL
+  int32_t* num_pol;      // [capacity] Record.result.policies.size()
+  float* values;         // [capacity][max_moves] Record.result.values
+  int32_t* num_values;   // [capacity]
+  int capacity, max_moves;
+};
+
+struct TrainBatch {   // device pointers; any of them except `s` may be NULL
+  void* s; int64_t s_stride; int fmt;
+  int64_t* offline_a; int nfa;
+  float* winner; float* mcts_scores; float* predicted_value;
+  int32_t* move_idx; int32_t* num_move; int32_t* aug_code;
+  int64_t* selfplay_ver;
+};
+
+// BoardFeature::coord2Action (board_feature.h:132-137) with Transform (:97-113); same integer arithmetic for any Coord
+template <int N>
+__device__ __forceinline__ int coord_to_action(int c, int d4) {
+  constexpr int S = N + 2;
+  if (c == M_PASS) return N * N;
+  int x = c % S - 1, y = c / S - 1;
+  const int rot = d4 & 3;
+  int ox = x, oy = y;
+  if (rot == 1) { ox = y; oy = N - x - 1; }
+  else if (rot == 2) { ox = N - x - 1; oy = N - y - 1; }
+  else if (rot == 3) { ox = N - y - 1; oy = x; }
+  if ((d4 >> 2) == 1) { int t = ox; ox = oy; oy = t; }
+  return ox * N + oy;
+}
+
+template <int N, class PoolT>
+__global__ __launch_bounds__(64) void k_replay_extract(PoolT pool, ReplayStore st, const int32_t* rec, const int32_t* move_to,
+                                                        const int32_t* d4s, int n, TrainBatch o) {
+  using G = Geo<N>;
+  __shared__ Slot<N> lds;
+  __shared__ u64 tpl[18][G::R];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int r = rfl(rec[i]);
+  const int d4 = rfl(d4s ? d4s[i] : 0) & 7;
+  const int nm = rfl(st.num_moves[r]);
+  int mt = rfl(move_to[i]);
+  if (mt > nm) mt = nm;   // the reference asserts move_to < size (go_state_ext.h:284)
+  const u16* mv = st.moves + (size_t)r * st.max_moves;
+  Board<N> bd;
+  bd.init(&lds, pool.zob, pool.skh(i), pool.ski(i));
+  bd.reset();                                   // _state.reset()
+  for (int t = 0; t < mt; ++t) {                // switchBeforeMove: for (i < move_to) _state.forward(moves[i])
+    const int c = rfl((int)mv[t]);
+    if (c == M_INVALID) continue;               // the reference throws here (go_state.cc:75-77); a refused move is skipped like any other
+    bd.forward(c);
+  }
+  bd.store(&pool.slots[i]);                     // the replayed GoState stays inspectable through elfgo_* (slot i)
+  // "s": extractStateExtAGZ -> BoardFeature::extractAGZ under the sample's D4 code
+  char* row = (char*)o.s + (size_t)i * o.s_stride * (o.fmt == FEAT_F16_NHWC ? 2 : 4);
+  extract_agz_row<N>(lds.hist, tpl, bd.hist_cnt, bd.next_player, d4, row, o.fmt, lane);
+  const int idx = bd.ply - 1;                   // every extractor's move_to = _state.getPly() - 1
+  if (lane == 0) {
+    if (o.move_idx) o.move_idx[i] = idx;
+    if (o.num_move) o.num_move[i] = nm;
+    if (o.aug_code) o.aug_code[i] = d4;
+    if (o.winner) o.winner[i] = st.winner[r];
+    if (o.selfplay_ver) o.selfplay_ver[i] = st.black_ver[r];
+    if (o.predicted_value) o.predicted_value[i] = idx < st.num_values[r] ? st.values[(size_t)r * st.max_moves + idx] : 0.0f;
+  }
+  if (o.offline_a) {                            // extractOfflineAction :129-139
+    for (int j = lane; j < o.nfa; j += 64) {
+      const int t = idx + j;
+      o.offline_a[(size_t)i * o.nfa + j] = t < nm ? (int64_t)coord_to_action<N>(mv[t], d4) : 0;
+    }
+  }
+  if (o.mcts_scores) {                          // extractMCTSPi :107-127
+    float* ms = o.mcts_scores + (size_t)i * G::NA;
+    const bool have = st.pol != nullptr && idx < rfl(st.num_pol[r]);
+    if (have) {
+      const unsigned char* pr = st.pol + ((size_t)r * st.max_moves + idx) * G::P;
+      static_assert(G::NA <= G::R * 64, "one action per lane per round");
+      float v[G::R];
+      float sum = 0.0f;                         // integers <= 255 * 362 < 2^24: the fp32 sum is exact in any order
+#pragma unroll
+      for (int k = 0; k < G::R; ++k) {
+        const int a = k * 64 + lane;
+        v[k] = 0.0f;
+        if (a < G::NA) {
+          int coord, a0;
+          action_to_coord<N>(a, d4, coord, a0);
+          v[k] = (float)pr[coord];
+          sum += v[k];
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+#pragma unroll
+      for (int k = 0; k < G::R; ++k) {
+        const int a = k * 64 + lane;
+        if (a < G::NA) ms[a] = __fdiv_rn(v[k], sum);
+      }
+    } else {
+      const int hot = idx < nm ? coord_to_action<N>(mv[idx], d4) : -1;
+      for (int a = lane; a < G::NA; a += 64) ms[a] = a == hot ? 1.0f : 0.0f;
+    }
+  }
+}
+
+}  // namespace elfgo

@@ -1,0 +1,127 @@
+// C ABI of the training-side replay loader (include/elf_amd.h, elftrain_*): record store in HBM + one-launch batch extraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+#include <random>
+#include <vector>
+
+#include "engine_host.h"
+#include "train.cuh"
+
+struct ElfReplay {
+  ElfGoEngine* eng = nullptr;
+  ReplayStore st{};
+  int P = 0;
+  std::vector<int32_t> h_num_moves;     // host mirror for elftrain_draw
+  std::vector<int32_t> filled;          // slots that hold a record, in first-put order
+  std::vector<uint8_t> is_filled;
+  std::mt19937 rng;                     // GoGameBase::_rng of the sampling thread (game_base.h:32-38)
+  std::vector<int32_t> h_draw;
+};
+
+extern "C" {
+
+int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_policies, uint32_t seed, ElfReplay** out) {
+  if (!e || !out || capacity <= 0 || max_moves <= 0 || max_moves > 65535) return ELFGO_E_BADARG;
+  ElfReplay* r = new (std::nothrow) ElfReplay();
+  if (!r) return ELFGO_E_NOMEM;
+  r->eng = e;
+  r->P = (e->n + 2) * (e->n + 2);
+  ReplayStore& st = r->st;
+  st.capacity = capacity; st.max_moves = max_moves;
+  HIPCHK(hipSetDevice(e->device));
+  const size_t cm = (size_t)capacity * max_moves;
+#define A(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { elftrain_destroy(r); return (int)_e; } \
+                           _e = hipMemset((ptr), 0, (bytes)); if (_e != hipSuccess) { elftrain_destroy(r); return (int)_e; } } while (0)
+  A(st.moves, cm * sizeof(u16)); A(st.num_moves, sizeof(int32_t) * capacity); A(st.winner, sizeof(float) * capacity);
+  A(st.black_ver, sizeof(int64_t) * capacity); A(st.num_pol, sizeof(int32_t) * capacity);
+  A(st.values, cm * sizeof(float)); A(st.num_values, sizeof(int32_t) * capacity);
+  if (with_policies) A(st.pol, cm * (size_t)r->P);
+#undef A
+  r->h_num_moves.assign(capacity, 0);
+  r->is_filled.assign(capacity, 0);
+  r->rng.seed(seed);
+  *out = r;
+  return 0;
+}
+
+int elftrain_destroy(ElfReplay* r) {
+  if (!r) return ELFGO_E_BADARG;
+  void* ptrs[] = {r->st.moves, r->st.num_moves, r->st.winner, r->st.black_ver, r->st.pol, r->st.num_pol, r->st.values, r->st.num_values};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete r;
+  return 0;
+}
+
+int elftrain_capacity(const ElfReplay* r) { return r ? r->st.capacity : ELFGO_E_BADARG; }
+int elftrain_max_moves(const ElfReplay* r) { return r ? r->st.max_moves : ELFGO_E_BADARG; }
+int elftrain_num_records(const ElfReplay* r) { return r ? (int)r->filled.size() : ELFGO_E_BADARG; }
+
+int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
+                 const uint8_t* policies_host, int num_policies, const float* values_host, int num_values) {
+  if (!r || slot < 0 || slot >= r->st.capacity || num_moves < 0 || num_moves > r->st.max_moves) return ELFGO_E_BADARG;
+  if ((num_moves > 0 && !moves_host) || num_policies < 0 || num_policies > r->st.max_moves || num_values < 0 ||
+      num_values > r->st.max_moves) return ELFGO_E_BADARG;
+  if ((num_policies > 0 && (!policies_host || !r->st.pol)) || (num_values > 0 && !values_host)) return ELFGO_E_BADARG;
+  ReplayStore& st = r->st;
+  const size_t base = (size_t)slot * st.max_moves;
+  if (num_moves) HIPCHK(hipMemcpy(st.moves + base, moves_host, sizeof(u16) * num_moves, hipMemcpyHostToDevice));
+  if (num_policies) HIPCHK(hipMemcpy(st.pol + base * r->P, policies_host, (size_t)num_policies * r->P, hipMemcpyHostToDevice));
+  if (num_values) HIPCHK(hipMemcpy(st.values + base, values_host, sizeof(float) * num_values, hipMemcpyHostToDevice));
+  const float w = reward > 0 ? 1.0f : -1.0f;   // fromRecord, go_state_ext.h:250
+  const int32_t nm = num_moves, np = num_policies, nv = num_values;
+  HIPCHK(hipMemcpy(st.num_moves + slot, &nm, 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(st.num_pol + slot, &np, 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(st.num_values + slot, &nv, 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(st.winner + slot, &w, 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(st.black_ver + slot, &black_ver, 8, hipMemcpyHostToDevice));
+  r->h_num_moves[slot] = num_moves;
+  if (!r->is_filled[slot]) { r->is_filled[slot] = 1; r->filled.push_back(slot); }
+  return 0;
+}
+
+// GoGameTrain::act :26-40: sample a record, switchRandomMove (move_to = rng() % (size - nfa + 1), records with
+// size <= nfa - 1 are rejected and resampled, go_state_ext.h:260-275), generateD4Code (rng() % 8, :277-279).
+// The record itself is drawn uniformly from the filled slots with the same stream (the reference's ReaderQueues
+// sampler belongs to the replay-buffer control plane).
+int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec_dev, int32_t* move_to_dev, int32_t* d4_dev, void* stream) {
+  if (!r || n <= 0 || num_future_actions < 1 || !rec_dev || !move_to_dev || !d4_dev) return ELFGO_E_BADARG;
+  bool any = false;
+  for (int32_t s : r->filled) any = any || r->h_num_moves[s] > num_future_actions - 1;
+  if (!any) return ELFGO_E_BADARG;
+  r->h_draw.resize((size_t)3 * n);
+  for (int i = 0; i < n; ++i) {
+    int32_t slot;
+    do { slot = r->filled[r->rng() % r->filled.size()]; } while (r->h_num_moves[slot] <= num_future_actions - 1);
+    r->h_draw[i] = slot;
+    r->h_draw[n + i] = (int32_t)(r->rng() % (uint32_t)(r->h_num_moves[slot] - num_future_actions + 1));
+    r->h_draw[2 * n + i] = (int32_t)(r->rng() % 8);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(rec_dev, r->h_draw.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(move_to_dev, r->h_draw.data() + n, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d4_dev, r->h_draw.data() + 2 * n, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // h_draw is reused by the next call
+  return 0;
+}
+
+int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, const int32_t* d4, int n, const ElfTrainBatch* b, void* stream) {
+  if (!r || !rec || !move_to || !b || n < 0 || n > r->eng->capacity) return ELFGO_E_BADARG;
+  if (n == 0) return 0;
+  const int nn = r->eng->n;
+  if (!b->s || b->s_stride < (int64_t)18 * nn * nn || (b->s_format != ELFGO_FEAT_F32_NCHW && b->s_format != ELFGO_FEAT_F16_NHWC)) return ELFGO_E_BADARG;
+  if (b->offline_a && b->num_future_actions < 1) return ELFGO_E_BADARG;
+  TrainBatch o;
+  o.s = b->s; o.s_stride = b->s_stride; o.fmt = b->s_format;
+  o.offline_a = b->offline_a; o.nfa = b->num_future_actions;
+  o.winner = b->winner; o.mcts_scores = b->mcts_scores; o.predicted_value = b->predicted_value;
+  o.move_idx = b->move_idx; o.num_move = b->num_move; o.aug_code = b->aug_code; o.selfplay_ver = b->selfplay_ver;
+  DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_extract<N, Pool<N>>), dim3(n), dim3(64), 0, (hipStream_t)stream, pool_of<N>(r->eng), r->st,
+                                      rec, move_to, d4, n, o));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -30,7 +30,8 @@ class SpOptions(C.Structure):
                 ("num_rollouts_per_thread", C.c_int32), ("persistent_tree", C.c_int32), ("root_epsilon", C.c_float),
                 ("root_alpha", C.c_float), ("seed", C.c_uint32), ("policy_distri_cutoff", C.c_int32),
                 ("move_cutoff", C.c_int32), ("resign_thres", C.c_float), ("never_resign_prob", C.c_float),
-                ("log_searches", C.c_int32), ("mcts", MctsOptions)]
+                ("log_searches", C.c_int32), ("keep_records", C.c_int32), ("policy_distri_training_for_all", C.c_int32),
+                ("model_ver", C.c_int32), ("mcts", MctsOptions)]
 
 
 class SpSearch(C.Structure):
@@ -50,7 +51,7 @@ class SelfPlay:
                  mcts_alpha=0.0, mcts_unexplored_q_zero=False, mcts_root_unexplored_q_zero=False, komi=7.5,
                  ply_pass_enabled=0, policy_distri_cutoff=0, move_cutoff=-1, resign_thres=0.0, never_resign_prob=0.0,
                  seed=0, nodes_per_game=None, log_searches=0, rotation_flip=True, remove_pass_if_dangerous=True,
-                 feature_format="f32_nchw"):
+                 feature_format="f32_nchw", keep_records=0, policy_distri_training_for_all=False, model_ver=0):
         if not torch.cuda.is_available():
             raise RuntimeError("elf_amd.SelfPlay needs a ROCm GPU (no CPU fallback exists)")
         self.L = _lib.lib()
@@ -67,7 +68,7 @@ class SelfPlay:
                          int(rotation_flip))
         self.opt = SpOptions(self.n, self.num_games, nodes_per_game, mcts_rollout_per_thread, int(mcts_persistent_tree),
                              mcts_epsilon, mcts_alpha, seed, policy_distri_cutoff, move_cutoff, resign_thres, never_resign_prob,
-                             log_searches, mo)
+                             log_searches, int(keep_records), int(policy_distri_training_for_all), int(model_ver), mo)
         z = np.fromfile(_lib.ZOBRIST_BIN, dtype="<u8")
         zz = np.ascontiguousarray(z[: (self.n + 2) ** 2])
         torch.cuda.set_device(self.device)
@@ -146,6 +147,18 @@ class SelfPlay:
 
     def games_finished(self):
         return int(self.L.elfsp_games_finished(self._h))
+
+    def pop_records(self):
+        """Record JSON text of every finished game not yet collected (GameNotifier::OnGameEnd -> GoStateExt::dumpRecord,
+        go_state_ext.h:131-148); needs keep_records > 0."""
+        out = []
+        need = C.c_size_t(0)
+        while self.L.elfsp_records_pending(self._h) > 0:
+            rc = self.L.elfsp_pop_record(self._h, None, 0, C.byref(need))
+            buf = C.create_string_buffer(need.value + 1)
+            check(self.L.elfsp_pop_record(self._h, buf, need.value + 1, C.byref(need)))
+            out.append(buf.raw[:need.value].decode())
+        return out
 
     def search_log(self):
         n = self.stats()["logged"]

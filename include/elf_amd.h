@@ -174,6 +174,9 @@ typedef struct ElfSpOptions {
   float resign_thres;               /* ClientCtrl.{black,white}_resign_thres */
   float never_resign_prob;          /* ClientCtrl.never_resign_prob */
   int32_t log_searches;             /* keep the first N search results for elfsp_search_log (tests) */
+  int32_t keep_records;             /* > 0: keep the Record JSON of the last N finished games for elfsp_pop_record */
+  int32_t policy_distri_training_for_all; /* GameOptions.policy_distri_training_for_all: record the MCTS policy of every move */
+  int32_t model_ver;                /* Record.request.vers.black_ver (the self-play model version; white_ver = -1) */
   ElfMctsOptions mcts;
 } ElfSpOptions;
 
@@ -194,11 +197,80 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
 /* out[9]: moves played, games finished, rollouts, net rows, steps, searches logged, steps per move, step in move,
  * tree nodes descended through (synchronises the device) */
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
+/* Self-play records: with ElfSpOptions.keep_records > 0 every finished game leaves the Record the reference's
+ * GameNotifier::OnGameEnd would send (GoStateExt::dumpRecord go_state_ext.h:131-148, Record::setJsonFields record.h:246-254),
+ * as the JSON text nlohmann::json::dump() produces.  elfsp_pop_record copies the oldest pending record (NUL-terminated) into buf
+ * and removes it; if cap is too small it returns ELFGO_E_BADSIZE, sets *len to the length needed (without NUL) and keeps the record.
+ * *len = 0 when nothing is pending. */
+int elfsp_records_pending(const ElfSelfPlay* sp);
+int elfsp_pop_record(ElfSelfPlay* sp, char* buf, size_t cap, size_t* len);
 /* games finished so far (host counter, no device synchronisation) */
 int64_t elfsp_games_finished(const ElfSelfPlay* sp);
 /* logged searches [first, first+n): records and root edges (host arrays, [n][edge_stride], may be NULL) */
 int elfsp_search_log(const ElfSelfPlay* sp, int first, int n, ElfSpSearch* rec, int32_t* coord, int32_t* visits, float* prior,
                      float* reward);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-side replay loader: the trainer's input pipeline on the device.  Replaces, for a whole batch in
+ * one launch, what the reference does on one std::thread per sample (2048 threads at batchsize 2048, start_server.sh:11-12):
+ *   elfgames/go/train/game_train.cc        GoGameTrain::act :23-58
+ *   elfgames/go/common/go_state_ext.h      GoStateExtOffline::fromRecord / switchRandomMove / switchBeforeMove :248-290
+ *   elfgames/go/common/game_feature.h      the "train" extractors :73-145 (s, offline_a, winner, mcts_scores, predicted_value,
+ *                                          move_idx, num_move, aug_code, selfplay_ver; schema :159-206)
+ * Records live in HBM (`capacity` slots padded to `max_moves` plies; with_policies adds the 441-byte quantised MCTS policy
+ * per ply, record.h:180-182).  Sample i of a batch replays in board slot i of engine `e` (capacity >= batch), so the
+ * replayed GoState can be inspected with elfgo_info / elfgo_legal_mask afterwards.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ElfReplay ElfReplay;
+
+typedef struct ElfTrainBatch {      /* device pointers, rows = samples; every pointer except s may be NULL */
+  void* s;                          /* "s" [n][18][N][N] in s_format (ELFGO_FEAT_*), rows s_stride elements apart */
+  int64_t s_stride;
+  int32_t s_format;
+  int32_t num_future_actions;       /* GameOptions.num_future_actions */
+  int64_t* offline_a;               /* [n][num_future_actions]  coord2Action of moves[move_idx + j] */
+  float* winner;                    /* [n]  +1 / -1 */
+  float* mcts_scores;               /* [n][N*N+1]  normalised recorded policy, or one-hot of the played move */
+  float* predicted_value;           /* [n]  Record.result.values[move_idx] */
+  int32_t* move_idx;                /* [n]  GoState::getPly() - 1 after the replay */
+  int32_t* num_move;                /* [n]  number of moves of the record */
+  int32_t* aug_code;                /* [n]  D4 code */
+  int64_t* selfplay_ver;            /* [n]  Record.request.vers.black_ver */
+} ElfTrainBatch;
+
+int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_policies, uint32_t seed, ElfReplay** out);
+int elftrain_destroy(ElfReplay* r);
+int elftrain_capacity(const ElfReplay* r);
+int elftrain_max_moves(const ElfReplay* r);
+int elftrain_num_records(const ElfReplay* r);
+/* GoStateExtOffline::fromRecord for record slot `slot`: moves_host = sgfstr2coords(Record.result.content) (see
+ * elfrec_sgfstr_to_coords), reward = Record.result.reward, policies_host u8 [num_policies][(N+2)^2], values_host f32.
+ * Host pointers; synchronous. */
+int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
+                 const uint8_t* policies_host, int num_policies, const float* values_host, int num_values);
+/* GoGameTrain::act's draws for n samples with the store's std::mt19937 (seeded at create): record, move_to =
+ * rng() % (num_moves - num_future_actions + 1), D4 code = rng() % 8; results into device int32 [n] arrays */
+int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec, int32_t* move_to, int32_t* d4, void* stream);
+/* one launch: replay record rec[i] up to move_to[i] (switchBeforeMove), then every extractor of the "train" batch under
+ * D4 code d4[i] (NULL = 0).  rec/move_to/d4 device int32 [n]; n <= elfgo_capacity(e) */
+int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, const int32_t* d4, int n, const ElfTrainBatch* out,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Record format helpers (host only, no GPU needed): the SGF move string of Record.result.content and the quantised policy.
+ * ------------------------------------------------------------------------------------------------ */
+/* coords2sgfstr (sgf/sgf.h:87-95): "(;B[xy];W[xy]...)". Returns the length (without NUL); out may be NULL to query it;
+ * ELFGO_E_BADSIZE if cap is too small. */
+int elfrec_coords_to_sgfstr(int board_size, const uint16_t* coords, int n, char* out, size_t cap);
+/* sgfstr2coords + str2coord (sgf/sgf.h:21-46,97-125): returns the number of moves in the string, stores the first `cap` */
+int elfrec_sgfstr_to_coords(int board_size, const char* sgf, uint16_t* out, int cap);
+/* Record (record.h:236-262) of one finished self-play game as JSON text, from plain host arrays -- the formatting half of
+ * elfsp_pop_record on its own (policies u8 [num_policies][(N+2)^2]).  Returns the length (without NUL); out may be NULL. */
+int elfrec_record_to_json(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const uint8_t* policies, int num_policies,
+                          const float* values, int num_values, float reward, int never_resign, int seq, uint64_t thread_id,
+                          uint64_t timestamp, char* out, size_t cap);
+/* GoStateExt::addMCTSPolicy (go_state_ext.h:158-181): out[(N+2)^2] = (unsigned char)(prob / max(prob) * 255) at each coord */
+int elfrec_quantise_policy(int board_size, const int32_t* coord, const float* prob, int n, uint8_t* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Glue for the PyTorch-ROCm policy/value net (the net itself stays on PyTorch, BASELINE.json north_star): the

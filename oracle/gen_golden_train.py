@@ -1,0 +1,117 @@
+"""Generates tests/golden/records_*.npz and train_*.npz from the REAL reference (oracle/_ref/libelfsp*.so). Build container only:
+    python oracle/gen_golden_train.py
+
+records_<n>_<case>.npz   Record JSON of finished self-play games exactly as GoStateExt::dumpRecord + Record::setJsonFields +
+                         json::dump() produce them (GameNotifierBase::OnGameEnd in oracle/ref_selfplay.cc), with the run's
+                         configuration, so the GPU self-play can be asked to reproduce them.
+train_<n>.npz            rows of the reference's "train" batch (real GoStateExtOffline::fromRecord / switchBeforeMove +
+                         GoFeature extractors) for chosen (record, move_to, D4 code, num_future_actions), over (a) the self-play
+                         records above and (b) long synthetic records: config-2 random games (captures, kos, passes) with random
+                         quantised policies and values, serialised as Record JSON.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from pyoracle import MCTS_DEFAULTS, Port, RefSelfPlay, playout_seeds  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+RECORD_CASES = {
+    "records_9_cutoff": (9, dict(rollouts_per_thread=64, max_searches=50, policy_distri_cutoff=6, net_salt=3, move_cutoff=24)),
+    "records_9_resign": (9, dict(rollouts_per_thread=32, max_searches=120, policy_distri_cutoff=4, net_salt=5, resign_thres=0.9,
+                                 move_cutoff=70)),
+    "records_19_cutoff": (19, dict(rollouts_per_thread=32, max_searches=64, policy_distri_cutoff=30, net_salt=9, move_cutoff=31)),
+}
+
+
+def split_records(txt):
+    return [json.dumps(j, separators=(",", ":")) for j in json.loads(txt)]
+
+
+def synth_record(n, seed, rng, with_policies):
+    """A long game by the config-2 policy as a Record dict (moves via the reference's own coords2sgfstr)."""
+    port = Port(n)
+    s = port.new()
+    mv = port.playout_moves(s, int(seed))
+    port.free(s)
+    R = RefSelfPlay(n)
+    P = (n + 2) ** 2
+    k = len(mv)
+    npol = int(rng.integers(0, k + 1)) if with_policies else 0
+    pol = np.zeros((npol, P), np.uint8)
+    for i in range(npol):
+        idx = rng.integers(0, P, size=int(rng.integers(1, 40)))
+        pol[i, idx] = rng.integers(1, 256, size=idx.size)
+    vals = np.round(np.tanh(rng.standard_normal(k)) * 1e4) / 1e4
+    return {"offline": False, "pri": 0.0,
+            "request": {"client_ctrl": {"async": False, "black_resign_thres": 0.0, "client_type": 1, "never_resign_prob": 0.0,
+                                        "num_game_thread_used": 1, "player_swap": False, "white_resign_thres": 0.0},
+                        "vers": {"black_ver": int(rng.integers(0, 1000)), "white_ver": -1,
+                                 "mcts_opt": {"alg_opt": {"c_puct": 1.5, "root_unexplored_q_zero": False, "unexplored_q_zero": False,
+                                                          "use_prior": True},
+                                              "log_prefix": "", "max_num_moves": 0, "num_rollouts_per_batch": 16,
+                                              "num_rollouts_per_thread": 64, "num_threads": 1, "persistent_tree": True,
+                                              "pick_method": "most_visited", "root_alpha": 0.03, "root_epsilon": 0.25, "seed": 0,
+                                              "verbose": False, "verbose_time": False, "virtual_loss": 1}}},
+            "result": {"black_never_resign": False, "white_never_resign": False, "content": R.coords2sgfstr(mv), "num_move": k,
+                       "policies": pol.tolist(), "reward": float(rng.choice([-7.5, 12.5, -0.5, 0.5])), "using_models": [0],
+                       "values": [float(np.float32(v)) for v in vals]},
+            "seq": int(rng.integers(2, 50)), "thread_id": 0, "timestamp": 0}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    by_size = {9: [], 19: []}
+    for name, (n, kw) in RECORD_CASES.items():
+        R = RefSelfPlay(n)
+        cfg = dict(MCTS_DEFAULTS)
+        cfg.update(kw)
+        r = R.run(**cfg)
+        recs = json.loads(r["records"])
+        exact = [R.record_roundtrip(t) for t in split_records(r["records"])]
+        assert len(recs) >= 1, name
+        # the round trip through Record::createFromJson must reproduce the text the game thread dumped
+        assert "[" + ",".join(exact) + "]" == r["records"], name
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), board_size=np.int32(n),
+                            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], np.float64),
+                            records=np.array(exact), searches=np.int32(len(r["search"])),
+                            move_played=np.array([s.move_played for s in r["search"]], np.int32))
+        print(name, "records", len(exact), [(j["seq"], j["result"]["num_move"], j["result"]["reward"], len(j["result"].get("policies", [])))
+                                            for j in recs])
+        by_size[n] += exact
+    for n in (9, 19):
+        R = RefSelfPlay(n)
+        rng = np.random.default_rng(100 + n)
+        recs = list(by_size[n])
+        for i, sd in enumerate(playout_seeds(6 if n == 19 else 8, base=300 + n)):
+            recs.append(json.dumps(synth_record(n, sd, rng, with_policies=(i % 3 != 2)), separators=(",", ":")))
+        rows = []
+        for ri, t in enumerate(recs):
+            j = json.loads(t)
+            nm = len(R.sgfstr2coords(j["result"]["content"]))
+            for nfa in (1, 3):
+                if nm < nfa:
+                    continue
+                last = nm - nfa
+                cand = sorted(set([0, 1, 2, 7, 8, 9, last // 2, max(last - 1, 0), last]))
+                for ci, mt in enumerate(c for c in cand if c <= last):
+                    d4 = (ri + ci + nfa) % 8
+                    o = R.train_sample(t, mt, d4, nfa)
+                    oa = np.zeros(3, np.int64)
+                    oa[:nfa] = o["offline_a"]
+                    rows.append(dict(rec=ri, move_to=mt, d4=d4, nfa=nfa, s=np.packbits(o["s"].astype(np.uint8).ravel()), offline_a=oa,
+                                     winner=o["winner"], mcts_scores=o["mcts_scores"], predicted_value=o["predicted_value"],
+                                     move_idx=o["move_idx"], num_move=o["num_move"], aug_code=o["aug_code"], selfplay_ver=o["selfplay_ver"]))
+        keys = rows[0].keys()
+        np.savez_compressed(os.path.join(OUT, "train_%d.npz" % n), board_size=np.int32(n), records=np.array(recs),
+                            **{k: np.array([r[k] for r in rows]) for k in keys})
+        print("train_%d: %d records, %d rows" % (n, len(recs), len(rows)))
+
+
+if __name__ == "__main__":
+    main()

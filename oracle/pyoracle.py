@@ -261,7 +261,47 @@ class RefSelfPlay:
         if k < 0:
             raise RuntimeError("refsp_run failed")
         return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
-                    batches=int(stats[0]), rows=int(stats[1]), usec=int(stats[2]))
+                    batches=int(stats[0]), rows=int(stats[1]), usec=int(stats[2]), records=self.last_records())
+
+    # ---- records (GoStateExt::dumpRecord) and the trainer's extractors (GoStateExtOffline + GoFeature)
+    def _text(self, fn, *args):
+        fn.restype = C.c_int64
+        n = fn(*args, None, C.c_int64(0))
+        if n < 0:
+            raise RuntimeError("reference threw")
+        buf = C.create_string_buffer(int(n) + 1)
+        fn(*args, buf, C.c_int64(n))
+        return buf.raw[:n].decode()
+
+    def last_records(self):
+        """JSON array text: Record of every game that finished during the last run()"""
+        return self._text(self.L.refsp_last_records)
+
+    def record_roundtrip(self, record_json):
+        return self._text(self.L.reftrain_record_roundtrip, record_json.encode())
+
+    def sgfstr2coords(self, sgf):
+        out = np.zeros(4096, np.uint16)
+        k = self.L.reftrain_sgfstr2coords(sgf.encode(), out.ctypes.data_as(C.c_void_p), 4096)
+        return out[:k].copy()
+
+    def coords2sgfstr(self, coords):
+        c = np.ascontiguousarray(coords, dtype=np.uint16)
+        return self._text(self.L.reftrain_coords2sgfstr, c.ctypes.data_as(C.c_void_p), C.c_int(c.size))
+
+    def train_sample(self, record_json, move_to, d4, num_future_actions=1):
+        """The reference's "train" batch row for (record, move_to, d4): dict of numpy arrays"""
+        n, na = self.n, self.na
+        s = np.zeros((18, n, n), np.float32); oa = np.zeros(num_future_actions, np.int64)
+        ms = np.zeros(na, np.float32)
+        w = C.c_float(); pv = C.c_float(); mi = C.c_int32(); nm = C.c_int32(); ac = C.c_int32(); sv = C.c_int64()
+        rc = self.L.reftrain_sample(record_json.encode(), C.c_int(move_to), C.c_int(d4), C.c_int(num_future_actions),
+                                    s.ctypes.data_as(C.c_void_p), oa.ctypes.data_as(C.c_void_p), C.byref(w),
+                                    ms.ctypes.data_as(C.c_void_p), C.byref(pv), C.byref(mi), C.byref(nm), C.byref(ac), C.byref(sv))
+        if rc != 0:
+            raise RuntimeError("reftrain_sample failed")
+        return dict(s=s, offline_a=oa, winner=np.float32(w.value), mcts_scores=ms, predicted_value=np.float32(pv.value),
+                    move_idx=mi.value, num_move=nm.value, aug_code=ac.value, selfplay_ver=sv.value)
 
 
 def stub_net(n, s, salt=7, tie_levels=0):
@@ -274,3 +314,116 @@ def stub_net(n, s, salt=7, tie_levels=0):
     L.orc_stub_net(s.ctypes.data_as(C.c_void_p), C.c_int(b), C.c_uint32(salt), C.c_int(tie_levels), pi.ctypes.data_as(C.c_void_p),
                    v.ctypes.data_as(C.c_void_p))
     return pi, v
+
+
+# ---- trainer side: CPU restatement of the "train" batch row (checker for tests; pinned on tests/golden/train_*.npz) -------
+def sgfstr2coords(n, sgf):
+    """sgfstr2coords + str2coord (sgf/sgf.h:21-46,97-125)"""
+    S, out = n + 2, []
+    if not sgf or sgf[0] != "(":
+        return np.zeros(0, np.uint16)
+    i = 1
+    while True:
+        if i >= len(sgf) or sgf[i] != ";":
+            break
+        while i < len(sgf) and sgf[i] != "[":
+            i += 1
+        if i == len(sgf):
+            break
+        i += 1
+        j = i
+        while j < len(sgf) and sgf[j] != "]":
+            j += 1
+        if j == len(sgf):
+            break
+        s = sgf[i:j]
+        if len(s) < 2:
+            c = 0
+        else:
+            t = [ch for ch in s if ch not in "\n "]
+            k = 0
+            while k < len(s) and s[k] in "\n ":
+                k += 1
+            if k == len(s):
+                c = 3
+            else:
+                x = ord(s[k]) - 97
+                k += 1
+                while k < len(s) and s[k] in "\n ":
+                    k += 1
+                if k == len(s):
+                    c = 3
+                else:
+                    y = ord(s[k]) - 97
+                    c = (y + 1) * S + (x + 1) if (0 <= x < n and 0 <= y < n) else 3
+            del t
+        out.append(c)
+        i = j + 1
+    return np.array(out, np.uint16)
+
+
+def coord2action(n, c, d4):
+    """BoardFeature::coord2Action (board_feature.h:132-137) with Transform (:97-113)"""
+    S = n + 2
+    if c == 0:
+        return n * n
+    x, y = c % S - 1, c // S - 1
+    rot = d4 % 4
+    if rot == 1:
+        x, y = y, n - x - 1
+    elif rot == 2:
+        x, y = n - x - 1, n - y - 1
+    elif rot == 3:
+        x, y = n - y - 1, x
+    if (d4 >> 2) == 1:
+        x, y = y, x
+    return x * n + y
+
+
+def action2coord(n, a, d4):
+    """BoardFeature::action2Coord (board_feature.h:139-144) with InvTransform (:115-130)"""
+    S = n + 2
+    if a == -1 or a == n * n:
+        return 0
+    x, y = a // n, a % n
+    if (d4 >> 2) == 1:
+        x, y = y, x
+    rot = d4 % 4
+    if rot == 1:
+        x, y = n - y - 1, x
+    elif rot == 2:
+        x, y = n - x - 1, n - y - 1
+    elif rot == 3:
+        x, y = y, n - x - 1
+    return (y + 1) * S + (x + 1)
+
+
+def port_train_sample(port, record, move_to, d4, nfa=1):
+    """Restatement of GoStateExtOffline::fromRecord + switchBeforeMove (go_state_ext.h:248-290) and the GoFeature "train"
+    extractors (game_feature.h:73-145) over the C port of the board engine.  record: parsed Record dict."""
+    n = port.n
+    res = record["result"]
+    mv = sgfstr2coords(n, res["content"])
+    st = port.new()
+    for c in mv[:move_to]:
+        if int(c) != 3:
+            port.forward(st, int(c))
+    idx = int(port.info(st)[0]) - 1
+    out = dict(s=port.extract_agz(st, d4), move_idx=idx, num_move=len(mv), aug_code=d4,
+               winner=np.float32(1.0 if res["reward"] > 0 else -1.0), selfplay_ver=int(record["request"]["vers"]["black_ver"]))
+    port.free(st)
+    vals = res["values"]
+    out["predicted_value"] = np.float32(vals[idx]) if idx < len(vals) else np.float32(0)
+    out["offline_a"] = np.array([coord2action(n, int(mv[idx + j]), d4) for j in range(nfa)], np.int64)
+    ms = np.zeros(n * n + 1, np.float32)
+    pol = res.get("policies") or []
+    if idx < len(pol):
+        p = pol[idx]
+        for a in range(n * n + 1):
+            ms[a] = p[action2coord(n, a, d4)]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ms = ms / ms.sum(dtype=np.float32)
+    else:
+        ms[coord2action(n, int(mv[idx]), d4)] = 1.0
+    out["mcts_scores"] = ms.astype(np.float32)
+    return out

@@ -10,7 +10,9 @@
 // Nothing from the reference is copied into this repository.
 //
 // Used (a) to generate tests/golden/mcts_*.npz (oracle/gen_golden_mcts.py), (b) as the CPU baseline of
-// kind "reference" for MCTS rollouts/s in bench.py.
+// kind "reference" for MCTS rollouts/s in bench.py, (c) for the self-play Record JSON of finished games
+// (GoStateExt::dumpRecord via GameNotifierBase::OnGameEnd) and the trainer's "train" batch extractors
+// (reftrain_*, the real GoStateExtOffline + GoFeature functions) behind tests/golden/records_*.{json,npz}.
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -19,6 +21,12 @@
 #include <thread>
 #include <vector>
 
+#include <bits/stdc++.h>   // every std header first, so that the access hack below only touches reference headers
+#include <nlohmann/json.hpp>
+#include "elf/logging/IndexedLoggerFactory.h"
+#define private public   // test infrastructure: reach GoStateExtOffline::_bf / _state to set a chosen D4 code and ply
+#include "elfgames/go/common/go_state_ext.h"
+#undef private
 #include "elf/base/context.h"
 #include "elf/base/dispatcher.h"
 #include "elfgames/go/common/dispatcher_callback.h"
@@ -112,7 +120,16 @@ struct Capture : public GameNotifierBase {
     count++;
   }
   int current_game = 0;   // parity runs use num_games == 1
+  std::vector<std::string> records;   // Record JSON of every finished game, in completion order
+  void OnGameEnd(const GoStateExt& s) override {
+    std::lock_guard<std::mutex> l(m);
+    json j;
+    s.dumpRecord().setJsonFields(j);
+    records.push_back(j.dump());
+  }
 };
+
+std::string g_last_records;   // JSON array text of the records of the last refsp_run
 
 struct Buffers {
   std::vector<float> s, pi, V;
@@ -258,6 +275,11 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
       stats[2] = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
     }
     ctx.stop();
+    {
+      g_last_records = "[";
+      for (size_t i = 0; i < cap.records.size(); ++i) g_last_records += (i ? "," : "") + cap.records[i];
+      g_last_records += "]";
+    }
 
     const int k = (int)cap.searches.size();
     for (int i = 0; i < k; ++i) out_search[i] = cap.searches[i];
@@ -270,6 +292,71 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     fprintf(stderr, "refsp_run: %s\n", e.what());
     return -1;
   }
+}
+
+// Record JSON (array text) of the games that finished during the last refsp_run; returns the length, copies min(len, cap)
+int64_t refsp_last_records(char* buf, int64_t cap) {
+  const int64_t n = (int64_t)g_last_records.size();
+  if (buf && cap > 0) memcpy(buf, g_last_records.data(), (size_t)std::min(n, cap));
+  return n;
+}
+
+// ---- trainer side: the real GoStateExtOffline + GoFeature "train" extractors on one record --------------------
+// record_json = one Record object; move_to / d4 chosen by the caller (the reference draws them with rng() in
+// GoGameTrain::act :33-40).  Returns 0, or -1 when the reference throws.
+int reftrain_sample(const char* record_json, int move_to, int d4, int num_future_actions, float* s, int64_t* offline_a,
+                    float* winner, float* mcts_scores, float* predicted_value, int32_t* move_idx, int32_t* num_move,
+                    int32_t* aug_code, int64_t* selfplay_ver) {
+  try {
+    Record r = Record::createFromJson(json::parse(record_json));
+    GameOptions opt;
+    opt.num_future_actions = num_future_actions;
+    GoStateExtOffline st(0, opt);
+    st.fromRecord(r);
+    st.switchBeforeMove((size_t)move_to);
+    st._bf.setD4Code(d4);
+    GoFeature::extractStateExtAGZ(st, s);
+    GoFeature::extractOfflineAction(st, offline_a);
+    GoFeature::extractWinner(st, winner);
+    GoFeature::extractMCTSPi(st, mcts_scores);
+    GoFeature::extractMoveIdx(st, move_idx);
+    GoFeature::extractNumMove(st, num_move);
+    GoFeature::extractAugCode(st, aug_code);
+    GoFeature::extractStateSelfplayVersion(st, selfplay_ver);
+    *predicted_value = (size_t)*move_idx < r.result.values.size() ? st.getPredictedValue(*move_idx) : 0.0f;
+    return 0;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "reftrain_sample: %s\n", e.what());
+    return -1;
+  }
+}
+
+// Record::createFromJson -> setJsonFields -> dump: the reference's reading of a record, re-serialised
+int64_t reftrain_record_roundtrip(const char* record_json, char* buf, int64_t cap) {
+  try {
+    Record r = Record::createFromJson(json::parse(record_json));
+    json j;
+    r.setJsonFields(j);
+    const std::string t = j.dump();
+    if (buf && cap > 0) memcpy(buf, t.data(), (size_t)std::min<int64_t>((int64_t)t.size(), cap));
+    return (int64_t)t.size();
+  } catch (const std::exception& e) {
+    fprintf(stderr, "reftrain_record_roundtrip: %s\n", e.what());
+    return -1;
+  }
+}
+
+// sgf/sgf.h helpers on their own
+int reftrain_sgfstr2coords(const char* sgf, uint16_t* out, int cap) {
+  std::vector<Coord> m = sgfstr2coords(std::string(sgf));
+  for (size_t i = 0; i < m.size() && (int)i < cap; ++i) out[i] = m[i];
+  return (int)m.size();
+}
+int64_t reftrain_coords2sgfstr(const uint16_t* coords, int n, char* buf, int64_t cap) {
+  std::vector<Coord> m(coords, coords + n);
+  const std::string t = coords2sgfstr(m);
+  if (buf && cap > 0) memcpy(buf, t.data(), (size_t)std::min<int64_t>((int64_t)t.size(), cap));
+  return (int64_t)t.size();
 }
 
 void refsp_stub_net(const float* s, int batch, uint32_t salt, int tie_levels, float* pi, float* v) {

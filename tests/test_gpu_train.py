@@ -1,0 +1,156 @@
+"""GPU: training-side replay loader (k_replay_extract, elftrain_*) and self-play record emission (elfsp_pop_record) through the
+C ABI, against the golden rows / records dumped by the REAL reference (oracle/gen_golden_train.py).  Bar: bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pyoracle import Port, port_train_sample, sgfstr2coords, stub_net
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def elf(built):
+    import elf_amd
+    return elf_amd
+
+
+def load_rows(n):
+    g = np.load(os.path.join(GOLDEN, "train_%d.npz" % n))
+    return g, [str(t) for t in g["records"]]
+
+
+@pytest.mark.parametrize("n", [9, 19])
+@pytest.mark.parametrize("fmt", ["f32_nchw", "f16_nhwc"])
+def test_train_batch_matches_reference_rows(elf, n, fmt):
+    import torch
+    g, recs = load_rows(n)
+    for nfa in (1, 3):
+        sel = np.nonzero(g["nfa"] == nfa)[0]
+        ld = elf.ReplayLoader(board_size=n, capacity=len(recs) + 3, batchsize=len(sel), num_future_actions=nfa, feature_format=fmt)
+        for i, t in enumerate(recs):
+            ld.put(i + 2, t)                       # slots need not start at 0
+        assert len(ld) == len(recs)
+        b = ld.extract(g["rec"][sel] + 2, g["move_to"][sel], g["d4"][sel])
+        torch.cuda.synchronize()
+        s = b["s"].float().cpu().numpy()
+        want_s = np.stack([np.unpackbits(g["s"][i])[: 18 * n * n].reshape(18, n, n) for i in sel]).astype(np.float32)
+        assert np.array_equal(s, want_s)
+        assert np.array_equal(b["offline_a"].cpu().numpy(), g["offline_a"][sel][:, :nfa])
+        assert np.array_equal(b["winner"].cpu().numpy(), g["winner"][sel])
+        assert np.array_equal(b["predicted_value"].cpu().numpy().view(np.uint32), g["predicted_value"][sel].view(np.uint32))
+        assert np.array_equal(b["move_idx"].cpu().numpy(), g["move_idx"][sel])
+        assert np.array_equal(b["num_move"].cpu().numpy(), g["num_move"][sel])
+        assert np.array_equal(b["aug_code"].cpu().numpy(), g["aug_code"][sel])
+        assert np.array_equal(b["selfplay_ver"].cpu().numpy(), g["selfplay_ver"][sel])
+        ms, want = b["mcts_scores"].cpu().numpy(), g["mcts_scores"][sel]
+        np.testing.assert_array_equal(ms, want)    # NaN rows (all-zero recorded policy: 0/0 in the reference too) compare equal
+        fin = np.isfinite(want)
+        assert np.array_equal(ms[fin].view(np.uint32), want[fin].view(np.uint32))
+        # the replayed GoState of sample i sits in board slot i of the loader's engine
+        info = ld.engine.info(n=len(sel)).cpu().numpy()
+        assert np.array_equal(info[:, 0] - 1, g["move_idx"][sel])
+        ld.close()
+
+
+def test_replayed_positions_and_draws(elf):
+    """sample(): draws within range and reproducible for a seed; replayed boards equal the oracle's replay (hash, legal mask)."""
+    import torch
+    n = 19
+    g, recs = load_rows(n)
+    parsed = [json.loads(t) for t in recs]
+    port = Port(n)
+    nfa = 2
+    outs = []
+    for rep in range(2):
+        ld = elf.ReplayLoader(board_size=n, capacity=len(recs), batchsize=96, num_future_actions=nfa, seed=42)
+        for i, t in enumerate(recs):
+            ld.put(i, t)
+        b = ld.sample(96)
+        torch.cuda.synchronize()
+        d = ld._draw.cpu().numpy()
+        outs.append((d.copy(), {k: v.clone() for k, v in b.items()}))
+        if rep == 0:
+            info = ld.engine.info(n=96).cpu().numpy()
+            mask = ld.engine.legal_mask(n=96).cpu().numpy()
+            for i in range(96):
+                r, mt, d4 = (int(d[k, i]) for k in range(3))
+                nm = parsed[r]["result"]["num_move"]
+                assert 0 <= mt <= nm - nfa and 0 <= d4 < 8
+                o = port_train_sample(port, parsed[r], mt, d4, nfa)
+                assert np.array_equal(b["s"][i].cpu().numpy(), o["s"]), i
+                assert np.array_equal(b["offline_a"][i].cpu().numpy(), o["offline_a"]), i
+                st = port.new()
+                for c in sgfstr2coords(n, parsed[r]["result"]["content"])[:mt]:
+                    port.forward(st, int(c))
+                h = (int(info[i, 13]) & 0xFFFFFFFF) | ((int(info[i, 14]) & 0xFFFFFFFF) << 32)
+                assert h == port.hash(st) and np.array_equal(mask[i], port.legal_mask(st)), i
+                port.free(st)
+        ld.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    assert len(set(outs[0][0][0].tolist())) > 1 and len(set(outs[0][0][2].tolist())) == 8
+
+
+def test_loader_argument_errors(elf):
+    import ctypes as C
+    L = elf.lib()
+    ld = elf.ReplayLoader(board_size=9, capacity=2, batchsize=4, with_policies=False)
+    mv = np.array([12, 13], np.uint16)
+    pol = np.zeros((1, 121), np.uint8)
+    assert L.elftrain_put(ld._h, 5, mv.ctypes.data, 2, C.c_float(1), 0, None, 0, None, 0) == -1      # slot out of range
+    assert L.elftrain_put(ld._h, 0, mv.ctypes.data, 9999, C.c_float(1), 0, None, 0, None, 0) == -1   # too many moves
+    assert L.elftrain_put(ld._h, 0, mv.ctypes.data, 2, C.c_float(1), 0, pol.ctypes.data, 1, None, 0) == -1   # store has no policies
+    assert L.elftrain_put(ld._h, 0, mv.ctypes.data, 2, C.c_float(1), 0, None, 0, None, 0) == 0
+    with pytest.raises(ValueError):
+        ld.extract([0] * 5, [0] * 5, [0] * 5)
+    import torch
+    d = torch.zeros(3, 4, dtype=torch.int32, device="cuda")
+    assert L.elftrain_draw(ld._h, 4, 3, C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()), C.c_void_p(d[2].data_ptr()), None) == -1  # no record long enough
+    ld.close()
+
+
+@pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_19_cutoff"])
+def test_selfplay_records_equal_reference_dump(elf, name):
+    """GPU self-play under the fixture's configuration leaves the same Record JSON text as the reference's
+    GoStateExt::dumpRecord for every finished game (content, quantised policies, predicted values, reward, seq), timestamp aside."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    n = int(g["board_size"])
+    want = [json.loads(str(t)) for t in g["records"]]
+    sp = elf.SelfPlay(
+        board_size=n, num_games=1, device=0, mcts_rollout_per_thread=int(cfg["rollouts_per_thread"]),
+        mcts_rollout_per_batch=int(cfg["rollouts_per_batch"]), mcts_puct=float(np.float32(cfg["c_puct"])),
+        mcts_virtual_loss=int(cfg["virtual_loss"]), mcts_use_prior=bool(cfg["use_prior"]),
+        mcts_persistent_tree=bool(cfg["persistent_tree"]), mcts_epsilon=float(np.float32(cfg["root_epsilon"])),
+        mcts_alpha=float(np.float32(cfg["root_alpha"])), komi=float(np.float32(cfg["komi"])),
+        ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
+        move_cutoff=int(cfg["move_cutoff"]), resign_thres=float(np.float32(cfg["resign_thres"])),
+        never_resign_prob=float(np.float32(cfg["never_resign_prob"])), seed=int(cfg["seed"]), keep_records=8, nodes_per_game=4096)
+    salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
+    got = []
+    for _ in range(200000):
+        rows = sp.begin_step()
+        if rows:
+            pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), salt, ties)
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        else:
+            sp.end_step(None, None)
+        got += sp.pop_records()
+        if len(got) >= len(want):
+            break
+    assert len(got) >= len(want)
+    for t, w in zip(got, want):
+        j = json.loads(t)
+        assert j["timestamp"] > 0
+        j["timestamp"] = w["timestamp"]
+        assert j == w
+        assert json.dumps(j, separators=(",", ":"), sort_keys=True) == json.dumps(w, separators=(",", ":"), sort_keys=True)
+        t2 = t.replace('"timestamp":%d' % json.loads(t)["timestamp"], '"timestamp":%d' % w["timestamp"])
+        assert t2 == str(g["records"][got.index(t)])   # text-identical to the reference's json::dump()
+    sp.close()

@@ -1,0 +1,108 @@
+"""CPU: the record format half of libelf_amd.so (elfrec_*, host-only code; no GPU needed): SGF move strings, policy
+quantisation and the Record JSON text, against the records the REAL reference dumped (tests/golden/records_*.npz,
+oracle/gen_golden_train.py) and, where oracle/_ref is present, against the reference directly."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pyoracle import RefSelfPlay, sgfstr2coords
+
+CASES = ["records_9_cutoff", "records_9_resign", "records_19_cutoff"]
+
+
+def sp_options(elf_amd, n, cfg, num_games=1):
+    from elf_amd.selfplay import MctsOptions, SpOptions
+    mo = MctsOptions(int(cfg["rollouts_per_batch"]), int(cfg["virtual_loss"]), int(cfg["use_prior"]), int(cfg["unexplored_q_zero"]),
+                     int(cfg["root_unexplored_q_zero"]), float(cfg["c_puct"]), float(cfg["komi"]), int(cfg["ply_pass_enabled"]), 1, 1)
+    return SpOptions(n, num_games, 1024, int(cfg["rollouts_per_thread"]), int(cfg["persistent_tree"]), float(cfg["root_epsilon"]),
+                     float(cfg["root_alpha"]), int(cfg["seed"]), int(cfg["policy_distri_cutoff"]), int(cfg["move_cutoff"]),
+                     float(cfg["resign_thres"]), float(cfg["never_resign_prob"]), 0, 1, 0, 0, mo)
+
+
+def to_json(elf_amd, opt, p, j):
+    L = elf_amd.lib()
+    mv, pol, val = p["moves"], p["policies"], p["values"]
+    args = (C.byref(opt), mv.ctypes.data, mv.size, pol.ctypes.data if pol.size else None, pol.shape[0], val.ctypes.data, val.size,
+            C.c_float(p["reward"]), int(j["result"]["black_never_resign"]), j["seq"], j["thread_id"], j["timestamp"])
+    n = L.elfrec_record_to_json(*args, None, 0)
+    assert n > 0
+    buf = C.create_string_buffer(n + 1)
+    assert L.elfrec_record_to_json(*args, buf, n + 1) == n
+    assert L.elfrec_record_to_json(*args, buf, n) == -2   # ELFGO_E_BADSIZE
+    return buf.raw[:n].decode()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_record_json_text_equals_reference_dump(built, name):
+    """parse the reference's record, re-serialise it through elfrec_record_to_json: the text must be identical."""
+    import elf_amd
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = int(g["board_size"])
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    opt = sp_options(elf_amd, n, cfg)
+    for t in g["records"]:
+        t = str(t)
+        j = json.loads(t)
+        p = elf_amd.parse_record(n, t)
+        assert np.array_equal(p["moves"], sgfstr2coords(n, j["result"]["content"]))
+        assert elf_amd.coords_to_sgfstr(n, p["moves"]) == j["result"]["content"]
+        assert to_json(elf_amd, opt, p, j) == t
+
+
+def test_sgf_strings_edge_cases(built):
+    import elf_amd
+    n = 19
+    S = n + 2
+    assert elf_amd.coords_to_sgfstr(n, []) == "()"
+    assert elf_amd.coords_to_sgfstr(n, [0, 1 * S + 1, 19 * S + 19]) == "(;B[];W[aa];B[ss])"   # pass, A1 corner, far corner
+    for s, want in [("", []), ("(", []), ("x(;B[aa])", []), ("(;B[aa", []), ("(;B[aa];W[bb])", [S + 1, 2 * S + 2]),
+                    ("(;B[aa]W[bb])", [S + 1]),                      # the loop stops at the first non-';' (sgf.h:104-106)
+                    ("(;B[];W[a];B[tt];W[ t];B[a b])", [0, 0, 3, 3, 2 * S + 1])]:   # <2 chars = pass; off board / blank = M_INVALID
+        got = elf_amd.sgfstr_to_coords(n, s)
+        assert list(got) == want, (s, list(got))
+        assert list(sgfstr2coords(n, s)) == want, s
+
+
+def test_quantise_policy(built):
+    """GoStateExt::addMCTSPolicy: c = (unsigned char)(p / max * 255), fp32 arithmetic (go_state_ext.h:158-181)"""
+    import elf_amd
+    L = elf_amd.lib()
+    rng = np.random.default_rng(3)
+    for n in (9, 19):
+        P = (n + 2) ** 2
+        for _ in range(50):
+            k = int(rng.integers(1, 60))
+            coord = rng.choice(P, size=k, replace=False).astype(np.int32)
+            visits = rng.integers(0, 500, size=k).astype(np.float32)
+            visits[rng.integers(0, k)] += 1
+            prob = (visits / visits.sum(dtype=np.float32)).astype(np.float32)
+            out = np.full(P, 7, np.uint8)
+            assert L.elfrec_quantise_policy(n, coord.ctypes.data, prob.ctypes.data, k, out.ctypes.data) == 0
+            want = np.zeros(P, np.uint8)
+            mx = np.float32(prob.max())
+            want[coord] = (np.float32(prob / mx) * np.float32(255)).astype(np.uint8)
+            assert np.array_equal(out, want)
+    bad = np.array([P], np.int32)
+    one = np.array([1.0], np.float32)
+    assert L.elfrec_quantise_policy(19, bad.ctypes.data, one.ctypes.data, 1, out.ctypes.data) == -1
+
+
+def test_against_reference_library(built):
+    if not RefSelfPlay.available(19):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    import elf_amd
+    R = RefSelfPlay(19)
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        k = int(rng.integers(0, 80))
+        coords = [0 if rng.random() < 0.1 else int((rng.integers(0, 19) + 1) * 21 + rng.integers(0, 19) + 1) for _ in range(k)]
+        s = R.coords2sgfstr(coords)
+        assert elf_amd.coords_to_sgfstr(19, coords) == s
+        assert np.array_equal(R.sgfstr2coords(s), elf_amd.sgfstr_to_coords(19, s))
+    g = np.load(os.path.join(GOLDEN, "records_19_cutoff.npz"))
+    for t in g["records"]:
+        assert R.record_roundtrip(str(t)) == str(t)   # the reference reads its own dump back to the same text
