@@ -316,12 +316,136 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     return res
 
 
+def synth_games(n, games, plies, dev, local_rank, seed):
+    """Random legal play on the product board engine (legal mask -> torch.multinomial -> forward), `games` games of up to `plies`
+    plies; pass when nothing is legal.  -> int64 tensor [games, plies] of reference Coords."""
+    import elf_amd
+    eng = elf_amd.GoEngine(n, games, local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    S = n + 2
+    out = torch.zeros((games, plies), dtype=torch.int64, device=dev)
+    for t in range(plies):
+        m = eng.legal_mask().float()
+        m[:, n * n] = (m[:, : n * n].sum(1) == 0).float()          # pass only when no point is legal
+        a = torch.multinomial(m, 1, generator=gen).reshape(-1)
+        x, y = a // n, a % n
+        c = torch.where(a == n * n, torch.zeros_like(a), (y + 1) * S + (x + 1))
+        eng.forward(None, c.to(torch.int32))
+        out[:, t] = c
+    eng.close()
+    return out
+
+
+def cpu_baseline_train(n, records_json, nfa):
+    """The reference's per-sample trainer work (GoGameTrain::act: fromRecord, switchRandomMove, generateD4Code + every "train"
+    extractor; oracle/_ref, the real reference) on the host cores, same records."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        from pyoracle import RefSelfPlay
+    except Exception as e:
+        return {"value": None, "unit": "samples/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
+    if not RefSelfPlay.available(n):
+        return {"value": None, "unit": "samples/s", "cores": 0, "kind": "unavailable", "sample": "oracle/_ref/libelfsp%d.so not built" % n}
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    R = RefSelfPlay(n)
+    samples = 4000 * cores
+    steps, sec = R.train_bench(records_json, samples, cores, nfa)
+    return {"value": samples / sec, "unit": "samples/s", "cores": cores, "kind": "reference", "board_steps_per_sec": steps / sec,
+            "sample": "%d samples of the same records (%d replayed board steps) on %d host threads, %.1f s" % (samples, steps, cores, sec)}
+
+
+def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
+    """the trainer's input pipeline.  One step = one "train" batch of --train-batch samples: draw (record, ply,
+    D4) like GoGameTrain::act, replay each record to its ply and extract every field, in ONE k_replay_extract launch."""
+    import ctypes as C
+    import elf_amd
+    from elf_amd.selfplay import MctsOptions, SpOptions
+    n, B, R, nfa = args.board_size, args.train_batch, args.train_records, 1
+    dev = torch.device("cuda", local_rank)
+    plies = 320 if n == 19 else 70
+    moves = synth_games(n, R, plies, dev, local_rank, 4242 + rank).cpu().numpy().astype(np.uint16)
+    rng = np.random.default_rng(7 + rank)
+    P = (n + 2) ** 2
+    ld = elf_amd.ReplayLoader(board_size=n, capacity=R, batchsize=B, device=local_rank, num_future_actions=nfa, seed=1234 + 1000 * rank,
+                              feature_format="f16_nhwc" if args.features in ("auto", "f16") else "f32_nchw")
+    recs_json = []
+    L = elf_amd.lib()
+    opt = SpOptions(n, 1, 1024, 1600, 1, 0.25, 0.03, 0, 30, -1, 0.0, 0.0, 0, 1, 1, 0, MctsOptions(16, 1, 1, 0, 0, 1.5, 7.5, 0, 1, 1))
+    for r in range(R):
+        pol = np.zeros((plies, P), np.uint8)                       # policy_distri_training_for_all: one policy per ply
+        idx = rng.integers(0, P, size=(plies, 24))
+        np.put_along_axis(pol, idx, rng.integers(1, 256, size=(plies, 24)).astype(np.uint8), axis=1)
+        pol[np.arange(plies), moves[r]] = 255
+        val = np.tanh(rng.standard_normal(plies)).astype(np.float32)
+        rec = dict(moves=moves[r], reward=float(rng.choice([-1.0, 1.0])), black_ver=0, policies=pol, values=val)
+        ld.put(r, rec)
+        if with_cpu and r < 32:                                    # the CPU baseline reads the same records as Record JSON
+            args_ = (C.byref(opt), moves[r].ctypes.data, plies, pol.ctypes.data, plies, val.ctypes.data, plies, C.c_float(rec["reward"]), 0, 2, 0, 0)
+            k = L.elfrec_record_to_json(*args_, None, 0)
+            buf = C.create_string_buffer(k + 1)
+            L.elfrec_record_to_json(*args_, buf, k + 1)
+            recs_json.append(buf.raw[:k].decode())
+    out = ld._alloc(B)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    mt_sum = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    d = ld._draw
+    for i in range(warmup):
+        ld.sample(B, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        check_rc = ld.L.elftrain_draw(ld._h, B, nfa, C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()), C.c_void_p(d[2].data_ptr()), ld._stream())
+        assert check_rc == 0
+        ev[i][0].record()
+        ld.extract(d[0, :B], d[1, :B], d[2, :B], out=out)          # the dominant kernel, on torch's current stream
+        ev[i][1].record()
+        mt_sum += out["move_idx"].sum()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    replayed = int(mt_sum.item())
+    dt_max, samples_all = reduce_max_sum(dist, dev, dt, B * steps)
+    ld.close()
+    if rank != 0:
+        return None
+    per_sample = replayed / (B * steps) * STEP_BYTES[n] + (26728 if n == 19 else 6008) + P + 4 * (n * n + 1) + 40
+    achieved = B * per_sample / (kern_ms / 1e3) / 1e9
+    res = {
+        "metric": "train_samples_per_sec (%dx%d replay to a random ply + every field of the reference's train batch)" % (n, n),
+        "value": samples_all / dt_max, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
+        "data": "synthetic",
+        "config": {"workload": "SURVEY.md 8f-1 trainer input pipeline: batch %d, %d records of %d plies (random legal play on the device "
+                               "engine), one MCTS policy per ply, num_future_actions %d, s rows %s" % (B, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
+                   "batch": B, "records": R, "board_size": n, "mean_replayed_plies": replayed / (B * steps),
+                   "replayed_board_steps_per_sec": replayed / dt, "parallelism": "independent samples per GPU, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": load_traffic("k_replay_extract<%d>" % n), "kernel": "k_replay_extract<%d>" % n, "avg_kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_sample": per_sample,
+                     "note": "bytes per sample = replayed plies x 8730 B (reference Board in+out+mask per forward, SURVEY.md 8d) + 26728 B "
+                             "features + 441 B policy row + 362 x 4 B scores + scalars; the replay itself runs in LDS, so like k_playout "
+                             "this is a rate against the HBM roof, not HBM traffic"},
+    }
+    res["cpu_baseline"] = cpu_baseline_train(n, "[" + ",".join(recs_json) + "]", nfa) if with_cpu else None
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["mcts", "board", "both"], default="both")
+    ap.add_argument("--workload", choices=["mcts", "board", "train", "both"], default="both",
+                    help="both (default) = mcts headline + board_step + train_loader sub-results")
+    ap.add_argument("--train-batch", type=int, default=2048)
+    ap.add_argument("--train-records", type=int, default=256)
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--board-size", type=int, default=19)
     ap.add_argument("--games", type=int, default=256, help="games per GPU (split over --groups)")
@@ -356,6 +480,14 @@ def main():
             res = b
         elif rank == 0:
             res["board_step"] = b
+    if args.workload in ("train", "both"):
+        tsteps = args.steps if (args.steps is not None and args.workload == "train") else 20
+        twarm = args.warmup if (args.warmup is not None and args.workload == "train") else 3
+        t = run_train(args, rank, local_rank, world, dist, tsteps, twarm, with_cpu)
+        if args.workload == "train":
+            res = t
+        elif rank == 0:
+            res["train_loader"] = t
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

@@ -289,6 +289,16 @@ class RefSelfPlay:
         c = np.ascontiguousarray(coords, dtype=np.uint16)
         return self._text(self.L.reftrain_coords2sgfstr, c.ctypes.data_as(C.c_void_p), C.c_int(c.size))
 
+    def train_bench(self, records_json_array, n_samples, threads, num_future_actions=1):
+        """-> (board steps replayed, seconds): GoGameTrain::act's per-sample work on `threads` host threads"""
+        sec = C.c_double(0)
+        self.L.reftrain_bench.restype = C.c_int64
+        st = self.L.reftrain_bench(records_json_array.encode(), C.c_int(n_samples), C.c_int(threads), C.c_int(num_future_actions),
+                                   C.byref(sec))
+        if st < 0:
+            raise RuntimeError("reftrain_bench failed")
+        return int(st), float(sec.value)
+
     def train_sample(self, record_json, move_to, d4, num_future_actions=1):
         """The reference's "train" batch row for (record, move_to, d4): dict of numpy arrays"""
         n, na = self.n, self.na

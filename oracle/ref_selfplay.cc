@@ -331,6 +331,56 @@ int reftrain_sample(const char* record_json, int move_to, int d4, int num_future
   }
 }
 
+// CPU baseline of the trainer's input pipeline: what GoGameTrain::act does per sample (fromRecord, switchRandomMove,
+// generateD4Code, then every "train" extractor the batcher would call on the sending thread), records parsed once,
+// `threads` host threads each producing samples into its own row buffers.  Returns the number of board steps replayed.
+int64_t reftrain_bench(const char* records_json_array, int n_samples, int threads, int num_future_actions, double* seconds) {
+  try {
+    std::vector<Record> recs = Record::createBatchFromJson(std::string(records_json_array));
+    if (recs.empty() || threads < 1) return -1;
+    GameOptions opt;
+    opt.num_future_actions = num_future_actions;
+    std::atomic<int64_t> steps{0};
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; ++t) {
+      th.emplace_back([&, t]() {
+        std::mt19937 rng(1234 + t);
+        GoStateExtOffline st(t, opt);
+        std::vector<float> s(MAX_NUM_AGZ_FEATURE * BOARD_SIZE * BOARD_SIZE), ms(BOARD_NUM_ACTION);
+        std::vector<int64_t> oa(num_future_actions);
+        float w, pv = 0; int32_t mi, nm, ac; int64_t sv;
+        int64_t local = 0;
+        for (int i = t; i < n_samples; i += threads) {
+          while (true) {
+            st.fromRecord(recs[rng() % recs.size()]);
+            if (st.switchRandomMove(&rng)) break;
+          }
+          st.generateD4Code(&rng);
+          GoFeature::extractStateExtAGZ(st, s.data());
+          GoFeature::extractOfflineAction(st, oa.data());
+          GoFeature::extractWinner(st, &w);
+          GoFeature::extractMCTSPi(st, ms.data());
+          GoFeature::extractMoveIdx(st, &mi);
+          GoFeature::extractNumMove(st, &nm);
+          GoFeature::extractAugCode(st, &ac);
+          GoFeature::extractStateSelfplayVersion(st, &sv);
+          local += mi;
+        }
+        (void)pv;
+        steps += local;
+      });
+    }
+    for (auto& x : th) x.join();
+    const auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    return steps.load();
+  } catch (const std::exception& e) {
+    fprintf(stderr, "reftrain_bench: %s\n", e.what());
+    return -1;
+  }
+}
+
 // Record::createFromJson -> setJsonFields -> dump: the reference's reading of a record, re-serialised
 int64_t reftrain_record_roundtrip(const char* record_json, char* buf, int64_t cap) {
   try {
