@@ -32,5 +32,19 @@ if per:
     res["k_mcts_search<19>"] = {"hbm_bytes_per_rollout": sum(per.values()) / roll, "per_kernel_bytes_per_launch": per, "rollouts_per_launch": roll,
                                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d steps of bench.py --workload mcts --net random --games 1024 "
                                         "--rollouts 2048 (16384 rollouts per step); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_mcts_search_only_rocprofv3.txt" % (n, tag)}
+t = os.path.join(out, "summary_train.txt")
+if os.path.exists(t):
+    for k, c in counters(t).items():
+        if "k_replay_extract" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            res["k_replay_extract<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
+                                           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d launches of bench.py --workload train "
+                                                   "(2048 samples per launch, ~159 replayed plies each); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_train_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
+t = os.path.join(out, "summary_feat.txt")
+if os.path.exists(t):
+    for k, c in counters(t).items():
+        if "k_extract_agz" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            res["k_extract_agz<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
+                                        "note": "tools/feat_bench.py: 16384 rows per launch, fp32 NCHW and fp16 NHWC launches averaged together (%d launches); "
+                                                "algorithmic bytes 26728 / 13732 per row; source profiles/%s_feat_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
 json.dump(res, open(p, "w"), indent=1)
 print(json.dumps(res, indent=1))
