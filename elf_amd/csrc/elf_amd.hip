@@ -152,9 +152,11 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
   bd.load(&pool.slots[b]);
   const u64 seed = seeds[blockIdx.x];
   int steps = 0;
+  ELF_PHASE(bd, 7);
   while (steps < max_steps && !bd.terminated()) {
     u64 legal, cand;
     bd.template legal_moves<true>(legal, cand);
+    ELF_PHASE(bd, 0);   // legal mask + true eyes
     // uniformly random candidate: r-th set bit of the lane-distributed candidate bitboard
     const int cnt = __popcll(cand);
     int pre[G::R + 1];
@@ -177,9 +179,11 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
       const int a = kw * 64 + (int)__builtin_ctzll(sel);
       pick = Board<N>::tr(Board<N>::a2i(a));
     }
+    ELF_PHASE(bd, 1);   // pick the k-th candidate
     if (!bd.forward(pick)) break;
     ++steps;
   }
+  ELF_PHASE_END(bd);
   bd.store(&pool.slots[b]);
   if (threadIdx.x == 0) {
     u64 h = bd.hash;
@@ -198,16 +202,18 @@ static int create_impl(ElfGoEngine* e, const uint64_t* zob_host) {
   HIPCHK(hipMalloc(&e->slots, (size_t)e->capacity * sizeof(Slot<N>)));
   HIPCHK(hipMalloc((void**)&e->sk_hash, (size_t)e->capacity * (G::MAXMOVE + 2) * sizeof(u64)));
   HIPCHK(hipMalloc((void**)&e->sk_img, (size_t)e->capacity * (G::MAXMOVE + 2) * G::SKW * sizeof(u64)));
-  HIPCHK(hipMalloc((void**)&e->zob, (size_t)(G::ZOBW + 3 * G::R) * sizeof(u64)));
+  HIPCHK(hipMalloc((void**)&e->zob, (size_t)(G::ZOBW + 4 * G::R) * sizeof(u64)));
   // reference Coord order -> internal (transposed) index order, followed by the per-word geometry masks
-  std::vector<u64> z(G::ZOBW + 3 * G::R, 0);
+  std::vector<u64> z(G::ZOBW + 4 * G::R, 0);
   for (int i = 0; i < G::P; ++i) z[i] = zob_host[(i % G::S) * G::S + i / G::S];
   for (int a = 0; a < G::NP; ++a) {
     const int k = a >> 6, y = a % N;
     const u64 bit = 1ull << (a & 63);
-    if (y != 0) z[G::ZOBW + 3 * k + 0] |= bit;
-    if (y != N - 1) z[G::ZOBW + 3 * k + 1] |= bit;
-    z[G::ZOBW + 3 * k + 2] |= bit;
+    const int x = a / N;
+    if (y != 0) z[G::ZOBW + 4 * k + 0] |= bit;
+    if (y != N - 1) z[G::ZOBW + 4 * k + 1] |= bit;
+    z[G::ZOBW + 4 * k + 2] |= bit;
+    if (x == 0 || x == N - 1 || y == 0 || y == N - 1) z[G::ZOBW + 4 * k + 3] |= bit;
   }
   HIPCHK(hipMemcpy(e->zob, z.data(), z.size() * sizeof(u64), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_reset<N>, dim3(e->capacity), dim3(WAVE), 0, 0, pool_of<N>(e), (const int32_t*)nullptr, e->capacity);

@@ -25,6 +25,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// phase markers for tools/playout_phases.hip (cycle attribution); compiled out of the library
+#ifndef ELF_PHASE
+#define ELF_PHASE(bd, k)
+#define ELF_PHASE_END(bd)
+#endif
+
 namespace elfgo {
 
 typedef unsigned short u16;
@@ -165,10 +171,13 @@ struct Board {
   int idx[R];          // LDS index of this lane's point in round k (clamped for invalid lanes)
   // lane-distributed bitboards in NN action order: lane k < R holds bits [64k, 64k+64); other lanes 0
   u64 Bw, Ww;          // black / white stones of the current position
-  u64 mTop, mBot, mValid;  // per-lane geometry masks: y != 0, y != N-1, a < N*N
+  u64 mTop, mBot, mValid, mEdge;  // per-lane geometry masks: y != 0, y != N-1, a < N*N, point on the first/last line
   // wave-uniform copy of the header (SGPRs); LDS/HBM copy is refreshed by store_hdr()
   u64 hash;
   int ply, next_player, ko_pt, ko_age, ko_color, lm0, lm1, lm2, lm3, b_cap, w_cap, hist_cnt, sk_len, superko;
+#ifdef ELF_PROFILE
+  unsigned long long ph_t, ph_acc[8];   // tools/playout_phases.hip
+#endif
 
   __device__ __forceinline__ static int a2i(int a) { return a + S + 1 + 2 * (a / N); }
   __device__ __forceinline__ static int tr(int i) { return (i % S) * S + i / S; }  // idx <-> reference Coord
@@ -189,9 +198,10 @@ struct Board {
       idx[k] = a2i(a < NP ? a : 0);
     }
     const u64* geo = z + G::ZOBW;
-    mTop = lane < R ? geo[lane * 3 + 0] : 0ull;
-    mBot = lane < R ? geo[lane * 3 + 1] : 0ull;
-    mValid = lane < R ? geo[lane * 3 + 2] : 0ull;
+    mTop = lane < R ? geo[lane * 4 + 0] : 0ull;
+    mBot = lane < R ? geo[lane * 4 + 1] : 0ull;
+    mValid = lane < R ? geo[lane * 4 + 2] : 0ull;
+    mEdge = lane < R ? geo[lane * 4 + 3] : 0ull;
     Bw = Ww = 0;
   }
 
@@ -204,6 +214,12 @@ struct Board {
     d |= (X >> N) | (n << (64 - N));                // a+N in X
     return d & mValid;
   }
+
+  // single-direction shifts of a lane-distributed bitboard: result bit a = X bit (a -/+ 1) within the column run, (a -/+ N)
+  __device__ __forceinline__ u64 sh_m1(u64 X) const { const u64 p = dpp_prev(X); return ((X << 1) | (p >> 63)) & mTop; }
+  __device__ __forceinline__ u64 sh_p1(u64 X) const { const u64 n = dpp_next(X); return ((X >> 1) | (n << 63)) & mBot; }
+  __device__ __forceinline__ u64 sh_mN(u64 X) const { const u64 p = dpp_prev(X); return (X << N) | (p >> (64 - N)); }
+  __device__ __forceinline__ u64 sh_pN(u64 X) const { const u64 n = dpp_next(X); return ((X >> N) | (n << (64 - N))) & mValid; }
 
   __device__ __forceinline__ void load_hdr() {
     u32 w = lane < 16 ? reinterpret_cast<const u32*>(&L->h)[lane] : 0u;
@@ -324,6 +340,7 @@ struct Board {
         if (!(saves(n0, l0) || saves(n1, l1) || saves(n2, l2) || saves(n3, l3))) return 0;
       }
     }
+    ELF_PHASE(*this, 2);   // TryPlay done
     // ---- _add_board_hash (go_state.cc:113-121): record the PRE-move position, skipped for pass
     if (c != M_PASS) {
       sk.record(sk_len, hash, Bw, Ww, lane);
@@ -333,6 +350,7 @@ struct Board {
         L->bloom[h2 >> 5] |= 1u << (h2 & 31);
       }
     }
+    ELF_PHASE(*this, 3);   // superko record + bloom insert
     int total_cap = 0, ko_c = 0;
     bool new_ko = false;
     if (is_move) {
@@ -412,6 +430,7 @@ struct Board {
         }
         wsync();
       }
+      ELF_PHASE(*this, 4);   // captures, stone placement, merges
       // liberties of the mover's group
       int newlibs;
       const int root = newv & 0x7FFF;
@@ -449,6 +468,7 @@ struct Board {
       hash ^= zob_col(zob[i], player);
       new_ko = (m == 0 && total_cap == 1 && newlibs == 1);                    // :1386
     }
+    ELF_PHASE(*this, 5);   // liberties of the mover's group
     // ---- history push (go_state.cc:90-92; BoardHistory(board) board_feature.h:45-56) as bitboards
     {
       const int slot = hist_cnt & (HIST - 1);
@@ -476,57 +496,45 @@ struct Board {
         if (sk.exact_hit(sk_len, hash, Bw, Ww, lane)) superko = 1;
       }
     }
+    ELF_PHASE(*this, 6);   // history, header, superko check
     return 1;
   }
 
   // ---- legal moves for the side to move (TryPlay :788-827 over every point) --------------------
-  // Results are lane-distributed bitboards (lane k holds actions [64k, 64k+64)).  Points with an empty
-  // neighbour are settled on bitboards (a handful of 64-bit VALU ops); only the surrounded empty points
-  // touch the LDS group tables, one predicated round per non-empty 64-point word.
-  // cand = legal minus the mover's own true eyes (isTrueEye, board.cc:1850-1914), for the config-2 policy.
+  // Results are lane-distributed bitboards (lane k holds actions [64k, 64k+64)).  Everything is settled on bitboards:
+  //   At    = stones whose group has exactly one liberty (the only LDS work: 2 x R independent reads, pt then libs[root])
+  //   legal = E & dilate(E | (Own & ~At) | (Opp & At))      an empty neighbour, or an own neighbour group that keeps a liberty,
+  //                                                         or an enemy neighbour group in atari  (isSuicideMove :201-232)
+  //   eye   = E & ~dilate(E | Opp) & legal & ~fake          isEye :1850-1860, isFakeEye :1887-1906 via the four diagonal shifts
+  // minus the simple-ko point (:234-240).  cand = legal minus the mover's own true eyes, for the config-2 policy.
   template <bool WITH_EYES>
   __device__ __forceinline__ void legal_moves(u64& legal, u64& cand) const {
     const int player = next_player;
-    const u32 ownbit = player == S_WHITE ? 0x8000u : 0u;
+    const u64 Own = player == S_BLACK ? Bw : Ww, Opp = player == S_BLACK ? Ww : Bw;
     const u64 E = ~(Bw | Ww) & mValid;
-    const u64 open = E & dilate(E);
-    const u64 need = E & ~open;
-    u64 okw = open, eyew = 0;
-    if (__ballot(need != 0)) {
+    u32 v[R], lb[R];
 #pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const u64 nk = rl64(need, k);
-        if (nk == 0) continue;
-        bool good = false, eye = false;
-        if (lane_bit(nk)) {
-          const int p = idx[k];
-          u32 a[4] = {L->pt[p - S], L->pt[p - 1], L->pt[p + S], L->pt[p + 1]};
-          u32 lb[4];
+    for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) lb[j] = L->libs[a[j] == PT_BORDER ? 0 : (a[j] & 0x7FFF)];
-          bool allown = true;
+    for (int k = 0; k < R; ++k) lb[k] = L->libs[is_stone(v[k]) ? (v[k] & 0x7FFF) : 0];
+    u64 At = 0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            bool border = a[j] == PT_BORDER;
-            bool own = (a[j] & 0x8000) == ownbit;
-            good |= !border && (own ? lb[j] > 1 : lb[j] == 1);
-            allown &= border || own;
-          }
-          if (WITH_EYES && allown && good) {
-            // isEye holds (board.cc:1850-1860); isFakeEye :1887-1906 on the diagonals
-            u32 d[4] = {L->pt[p - S - 1], L->pt[p - S + 1], L->pt[p + S - 1], L->pt[p + S + 1]};
-            int nopp = 0, nb = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              nb += d[j] == PT_BORDER;
-              nopp += d[j] != PT_BORDER && d[j] != 0 && (d[j] & 0x8000) != ownbit;
-            }
-            bool fake = (nb > 0 && nopp >= 1) || (nb == 0 && nopp >= 2);
-            eye = !fake;
-          }
-        }
-        const u64 gb = __ballot(good), eb = __ballot(eye);
-        if (lane == k) { okw |= gb; eyew = eb; }
+    for (int k = 0; k < R; ++k) {
+      const u64 bal = __ballot(is_stone(v[k]) && lb[k] == 1);
+      if (lane == k) At = bal;
+    }
+    At &= (Bw | Ww);   // drops the clamped lanes of the last round (they re-read point 0)
+    u64 okw = E & dilate(E | (Own & ~At) | (Opp & At));
+    u64 eyew = 0;
+    if (WITH_EYES) {
+      const u64 allown = okw & ~dilate(E | Opp);
+      if (__ballot(allown != 0)) {
+        const u64 om = sh_m1(Opp), op = sh_p1(Opp);
+        const u64 d1 = sh_mN(om), d2 = sh_mN(op), d3 = sh_pN(om), d4 = sh_pN(op);
+        const u64 ge1 = d1 | d2 | d3 | d4;
+        const u64 ge2 = (d1 & d2) | (d3 & d4) | ((d1 | d2) & (d3 | d4));
+        const u64 fake = (mEdge & ge1) | (~mEdge & ge2);
+        eyew = allown & ~fake;
       }
     }
     if (ko_age == 0 && ko_color == player && ko_pt != 0) {
