@@ -176,7 +176,7 @@ struct Board {
   u64 hash;
   int ply, next_player, ko_pt, ko_age, ko_color, lm0, lm1, lm2, lm3, b_cap, w_cap, hist_cnt, sk_len, superko;
 #ifdef ELF_PROFILE
-  unsigned long long ph_t, ph_acc[8];   // tools/playout_phases.hip
+  unsigned long long ph_t, ph_acc[16];   // tools/playout_phases.hip
 #endif
 
   __device__ __forceinline__ static int a2i(int a) { return a + S + 1 + 2 * (a / N); }
@@ -313,8 +313,9 @@ struct Board {
     const int player = next_player, opp = S_BLACK + S_WHITE - player;
     const bool is_move = !(c == M_PASS || c == M_RESIGN);
     int i = 0, ka = 0;
-    u64 abit = 0;
-    int n0 = 0, n1 = 0, n2 = 0, n3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    u64 abit = 0, zi = 0;
+    u32 nv = 0, nl = 0;   // lanes 0..3: label of the neighbour in delta4 order / liberties of its group
+    u32 emp4 = 0;         // bit j: neighbour j is empty
     const int dl = dir4(lane & 3);
     if (is_move) {
       // ---- TryPlay, board.cc:788-827
@@ -326,18 +327,16 @@ struct Board {
       ka = a >> 6; abit = 1ull << (a & 63);
       if (rl64(Bw | Ww, ka) & abit) return 0;                                 // :808 occupied
       if (ko_pt == c && ko_age == 0 && ko_color == player) return 0;          // :234-240
-      u32 nv = 0, nl = 0;
+      zi = zob[i];                                                            // issued now, hashed in after Play
       if (lane < 4) {                                                         // StoneLibertyAnalysis :161-199
         nv = L->pt[i + dl];
         nl = is_stone(nv) ? L->libs[nv & 0x7FFF] : 0;
       }
-      n0 = rl((int)nv, 0); n1 = rl((int)nv, 1); n2 = rl((int)nv, 2); n3 = rl((int)nv, 3);
-      l0 = rl((int)nl, 0); l1 = rl((int)nl, 1); l2 = rl((int)nl, 2); l3 = rl((int)nl, 3);
-      int nempty = (n0 == 0) + (n1 == 0) + (n2 == 0) + (n3 == 0);
-      if (nempty == 0) {                                                      // isSuicideMove :201-232
-        const int pb = player == S_WHITE ? 0x8000 : 0;
-        auto saves = [&](int n, int l) { return n != PT_BORDER && (((n & 0x8000) == pb) ? l > 1 : l == 1); };
-        if (!(saves(n0, l0) || saves(n1, l1) || saves(n2, l2) || saves(n3, l3))) return 0;
+      emp4 = (u32)__ballot(lane < 4 && nv == 0);
+      if (emp4 == 0) {                                                        // isSuicideMove :201-232
+        const u32 pb = player == S_WHITE ? 0x8000u : 0u;
+        const bool saves = lane < 4 && nv != PT_BORDER && (((nv & 0x8000u) == pb) ? nl > 1 : nl == 1);
+        if (__ballot(saves) == 0) return 0;
       }
     }
     ELF_PHASE(*this, 2);   // TryPlay done
@@ -346,8 +345,8 @@ struct Board {
       sk.record(sk_len, hash, Bw, Ww, lane);
       if (lane == 0) {
         const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
-        L->bloom[h1 >> 5] |= 1u << (h1 & 31);
-        L->bloom[h2 >> 5] |= 1u << (h2 & 31);
+        atomicOr(&L->bloom[h1 >> 5], 1u << (h1 & 31));   // ds_or_b32, no return value to wait for
+        atomicOr(&L->bloom[h2 >> 5], 1u << (h2 & 31));
       }
     }
     ELF_PHASE(*this, 3);   // superko record + bloom insert
@@ -355,30 +354,24 @@ struct Board {
     bool new_ko = false;
     if (is_move) {
       // ---- Play, board.cc:1297-1401
-      const int ownbit = player == S_WHITE ? 0x8000 : 0;
-      // classify the <=4 distinct neighbour groups (first occurrence wins, like GroupId4 slots)
-      auto stone = [](int n) { return n != 0 && n != PT_BORDER; };
-      const bool f0 = stone(n0), f1 = stone(n1) && n1 != n0, f2 = stone(n2) && n2 != n0 && n2 != n1,
-                 f3 = stone(n3) && n3 != n0 && n3 != n1 && n3 != n2;
-      auto isown = [&](int n) { return (n & 0x8000) == ownbit; };
-      const int o0 = (f0 && isown(n0)) ? n0 : -1, o1 = (f1 && isown(n1)) ? n1 : -1, o2 = (f2 && isown(n2)) ? n2 : -1,
-                o3 = (f3 && isown(n3)) ? n3 : -1;
-      const int c0 = (f0 && !isown(n0) && l0 == 1) ? n0 : -1, c1 = (f1 && !isown(n1) && l1 == 1) ? n1 : -1,
-                c2 = (f2 && !isown(n2) && l2 == 1) ? n2 : -1, c3 = (f3 && !isown(n3) && l3 == 1) ? n3 : -1;
-      const int m = (o0 >= 0) + (o1 >= 0) + (o2 >= 0) + (o3 >= 0);
-      const bool anycap = (c0 >= 0) | (c1 >= 0) | (c2 >= 0) | (c3 >= 0);
-      // enemy groups that survive lose the liberty at i (:1327)
-      if (lane < 4) {
-        int n = lane == 0 ? n0 : lane == 1 ? n1 : lane == 2 ? n2 : n3;
-        int l = lane == 0 ? l0 : lane == 1 ? l1 : lane == 2 ? l2 : l3;
-        bool f = lane == 0 ? f0 : lane == 1 ? f1 : lane == 2 ? f2 : f3;
-        if (f && !isown(n) && l != 1) L->libs[n & 0x7FFF] = (u16)(l - 1);
-      }
-      const int first_own = o0 >= 0 ? o0 : o1 >= 0 ? o1 : o2 >= 0 ? o2 : o3;
-      const u32 newv = m > 0 ? (u32)first_own : (u32)(ownbit | i);
+      const u32 ownbit = player == S_WHITE ? 0x8000u : 0u;
+      // classify the <=4 distinct neighbour groups on lanes 0..3 (first occurrence wins, like GroupId4 slots)
+      const u32 p1 = __builtin_amdgcn_update_dpp(0u, nv, 0x111, 0xf, 0xf, true), p2 = __builtin_amdgcn_update_dpp(0u, nv, 0x112, 0xf, 0xf, true),
+                p3 = __builtin_amdgcn_update_dpp(0u, nv, 0x113, 0xf, 0xf, true);   // lane j <- lanes j-1, j-2, j-3 (0 before lane 0)
+      const bool first = lane < 4 && is_stone(nv) && nv != p1 && nv != p2 && nv != p3;
+      const bool own = (nv & 0x8000u) == ownbit;
+      const u32 bo = (u32)__ballot(first && own);                 // own groups touched (merge candidates)
+      const u32 bc = (u32)__ballot(first && !own && nl == 1);     // enemy groups captured by this move
+      if (first && !own && nl != 1) L->libs[nv & 0x7FFF] = (u16)(nl - 1);   // surviving enemy groups lose the liberty at i (:1327)
+      const int m = __popc(bo);
+      const bool anycap = bc != 0;
+      const u32 newv = m > 0 ? (u32)rl((int)nv, (int)__builtin_ctz(bo)) : (ownbit | (u32)i);
+      ELF_PHASE(*this, 8);    // neighbour classification + enemy liberty decrement
       u64 capw = 0;   // lane-distributed bitboard of the stones captured by this move
       if (anycap) {
         // EmptyGroup / RemoveStoneAndAddLiberty (:526-572): wave-parallel removal
+        const int c0 = (bc & 1) ? rl((int)nv, 0) : -1, c1 = (bc & 2) ? rl((int)nv, 1) : -1, c2 = (bc & 4) ? rl((int)nv, 2) : -1,
+                  c3 = (bc & 8) ? rl((int)nv, 3) : -1;
         u64 xh = 0;
         u32 v[R];
 #pragma unroll
@@ -398,10 +391,13 @@ struct Board {
         hash ^= wave_xor64(xh);
         if (player == S_BLACK) Ww &= ~capw; else Bw &= ~capw;
       }
+      ELF_PHASE(*this, 9);    // capture removal
       // place the stone with its final label; fold further own groups into it (MergeGroups :712-752)
       if (lane == 0) L->pt[i] = (u16)newv;
       if (lane == ka) { if (player == S_BLACK) Bw |= abit; else Ww |= abit; }
       if (m >= 2) {
+        const int o0 = (bo & 1) ? rl((int)nv, 0) : -1, o1 = (bo & 2) ? rl((int)nv, 1) : -1, o2 = (bo & 4) ? rl((int)nv, 2) : -1,
+                  o3 = (bo & 8) ? rl((int)nv, 3) : -1;
         u32 v[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
@@ -412,6 +408,7 @@ struct Board {
         }
       }
       wsync();
+      ELF_PHASE(*this, 10);   // placement + merge relabel
       if (anycap) {
         // liberty give-back: every removed stone returns one liberty to each DISTINCT adjacent group (:533-538)
 #pragma unroll
@@ -430,24 +427,27 @@ struct Board {
         }
         wsync();
       }
-      ELF_PHASE(*this, 4);   // captures, stone placement, merges
+      ELF_PHASE(*this, 4);   // liberty give-back
       // liberties of the mover's group
       int newlibs;
       const int root = newv & 0x7FFF;
       if (m == 0) {
         // createNewGroup (:661-671): its liberties are the empty neighbours after captures
-        u32 e = lane < 4 ? L->pt[i + dl] : 1u;
-        newlibs = __popcll(__ballot(e == 0));
+        if (anycap) {
+          u32 e = lane < 4 ? L->pt[i + dl] : 1u;
+          newlibs = __popcll(__ballot(e == 0));
+        } else {
+          newlibs = __popc(emp4);
+        }
       } else if (m == 1) {
         // MergeToGroup (:677-708) restated: the played point stops being a liberty; each previously
         // empty neighbour e counts only if no other stone of the group already touches it.
         const int kk = lane / 3, jj = lane - 3 * kk;   // lanes 0..11: neighbour kk, its jj-th side not facing i
-        const int nk = kk == 0 ? n0 : kk == 1 ? n1 : kk == 2 ? n2 : n3;
         bool touch = false;
-        if (lane < 12 && nk == 0) touch = L->pt[i + dir4(kk) + dir4((kk + 3 + jj) & 3)] == newv;
-        const u64 t = __ballot(touch);
-        const int add = ((n0 == 0) && ((t & 7ull) == 0)) + ((n1 == 0) && (((t >> 3) & 7ull) == 0)) +
-                        ((n2 == 0) && (((t >> 6) & 7ull) == 0)) + ((n3 == 0) && (((t >> 9) & 7ull) == 0));
+        if (lane < 12 && ((emp4 >> kk) & 1u)) touch = L->pt[i + dir4(kk) + dir4((kk + 3 + jj) & 3)] == newv;
+        const u32 t = (u32)__ballot(touch);
+        const int add = ((emp4 & 1u) && ((t & 7u) == 0)) + ((emp4 & 2u) && (((t >> 3) & 7u) == 0)) +
+                        ((emp4 & 4u) && (((t >> 6) & 7u) == 0)) + ((emp4 & 8u) && (((t >> 9) & 7u) == 0));
         newlibs = (int)L->libs[root] - 1 + add;
       } else {
         // RecomputeGroupLiberties (:754-782): |dilate(group) & empty| on bitboards
@@ -465,7 +465,7 @@ struct Board {
       }
       newlibs = rfl(newlibs);
       if (lane == 0) L->libs[root] = (u16)newlibs;
-      hash ^= zob_col(zob[i], player);
+      hash ^= zob_col(zi, player);
       new_ko = (m == 0 && total_cap == 1 && newlibs == 1);                    // :1386
     }
     ELF_PHASE(*this, 5);   // liberties of the mover's group
