@@ -216,7 +216,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     if args.net == "resnet":
         torch.backends.cudnn.benchmark = True
         net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0, fold_bn=not args.no_fold_bn)
-        if args.no_fold_bn or dtype != torch.float16:
+        if args.no_fold_bn or dtype == torch.float32:
             args.net_impl = "eager"   # the fused epilogue is an fp16, BN-folded inference path
         if args.net_impl != "eager":
             from elf_amd.net import FusedInferenceNet

@@ -69,6 +69,7 @@ SIGNATURES = {
     "elfrec_record_to_json": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _i, _i, C.c_uint64, C.c_uint64, _vp, _sz]),
     "elfrec_quantise_policy": (_i, [_i, _vp, _vp, _i, _vp]),
     "elfnet_bias_act_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "elfnet_bias_act_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfgo_malloc": (_i, [C.POINTER(_vp), _sz]),
     "elfgo_free": (_i, [_vp]),
     "elfgo_memcpy_h2d": (_i, [_vp, _vp, _sz]),

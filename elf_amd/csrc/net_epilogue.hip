@@ -3,6 +3,7 @@
 // conv -> BatchNorm -> ReLU / (+x) -> ReLU as separate PyTorch kernels (src_py/elfgames/go/df_model3.py:62-110); with
 // eval BatchNorm folded into the conv weights what remains per conv is exactly this epilogue.
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
@@ -10,10 +11,30 @@
 
 namespace {
 
-struct alignas(16) H8 { __half2 v[4]; };
+struct alignas(16) H8 { unsigned int v[4]; };   // 8 x 16-bit floats
+
+// unpack / pack two 16-bit floats of one dword; BF = bfloat16 (upper half of an fp32), else IEEE half
+template <bool BF>
+__device__ __forceinline__ float2 unpack2(unsigned int w) {
+  if (BF) return make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u));
+  return __half22float2(*reinterpret_cast<const __half2*>(&w));
+}
+template <bool BF>
+__device__ __forceinline__ unsigned int pack2(float2 f) {
+  if (BF) {   // round to nearest even, NaN kept quiet
+    auto r = [](float x) -> unsigned int {
+      unsigned int u = __float_as_uint(x);
+      if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+      return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    };
+    return r(f.x) | (r(f.y) << 16);
+  }
+  __half2 h = __float22half2_rn(f);
+  return *reinterpret_cast<unsigned int*>(&h);
+}
 
 // lanes own 16 B (8 halfs); a wave covers 1 KiB per load/store instruction; grid-stride so that ~8 waves per SIMD cover any size
-template <bool RES, bool BIAS>
+template <bool RES, bool BIAS, bool BF>
 __global__ __launch_bounds__(256) void k_bias_act(H8* __restrict__ x, const H8* __restrict__ bias, const H8* __restrict__ res,
                                                   int64_t n8, int c8, int relu) {
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
@@ -24,11 +45,11 @@ __global__ __launch_bounds__(256) void k_bias_act(H8* __restrict__ x, const H8* 
     if (RES) r = res[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float2 f = __half22float2(a.v[k]);
-      if (BIAS) { float2 g = __half22float2(b.v[k]); f.x += g.x; f.y += g.y; }
-      if (RES) { float2 g = __half22float2(r.v[k]); f.x += g.x; f.y += g.y; }
+      float2 f = unpack2<BF>(a.v[k]);
+      if (BIAS) { float2 g = unpack2<BF>(b.v[k]); f.x += g.x; f.y += g.y; }
+      if (RES) { float2 g = unpack2<BF>(r.v[k]); f.x += g.x; f.y += g.y; }
       if (relu) { f.x = fmaxf(f.x, 0.0f); f.y = fmaxf(f.y, 0.0f); }
-      a.v[k] = __float22half2_rn(f);
+      a.v[k] = pack2<BF>(f);
     }
     x[i] = a;
   }
@@ -36,7 +57,8 @@ __global__ __launch_bounds__(256) void k_bias_act(H8* __restrict__ x, const H8* 
 
 }  // namespace
 
-extern "C" int elfnet_bias_act_f16(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream) {
+template <bool BF>
+static int launch_bias_act(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream) {
   if (!x || rows < 0 || channels <= 0 || (channels & 7) != 0) return ELFGO_E_BADARG;
   if ((((uintptr_t)x | (uintptr_t)bias | (uintptr_t)res) & 15) != 0) return ELFGO_E_BADARG;
   const int64_t n8 = rows * (int64_t)(channels / 8);
@@ -46,10 +68,17 @@ extern "C" int elfnet_bias_act_f16(void* x, const void* bias, const void* res, i
   if (blocks > 256 * 32) blocks = 256 * 32;   // 256 CUs x 32 resident waves / 4 waves per block, x4 oversubscription
   dim3 g((unsigned)blocks), b(256);
   hipStream_t st = (hipStream_t)stream;
-  if (res && bias) hipLaunchKernelGGL((k_bias_act<true, true>), g, b, 0, st, (H8*)x, (const H8*)bias, (const H8*)res, n8, c8, relu);
-  else if (res) hipLaunchKernelGGL((k_bias_act<true, false>), g, b, 0, st, (H8*)x, (const H8*)nullptr, (const H8*)res, n8, c8, relu);
-  else if (bias) hipLaunchKernelGGL((k_bias_act<false, true>), g, b, 0, st, (H8*)x, (const H8*)bias, (const H8*)nullptr, n8, c8, relu);
-  else hipLaunchKernelGGL((k_bias_act<false, false>), g, b, 0, st, (H8*)x, (const H8*)nullptr, (const H8*)nullptr, n8, c8, relu);
+  if (res && bias) hipLaunchKernelGGL((k_bias_act<true, true, BF>), g, b, 0, st, (H8*)x, (const H8*)bias, (const H8*)res, n8, c8, relu);
+  else if (res) hipLaunchKernelGGL((k_bias_act<true, false, BF>), g, b, 0, st, (H8*)x, (const H8*)nullptr, (const H8*)res, n8, c8, relu);
+  else if (bias) hipLaunchKernelGGL((k_bias_act<false, true, BF>), g, b, 0, st, (H8*)x, (const H8*)bias, (const H8*)nullptr, n8, c8, relu);
+  else hipLaunchKernelGGL((k_bias_act<false, false, BF>), g, b, 0, st, (H8*)x, (const H8*)nullptr, (const H8*)nullptr, n8, c8, relu);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int elfnet_bias_act_f16(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream) {
+  return launch_bias_act<false>(x, bias, res, rows, channels, relu, stream);
+}
+extern "C" int elfnet_bias_act_bf16(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream) {
+  return launch_bias_act<true>(x, bias, res, rows, channels, relu, stream);
 }

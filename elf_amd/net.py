@@ -116,8 +116,9 @@ class FusedInferenceNet:
         import ctypes as C
         from . import _lib
         p = next(net.parameters())
-        if p.dtype != torch.float16:
-            raise ValueError("FusedInferenceNet needs an fp16 net")
+        if p.dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("FusedInferenceNet needs an fp16 or bf16 net")
+        self.dtype = p.dtype
         if any(isinstance(m, nn.BatchNorm2d) for m in net.modules()):
             raise ValueError("fold BatchNorm first (make_net(fold_bn=True))")
         self.net, self.C = net, C
@@ -130,7 +131,8 @@ class FusedInferenceNet:
     def _ep(self, x, bias, res, relu=True):
         rows = x.numel() // x.shape[1]
         C = self.C
-        self.check(self.L.elfnet_bias_act_f16(C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()),
+        fn = self.L.elfnet_bias_act_f16 if self.dtype == torch.float16 else self.L.elfnet_bias_act_bf16
+        self.check(fn(C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()),
                                              C.c_void_p(res.data_ptr()) if res is not None else None, rows, x.shape[1], int(relu),
                                              C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
         return x
@@ -144,8 +146,8 @@ class FusedInferenceNet:
     def __call__(self, batch):
         net = self.net
         s = batch["s"] if isinstance(batch, dict) else batch
-        if s.dtype != torch.float16:
-            s = s.to(torch.float16)
+        if s.dtype != self.dtype:
+            s = s.to(self.dtype)
         s = s.contiguous(memory_format=torch.channels_last)   # no-op for SelfPlay(feature_format="f16_nhwc")
         h = self._conv(s, self.first)
         for lo, up in self.blocks:

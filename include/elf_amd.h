@@ -281,6 +281,8 @@ int elfrec_quantise_policy(int board_size, const int32_t* coord, const float* pr
  *   (channels % 8 == 0, 16-B aligned), bias fp16 [channels] or NULL, relu != 0 applies max(.,0).
  * fp32 arithmetic, one rounding to fp16. */
 int elfnet_bias_act_f16(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream);
+/* the same pass for a bfloat16 activation (round to nearest even) */
+int elfnet_bias_act_bf16(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream);
 
 /* convenience for callers without a HIP runtime of their own (tests, cgo/ctypes stubs) */
 int elfgo_malloc(void** dptr, size_t bytes);

@@ -44,6 +44,30 @@ def test_bias_act_epilogue(elf, rows, ch, use_bias, use_res, relu):
         assert torch.equal(y, want)   # at most two addends: bit-exact
 
 
+@pytest.mark.parametrize("use_res", [False, True])
+def test_bias_act_epilogue_bf16(elf, use_res):
+    """the bfloat16 variant: fp32 arithmetic, one round-to-nearest-even to bf16"""
+    import torch
+    L = elf.lib()
+    rows, ch = 3000, 256
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((rows, ch), device="cuda", generator=g).bfloat16()
+    b = torch.randn((ch,), device="cuda", generator=g).bfloat16()
+    r = torch.randn((rows, ch), device="cuda", generator=g).bfloat16() if use_res else None
+    want = x.float() + b.float()
+    if use_res:
+        want = want + r.float()
+    want = torch.relu(want).bfloat16()
+    y = x.clone()
+    assert L.elfnet_bias_act_bf16(C.c_void_p(y.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(r.data_ptr()) if use_res else None,
+                                  rows, ch, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    if use_res:
+        assert torch.allclose(y.float(), want.float(), rtol=2 ** -7, atol=1e-3)
+    else:
+        assert torch.equal(y, want)
+
+
 def test_bias_act_argument_errors(elf):
     import torch
     L = elf.lib()
