@@ -62,7 +62,7 @@ def cpu_baseline_board(n, budget_s=12.0):
         dt = time.time() - t0
         return {"value": tot / dt, "unit": "board_steps/s", "cores": cores, "kind": "reference",
                 "per_core": tot / dt / cores,
-                "sample": "%d of the same 19x19 config-2 games (%d board steps) on %d host threads, %.1f s" % (games, tot, cores, dt)}
+                "sample": "%d of the same %dx%d config-2 games (%d board steps) on %d host threads, %.1f s" % (games, n, n, tot, cores, dt)}
     P = Port(n)
     t0, tot, games = time.time(), 0, 0
     while time.time() - t0 < budget_s:
