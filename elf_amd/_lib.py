@@ -54,6 +54,9 @@ SIGNATURES = {
     "elfsp_stats": (_i, [_vp, _vp]),
     "elfsp_games_finished": (_i64, [_vp]),
     "elfsp_search_log": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "elfsp_play": (_i, [_vp, _vp, _vp]),
+    "elfsp_restart": (_i, [_vp, _vp, _i, _vp]),
+    "elfsp_last_score": (_i, [_vp, _vp]),
     "elfsp_records_pending": (_i, [_vp]),
     "elfsp_pop_record": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "elftrain_create": (_i, [_vp, _i, _i, _i, C.c_uint32, C.POINTER(_vp)]),

@@ -778,7 +778,8 @@ __global__ __launch_bounds__(64) void k_mcts_advance(TreePool<N> tp, const int32
   NR* nodes = tp.game_nodes(g);
   int* fs = tp.free_stack + (size_t)g * tp.C;
   GameState& gs = tp.gs[g];
-  const int old_root = rfl(gs.root), mv = moves[g];
+  const int old_root = rfl(gs.root), mv = rfl(moves[g]);
+  if (mv < 0) return;                        // no move for this game (elfsp_play with a partial move list)
   const NR& r = nodes[old_root];
   const int n = rfl(r.h.n_edges);
   int next_root = -1;

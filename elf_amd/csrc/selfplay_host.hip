@@ -38,6 +38,7 @@ struct SpGame {
   float last_predicted = 0.0f;
   int ply = 1;             // GoState::getPly of the game board
   int seq = 0;             // games finished by this slot
+  float last_final = 0.0f; // GoStateExt::getLastGameFinalValue (go_state_ext.h:153-155)
   SpRecord rec;            // GoStateExt::_mcts_policies / _predicted_values / the game's moves (go_state_ext.h:131-148)
 };
 
@@ -75,6 +76,7 @@ struct ElfSelfPlay {
 
 static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int final_ply) {
   SpGame& gm = sp->games[g];
+  gm.last_final = final_value;
   if (sp->opt.keep_records > 0) {
     SpRecord& r = gm.rec;
     r.reward = final_value;                      // _state.getFinalValue()
@@ -365,6 +367,74 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
   sp->n_rollouts += (int64_t)sp->G * sp->K;
   sp->n_steps++;
   if (++sp->step_in_move >= sp->steps_per_move) SPCHK(sp_finish_move(sp));
+  return 0;
+}
+
+// the human half of GoGameSelfPlay::act (game_selfplay.cc:290-330): an externally chosen move is forwarded on the game board,
+// the tree follows at the next search (MCTSAI_T::align_state -> advanceMoves, mcts.h:141-167).  moves_host[g] < 0 = no move.
+int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream) {
+  if (!sp || !moves_host || sp->search_open) return ELFGO_E_BADARG;
+  sp->stream = (hipStream_t)stream;
+  const int G = sp->G;
+  std::vector<int32_t> ids, mv;
+  for (int g = 0; g < G; ++g) if (moves_host[g] >= 0) { ids.push_back(g); mv.push_back(moves_host[g]); }
+  if (ids.empty()) return 0;
+  const int k = (int)ids.size();
+  HIPCHK(hipMemcpyAsync(sp->d_ids, ids.data(), 4 * k, hipMemcpyHostToDevice, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->d_moves, mv.data(), 4 * k, hipMemcpyHostToDevice, sp->stream));
+  SPCHK(elfgo_forward(sp->eng, sp->d_ids, sp->d_moves, k, sp->d_ok, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_ok.data(), sp->d_ok, k, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  // "Invalid move ... please try again" (:323-327): refused moves leave their game untouched
+  std::vector<int32_t> adv(G, -1);
+  int bad = 0;
+  for (int j = 0; j < k; ++j) {
+    if (sp->h_ok[j] != 1) { bad++; continue; }
+    adv[ids[j]] = mv[j];
+  }
+  if (sp->opt.persistent_tree) {
+    HIPCHK(hipMemcpyAsync(sp->d_moves, adv.data(), 4 * G, hipMemcpyHostToDevice, sp->stream));
+    SPCHK(elfmcts_advance(sp->mcts, sp->d_moves, sp->stream));
+  }
+  SPCHK(elfgo_info(sp->eng, nullptr, G, sp->d_binfo, sp->stream));
+  HIPCHK(hipMemcpyAsync(sp->h_binfo.data(), sp->d_binfo, sizeof(int32_t) * G * ELFGO_INFO_WORDS, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  for (int g = 0; g < G; ++g) {
+    if (adv[g] < 0) continue;
+    SpGame& gm = sp->games[g];
+    gm.ply = sp->h_binfo[g * ELFGO_INFO_WORDS];
+    if (sp->opt.keep_records > 0) gm.rec.moves.push_back((uint16_t)adv[g]);
+  }
+  sp->n_moves += k - bad;
+  return bad ? ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD : 0;
+}
+
+// finish_game(FR_CLEAR) + restart (game_selfplay.cc:121-149,302-307): the listed games start over from the empty board
+int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* stream) {
+  if (!sp || n < 0 || n > sp->G || (n > 0 && !games_host) || sp->search_open) return ELFGO_E_BADARG;
+  if (n == 0) return 0;
+  sp->stream = (hipStream_t)stream;
+  for (int j = 0; j < n; ++j) if (games_host[j] < 0 || games_host[j] >= sp->G) return ELFGO_E_BADARG;
+  HIPCHK(hipMemcpyAsync(sp->d_ids, games_host, 4 * n, hipMemcpyHostToDevice, sp->stream));
+  SPCHK(elfgo_evaluate(sp->eng, sp->d_ids, n, sp->opt.mcts.komi, sp->d_val, sp->stream));   // setFinalValue: evaluate(komi)
+  HIPCHK(hipMemcpyAsync(sp->h_val.data(), sp->d_val, sizeof(float) * n, hipMemcpyDeviceToHost, sp->stream));
+  SPCHK(elfgo_reset(sp->eng, sp->d_ids, n, sp->stream));
+  SPCHK(elfmcts_clear(sp->mcts, sp->d_ids, n, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  for (int j = 0; j < n; ++j) {
+    SpGame& gm = sp->games[games_host[j]];
+    sp_finish_record(sp, games_host[j], sp->h_val[j], gm.ply);
+    gm.ply = 1; gm.never_resign = false; gm.has_calculated_never_resign = false; gm.last_predicted = 0.0f;
+    gm.seq++;
+  }
+  sp->n_games += n;
+  return 0;
+}
+
+// GoGameSelfPlay::getLastScore (GoStateExt::getLastGameFinalValue): final value of the last finished game of each game slot
+int elfsp_last_score(const ElfSelfPlay* sp, float* out_host) {
+  if (!sp || !out_host) return ELFGO_E_BADARG;
+  for (int g = 0; g < sp->G; ++g) out_host[g] = sp->games[g].last_final;
   return 0;
 }
 

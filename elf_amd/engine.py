@@ -96,9 +96,21 @@ class GoEngine:
         check(self.L.elfgo_create(self.n, self.capacity, device, zz.ctypes.data, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def borrow(cls, handle, board_size, capacity, device):
+        """A non-owning view of an engine another object owns (the game boards of a SelfPlay): close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.L = _lib.lib()
+        self.n, self.capacity, self.device = int(board_size), int(capacity), device
+        self.num_action = self.n * self.n + 1
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self.L.elfgo_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.L.elfgo_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -148,6 +148,30 @@ class SelfPlay:
     def games_finished(self):
         return int(self.L.elfsp_games_finished(self._h))
 
+    # ---- interactive play (the human_actor half of GoGameSelfPlay::act, game_selfplay.cc:290-330)
+    def play(self, moves):
+        """Forward externally chosen moves between two searches: moves[g] = reference Coord, -1 = none.  Raises ElfGoError if a
+        move is refused (that game is left untouched)."""
+        mv = np.ascontiguousarray(moves, dtype=np.int32)
+        if mv.size != self.num_games:
+            raise ValueError("one entry per game")
+        check(self.L.elfsp_play(self._h, mv.ctypes.data, self._stream()))
+
+    def restart(self, games):
+        """finish_game(FR_CLEAR) + restart for the listed games"""
+        g = np.ascontiguousarray(games, dtype=np.int32)
+        check(self.L.elfsp_restart(self._h, g.ctypes.data, g.size, self._stream()))
+
+    def last_score(self):
+        out = np.zeros(self.num_games, np.float32)
+        check(self.L.elfsp_last_score(self._h, out.ctypes.data))
+        return out
+
+    def board_engine(self):
+        """GoEngine view of the game boards (slot g = game g), for showBoard / getNextPlayer / getLastMove / getScore"""
+        from .engine import GoEngine
+        return GoEngine.borrow(self.L.elfsp_engine(self._h), self.n, self.num_games, self.device)
+
     def pop_records(self):
         """Record JSON text of every finished game not yet collected (GameNotifier::OnGameEnd -> GoStateExt::dumpRecord,
         go_state_ext.h:131-148); needs keep_records > 0."""

@@ -197,6 +197,14 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
 /* out[9]: moves played, games finished, rollouts, net rows, steps, searches logged, steps per move, step in move,
  * tree nodes descended through (synchronises the device) */
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
+/* Interactive play (the human_actor half of GoGameSelfPlay::act, game_selfplay.cc:290-330, that the GTP console
+ * drives): between two searches, forward externally chosen moves (moves_host[g] = reference Coord, < 0 = none) on the game boards;
+ * the trees follow.  Refused moves leave their game untouched and make the call return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD. */
+int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream);
+/* finish_game(FR_CLEAR) + restart for the listed games (clear_board) */
+int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* stream);
+/* GoGameSelfPlay::getLastScore: final value of the last finished game of every game slot, host f32 [num_games] */
+int elfsp_last_score(const ElfSelfPlay* sp, float* out_host);
 /* Self-play records: with ElfSpOptions.keep_records > 0 every finished game leaves the Record the reference's
  * GameNotifier::OnGameEnd would send (GoStateExt::dumpRecord go_state_ext.h:131-148, Record::setJsonFields record.h:246-254),
  * as the JSON text nlohmann::json::dump() produces.  elfsp_pop_record copies the oldest pending record (NUL-terminated) into buf

@@ -1,0 +1,85 @@
+"""GPU: the GTP front-end (elf_amd/gtp.py over elfsp_play / elfsp_restart / the search loop) -- the reference console's command
+set and replies (scripts/elfgames/go/console_lib.py:207-372), board state checked against the CPU oracle."""
+import numpy as np
+import pytest
+
+from pyoracle import Port
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def elf(built):
+    import elf_amd
+    return elf_amd
+
+
+def make_actor(n, seed=0):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+
+    def actor(batch):
+        b = batch["s"].shape[0]
+        pi = torch.softmax(2.0 * torch.randn((b, n * n + 1), device="cuda", generator=g), dim=1)
+        v = torch.round(torch.tanh(torch.randn((b,), device="cuda", generator=g)) * 64) / 64
+        return dict(pi=pi, V=v)
+    return actor
+
+
+def test_gtp_session(elf):
+    from elf_amd.gtp import GtpEngine, move2xy, xy2move
+    n = 9
+    eng = GtpEngine(make_actor(n), board_size=n, mcts_rollout_per_thread=64, nodes_per_game=2048, keep_records=4)
+    port = Port(n)
+    st = port.new()
+    S = n + 2
+
+    def coord(mv):
+        x, y = move2xy(mv)
+        return 0 if x < 0 else (y + 1) * S + (x + 1)
+
+    assert eng.command("protocol_version") == "= 2\n\n"
+    assert eng.command("name") == "= DF2\n\n"
+    assert eng.command("boardsize 9") == "= \n\n"
+    assert eng.command("boardsize 19").startswith("? We only support 9x9")
+    assert eng.command("komi 7.5") == "= \n\n" and eng.command("komi 6.5").startswith("? We only support")
+    assert "genmove" in eng.command("list_commands") and eng.command("foo").startswith("?")
+    assert eng.command("clear_board") == "= \n\n"
+    assert eng.command("play b D4") == "= \n\n"
+    assert port.forward(st, coord("D4")) == 1
+    assert eng.command("play b E5").startswith("? Specified next player b is not the same as the next player W")
+    assert eng.command("play w D4") == "? illegal move\n\n"          # occupied: the game is untouched
+    assert eng.command("play w Z9") == "? illegal move\n\n"
+    r = eng.command("genmove w")
+    assert r.startswith("= ")
+    mv = r[2:].strip()
+    assert port.forward(st, coord(mv)) == 1, mv
+    assert eng.command("genmove w").startswith("? Specified next player")
+    assert eng.command("play b pass") == "= \n\n"
+    assert port.forward(st, 0) == 1
+    for _ in range(3):                       # engine and human alternate a few more moves, J-column letters included
+        r = eng.command("genmove " + eng.next_player().lower())
+        assert r.startswith("= ")
+        assert port.forward(st, coord(r[2:].strip())) == 1
+        legal = port.legal_mask(st)
+        a = int(np.nonzero(legal[: n * n])[0][-1])          # the last legal point (high x: exercises the skipped letter I)
+        mvs = xy2move(a // n, a % n)
+        assert eng.command("play %s %s" % (eng.next_player().lower(), mvs)) == "= \n\n"
+        assert port.forward(st, coord(mvs)) == 1
+    info = eng.boards.info_host(n=1)
+    assert int(info["hash"][0]) == port.hash(st) and int(info["ply"][0]) == int(port.info(st)[0])
+    sb = eng.command("showboard")
+    assert sb.startswith("= \n") and " X" in sb and " O" in sb and "Next:" in sb
+    score = port.evaluate(st, 7.5)
+    want = ("B+%.1f" % score) if score > 0 else ("W+%.1f" % -score)
+    assert eng.command("final_score") == "= %s\n\n" % want
+    assert eng.command("clear_board") == "= \n\n"
+    assert int(eng.boards.info_host(n=1)["ply"][0]) == 1
+    assert eng.command("final_score") == "= %s\n\n" % want          # getLastScore of the game just cleared
+    recs = eng.sp.pop_records()
+    assert len(recs) == 2                                            # both clear_board calls finished a game (the first one empty)
+    import json
+    j = json.loads(recs[1])
+    assert j["result"]["num_move"] == int(port.info(st)[0]) - 1 and abs(j["result"]["reward"] - score) < 1e-6
+    assert eng.command("quit") == "= \n\n" and eng.exit
+    eng.close()
