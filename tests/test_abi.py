@@ -74,3 +74,18 @@ def test_engine_refuses_to_run_without_gpu(built):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         elf_amd.GoEngine(19, 4)
+
+
+def test_header_is_plain_c_and_links_from_c(built, tmp_path):
+    """include/elf_amd.h compiles as C11 with -Wall -Werror -pedantic; a C program linked against libelf_amd.so runs the
+    host-only entry points (record format helpers) without a GPU."""
+    import subprocess
+    exe = str(tmp_path / "abi_c_check")
+    lib = os.path.join(ROOT, "elf_amd", "lib")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "native", "abi_c_check.c"), "-o", exe, "-L", lib, "-lelf_amd",
+           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "abi_c_check ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
