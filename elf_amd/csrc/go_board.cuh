@@ -107,6 +107,16 @@ __device__ __forceinline__ u64 dpp_next(u64 v) {
   u32 hi = __builtin_amdgcn_update_dpp(0u, (u32)(v >> 32), 0x101, 0xf, 0xf, true);
   return ((u64)hi << 32) | lo;
 }
+// v_writelane_b32 through the LLVM intrinsic (this clang has no __builtin_amdgcn_writelane): the compiler picks an immediate or
+// m0 lane select and handles the hazards itself.
+extern "C" __device__ int elf_llvm_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane");
+// X (lane-distributed) gets the wave-uniform 64-bit value `val` in lane k (wave-uniform): two v_writelane_b32 instead of
+// compare + two selects through VGPR copies.
+__device__ __forceinline__ void set_lane64(u64& X, int k, u64 val) {
+  const u32 lo = (u32)elf_llvm_writelane((int)(u32)val, k, (int)(u32)X);
+  const u32 hi = (u32)elf_llvm_writelane((int)(u32)(val >> 32), k, (int)(u32)(X >> 32));
+  X = ((u64)hi << 32) | lo;
+}
 __device__ __forceinline__ bool lane_bit(u64 uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
 __device__ __forceinline__ u64 wave_xor64(u64 v) {
 #pragma unroll
@@ -382,7 +392,7 @@ struct Board {
           bool isc = vv == c0 || vv == c1 || vv == c2 || vv == c3;   // c* are stones: never matches pad/border
           u64 bal = __ballot(isc) & rl64(mValid, k);
           if (bal) {
-            if (lane == k) capw = bal;
+            set_lane64(capw, k, bal);
             total_cap += __popcll(bal);
             if (lane_bit(bal)) { L->pt[idx[k]] = 0; xh ^= zob_col(zob[idx[k]], opp); }
             if (total_cap == 1 && ko_c == 0) ko_c = tr(a2i(k * 64 + (int)__builtin_ctzll(bal)));   // :1355 capture_c
@@ -458,7 +468,7 @@ struct Board {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
           u64 bal = __ballot(v[k] == newv);
-          if (lane == k) gw = bal;
+          set_lane64(gw, k, bal);
         }
         gw &= mValid;
         newlibs = popc_lanes(dilate(gw) & ~(Bw | Ww));
@@ -516,12 +526,12 @@ struct Board {
 #pragma unroll
     for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
-    for (int k = 0; k < R; ++k) lb[k] = L->libs[is_stone(v[k]) ? (v[k] & 0x7FFF) : 0];
+    for (int k = 0; k < R; ++k) lb[k] = L->libs[(((v[k] + 1u) & 0xFFFFu) > 1u) ? (v[k] & 0x7FFFu) : 0u];
     u64 At = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      const u64 bal = __ballot(is_stone(v[k]) && lb[k] == 1);
-      if (lane == k) At = bal;
+      const u64 bal = __ballot((((v[k] + 1u) & 0xFFFFu) > 1u) & (lb[k] == 1u));   // is_stone & atari, branch-free
+      set_lane64(At, k, bal);
     }
     At &= (Bw | Ww);   // drops the clamped lanes of the last round (they re-read point 0)
     u64 okw = E & dilate(E | (Own & ~At) | (Opp & At));
