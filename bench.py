@@ -239,6 +239,12 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     uni_pi = torch.full((rows_max, na), 1.0 / na, dtype=torch.float32, device=dev)
     zero_v = torch.zeros(rows_max, dtype=torch.float32, device=dev)
     rows_log = []
+    if net is not None:
+        # initialisation, not a step: the first call of each convolution shape runs MIOpen's find (tens of seconds on a fresh box).
+        # Done here so that even --warmup 0 times steady-state steps only.
+        with torch.no_grad():
+            net({"s": sp.groups[0].s})
+        torch.cuda.synchronize()
 
     def net_fn(s, rows):
         if net is not None:
@@ -272,6 +278,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     my_rows = int(sum(rows_log[warmup:]))
     sel_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_select])) / steps
     exp_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_expand])) / steps
+    net_ms = float(np.mean([a.elapsed_time(b) for a, b in sp.t_net])) if sp.t_net else 0.0   # per net call (one group)
     dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
     st = sp.stats()
     sp.close()
@@ -312,6 +319,18 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                      "mean_depth": depth},
         "selfplay_stats": st,
     }
+    if net is not None:
+        # the kernel that dominates the timed region is not this library's: PyTorch-ROCm's convolution (north_star leaves the
+        # net on PyTorch).  Reported for transparency: algorithmic flops of the 20x256 net per position / measured call time.
+        d = n * n
+        flops_pos = 2.0 * d * 9 * (18 * args.net_dim + 2 * args.net_blocks * args.net_dim * args.net_dim) \
+            + 2.0 * d * args.net_dim * 3 + 2.0 * (2 * d * (d + 1) + d * 256 + 256)
+        rows_call = Gg * K
+        ach = flops_pos * rows_call / (net_ms / 1e3) / 1e12 if net_ms > 0 else None
+        res["net_roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None,
+                               "traffic": None, "kernel": "PyTorch-ROCm net call (MIOpen CK implicit-GEMM 3x3 conv x41 + elfnet_bias_act_f16 epilogues)",
+                               "avg_call_ms": net_ms, "rows_per_call": rows_call, "flops_per_position": flops_pos,
+                               "note": "not a kernel of this library; dense fp16/bf16 MFMA peak from MI355X_MICROARCH.md"}
     res["cpu_baseline"] = cpu_baseline_mcts(n, K) if with_cpu else None
     return res
 

@@ -20,6 +20,7 @@ class PipelinedSelfPlay:
         self.num_games = sum(g.num_games for g in self.groups)
         self.timing = False
         self.t_select, self.t_expand = [], []   # (start, end) HIP event pairs on the search stream
+        self.t_net = []                         # (start, end) pairs around the net callback on the net stream
 
     def close(self):
         for g in self.groups:
@@ -48,7 +49,13 @@ class PipelinedSelfPlay:
             ev_sel.record(self.search_stream)
             with torch.cuda.stream(self.net_stream):
                 self.net_stream.wait_event(ev_sel)          # features of group i are in g.s
+                if self.timing:
+                    n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    n0.record(self.net_stream)
                 pi, v = net_fn(g.s, self._rows[i])
+                if self.timing:
+                    n1.record(self.net_stream)
+                    self.t_net.append((n0, n1))
                 ev_net = torch.cuda.Event()
                 ev_net.record(self.net_stream)
             # next group's select overlaps this group's net
