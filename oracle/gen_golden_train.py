@@ -25,6 +25,11 @@ RECORD_CASES = {
     "records_9_cutoff": (9, dict(rollouts_per_thread=64, max_searches=50, policy_distri_cutoff=6, net_salt=3, move_cutoff=24)),
     "records_9_resign": (9, dict(rollouts_per_thread=32, max_searches=120, policy_distri_cutoff=4, net_salt=5, resign_thres=0.9,
                                  move_cutoff=70)),
+    # a game to the move limit (FR_MAX_STEP at ply 162) and one ended by two passes (FR_TWO_PASSES), pass enabled from ply 6
+    "records_9_twopass": (9, dict(rollouts_per_thread=48, max_searches=340, policy_distri_cutoff=4, net_salt=13, ply_pass_enabled=6)),
+    # never_resign_prob 0.5: two games draw "never resign" and run to the cutoff, one is resigned by Black, one by White
+    "records_9_neverresign": (9, dict(rollouts_per_thread=32, max_searches=230, policy_distri_cutoff=3, net_salt=21, resign_thres=0.9,
+                                      never_resign_prob=0.5, move_cutoff=64, seed=5)),
     "records_19_cutoff": (19, dict(rollouts_per_thread=32, max_searches=64, policy_distri_cutoff=30, net_salt=9, move_cutoff=31)),
 }
 
