@@ -28,7 +28,7 @@ RECORD_CASES = {
     # a game to the move limit (FR_MAX_STEP at ply 162) and one ended by two passes (FR_TWO_PASSES), pass enabled from ply 6
     "records_9_twopass": (9, dict(rollouts_per_thread=48, max_searches=340, policy_distri_cutoff=4, net_salt=13, ply_pass_enabled=6)),
     # never_resign_prob 0.5: two games draw "never resign" and run to the cutoff, one is resigned by Black, one by White
-    "records_9_neverresign": (9, dict(rollouts_per_thread=32, max_searches=230, policy_distri_cutoff=3, net_salt=21, resign_thres=0.9,
+    "records_9_neverresign": (9, dict(rollouts_per_thread=32, max_searches=236, policy_distri_cutoff=3, net_salt=21, resign_thres=0.9,
                                       never_resign_prob=0.5, move_cutoff=64, seed=5)),
     "records_19_cutoff": (19, dict(rollouts_per_thread=32, max_searches=64, policy_distri_cutoff=30, net_salt=9, move_cutoff=31)),
 }
@@ -85,7 +85,11 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), board_size=np.int32(n),
                             cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], np.float64),
                             records=np.array(exact), searches=np.int32(len(r["search"])),
-                            move_played=np.array([s.move_played for s in r["search"]], np.int32))
+                            move_played=np.array([s.move_played for s in r["search"]], np.int32),
+                            best_action=np.array([s.best_action for s in r["search"]], np.int32),
+                            n_edges=np.array([s.n_edges for s in r["search"]], np.int32),
+                            root_value=np.array([s.root_value for s in r["search"]], np.float32),
+                            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"])
         print(name, "records", len(exact), [(j["seq"], j["result"]["num_move"], j["result"]["reward"], len(j["result"].get("policies", [])))
                                             for j in recs])
         by_size[n] += exact

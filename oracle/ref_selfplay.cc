@@ -91,8 +91,10 @@ struct Capture : public GameNotifierBase {
   std::atomic<int> count{0};
   int game_of_thread(const std::thread::id&) { return 0; }
 
+  int total_calls = 0;   // every search, recorded or not
   void OnMCTSResult(Coord c, const MCTSResult& r) override {
     std::lock_guard<std::mutex> l(m);
+    ++total_calls;
     if ((int)searches.size() >= max_searches) return;
     RefSpSearch s;
     memset(&s, 0, sizeof(s));
@@ -123,6 +125,9 @@ struct Capture : public GameNotifierBase {
   std::vector<std::string> records;   // Record JSON of every finished game, in completion order
   void OnGameEnd(const GoStateExt& s) override {
     std::lock_guard<std::mutex> l(m);
+    // searches past max_searches run while the driver is already shutting the context down (replies are FAILED batches):
+    // a game whose last search is one of those is not a valid reference game
+    if (total_calls > max_searches) return;
     json j;
     s.dumpRecord().setJsonFields(j);
     records.push_back(j.dump());

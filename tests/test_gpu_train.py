@@ -131,7 +131,8 @@ def test_selfplay_records_equal_reference_dump(elf, name):
         mcts_alpha=float(np.float32(cfg["root_alpha"])), komi=float(np.float32(cfg["komi"])),
         ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
         move_cutoff=int(cfg["move_cutoff"]), resign_thres=float(np.float32(cfg["resign_thres"])),
-        never_resign_prob=float(np.float32(cfg["never_resign_prob"])), seed=int(cfg["seed"]), keep_records=8, nodes_per_game=4096)
+        never_resign_prob=float(np.float32(cfg["never_resign_prob"])), seed=int(cfg["seed"]), keep_records=8, nodes_per_game=4096,
+        log_searches=int(g["searches"]))
     salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
     got = []
     for _ in range(200000):
@@ -145,10 +146,30 @@ def test_selfplay_records_equal_reference_dump(elf, name):
         if len(got) >= len(want):
             break
     assert len(got) >= len(want)
+    # every search of the run, across game ends and restarts: root edges in iteration order, visits, priors, rewards, move played
+    rec, coord, visits, prior, reward = sp.search_log()
+    m = min(len(rec), int(g["searches"]))
+    assert m > 20
+    for i in range(m):
+        ne = int(g["n_edges"][i])
+        ctx = "%s search %d" % (name, i)
+        assert rec[i].n_edges == ne, ctx
+        assert np.array_equal(coord[i, :ne], g["coord"][i, :ne].astype(np.int32)), ctx
+        assert np.array_equal(visits[i, :ne], g["visits"][i, :ne]), ctx
+        assert np.array_equal(prior[i, :ne].view(np.uint32), g["prior"][i, :ne].view(np.uint32)), ctx
+        assert np.array_equal(reward[i, :ne].view(np.uint32), g["reward"][i, :ne].view(np.uint32)), ctx
+        assert rec[i].move_played == int(g["move_played"][i]) and rec[i].best_action == int(g["best_action"][i]), ctx
+        assert np.float32(rec[i].root_value) == g["root_value"][i], ctx
     for t, w in zip(got, want):
         j = json.loads(t)
         assert j["timestamp"] > 0
         j["timestamp"] = w["timestamp"]
+        for k in w["result"]:
+            a, b = j["result"].get(k), w["result"][k]
+            if isinstance(b, list) and isinstance(a, list) and a != b:
+                d = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
+                raise AssertionError((name, w["seq"], k, len(a), len(b), d[:5], [(a[i], b[i]) for i in d[:3]] if k != "policies" else "..."))
+            assert a == b, (name, w["seq"], k, a, b)
         assert j == w
         assert json.dumps(j, separators=(",", ":"), sort_keys=True) == json.dumps(w, separators=(",", ":"), sort_keys=True)
         t2 = t.replace('"timestamp":%d' % json.loads(t)["timestamp"], '"timestamp":%d' % w["timestamp"])
