@@ -214,7 +214,52 @@ class GameContext:
         return _Client(self)
 
     def getGame(self, game_idx):
-        return None
+        """GoGameSelfPlay accessors the console uses (common/game_selfplay.h:41-56, inference/Pybind.cc:31-45)"""
+        self._build()
+        return _GameView(self, int(game_idx))
+
+
+class _GameView:
+    def __init__(self, gc, g):
+        self._gc, self._g = gc, g
+
+    def _boards(self):
+        return self._gc._sp.board_engine()
+
+    def _info(self):
+        return self._boards().info_host(ids=[self._g])
+
+    def getNextPlayer(self):
+        return "B" if int(self._info()["next_player"][0]) == 1 else "W"      # player2str, sgf/sgf.h:59-72
+
+    def getLastMove(self):
+        """coord2str2 (sgf/sgf.h:74-85): "PASS", "RESIGN" or letter (no I) + row"""
+        c = int(self._info()["last_move"][0])
+        if c == 0:
+            return "PASS"
+        if c == 1:
+            return "RESIGN"
+        S = self._gc.opt.board_size + 2
+        x, y = c % S - 1, c // S - 1
+        if x >= 8:
+            x += 1
+        return chr(ord("A") + x) + str(y + 1)
+
+    def getScore(self):
+        return float(self._boards().evaluate(ids=[self._g], komi=self._gc.opt.komi).cpu()[0])
+
+    def getLastScore(self):
+        return float(self._gc._sp.last_score()[self._g])
+
+    def showBoard(self):
+        n = self._gc.opt.board_size
+        col, _ = self._boards().export_board(ids=[self._g])
+        col = col.cpu().numpy()[0].reshape(n, n)
+        rows = []
+        for y in range(n - 1, -1, -1):
+            rows.append("%2d " % (y + 1) + " ".join(".XO"[int(col[x, y])] for x in range(n)))
+        rows.append("   " + " ".join(chr(ord("A") + (x + 1 if x >= 8 else x)) for x in range(n)))
+        return "\n".join(rows)
 
 
 class Batch:

@@ -91,3 +91,11 @@ def test_reference_style_loop_reproduces_fixture(built):
         assert np.array_equal(visits[i, :ne], g["visits"][i, :ne])
         assert rec[i].move_played == int(g["move_played"][i])
     assert max(calls) <= 16
+    # GoGameSelfPlay accessors the console uses (inference/Pybind.cc:31-45)
+    game = GC.getGame(0)
+    assert game.getNextPlayer() in ("B", "W") and game.getNextPlayer() == ("B" if m % 2 == 0 else "W")
+    last = int(g["move_played"][m - 1])
+    x, y = last % 21 - 1, last // 21 - 1
+    assert game.getLastMove() == chr(ord("A") + (x + 1 if x >= 8 else x)) + str(y + 1)
+    sb = game.showBoard()
+    assert sb.count("X") + sb.count("O") >= m - 2 and isinstance(game.getScore(), float) and game.getLastScore() == 0.0
