@@ -73,3 +73,19 @@ def test_search_matches_reference(elf, name):
 def test_config3_8192_rollouts(elf):
     """BASELINE config 3 search settings: bs 16, 8192 rollouts/move, puct 1.5, vloss 1, eps 0.25 / alpha 0.03."""
     run_case(elf, "mcts_19_r8192")
+
+
+def test_exhausted_node_pool_is_a_status_code(elf):
+    """A tree that outgrows nodes_per_game surfaces as ELFGO_E_MCTS_BASE - ELFMCTS_E_POOL (an exception in Python), not as
+    corrupted statistics or a hang."""
+    import torch
+    sp = elf.SelfPlay(board_size=9, num_games=2, mcts_rollout_per_thread=512, mcts_rollout_per_batch=16, nodes_per_game=64, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    with pytest.raises(elf.ElfGoError) as e:
+        for _ in range(64):
+            rows = sp.begin_step()
+            pi = torch.softmax(torch.randn((sp.max_rows, 82), device="cuda", generator=g), dim=1)
+            v = torch.zeros(sp.max_rows, device="cuda")
+            sp.end_step(pi, v)
+    assert "-101" in str(e.value)
+    sp.close()

@@ -175,3 +175,58 @@ def test_selfplay_records_equal_reference_dump(elf, name):
         t2 = t.replace('"timestamp":%d' % json.loads(t)["timestamp"], '"timestamp":%d' % w["timestamp"])
         assert t2 == str(g["records"][got.index(t)])   # text-identical to the reference's json::dump()
     sp.close()
+
+
+def test_selfplay_soak_records_replay_on_the_oracle(elf):
+    """Many concurrent games through hundreds of game ends and restarts (move limit, two passes, resignation) with a random
+    net: every record the engine emits must replay move by move on the CPU oracle (each move legal, same ply), non-resigned
+    games must carry the oracle's Tromp-Taylor result, and the node pools must not leak across restarts."""
+    import ctypes as C
+    import torch
+    n, G = 9, 96
+    sp = elf.SelfPlay(board_size=n, num_games=G, mcts_rollout_per_thread=32, mcts_rollout_per_batch=16, mcts_puct=1.5,
+                      mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=20,
+                      policy_distri_cutoff=8, resign_thres=0.35, never_resign_prob=0.2, seed=4321, nodes_per_game=1024,
+                      keep_records=100000)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    recs = []
+    for step in range(6000):
+        rows = sp.begin_step()
+        pi = torch.softmax(3.0 * torch.randn((sp.max_rows, n * n + 1), device="cuda", generator=gen), dim=1)
+        v = torch.tanh(0.8 * torch.randn((sp.max_rows,), device="cuda", generator=gen))
+        sp.end_step(pi, v)
+        if step % 64 == 0:
+            recs += sp.pop_records()
+            if len(recs) >= 400:
+                break
+    recs += sp.pop_records()
+    st = sp.stats()
+    assert len(recs) >= 400 and st["games"] == len(recs)
+    port = Port(n)
+    ends = {"resign": 0, "limit": 0, "twopass": 0}
+    for t in recs:
+        j = json.loads(t)
+        res = j["result"]
+        mv = sgfstr2coords(n, res["content"])
+        assert len(mv) == res["num_move"] and len(res["values"]) in (len(mv), len(mv) + 1)
+        s = port.new()
+        for c in mv:
+            assert port.forward(s, int(c)) == 1
+        if len(res["values"]) == len(mv) + 1:          # the last search ended in a resignation: no move, reward +-1
+            assert res["reward"] in (1.0, -1.0) and len(mv) + 1 >= 50
+            assert res["reward"] == (1.0 if len(mv) % 2 == 1 else -1.0)     # the side to move resigned
+            ends["resign"] += 1
+        else:
+            assert port.terminated(s) and res["reward"] == port.evaluate(s, 7.5)
+            ends["twopass" if (len(mv) >= 2 and mv[-1] == 0 and mv[-2] == 0) else "limit"] += 1
+        assert len(res.get("policies", [])) == min(8, len(res["values"]))
+        port.free(s)
+    assert ends["resign"] > 0 and ends["limit"] + ends["twopass"] > 0, ends
+    # node pools: after the last move every game holds at most the kept subtree; nothing leaked over ~400 restarts
+    L = elf.lib()
+    info = torch.zeros((G, 8), dtype=torch.int32, device="cuda")
+    assert L.elfmcts_root(L.elfsp_mcts(sp._h), C.c_void_p(info.data_ptr()), None, None, None, None, None, None) == 0
+    torch.cuda.synchronize()
+    free = info[:, 7].cpu().numpy()
+    assert (free >= 1024 - 32 * 4 - 64).all(), free.min()
+    sp.close()
