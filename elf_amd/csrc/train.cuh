@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64) void k_replay_extract(PoolT pool, ReplayStore s
   __shared__ Slot<N> lds;
   __shared__ u64 tpl[18][G::R];
   const int i = blockIdx.x, lane = threadIdx.x;
-  const int r = rfl(rec[i]);
+  int r = rfl(rec[i]);
+  r = r < 0 ? 0 : (r >= st.capacity ? st.capacity - 1 : r);   // an out-of-range record id must not read outside the store
   const int d4 = rfl(d4s ? d4s[i] : 0) & 7;
   const int nm = rfl(st.num_moves[r]);
   int mt = rfl(move_to[i]);
