@@ -377,3 +377,28 @@ class GCWrapper:
         while self._games_seen < done:
             self._cb["game_end"](Batch(_GC=self.GC), *args, **kwargs)
             self._games_seen += 1
+
+
+def install_reference_module_names():
+    """Register this module under the names the reference's Python imports for its pybind11 extensions, so that
+    `import _elfgames_go_inference as go` / `import _elfgames_go as go` (src_py/elfgames/go/game_inference.py:15, game.py:15:
+    go.ContextOptions(), go.GameOptions(), go.GameContext(co, opt)) and `from _elf import *` (src_py/elf/__init__.py:8: TSOptions,
+    SearchAlgoOptions) resolve to the device-resident engine.  Idempotent; never overwrites a real extension module."""
+    import sys
+    import types
+    me = sys.modules[__name__]
+    names = {"_elf": ("TSOptions", "SearchAlgoOptions", "ContextOptions"),
+             "_elfgames_go_inference": ("ContextOptions", "GameOptions", "GameContext", "TSOptions", "SearchAlgoOptions"),
+             "_elfgames_go": ("ContextOptions", "GameOptions", "GameContext", "TSOptions", "SearchAlgoOptions", "GameStats")}
+    installed = []
+    for mod, attrs in names.items():
+        if mod in sys.modules and not getattr(sys.modules[mod], "__elf_amd_shim__", False):
+            continue
+        m = types.ModuleType(mod, "elf_amd.compat shim for the reference's pybind11 module " + mod)
+        m.__elf_amd_shim__ = True
+        for a in attrs:
+            setattr(m, a, getattr(me, a))
+        m.__all__ = list(attrs)
+        sys.modules[mod] = m
+        installed.append(mod)
+    return installed

@@ -48,6 +48,21 @@ def test_error_behaviour_matches_the_reference():
         b["zzz"]
 
 
+def test_reference_module_names_resolve(built):
+    """the import lines of src_py/elfgames/go/game_inference.py:15 and src_py/elf/__init__.py:8 work against the shim"""
+    from elf_amd import compat
+    compat.install_reference_module_names()
+    import _elfgames_go_inference as go
+    import _elfgames_go as go2
+    from _elf import TSOptions, SearchAlgoOptions   # noqa: F401
+    co, opt = go.ContextOptions(), go.GameOptions()
+    co.mcts_options.alg_opt.c_puct = 1.5
+    assert isinstance(co.mcts_options, TSOptions) and go2.GameContext is go.GameContext
+    GC = go.GameContext(co, opt)
+    assert GC.getParams()["num_action"] == 362 and GC.getParams()["ACTION_PASS"] == -99
+    assert compat.install_reference_module_names() is not None   # idempotent
+
+
 @pytest.mark.gpu
 def test_reference_style_loop_reproduces_fixture(built):
     import torch
