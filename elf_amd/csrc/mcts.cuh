@@ -441,17 +441,29 @@ struct ExpandLds {
   static constexpr int NA = N * N + 1;
   static constexpr int NE = NodeRec<N>::NE;
   static constexpr int PP = Geo<N>::PP;
-  Slot<N> board;
-  float prob[NE];     // candidate priors (insertion order once sorted)
-  u16 key[NE];        // candidate coords
-  float sprob[NE];    // sorted
+  // Three consecutive lifetimes share one region, which is what sets the kernel's occupancy (6.1 KB instead of 11.4 KB per
+  // wave at 19x19: 26 instead of 14 resident waves per CU):
+  //   1. board      -- until legal_moves has produced the legal bitboard (registers -> legalw)
+  //   2. prob, key  -- the net's priors and coords in ACTION order: inputs of the register sort and of the exact std::sort replay
+  //   3. seq..sx    -- scratch of umap_order_wave, after the sorted candidates sit in sprob/skey
+  union {
+    Slot<N> board;
+    struct {
+      float prob[NE];   // candidate priors in action order
+      u16 key[NE];      // candidate coords in action order
+    };
+    struct {
+      u16 seq[NE];      // epoch insertion sequence (indices into skey)
+      u16 nseq[NE];
+      u16 tkey[PP];     // time of key in the current epoch, 0xFFFF = absent
+      u16 sx[NE];       // exclusive prefix of group sizes at group-first times
+    };
+  };
+  float sprob[NE];      // sorted (insertion order of the reference's map)
   u16 skey[NE];
-  u16 seq[NE];        // epoch insertion sequence (indices into skey)
-  u16 nseq[NE];
-  u16 tkey[PP];       // time of key in the current epoch, 0xFFFF = absent
-  u16 sx[NE];         // exclusive prefix of group sizes at group-first times
-  u64 legalw[8];      // legal-move bitboard words (D4-0 action order)
+  u64 legalw[8];        // legal-move bitboard words (D4-0 action order)
 };
+static_assert(sizeof(ExpandLds<19>) <= 6400, "expand LDS per wave");
 
 // iteration order of the reference's unordered_map after inserting skey[0..n) (see stl_emul.h); result in L.seq
 template <int N>
