@@ -451,6 +451,7 @@ struct ExpandLds {
     struct {
       float prob[NE];   // candidate priors in action order
       u16 key[NE];      // candidate coords in action order
+      int sort_stack[3 * stl_emul::kSortStack];   // explicit introsort stack of the exact std::sort replay (ties only)
     };
     struct {
       u16 seq[NE];      // epoch insertion sequence (indices into skey)
@@ -493,6 +494,8 @@ __device__ __forceinline__ void umap_order_wave(ExpandLds<N>& L, int n, int lane
       int carry = 0;
 #pragma unroll
       for (int k = 0; k < RR; ++k) {
+        ftv[k] = 0xFFFF; rkv[k] = 0;
+        if (k * 64 >= m) continue;   // wave-uniform: the early epochs hold at most 13 / 29 / 59 elements, one round of 64
         const int t = k * 64 + lane;
         int ft = 0xFFFF, cnt = 0, rk = 0;
         if (t < m) {
@@ -527,6 +530,15 @@ __device__ __forceinline__ void umap_order_wave(ExpandLds<N>& L, int n, int lane
   }
 }
 
+// phase markers for cycle attribution (make FLAGS+=-DELF_PROFILE_EXPAND on the GPU box; compiled out of the library)
+#ifdef ELF_PROFILE_EXPAND
+__device__ unsigned long long g_expand_phase[65536][8];   // per block id: no atomics, summed on the host
+__device__ unsigned long long g_expand_rowmax[65536];     // per block id: longest row (ticks) over all launches
+#define EXP_PHASE(k) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); ph_acc[k] += _t - ph_t; ph_t = _t; } while (0)
+#else
+#define EXP_PHASE(k)
+#endif
+
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* zob, const RowRec* rowmap, const float* __restrict__ pi,
                                                      int64_t pi_stride, const float* __restrict__ value, int n_rows, TreeCfg cfg) {
@@ -538,9 +550,13 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
   if (row >= n_rows) return;
   const int g = rowmap[row].game, node = rowmap[row].node, d4 = rowmap[row].d4;
   NR& nd = tp.game_nodes(g)[node];
+#ifdef ELF_PROFILE_EXPAND
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#endif
   Board<N> bd;
   bd.init(&L.board, zob, nullptr, nullptr);
   bd.load(&nd.board);
+  EXP_PHASE(0);   // row map + board load
   // ---- post_nn_result :209-230
   bool pass_enabled = bd.ply >= cfg.ply_pass_enabled;
   if (cfg.remove_pass_if_dangerous && pass_enabled && bd.lm0 != M_PASS) {   // :232-242
@@ -552,6 +568,7 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
   // ---- pi2response :256-332.  The reference sorts all N*N+1 (coord, prior) pairs by prior (descending) and then keeps
   // the valid ones in that order.  If no two VALID candidates share a prior the result is the unique descending order
   // of the valid ones: a register bitonic sort of 512 slots (8 per lane), invalid candidates keyed last.
+  EXP_PHASE(1);   // pass rule (Tromp-Taylor when enabled) + legal mask
   const float* prow = pi + (size_t)row * pi_stride;
   if (lane < G::R) L.legalw[lane] = legal;
   Board<N>::wsync();
@@ -579,6 +596,7 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
     const u32 ukey = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
     sx[k] = valid ? (((u64)(~ukey) << 32) | (u32)coord) : ~0ull;
   }
+  EXP_PHASE(2);   // reply read, action->coord, validity, sort keys
   int n = 0;   // number of edges
   bool tie = false;
   float sp[R];
@@ -618,6 +636,7 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
         }
       }
     }
+    EXP_PHASE(3);   // register bitonic sort of 512 slots
     // sorted element e = k*64 + lane (e < n <= N*N+1 <= 6*64): prior back from the key, coord from the payload
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
       // equal priors among valid candidates: the order is whatever libstdc++'s unstable std::sort makes of ALL pairs
       // (go/mcts/mcts.h:292-297): replay it exactly, then filter
       if (lane == 0) {
-        stl_emul::sort_desc<u16>(L.key, L.prob, NA);
+        stl_emul::sort_desc<u16>(L.key, L.prob, NA, L.sort_stack);
         int w = 0;
         for (int i = 0; i < NA; ++i) {
           const int coord = L.key[i];
@@ -654,13 +673,26 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
 #pragma unroll
       for (int k = 0; k < R; ++k) { const int e = k * 64 + lane; sp[k] = e < n ? L.sprob[e] : 0.0f; }
     }
-    // normalize :244-254: total = 1e-10 + sequential fp32 sum in sorted order (readlane chain, no LDS round trips)
+    EXP_PHASE(4);   // sorted rows to LDS, tie test (+ exact std::sort replay on ties)
+    // normalize :244-254: total = 1e-10 + sequential fp32 sum in sorted order.  The chain of n dependent adds is the cost; every
+    // lane runs it redundantly on broadcast 16-B LDS reads of the sorted priors (issued ahead of the adds), which beats a
+    // readlane per element.  The tail is padded with +0.0f: x + 0.0f == x for the positive running total, so summing to the
+    // next multiple of 16 is the same sequence of roundings.
+    for (int e = n + lane; e < ExpandLds<N>::NE; e += 64) L.sprob[e] = 0.0f;
+    Board<N>::wsync();
     float total = 1e-10f;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const int cnt = n - k * 64 < 64 ? n - k * 64 : 64;
-      for (int l = 0; l < cnt; ++l) total = __fadd_rn(total, rlf(sp[k], l));
+    {
+      const float4* s4 = reinterpret_cast<const float4*>(L.sprob);
+      const int n16 = (n + 15) >> 4;
+      for (int c = 0; c < n16; ++c) {
+        const float4 q0 = s4[4 * c], q1 = s4[4 * c + 1], q2 = s4[4 * c + 2], q3 = s4[4 * c + 3];
+        total = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(total, q0.x), q0.y), q0.z), q0.w);
+        total = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(total, q1.x), q1.y), q1.z), q1.w);
+        total = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(total, q2.x), q2.y), q2.z), q2.w);
+        total = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(total, q3.x), q3.y), q3.z), q3.w);
+      }
     }
+    Board<N>::wsync();
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const int e = k * 64 + lane;
@@ -668,8 +700,10 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
     }
   }
   Board<N>::wsync();
+  EXP_PHASE(5);   // sequential fp32 normalisation
   // ---- setEvaluation :176-203: insert in this order; store edges in the map's ITERATION order
   umap_order_wave<N>(L, n, lane);
+  EXP_PHASE(6);   // unordered_map iteration order
   for (int jn = lane; jn < n; jn += 64) {
     const int src = L.seq[jn];
     nd.stat[jn] = make_float4(L.sprob[src], 0.0f, __int_as_float(0), 0.0f);
@@ -682,6 +716,11 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
     nd.h.flip = bd.next_player == S_WHITE;                // pre_evaluate :186
     nd.h.status = NS_VISITED;
   }
+  EXP_PHASE(7);   // edge records to HBM
+#ifdef ELF_PROFILE_EXPAND
+  if (lane == 0) { unsigned long long t = 0; for (int k = 0; k < 8; ++k) t += ph_acc[k]; if (t > g_expand_rowmax[blockIdx.x & 65535]) g_expand_rowmax[blockIdx.x & 65535] = t; }
+  if (lane < 8) g_expand_phase[blockIdx.x & 65535][lane] += lane == 0 ? ph_acc[0] : lane == 1 ? ph_acc[1] : lane == 2 ? ph_acc[2] : lane == 3 ? ph_acc[3] : lane == 4 ? ph_acc[4] : lane == 5 ? ph_acc[5] : lane == 6 ? ph_acc[6] : ph_acc[7];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -202,6 +202,23 @@ int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const 
   return 0;
 }
 
+#ifdef ELF_PROFILE_EXPAND
+// profile builds only: accumulated s_memtime ticks per k_mcts_expand phase (see EXP_PHASE in mcts.cuh)
+extern "C" int elfprof_expand_phases(unsigned long long* out8) {
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<unsigned long long> all((size_t)65536 * 8);
+  HIPCHK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(elfgo::g_expand_phase), all.size() * sizeof(unsigned long long)));
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (size_t i = 0; i < all.size(); ++i) out8[i & 7] += all[i];
+  return 0;
+}
+extern "C" int elfprof_expand_rowmax(unsigned long long* out65536) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out65536, HIP_SYMBOL(elfgo::g_expand_rowmax), 65536 * sizeof(unsigned long long)));
+  return 0;
+}
+#endif
+
 int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, float* prior, float* reward, int32_t* child, void* stream) {
   if (!m || !info) return ELFGO_E_BADARG;
   static_assert(sizeof(RootInfo) == ELFMCTS_ROOT_WORDS * 4, "RootInfo layout");

@@ -173,14 +173,18 @@ STL_HD int partition_pivot(PairRef<K> p, int first, int last) {   // __unguarded
 }
 
 // std::sort(v.begin(), v.end(), [](a, b){ return a.second > b.second; }) on n <= 1024 pairs
+// `stk` = 3 * kSortStack ints of scratch for the explicit introsort stack.  The device passes LDS: a private array would give the
+// whole kernel a scratch segment (and with it a fraction of the occupancy) for a path that runs on prior ties only.
+constexpr int kSortStack = 64;
 template <typename K>
-STL_HD void sort_desc(K* keys, float* vals, int n) {
+STL_HD void sort_desc(K* keys, float* vals, int n, int* stk) {
   if (n <= 0) return;
   PairRef<K> p{keys, vals};
   int lg = 0;
   for (int t = n; t > 1; t >>= 1) ++lg;
   // __introsort_loop with an explicit stack (recursion on the right part, loop on the left)
-  int stk_first[64], stk_last[64], stk_depth[64], sp = 0;
+  int* stk_first = stk; int* stk_last = stk + kSortStack; int* stk_depth = stk + 2 * kSortStack;
+  int sp = 0;
   stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
   while (sp > 0) {
     --sp;
@@ -202,5 +206,13 @@ STL_HD void sort_desc(K* keys, float* vals, int n) {
     insertion_sort(p, 0, n);
   }
 }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+template <typename K>
+static inline void sort_desc(K* keys, float* vals, int n) {   // host convenience (tests)
+  int stk[3 * kSortStack];
+  sort_desc<K>(keys, vals, n, stk);
+}
+#endif
 
 }  // namespace stl_emul
