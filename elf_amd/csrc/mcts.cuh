@@ -530,6 +530,122 @@ __device__ __forceinline__ void umap_order_wave(ExpandLds<N>& L, int n, int lane
   }
 }
 
+// ascending bitonic sort of 512 u64 slots held 8 per lane (slot e = k*64 + lane)
+__device__ __forceinline__ void bitonic_sort512(u64 (&sx)[8], int lane) {
+  constexpr int SK = 8;
+#pragma unroll
+  for (int size = 2; size <= 64 * SK; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= 64) {
+#pragma unroll
+        for (int k = 0; k < SK; ++k) {
+          const int kp = k ^ (stride >> 6);
+          if (kp > k) {
+            const bool up = ((k * 64) & size) == 0;
+            const u64 a = sx[k], b = sx[kp];
+            const bool sw = up ? (a > b) : (a < b);
+            sx[k] = sw ? b : a;
+            sx[kp] = sw ? a : b;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < SK; ++k) {
+          const u64 y = __shfl_xor(sx[k], stride, 64);
+          const bool up = (((k * 64 + lane) & size) == 0);
+          const bool keep_min = (((lane & stride) == 0) == up);
+          const bool less = sx[k] < y;
+          sx[k] = (keep_min == less) ? sx[k] : y;
+        }
+      }
+    }
+  }
+}
+
+// monotone float -> u32 key (ascending with the value) and back
+__device__ __forceinline__ u32 f2ukey(float p) { const u32 b = __float_as_uint(p); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ukey2f(u32 k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// The introsort loop of std::sort(pairs, a.second > b.second) over L.key / L.prob [0, n), wave-parallel and exact: the
+// pairing formulation of stl_emul.h (sort_desc_pairing, checked against libstdc++ on the host).  One partition = flags + ranks by
+// ballots over the <= 6 rounds that overlap the range, positions through LDS scratch (the sprob area, not yet in use), parallel
+// swaps.  Leaves the array as __introsort_loop does; the caller finishes with a stable sort (= __final_insertion_sort).
+template <int N>
+__device__ void introsort_loop_wave(ExpandLds<N>& L, int n, int lane) {
+  constexpr int NE = ExpandLds<N>::NE, RR = (NE + 63) / 64, KS = stl_emul::kSortStack;
+  u16* upos = reinterpret_cast<u16*>(L.sprob);
+  u16* dpos = upos + NE;
+  stl_emul::PairRef<u16> p{L.key, L.prob};
+  int* stk = L.sort_stack;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  if (lane == 0) { stk[0] = 0; stk[KS] = n; stk[2 * KS] = 2 * lg; }
+  int sp = 1;
+  Board<N>::wsync();
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  while (sp > 0) {
+    --sp;
+    int first = rfl(stk[sp]), last = rfl(stk[KS + sp]), depth = rfl(stk[2 * KS + sp]);
+    while (last - first > 16) {
+      if (depth == 0) {                         // __partial_sort fallback: rare, serial
+        if (lane == 0) stl_emul::heap_sort(p, first, last);
+        Board<N>::wsync();
+        break;
+      }
+      --depth;
+      if (lane == 0) stl_emul::median_to_first(p, first, last);
+      Board<N>::wsync();
+      const float P = L.prob[first];
+      int nu = 0, nd = 0;
+      u64 md[RR];
+#pragma unroll
+      for (int k = 0; k < RR; ++k) {
+        md[k] = 0;
+        if (k * 64 >= last || k * 64 + 63 <= first) continue;        // round outside (first, last): wave-uniform
+        const int e = k * 64 + lane;
+        const bool in = e > first && e < last;
+        const float v = L.prob[in ? e : first];
+        const bool u = in && v <= P, d = in && v >= P;
+        const u64 mu = __ballot(u);
+        md[k] = __ballot(d);
+        if (u) upos[nu + __popcll(mu & lt_mask)] = (u16)e;
+        nu += __popcll(mu);
+      }
+#pragma unroll
+      for (int k = RR - 1; k >= 0; --k) {
+        if (md[k] == 0) continue;
+        const int e = k * 64 + lane;
+        if ((md[k] >> lane) & 1) dpos[nd + __popcll(md[k] & ~lt_mask & ~(1ull << lane))] = (u16)e;
+        nd += __popcll(md[k]);
+      }
+      Board<N>::wsync();
+      const int mn = nu < nd ? nu : nd;
+      int T = 0;                                 // upos ascending, dpos descending: upos[t] < dpos[t] holds exactly for t < T
+      for (int base = 0; base < mn; base += 64) {
+        const int t = base + lane;
+        const bool ok = t < mn && upos[t] < dpos[t];
+        T += __popcll(__ballot(ok));
+      }
+      for (int t = lane; t < T; t += 64) {
+        const int a = upos[t], b = dpos[t];
+        const float va = L.prob[a], vb = L.prob[b];
+        const u16 ka = L.key[a], kb = L.key[b];
+        L.prob[a] = vb; L.prob[b] = va;
+        L.key[a] = kb; L.key[b] = ka;
+      }
+      Board<N>::wsync();
+      const int hi_prev = T > 0 ? rfl((int)dpos[T - 1]) : last;
+      const int ut = T < nu ? rfl((int)upos[T]) : 0x7FFFFFFF;
+      const int cut = ut < hi_prev ? ut : hi_prev;
+      if (lane == 0) { stk[sp] = first; stk[KS + sp] = cut; stk[2 * KS + sp] = depth; }
+      ++sp;
+      first = cut;
+      Board<N>::wsync();
+    }
+  }
+}
+
 // phase markers for cycle attribution (make FLAGS+=-DELF_PROFILE_EXPAND on the GPU box; compiled out of the library)
 #ifdef ELF_PROFILE_EXPAND
 __device__ unsigned long long g_expand_phase[65536][8];   // per block id: no atomics, summed on the host
@@ -608,34 +724,7 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
     n = 1;
   } else {
     n = nvalid;
-#pragma unroll
-    for (int size = 2; size <= 64 * SK; size <<= 1) {
-#pragma unroll
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        if (stride >= 64) {
-#pragma unroll
-          for (int k = 0; k < SK; ++k) {
-            const int kp = k ^ (stride >> 6);
-            if (kp > k) {
-              const bool up = ((k * 64) & size) == 0;
-              const u64 a = sx[k], b = sx[kp];
-              const bool sw = up ? (a > b) : (a < b);
-              sx[k] = sw ? b : a;
-              sx[kp] = sw ? a : b;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < SK; ++k) {
-            const u64 y = __shfl_xor(sx[k], stride, 64);
-            const bool up = (((k * 64 + lane) & size) == 0);
-            const bool keep_min = (((lane & stride) == 0) == up);
-            const bool less = sx[k] < y;
-            sx[k] = (keep_min == less) ? sx[k] : y;
-          }
-        }
-      }
-    }
+    bitonic_sort512(sx, lane);
     EXP_PHASE(3);   // register bitonic sort of 512 slots
     // sorted element e = k*64 + lane (e < n <= N*N+1 <= 6*64): prior back from the key, coord from the payload
 #pragma unroll
@@ -653,21 +742,37 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
       if (e + 1 < n) tie |= (sp[k] == L.sprob[e + 1]);
     }
     if (__any(tie)) {
-      // equal priors among valid candidates: the order is whatever libstdc++'s unstable std::sort makes of ALL pairs
-      // (go/mcts/mcts.h:292-297): replay it exactly, then filter
-      if (lane == 0) {
-        stl_emul::sort_desc<u16>(L.key, L.prob, NA, L.sort_stack);
-        int w = 0;
-        for (int i = 0; i < NA; ++i) {
-          const int coord = L.key[i];
-          bool valid;
+      // equal priors among valid candidates: the order is whatever libstdc++'s unstable std::sort makes of ALL N*N+1 pairs
+      // (go/mcts/mcts.h:292-297).  Replayed exactly and wave-parallel: the introsort loop on the action-order arrays in LDS, then
+      // __final_insertion_sort as what it is, a stable sort by (prior desc, position asc) on the bitonic network, then the filter.
+      introsort_loop_wave<N>(L, NA, lane);
+#pragma unroll
+      for (int k = 0; k < SK; ++k) {
+        const int i = k * 64 + lane;
+        sx[k] = i < NA ? (((u64)(~f2ukey(L.prob[i])) << 32) | ((u32)i << 16) | (u32)L.key[i]) : ~0ull;
+      }
+      Board<N>::wsync();
+      bitonic_sort512(sx, lane);
+      int w = 0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int e = k * 64 + lane;
+        const int coord = (int)(sx[k] & 0xFFFFu);
+        bool valid = false;
+        if (e < NA) {
           if (coord == M_PASS) valid = pass_enabled;
           else {
             const int x = coord % G::S - 1, y = coord / G::S - 1, a0 = x * N + y;
             valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;
           }
-          if (valid) { L.sprob[w] = L.prob[i]; L.skey[w] = (u16)coord; ++w; }
         }
+        const u64 mv = __ballot(valid);
+        if (valid) {
+          const int dst = w + __popcll(mv & ((1ull << lane) - 1ull));
+          L.sprob[dst] = ukey2f(~(u32)(sx[k] >> 32));
+          L.skey[dst] = (u16)coord;
+        }
+        w += __popcll(mv);
       }
       Board<N>::wsync();
 #pragma unroll

@@ -19,6 +19,9 @@
 // Host and device (gfx950) compile the same code; the device uses the serial forms only on rare paths.
 #pragma once
 #include <stdint.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <vector>
+#endif
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define STL_HD __host__ __device__ __forceinline__
@@ -207,7 +210,76 @@ STL_HD void sort_desc(K* keys, float* vals, int n, int* stk) {
   }
 }
 
+// ---- the same std::sort in a form that maps onto a wavefront ------------------------------------------------------------------
+// (a) __unguarded_partition is a pairing problem.  With pivot P = v[first] let U = positions in (first, last) holding v <= P in
+//     ASCENDING order (where the up-scan `while (v[lo] > P) ++lo` can stop) and D = positions holding v >= P in DESCENDING order
+//     (where the down-scan `while (P > v[hi]) --hi` can stop).  The loop swaps (U[t], D[t]) for t = 0, 1, ... while U[t] < D[t];
+//     with T swaps done it returns U[T] if that still lies below D[T-1] (or below `last` when T = 0), else D[T-1], the position
+//     that received the last swapped-in value <= P.  Flags, ranks and swaps are all data-parallel.
+// (b) __final_insertion_sort only ever moves an element left past strictly smaller ones: its result is the STABLE descending sort
+//     of whatever the introsort loop left behind, i.e. a sort by (value desc, position asc) -- a bitonic network on the device.
+// sort_desc_pairing is this formulation run serially; tests/native/stl_emul_check.cc checks it against std::sort, and the expand
+// kernel (mcts.cuh, sort_desc_wave) follows it step for step.
+template <typename K>
+STL_HD void median_to_first(PairRef<K> p, int first, int last) {   // __move_median_to_first(first, first+1, mid, last-1)
+  const int mid = first + (last - first) / 2;
+  const int a = first + 1, b = mid, c = last - 1;
+  if (p.v[a] > p.v[b]) {
+    if (p.v[b] > p.v[c]) pr_swap(p, first, b);
+    else if (p.v[a] > p.v[c]) pr_swap(p, first, c);
+    else pr_swap(p, first, a);
+  } else if (p.v[a] > p.v[c]) pr_swap(p, first, a);
+  else if (p.v[b] > p.v[c]) pr_swap(p, first, c);
+  else pr_swap(p, first, b);
+}
+
 #if !defined(__HIP_DEVICE_COMPILE__)
+template <typename K>
+static inline int partition_pairing(PairRef<K> p, int first, int last, int* upos, int* dpos) {
+  median_to_first(p, first, last);
+  const float P = p.v[first];
+  int nu = 0, nd = 0;
+  for (int i = first + 1; i < last; ++i) if (p.v[i] <= P) upos[nu++] = i;
+  for (int i = last - 1; i > first; --i) if (p.v[i] >= P) dpos[nd++] = i;
+  int T = 0;
+  while (T < nu && T < nd && upos[T] < dpos[T]) ++T;
+  for (int t = 0; t < T; ++t) pr_swap(p, upos[t], dpos[t]);
+  const int hi_prev = T > 0 ? dpos[T - 1] : last;
+  return (T < nu && upos[T] < hi_prev) ? upos[T] : hi_prev;
+}
+
+template <typename K>
+static inline void sort_desc_pairing(K* keys, float* vals, int n) {
+  if (n <= 0) return;
+  PairRef<K> p{keys, vals};
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  std::vector<int> upos(n + 1), dpos(n + 1);
+  int stk_first[kSortStack], stk_last[kSortStack], stk_depth[kSortStack], sp = 0;
+  stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    while (last - first > 16) {
+      if (depth == 0) { heap_sort(p, first, last); break; }
+      --depth;
+      const int cut = partition_pairing(p, first, last, upos.data(), dpos.data());
+      stk_first[sp] = first; stk_last[sp] = cut; stk_depth[sp] = depth; ++sp;
+      first = cut;
+    }
+  }
+  // stable descending sort = __final_insertion_sort
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  std::vector<K> k2(keys, keys + n);
+  std::vector<float> v2(vals, vals + n);
+  for (int i = 0; i < n; ++i) {
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (v2[j] > v2[i]) || (v2[j] == v2[i] && j < i);
+    keys[r] = k2[i]; vals[r] = v2[i];
+  }
+}
+
 template <typename K>
 static inline void sort_desc(K* keys, float* vals, int n) {   // host convenience (tests)
   int stk[3 * kSortStack];

@@ -40,6 +40,13 @@ static int check_sort(std::vector<float> vals) {
   stl_emul::sort_desc(k.data(), v.data(), n);
   for (int i = 0; i < n; ++i)
     if (ref[i].first != k[i] || ref[i].second != v[i]) return 1;
+  // the wavefront formulation (pairing partition + stable final sort) must give the same permutation
+  std::vector<Coord> k2(n);
+  std::vector<float> v2(n);
+  for (int i = 0; i < n; ++i) { k2[i] = (Coord)i; v2[i] = vals[i]; }
+  stl_emul::sort_desc_pairing(k2.data(), v2.data(), n);
+  for (int i = 0; i < n; ++i)
+    if (ref[i].first != k2[i] || ref[i].second != v2[i]) return 1;
   return 0;
 }
 
@@ -75,6 +82,13 @@ int main() {
       if (i % 2 == 1) { v[i - 1] = (float)-i; v[i] = (float)-(k + i); }
       v[k + i - 1] = (float)-(2 * i);
     }
+    sbad += check_sort(v); ++scases;
+  }
+  for (int rep = 0; rep < 4000; ++rep) {   // the expand kernel's shape: 362 / 82 priors, few distinct values
+    const int n = (rep & 1) ? 362 : 82;
+    const int levels = 1 + (int)(rng() % (rep % 5 == 0 ? 400u : 12u));
+    std::vector<float> v(n);
+    for (auto& x : v) x = (float)(rng() % (unsigned)levels) / 7.0f;
     sbad += check_sort(v); ++scases;
   }
   printf("sort cases %d bad %d\n", scases, sbad);
