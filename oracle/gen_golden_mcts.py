@@ -28,6 +28,14 @@ CASES = {
     "mcts_19_r128_fresh": (19, dict(rollouts_per_thread=128, persistent_tree=0, max_searches=10, root_epsilon=0.0,
                                     unexplored_q_zero=1)),
     "mcts_9_r512": (9, dict(rollouts_per_thread=512, max_searches=70, policy_distri_cutoff=6, net_salt=3)),   # plays to game end
+    # option space of TSOptions / SearchAlgoOptions (tree_search_options.h:23-229)
+    "mcts_19_r128_vl0": (19, dict(rollouts_per_thread=128, max_searches=8, virtual_loss=0, net_salt=31)),
+    "mcts_19_r128_noprior": (19, dict(rollouts_per_thread=128, max_searches=8, use_prior=0, virtual_loss=3, net_salt=32, root_epsilon=0.0)),
+    "mcts_9_r128_rootq0": (9, dict(rollouts_per_thread=128, max_searches=30, root_unexplored_q_zero=1, virtual_loss=3, c_puct=0.5,
+                                   net_salt=33, policy_distri_cutoff=5)),
+    "mcts_9_r96_bs4": (9, dict(rollouts_per_thread=96, rollouts_per_batch=4, batchsize=4, max_searches=30, net_salt=34, net_tie_levels=4)),
+    "mcts_9_r128_bs64": (9, dict(rollouts_per_thread=128, rollouts_per_batch=64, batchsize=64, max_searches=30, net_salt=35,
+                                 ply_pass_enabled=4, komi=5.5)),
     "mcts_9_r64_ties": (9, dict(rollouts_per_thread=64, max_searches=60, net_tie_levels=3, root_epsilon=0.1, root_alpha=0.5)),
 }
 
@@ -35,6 +43,8 @@ CASES = {
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, (n, kw) in CASES.items():
+        if "--all" not in sys.argv and os.path.exists(os.path.join(OUT, name + ".npz")):
+            continue
         R = RefSelfPlay(n)
         cfg = dict(MCTS_DEFAULTS)
         cfg.update(kw)

@@ -65,7 +65,8 @@ def elf(built):
 
 
 @pytest.mark.parametrize("name", ["mcts_19_r128_fresh", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512_client",
-                                  "mcts_9_r512", "mcts_9_r64_ties"])
+                                  "mcts_9_r512", "mcts_9_r64_ties", "mcts_19_r128_vl0", "mcts_19_r128_noprior", "mcts_9_r128_rootq0",
+                                  "mcts_9_r96_bs4", "mcts_9_r128_bs64"])
 def test_search_matches_reference(elf, name):
     run_case(elf, name)
 

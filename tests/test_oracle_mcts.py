@@ -11,7 +11,7 @@ from conftest import GOLDEN
 from pyoracle import MCTS_DEFAULTS, RefSelfPlay, stub_net
 
 CASES = ["mcts_19_r8192", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512_client", "mcts_19_r128_fresh", "mcts_9_r512",
-         "mcts_9_r64_ties"]
+         "mcts_9_r64_ties", "mcts_19_r128_vl0", "mcts_19_r128_noprior", "mcts_9_r128_rootq0", "mcts_9_r96_bs4", "mcts_9_r128_bs64"]
 
 
 @pytest.mark.parametrize("n", [19, 9])
