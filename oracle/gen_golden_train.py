@@ -30,6 +30,8 @@ RECORD_CASES = {
     # never_resign_prob 0.5: two games draw "never resign" and run to the cutoff, one is resigned by Black, one by White
     "records_9_neverresign": (9, dict(rollouts_per_thread=32, max_searches=236, policy_distri_cutoff=3, net_salt=21, resign_thres=0.9,
                                       never_resign_prob=0.5, move_cutoff=64, seed=5)),
+    "records_19_resign": (19, dict(rollouts_per_thread=32, max_searches=130, policy_distri_cutoff=12, net_salt=41, resign_thres=0.9,
+                                   move_cutoff=80, seed=9)),                         # White resigns one game, Black the next
     "records_19_cutoff": (19, dict(rollouts_per_thread=32, max_searches=64, policy_distri_cutoff=30, net_salt=9, move_cutoff=31)),
 }
 
