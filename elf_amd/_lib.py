@@ -55,6 +55,7 @@ SIGNATURES = {
     "elfsp_games_finished": (_i64, [_vp]),
     "elfsp_search_log": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "elfsp_play": (_i, [_vp, _vp, _vp]),
+    "elfsp_preload": (_i, [_vp, _vp, _i, _i, _vp]),
     "elfsp_restart": (_i, [_vp, _vp, _i, _vp]),
     "elfsp_last_score": (_i, [_vp, _vp]),
     "elfsp_records_pending": (_i, [_vp]),

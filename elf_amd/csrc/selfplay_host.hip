@@ -39,6 +39,7 @@ struct SpGame {
   int ply = 1;             // GoState::getPly of the game board
   int seq = 0;             // games finished by this slot
   float last_final = 0.0f; // GoStateExt::getLastGameFinalValue (go_state_ext.h:153-155)
+  int sgf_iter = 0;        // GoGameSelfPlay::_sgf_iter (game_selfplay.h): next move of the preloaded SGF
   SpRecord rec;            // GoStateExt::_mcts_policies / _predicted_values / the game's moves (go_state_ext.h:131-148)
 };
 
@@ -72,6 +73,7 @@ struct ElfSelfPlay {
   // finished-game records (GameNotifier::OnGameEnd -> GoStateExt::dumpRecord), newest at the back
   std::deque<std::string> records;
   SpRecordMeta meta{};
+  std::vector<int32_t> sgf;   // GameOptions.preload_sgf as reference Coords (elfsp_preload)
 };
 
 static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int final_ply) {
@@ -146,7 +148,7 @@ static int sp_finish_move(ElfSelfPlay* sp) {
   HIPCHK(hipMemcpyAsync(sp->h_prior.data(), sp->d_prior, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
   HIPCHK(hipMemcpyAsync(sp->h_reward.data(), sp->d_reward, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
   HIPCHK(hipStreamSynchronize(sp->stream));
-  std::vector<int> finished;
+  std::vector<int> finished, sgf_done;
   for (int g = 0; g < G; ++g) {
     SpGame& gm = sp->games[g];
     const int32_t* info = &sp->h_info[g * ELFMCTS_ROOT_WORDS];
@@ -235,9 +237,28 @@ static int sp_finish_move(ElfSelfPlay* sp) {
       const float fv = ((gm.ply & 1) == 1) ? -1.0f : 1.0f;   // setFinalValue FR_RESIGN (go_state_ext.h:83-85)
       sp->sum_final += fv;
       sp_finish_record(sp, g, fv, gm.ply);
-      gm.ply = -1;                   // marks "finished by resignation"
+      gm.ply = -1;                   // marks "finished without a move"
+    } else if (!sp->sgf.empty() && gm.sgf_iter >= (int)sp->sgf.size()) {
+      sgf_done.push_back(g);         // preloaded SGF exhausted: finish_game(FR_MAX_STEP), game_selfplay.cc:392-396
+      sp->h_moves[g] = M_PASS;
     } else {
+      if (!sp->sgf.empty()) c = sp->sgf[gm.sgf_iter++];       // "Move changes from {} to {}" :397-405
       sp->h_moves[g] = c;
+    }
+  }
+  if (!sgf_done.empty()) {
+    // setFinalValue(FR_MAX_STEP) = GoState::evaluate(komi) of the position the search started from; no move is forwarded
+    std::vector<int32_t> ids(sgf_done.begin(), sgf_done.end());
+    HIPCHK(hipMemcpyAsync(sp->d_ids, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, sp->stream));
+    SPCHK(elfgo_evaluate(sp->eng, sp->d_ids, (int)ids.size(), sp->opt.mcts.komi, sp->d_val, sp->stream));
+    HIPCHK(hipMemcpyAsync(sp->h_val.data(), sp->d_val, sizeof(float) * ids.size(), hipMemcpyDeviceToHost, sp->stream));
+    HIPCHK(hipStreamSynchronize(sp->stream));
+    for (size_t i = 0; i < ids.size(); ++i) {
+      SpGame& gm = sp->games[ids[i]];
+      sp->sum_final += sp->h_val[i];
+      sp_finish_record(sp, ids[i], sp->h_val[i], gm.ply);
+      gm.ply = -1;
+      finished.push_back(ids[i]);
     }
   }
   sp->n_moves += G;
@@ -407,6 +428,32 @@ int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream) {
   }
   sp->n_moves += k - bad;
   return bad ? ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD : 0;
+}
+
+// GameOptions.preload_sgf / preload_sgf_move_to (GoGameSelfPlay::restart, game_selfplay.cc:202-219): every game follows the
+// given move list -- the first move_to moves are forwarded now, afterwards each search's move is replaced by the next SGF move
+// (:392-405) and the game is finished (FR_MAX_STEP) by the search that finds the list exhausted.
+int elfsp_preload(ElfSelfPlay* sp, const uint16_t* moves_host, int n, int move_to, void* stream) {
+  if (!sp || n < 0 || (n > 0 && !moves_host) || sp->search_open || sp->n_moves != 0) return ELFGO_E_BADARG;
+  sp->stream = (hipStream_t)stream;
+  sp->sgf.assign(moves_host, moves_host + n);
+  const int G = sp->G;
+  int fwd = 0;
+  for (; fwd < n && fwd < move_to; ++fwd) {            // while (!_sgf_iter.done() && i < preload_sgf_move_to)
+    std::vector<int32_t> mv(G, (int32_t)sp->sgf[fwd]);
+    HIPCHK(hipMemcpyAsync(sp->d_moves, mv.data(), 4 * G, hipMemcpyHostToDevice, sp->stream));
+    SPCHK(elfgo_forward(sp->eng, nullptr, sp->d_moves, G, sp->d_ok, sp->stream));
+    HIPCHK(hipMemcpyAsync(sp->h_ok.data(), sp->d_ok, G, hipMemcpyDeviceToHost, sp->stream));
+    HIPCHK(hipStreamSynchronize(sp->stream));
+    for (int g = 0; g < G; ++g)
+      if (sp->h_ok[g] != 1) return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD;   // "Preload sgf: move not valid!" :211-215
+    for (int g = 0; g < G; ++g) {
+      sp->games[g].ply++;
+      if (sp->opt.keep_records > 0) sp->games[g].rec.moves.push_back(sp->sgf[fwd]);
+    }
+  }
+  for (int g = 0; g < G; ++g) sp->games[g].sgf_iter = fwd;
+  return 0;
 }
 
 // finish_game(FR_CLEAR) + restart (game_selfplay.cc:121-149,302-307): the listed games start over from the empty board

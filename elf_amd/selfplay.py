@@ -157,6 +157,12 @@ class SelfPlay:
             raise ValueError("one entry per game")
         check(self.L.elfsp_play(self._h, mv.ctypes.data, self._stream()))
 
+    def preload(self, moves, move_to=-1):
+        """GameOptions.preload_sgf / preload_sgf_move_to: follow `moves` (reference Coords) in every game; the first move_to are
+        forwarded now, later searches have their move replaced by the next listed one (game_selfplay.cc:202-219,392-405)."""
+        mv = np.ascontiguousarray(moves, dtype=np.uint16)
+        check(self.L.elfsp_preload(self._h, mv.ctypes.data, mv.size, int(move_to), self._stream()))
+
     def restart(self, games):
         """finish_game(FR_CLEAR) + restart for the listed games"""
         g = np.ascontiguousarray(games, dtype=np.int32)

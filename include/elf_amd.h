@@ -201,6 +201,11 @@ int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
  * drives): between two searches, forward externally chosen moves (moves_host[g] = reference Coord, < 0 = none) on the game boards;
  * the trees follow.  Refused moves leave their game untouched and make the call return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD. */
 int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream);
+/* GameOptions.preload_sgf / preload_sgf_move_to (GoGameSelfPlay::restart, game_selfplay.cc:202-219): before the first search,
+ * make every game follow the move list moves_host[0..n) (reference Coords): the first move_to moves are forwarded at once, then
+ * each search's move is replaced by the next listed move (:392-405); the search that finds the list exhausted finishes the game
+ * (FR_MAX_STEP).  An illegal listed move returns ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD ("Preload sgf: move not valid!"). */
+int elfsp_preload(ElfSelfPlay* sp, const uint16_t* moves_host, int n, int move_to, void* stream);
 /* finish_game(FR_CLEAR) + restart for the listed games (clear_board) */
 int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* stream);
 /* GoGameSelfPlay::getLastScore: final value of the last finished game of every game slot, host f32 [num_games] */

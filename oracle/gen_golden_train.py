@@ -32,6 +32,11 @@ RECORD_CASES = {
                                       never_resign_prob=0.5, move_cutoff=64, seed=5)),
     "records_19_resign": (19, dict(rollouts_per_thread=32, max_searches=130, policy_distri_cutoff=12, net_salt=41, resign_thres=0.9,
                                    move_cutoff=80, seed=9)),                         # White resigns one game, Black the next
+    # GameOptions.preload_sgf (game_selfplay.cc:202-219,392-405): 40 moves of a capture-rich random game forwarded, then 40
+    # searches whose move is replaced by the SGF's, the game finished by the search that finds the SGF exhausted, and the
+    # degenerate one-search games that follow; exercises treeAdvance along moves the search did not choose
+    "records_9_preload": (9, dict(rollouts_per_thread=64, max_searches=44, policy_distri_cutoff=50, net_salt=17,
+                                  preload=(909, 80, 40))),
     "records_19_cutoff": (19, dict(rollouts_per_thread=32, max_searches=64, policy_distri_cutoff=30, net_salt=9, move_cutoff=31)),
 }
 
@@ -77,8 +82,22 @@ def main():
     for name, (n, kw) in RECORD_CASES.items():
         R = RefSelfPlay(n)
         cfg = dict(MCTS_DEFAULTS)
+        kw = dict(kw)
+        pre = kw.pop("preload", None)
+        extra = {}
+        if pre is not None:
+            port = Port(n)
+            st = port.new()
+            mv = port.playout_moves(st, int(playout_seeds(1, base=pre[0])[0]))[: pre[1]]
+            port.free(st)
+            path = "/tmp/elf_preload_%s.sgf" % name
+            with open(path, "w") as fh:
+                fh.write("(;GM[1]FF[4]SZ[%d]KM[7.5]" % n + R.coords2sgfstr(mv)[1:])
+            R.set_preload(path, pre[2])
+            extra = dict(preload_moves=np.array(mv, np.uint16), preload_move_to=np.int32(pre[2]))
         cfg.update(kw)
         r = R.run(**cfg)
+        R.set_preload("", -1)
         recs = json.loads(r["records"])
         exact = [R.record_roundtrip(t) for t in split_records(r["records"])]
         assert len(recs) >= 1, name
@@ -91,7 +110,7 @@ def main():
                             best_action=np.array([s.best_action for s in r["search"]], np.int32),
                             n_edges=np.array([s.n_edges for s in r["search"]], np.int32),
                             root_value=np.array([s.root_value for s in r["search"]], np.float32),
-                            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"])
+                            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"], **extra)
         print(name, "records", len(exact), [(j["seq"], j["result"]["num_move"], j["result"]["reward"], len(j["result"].get("policies", [])))
                                             for j in recs])
         by_size[n] += exact

@@ -273,6 +273,10 @@ class RefSelfPlay:
         fn(*args, buf, C.c_int64(n))
         return buf.raw[:n].decode()
 
+    def set_preload(self, path, move_to=-1):
+        """GameOptions.preload_sgf / preload_sgf_move_to for the following run() calls ("" = off)"""
+        self.L.refsp_set_preload(C.c_char_p((path or "").encode()), C.c_int(move_to))
+
     def last_records(self):
         """JSON array text: Record of every game that finished during the last run()"""
         return self._text(self.L.refsp_last_records)

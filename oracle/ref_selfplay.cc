@@ -134,6 +134,8 @@ struct Capture : public GameNotifierBase {
   }
 };
 
+std::string g_preload_sgf;     // GameOptions.preload_sgf for the next refsp_run ("" = none)
+int g_preload_move_to = -1;
 std::string g_last_records;   // JSON array text of the records of the last refsp_run
 
 struct Buffers {
@@ -179,6 +181,8 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     opt.move_cutoff = cfg->move_cutoff;
     opt.use_mcts = true;
     opt.port = 0;
+    opt.preload_sgf = g_preload_sgf;
+    opt.preload_sgf_move_to = g_preload_move_to;
 
     const int n = cfg->num_games, B = cfg->batchsize;
     elf::Context ctx;
@@ -297,6 +301,12 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     fprintf(stderr, "refsp_run: %s\n", e.what());
     return -1;
   }
+}
+
+// GameOptions.preload_sgf / preload_sgf_move_to for the following refsp_run calls (path "" switches it off)
+void refsp_set_preload(const char* path, int move_to) {
+  g_preload_sgf = path ? path : "";
+  g_preload_move_to = move_to;
 }
 
 // Record JSON (array text) of the games that finished during the last refsp_run; returns the length, copies min(len, cap)

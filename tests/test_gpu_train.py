@@ -114,7 +114,7 @@ def test_loader_argument_errors(elf):
     ld.close()
 
 
-@pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_19_resign", "records_19_cutoff"])
+@pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff"])
 def test_selfplay_records_equal_reference_dump(elf, name):
     """GPU self-play under the fixture's configuration leaves the same Record JSON text as the reference's
     GoStateExt::dumpRecord for every finished game (content, quantised policies, predicted values, reward, seq), timestamp aside."""
@@ -133,6 +133,8 @@ def test_selfplay_records_equal_reference_dump(elf, name):
         move_cutoff=int(cfg["move_cutoff"]), resign_thres=float(np.float32(cfg["resign_thres"])),
         never_resign_prob=float(np.float32(cfg["never_resign_prob"])), seed=int(cfg["seed"]), keep_records=8, nodes_per_game=4096,
         log_searches=int(g["searches"]))
+    if "preload_moves" in g.files:
+        sp.preload(g["preload_moves"], int(g["preload_move_to"]))
     salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
     got = []
     for _ in range(200000):

@@ -11,7 +11,7 @@ import pytest
 from conftest import GOLDEN
 from pyoracle import RefSelfPlay, sgfstr2coords
 
-CASES = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_19_resign", "records_19_cutoff"]
+CASES = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff"]
 
 
 def sp_options(elf_amd, n, cfg, num_games=1):
