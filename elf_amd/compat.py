@@ -195,6 +195,9 @@ class GameContext:
             mcts_root_unexplored_q_zero=ts.alg_opt.root_unexplored_q_zero, komi=opt.komi, ply_pass_enabled=opt.ply_pass_enabled,
             policy_distri_cutoff=opt.policy_distri_cutoff, move_cutoff=opt.move_cutoff, resign_thres=self._resign,
             never_resign_prob=0.0, seed=opt.seed, nodes_per_game=opt.nodes_per_game, log_searches=opt.log_searches)
+        if opt.preload_sgf:
+            # GoGameSelfPlay::restart (game_selfplay.cc:202-219): follow the main line of the SGF while playing
+            self._sp.preload(sgf_main_line(opt.preload_sgf, opt.board_size), opt.preload_sgf_move_to)
 
     def ctx(self):
         return _Context(self)   # the device engine is built at the first wait(): setRequest() may still arrive after start()
@@ -217,6 +220,23 @@ class GameContext:
         """GoGameSelfPlay accessors the console uses (common/game_selfplay.h:41-56, inference/Pybind.cc:31-45)"""
         self._build()
         return _GameView(self, int(game_idx))
+
+
+def sgf_main_line(path, board_size):
+    """Main-line moves of an SGF file as reference Coords (what Sgf::load + SgfIterator yield, sgf/sgf.cc; "" or "tt" = pass)"""
+    import re
+    txt = open(path).read()
+    S = board_size + 2
+    out = []
+    for _, mv in re.findall(r";\s*([BW])\s*\[([a-z]{0,2})\]", txt):
+        if len(mv) < 2 or (mv == "tt" and board_size <= 19):
+            out.append(0)
+            continue
+        x, y = ord(mv[0]) - 97, ord(mv[1]) - 97
+        if not (0 <= x < board_size and 0 <= y < board_size):
+            raise ValueError("SGF move off board: " + mv)
+        out.append((y + 1) * S + (x + 1))
+    return out
 
 
 class _GameView:

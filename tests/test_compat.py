@@ -48,6 +48,20 @@ def test_error_behaviour_matches_the_reference():
         b["zzz"]
 
 
+def test_sgf_main_line_matches_reference_loader(built):
+    """compat.sgf_main_line against the reference's own Sgf loader (via oracle/_ref) on ladder-suite files"""
+    import glob
+    from elf_amd import compat
+    from pyoracle import Ref
+    files = sorted(glob.glob("/root/reference/ladder_suite/ladder/*.sgf"))[:25]
+    if not files or not Ref.available(19):
+        pytest.skip("reference tree / oracle/_ref not present")
+    R = Ref(19)
+    for f in files:
+        mv, _ = R.sgf_moves(f)
+        assert compat.sgf_main_line(f, 19) == [int(c) for c in mv], f
+
+
 def test_reference_module_names_resolve(built):
     """the import lines of src_py/elfgames/go/game_inference.py:15 and src_py/elf/__init__.py:8 work against the shim"""
     from elf_amd import compat
