@@ -360,6 +360,6 @@ const char* elfgo_error_string(int status) {
   if (status == ELFGO_E_NOMEM) return "elfgo: out of host memory";
   return hipGetErrorString((hipError_t)status);
 }
-const char* elfgo_version(void) { return "elf_amd 0.1 (gfx950)"; }
+const char* elfgo_version(void) { return "elf_amd 0.2 (gfx950)"; }
 
 }  // extern "C"

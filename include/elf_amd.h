@@ -14,6 +14,9 @@
  *    in _host; `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue
  *    work and return; use elfgo_sync() or your own stream sync before reading results.
  *  - `ids` may be NULL, meaning slots [0, n).
+ *  - threading: a handle (engine, search, self-play context, replay store) may be driven by one host thread at a time; different
+ *    handles are independent.  Calls on one handle are ordered by the stream they are given; results written by a call on
+ *    stream A may be consumed by a call on stream B only after the caller has ordered the streams (event / sync).
  *  - moves are reference Coords: c = (y+1)*(N+2) + (x+1), M_PASS=0, M_RESIGN=1 (base/board.h:183,
  *    base/common.h:43-47).  Actions are NN action ids a = x*N + y, pass = N*N (board.h:189).
  */
