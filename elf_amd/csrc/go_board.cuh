@@ -179,6 +179,9 @@ struct Board {
   u64* sk_img;         // this board's superko images   [MAXMOVE+2][SKW]   (HBM)
   int lane;
   int idx[R];          // LDS index of this lane's point in round k (clamped for invalid lanes)
+  int dl4;             // lanes 0..3: LDS offset of the neighbour in delta4 order (dir4(lane & 3))
+  int kk3, off12;      // lanes 0..11: neighbour kk3 = lane / 3 and the offset from the played point to that neighbour's
+                       // jj-th side not facing it (MergeToGroup liberty test)
   // lane-distributed bitboards in NN action order: lane k < R holds bits [64k, 64k+64); other lanes 0
   u64 Bw, Ww;          // black / white stones of the current position
   u64 mTop, mBot, mValid, mEdge;  // per-lane geometry masks: y != 0, y != N-1, a < N*N, point on the first/last line
@@ -207,6 +210,9 @@ struct Board {
       int a = k * 64 + lane;
       idx[k] = a2i(a < NP ? a : 0);
     }
+    dl4 = dir4(lane & 3);
+    kk3 = (lane < 12 ? lane : 0) / 3;
+    off12 = dir4(kk3) + dir4((kk3 + 3 + ((lane < 12 ? lane : 0) - 3 * kk3)) & 3);
     const u64* geo = z + G::ZOBW;
     mTop = lane < R ? geo[lane * 4 + 0] : 0ull;
     mBot = lane < R ? geo[lane * 4 + 1] : 0ull;
@@ -326,7 +332,7 @@ struct Board {
     u64 abit = 0, zi = 0;
     u32 nv = 0, nl = 0;   // lanes 0..3: label of the neighbour in delta4 order / liberties of its group
     u32 emp4 = 0;         // bit j: neighbour j is empty
-    const int dl = dir4(lane & 3);
+    const int dl = dl4;
     if (is_move) {
       // ---- TryPlay, board.cc:788-827
       if (c >= G::P) return 0;
@@ -452,9 +458,8 @@ struct Board {
       } else if (m == 1) {
         // MergeToGroup (:677-708) restated: the played point stops being a liberty; each previously
         // empty neighbour e counts only if no other stone of the group already touches it.
-        const int kk = lane / 3, jj = lane - 3 * kk;   // lanes 0..11: neighbour kk, its jj-th side not facing i
-        bool touch = false;
-        if (lane < 12 && ((emp4 >> kk) & 1u)) touch = L->pt[i + dir4(kk) + dir4((kk + 3 + jj) & 3)] == newv;
+        bool touch = false;                              // lanes 0..11: neighbour kk3, its jj-th side not facing i
+        if (lane < 12 && ((emp4 >> kk3) & 1u)) touch = L->pt[i + off12] == newv;
         const u32 t = (u32)__ballot(touch);
         const int add = ((emp4 & 1u) && ((t & 7u) == 0)) + ((emp4 & 2u) && (((t >> 3) & 7u) == 0)) +
                         ((emp4 & 4u) && (((t >> 6) & 7u) == 0)) + ((emp4 & 8u) && (((t >> 9) & 7u) == 0));
@@ -526,7 +531,7 @@ struct Board {
 #pragma unroll
     for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
-    for (int k = 0; k < R; ++k) lb[k] = L->libs[(((v[k] + 1u) & 0xFFFFu) > 1u) ? (v[k] & 0x7FFFu) : 0u];
+    for (int k = 0; k < R; ++k) lb[k] = L->libs[v[k] & 0x7FFFu];   // on-board points hold 0 or a stone label (never the border mark): index <= P
     u64 At = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
