@@ -113,6 +113,9 @@ def init_dist(args):
             dist.init_process_group(backend=backend)
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+    if world > 1:
+        # one process per GPU on one node: keep the host-side thread pools of the ranks from oversubscribing the cores
+        torch.set_num_threads(max(1, len(os.sched_getaffinity(0)) // world))
     return rank, local_rank, world, dist
 
 
