@@ -248,9 +248,27 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         with torch.no_grad():
             net({"s": sp.groups[0].s})
         torch.cuda.synchronize()
+    graphs = {}
+    if net is not None and args.net_graph:
+        # one HIP graph per game group (PyTorch's CUDAGraph on ROCm): the ~85 kernel launches of a net call (41 convolutions, 41
+        # epilogue passes, heads) become one graph launch; the graph reads the group's own "s" tensor, which is where the select
+        # kernel writes the leaf features, and its output tensors are what the expand kernel reads
+        from elf_amd.net import GraphedNet
+        try:
+            for g in sp.groups:
+                graphs[g.s.data_ptr()] = GraphedNet(net, g.s)
+        except Exception as e:   # capture is a launch mechanism, not a compute path: the same kernels run eagerly instead
+            sys.stderr.write("bench: HIP graph capture of the net call failed (%s); launching eagerly\n" % repr(e)[:200])
+            graphs = {}
+            args.net_graph = 0
+        torch.cuda.synchronize()
 
     def net_fn(s, rows):
         if net is not None:
+            gn = graphs.get(s.data_ptr())
+            if gn is not None:
+                out = gn()
+                return out["pi"], out["V"]
             with torch.no_grad():
                 out = net({"s": s})   # fixed shape [Gg*K, 18, N, N]: rows >= `rows` are stale and ignored (no MIOpen re-tuning)
             return out["pi"], out["V"]
@@ -302,7 +320,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                "persistent tree, %s, %d games per GPU in %d lock-step group(s) pipelined against the net"
                                % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s%s; leaf features %s)"
                                   % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs",
-                                     {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl],
+                                     {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl] + (", one HIP graph per net call" if args.net_graph else ""),
                                      feat_fmt)
                                   if net is not None else "NO conv net (--net %s: search kernels only)" % args.net, G, groups),
                    "games_per_gpu": G, "board_size": n, "rollouts_per_step": G * K, "net_rows_per_step": my_rows / steps,
@@ -482,6 +500,7 @@ def main():
     ap.add_argument("--net-dtype", choices=["fp16", "bf16", "fp32"], default="fp16")
     ap.add_argument("--net-impl", choices=["eager", "fused"], default="fused",
                     help="eager: plain PyTorch modules; fused: PyTorch convs + one HIP epilogue pass per conv (elfnet_bias_act_f16)")
+    ap.add_argument("--net-graph", type=int, default=1, help="1: replay each group's net call as one HIP graph; 0: eager launches")
     ap.add_argument("--features", choices=["auto", "f32", "f16"], default="auto",
                     help="leaf feature rows: f32 NCHW (reference layout) or f16 channels_last (auto: f16 when the net is fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
