@@ -226,7 +226,6 @@ __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool
 // ------------------------------------------------------------------------------------------------
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
-  using G = Geo<N>;
   using NR = NodeRec<N>;
   constexpr int R = (N * N + 1 + 63) / 64;
   __shared__ Slot<N> lds;
