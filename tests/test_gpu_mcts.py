@@ -90,3 +90,56 @@ def test_exhausted_node_pool_is_a_status_code(elf):
             sp.end_step(pi, v)
     assert "-101" in str(e.value)
     sp.close()
+
+
+LIVE = [
+    (9, dict(rollouts_per_thread=96, max_searches=40, seed=4242, net_salt=77, policy_distri_cutoff=9, virtual_loss=2, c_puct=1.1,
+             root_epsilon=0.3, root_alpha=0.2, ply_pass_enabled=12, komi=6.5)),
+    (9, dict(rollouts_per_thread=48, rollouts_per_batch=12, batchsize=12, max_searches=60, seed=31337, net_salt=78, net_tie_levels=6,
+             persistent_tree=0, unexplored_q_zero=1, move_cutoff=25)),
+    (19, dict(rollouts_per_thread=80, max_searches=7, seed=2718, net_salt=79, policy_distri_cutoff=3, virtual_loss=4, c_puct=2.0)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(LIVE)))
+def test_live_differential_against_the_reference_stack(elf, case):
+    """Not a committed fixture: the REAL reference self-play stack (oracle/_ref/libelfsp*.so, prebuilt, travels with the repo)
+    is run here on the host cores with a configuration no fixture uses, and the GPU engine must reproduce every search of it."""
+    import torch
+    from pyoracle import MCTS_DEFAULTS, RefSelfPlay
+    n, kw = LIVE[case]
+    if not RefSelfPlay.available(n):
+        pytest.skip("oracle/_ref/libelfsp%d.so not present" % n)
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(kw)
+    ref = RefSelfPlay(n).run(**cfg)
+    S = ref["search"]
+    m = len(S)
+    assert m == cfg["max_searches"]
+    sp = elf.SelfPlay(
+        board_size=n, num_games=1, device=0, mcts_rollout_per_thread=cfg["rollouts_per_thread"], mcts_rollout_per_batch=cfg["rollouts_per_batch"],
+        mcts_puct=cfg["c_puct"], mcts_virtual_loss=cfg["virtual_loss"], mcts_use_prior=bool(cfg["use_prior"]),
+        mcts_persistent_tree=bool(cfg["persistent_tree"]), mcts_epsilon=cfg["root_epsilon"], mcts_alpha=cfg["root_alpha"],
+        mcts_unexplored_q_zero=bool(cfg["unexplored_q_zero"]), mcts_root_unexplored_q_zero=bool(cfg["root_unexplored_q_zero"]),
+        komi=cfg["komi"], ply_pass_enabled=cfg["ply_pass_enabled"], policy_distri_cutoff=cfg["policy_distri_cutoff"],
+        move_cutoff=cfg["move_cutoff"], resign_thres=cfg["resign_thres"], never_resign_prob=cfg["never_resign_prob"], seed=cfg["seed"],
+        log_searches=m, nodes_per_game=4096)
+    while sp.stats()["logged"] < m:
+        rows = sp.begin_step()
+        if rows:
+            pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), cfg["net_salt"], cfg["net_tie_levels"])
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        else:
+            sp.end_step(None, None)
+    rec, coord, visits, prior, reward = sp.search_log()
+    for i in range(m):
+        ne = S[i].n_edges
+        ctx = "live case %d search %d" % (case, i)
+        assert rec[i].n_edges == ne, ctx
+        assert np.array_equal(coord[i, :ne], ref["coord"][i, :ne]), ctx
+        assert np.array_equal(visits[i, :ne], ref["visits"][i, :ne]), ctx
+        assert np.array_equal(prior[i, :ne].view(np.uint32), ref["prior"][i, :ne].view(np.uint32)), ctx
+        assert np.array_equal(reward[i, :ne].view(np.uint32), ref["reward"][i, :ne].view(np.uint32)), ctx
+        assert rec[i].move_played == S[i].move_played and rec[i].best_action == S[i].best_action, ctx
+        assert np.float32(rec[i].root_value) == np.float32(S[i].root_value), ctx
+    sp.close()
