@@ -9,26 +9,177 @@
 #include <math.h>
 #include <string.h>
 
-#include <charconv>
+#include <vector>
 
 #include "../../include/elf_amd.h"
 
 namespace {
 
-// nlohmann 3.1 dtoa: to_chars / format_buffer with min_exp = -4, max_exp = 15 (digits10 of double)
+// ---- shortest-digit generation: Grisu2 (F. Loitsch, "Printing Floating-Point Numbers Quickly and Accurately with Integers",
+// PLDI 2010), the algorithm nlohmann::json 3.1 prints floats with.  Grisu2's digits are short and round-trip, but they are not
+// always the closest/shortest decimal (std::to_chars differs on ~0.7 % of doubles), so text identity with the reference's
+// json::dump() needs this very algorithm: 64-bit "do-it-yourself" floats, a cached power of ten chosen so that the scaled value's
+// binary exponent lies in [-60, -32], digit generation inside the rounding interval shrunk by one unit on each side, and the
+// final weeding step towards the exact scaled value.
+struct DiyFp {
+  uint64_t f;
+  int e;
+};
+
+DiyFp diy_normalize(DiyFp x) {
+  while ((x.f >> 63) == 0) { x.f <<= 1; x.e--; }
+  return x;
+}
+
+// upper 64 bits of the 128-bit product, rounded (ties up)
+DiyFp diy_mul(DiyFp x, DiyFp y) {
+  const unsigned __int128 p = (unsigned __int128)x.f * y.f + ((unsigned __int128)1 << 63);
+  return DiyFp{(uint64_t)(p >> 64), x.e + y.e + 64};
+}
+
+// 10^k as a normalized 64-bit significand, k = -300, -292, ..., 324, computed exactly with a small big-integer and rounded to nearest
+struct Pow10 { uint64_t f; int e; };
+struct BigUInt {
+  std::vector<uint32_t> w;   // little endian
+  void mul_small(uint32_t m) {
+    uint64_t c = 0;
+    for (auto& x : w) { c += (uint64_t)x * m; x = (uint32_t)c; c >>= 32; }
+    if (c) w.push_back((uint32_t)c);
+  }
+  uint32_t div_small(uint32_t d) {   // in place, returns the remainder
+    uint64_t r = 0;
+    for (size_t i = w.size(); i-- > 0;) { r = (r << 32) | w[i]; w[i] = (uint32_t)(r / d); r %= d; }
+    while (!w.empty() && w.back() == 0) w.pop_back();
+    return (uint32_t)r;
+  }
+  int bits() const {
+    if (w.empty()) return 0;
+    int b = 32 * (int)(w.size() - 1);
+    for (uint32_t t = w.back(); t; t >>= 1) ++b;
+    return b;
+  }
+  bool bit(int i) const { return i >= 0 && (size_t)(i >> 5) < w.size() && ((w[i >> 5] >> (i & 31)) & 1u); }
+  bool any_below(int i) const {   // any set bit at a position < i
+    for (int j = 0; j < i && (size_t)(j >> 5) < w.size(); ++j) if (bit(j)) return true;
+    return false;
+  }
+  uint64_t top64(int* exp2, bool sticky_extra) const {   // round to nearest (ties to even; `sticky_extra` = truncated tail beyond w)
+    const int L = bits();
+    uint64_t f = 0;
+    for (int i = 0; i < 64; ++i) f = (f << 1) | (bit(L - 1 - i) ? 1u : 0u);
+    const bool half = bit(L - 65);
+    const bool rest = any_below(L - 65) || sticky_extra;
+    int e = L - 64;
+    if (half && (rest || (f & 1))) { if (++f == 0) { f = (uint64_t)1 << 63; ++e; } }
+    *exp2 = e;
+    return f;
+  }
+};
+
+const Pow10& cached_pow10(int index) {   // index 0 <-> k = -300
+  static Pow10 table[79];
+  static bool ready = false;
+  if (!ready) {
+    for (int i = 0; i < 79; ++i) {
+      const int k = -300 + 8 * i;
+      BigUInt b;
+      int e = 0;
+      if (k >= 0) {
+        b.w = {1u};
+        for (int j = 0; j < k; ++j) b.mul_small(10u);
+        table[i].f = b.top64(&e, false);
+        table[i].e = e;
+      } else {
+        const int m = 1200;   // 2^m / 10^|k| keeps > 190 significant bits for |k| <= 300
+        b.w.assign(m / 32 + 1, 0u);
+        b.w[m / 32] = 1u << (m % 32);
+        bool sticky = false;
+        for (int j = 0; j < -k; ++j) sticky |= b.div_small(10u) != 0;
+        table[i].f = b.top64(&e, sticky);
+        table[i].e = e - m;
+      }
+    }
+    ready = true;
+  }
+  return table[index];
+}
+
+// digits of v > 0 (finite): v ~= digits * 10^decimal_exponent
+void grisu2_digits(double v, char* buf, int* len, int* decimal_exponent) {
+  uint64_t bits;
+  memcpy(&bits, &v, 8);
+  const uint64_t E = bits >> 52, F = bits & (((uint64_t)1 << 52) - 1);
+  const DiyFp x = E == 0 ? DiyFp{F, 1 - 1075} : DiyFp{F + ((uint64_t)1 << 52), (int)E - 1075};
+  // rounding interval: half way to the neighbours; the lower neighbour is twice as close at a power of two
+  const bool closer_below = F == 0 && E > 1;
+  const DiyFp mp = diy_normalize(DiyFp{2 * x.f + 1, x.e - 1});
+  DiyFp mm = closer_below ? DiyFp{4 * x.f - 1, x.e - 2} : DiyFp{2 * x.f - 1, x.e - 1};
+  mm.f <<= (mm.e - mp.e); mm.e = mp.e;
+  const DiyFp w0 = diy_normalize(x);
+  // cached power: smallest k with 10^k >= 2^(alpha - e - 1), alpha = -60
+  const int fexp = -60 - mp.e - 1;
+  const int k = (fexp * 78913) / (1 << 18) + (fexp > 0);
+  const int index = (300 + k + 7) / 8;
+  const Pow10& c = cached_pow10(index);
+  const int ck = -300 + 8 * index;
+  const DiyFp cp{c.f, c.e};
+  const DiyFp W = diy_mul(w0, cp), Wm = diy_mul(mm, cp), Wp = diy_mul(mp, cp);
+  const DiyFp Mm{Wm.f + 1, Wm.e}, Mp{Wp.f - 1, Wp.e};   // shrink by one unit: the products carry an error below one unit
+  *decimal_exponent = -ck;
+  // ---- digit generation in [Mm, Mp]
+  uint64_t delta = Mp.f - Mm.f, dist = Mp.f - W.f;
+  const int sh = -Mp.e;                       // 32 <= sh <= 60
+  const uint64_t one = (uint64_t)1 << sh;
+  uint32_t p1 = (uint32_t)(Mp.f >> sh);
+  uint64_t p2 = Mp.f & (one - 1);
+  auto weed = [&](uint64_t rest, uint64_t unit) {   // move the last digit down while that brings the number closer to W
+    while (rest < dist && delta - rest >= unit && (rest + unit < dist || dist - rest > rest + unit - dist)) {
+      buf[*len - 1]--;
+      rest += unit;
+    }
+  };
+  uint32_t pow10 = 1;
+  int n = 1;
+  while (n < 10 && p1 >= pow10 * 10u) { pow10 *= 10u; ++n; }
+  *len = 0;
+  while (n > 0) {
+    const uint32_t d = p1 / pow10;
+    p1 %= pow10;
+    buf[(*len)++] = (char)('0' + d);
+    --n;
+    const uint64_t rest = ((uint64_t)p1 << sh) + p2;
+    if (rest <= delta) {
+      *decimal_exponent += n;
+      weed(rest, (uint64_t)pow10 << sh);
+      return;
+    }
+    pow10 /= 10u;
+  }
+  int m = 0;
+  for (;;) {
+    p2 *= 10;
+    const uint64_t d = p2 >> sh;
+    p2 &= one - 1;
+    buf[(*len)++] = (char)('0' + d);
+    ++m;
+    delta *= 10;
+    dist *= 10;
+    if (p2 <= delta) break;
+  }
+  *decimal_exponent -= m;
+  weed(p2, one);
+}
+
+// nlohmann's number layout: fixed notation for 10^-4 <= v < 10^15, else d[.ddd]e+-XX
 void put_double(std::string& o, double v) {
   if (!std::isfinite(v)) { o += "null"; return; }
   if (std::signbit(v)) { o += '-'; v = -v; }
   if (v == 0) { o += "0.0"; return; }
-  char sci[64];
-  auto res = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);   // shortest round-trip digits
-  std::string t(sci, res.ptr);
-  const size_t e = t.find('e');
-  std::string digits;
-  for (size_t i = 0; i < e; ++i) if (t[i] != '.') digits += t[i];
-  const int exp10 = atoi(t.c_str() + e + 1);
-  const int k = (int)digits.size();
-  const int n = exp10 + 1;              // decimal point position: value = 0.digits * 10^n
+  char dg[32];
+  int k = 0, dexp = 0;
+  grisu2_digits(v, dg, &k, &dexp);
+  const std::string digits(dg, dg + k);
+  const int n = k + dexp;               // position of the decimal point relative to the first digit
   if (k <= n && n <= 15) { o += digits; o.append((size_t)(n - k), '0'); o += ".0"; return; }
   if (0 < n && n <= 15) { o.append(digits, 0, (size_t)n); o += '.'; o.append(digits, (size_t)n, std::string::npos); return; }
   if (-4 < n && n <= 0) { o += "0."; o.append((size_t)(-n), '0'); o += digits; return; }
