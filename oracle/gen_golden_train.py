@@ -120,6 +120,15 @@ def main():
         recs = list(by_size[n])
         for i, sd in enumerate(playout_seeds(6 if n == 19 else 8, base=300 + n)):
             recs.append(json.dumps(synth_record(n, sd, rng, with_policies=(i % 3 != 2)), separators=(",", ":")))
+        # a record with moves GoState::forward refuses (a stone on an occupied point, twice): the replay skips them, so every
+        # extractor's index (getPly() - 1) falls behind the requested ply
+        bad = synth_record(n, playout_seeds(1, base=777 + n)[0], rng, with_policies=True)
+        mvb = [int(c) for c in RefSelfPlay(n).sgfstr2coords(bad["result"]["content"])]
+        mvb[10] = mvb[8]
+        mvb[21] = mvb[19]
+        bad["result"]["content"] = RefSelfPlay(n).coords2sgfstr(mvb)
+        recs.append(json.dumps(bad, separators=(",", ":")))
+        bad_index = len(recs) - 1
         rows = []
         for ri, t in enumerate(recs):
             j = json.loads(t)
@@ -128,7 +137,7 @@ def main():
                 if nm < nfa:
                     continue
                 last = nm - nfa
-                cand = sorted(set([0, 1, 2, 7, 8, 9, last // 2, max(last - 1, 0), last]))
+                cand = sorted(set([0, 1, 2, 7, 8, 9, last // 2, max(last - 1, 0), last] + ([10, 11, 12, 21, 22, 23, 30] if ri == bad_index else [])))
                 for ci, mt in enumerate(c for c in cand if c <= last):
                     d4 = (ri + ci + nfa) % 8
                     o = R.train_sample(t, mt, d4, nfa)
