@@ -164,7 +164,7 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
 #pragma unroll
     for (int k = 0; k < G::R; ++k) pre[k + 1] = pre[k] + rl(cnt, k);
     const int total = pre[G::R];
-    int pick = M_PASS;
+    int pick_a = -1;   // action id of the chosen candidate, -1 = pass
     if (total > 0) {
       const int r = (int)(playout_rng(seed, (u32)bd.ply) % (u32)total);
       int kw = 0;
@@ -176,11 +176,11 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
       const u64 wk = rl64(cand, kw);
       const int rank = __builtin_amdgcn_mbcnt_hi((u32)(wk >> 32), __builtin_amdgcn_mbcnt_lo((u32)wk, 0));
       const u64 sel = __ballot(lane_bit(wk) && rank == r - base);
-      const int a = kw * 64 + (int)__builtin_ctzll(sel);
-      pick = Board<N>::tr(Board<N>::a2i(a));
+      pick_a = kw * 64 + (int)__builtin_ctzll(sel);
     }
     ELF_PHASE(bd, 1);   // pick the k-th candidate
-    if (!bd.forward(pick)) break;
+    // a candidate comes from the legal mask of this very position: forward_legal_action skips TryPlay's re-check
+    if (!(pick_a >= 0 ? bd.forward_legal_action(pick_a) : bd.forward(M_PASS))) break;
     ++steps;
   }
   ELF_PHASE_END(bd);

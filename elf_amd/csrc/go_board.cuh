@@ -323,11 +323,20 @@ struct Board {
     return forward(c, sk);
   }
   template <class SK>
-  __device__ int forward(int c, const SK& sk) {
+  __device__ int forward(int c, const SK& sk) { return forward_impl<false>(c, 0, sk); }
+  // a move the caller took from legal_moves() of THIS position (k_playout): action id a, neither pass nor resign.  TryPlay's
+  // verdict is known, so the Coord decode, the occupancy / simple-ko / suicide tests and the terminated() test are skipped;
+  // the neighbour analysis that Play needs is not.
+  __device__ int forward_legal_action(int a) {
+    GameSK<N> sk{sk_hash, sk_img};
+    return forward_impl<true>(tr(a2i(a)), a, sk);
+  }
+  template <bool TRUSTED, class SK>
+  __device__ int forward_impl(int c, int a_trusted, const SK& sk) {
     c = rfl(c);
-    if (terminated()) return 0;
+    if (!TRUSTED && terminated()) return 0;
     const int player = next_player, opp = S_BLACK + S_WHITE - player;
-    const bool is_move = !(c == M_PASS || c == M_RESIGN);
+    const bool is_move = TRUSTED || !(c == M_PASS || c == M_RESIGN);
     int i = 0, ka = 0;
     u64 abit = 0, zi = 0;
     u32 nv = 0, nl = 0;   // lanes 0..3: label of the neighbour in delta4 order / liberties of its group
@@ -335,21 +344,29 @@ struct Board {
     const int dl = dl4;
     if (is_move) {
       // ---- TryPlay, board.cc:788-827
-      if (c >= G::P) return 0;
-      int x = c % S - 1, y = c / S - 1;
-      if (x < 0 || x >= N || y < 0 || y >= N) return 0;                       // :803
-      i = (x + 1) * S + (y + 1);
-      const int a = x * N + y;
+      int a;
+      if (TRUSTED) {
+        a = rfl(a_trusted);
+        i = a2i(a);
+      } else {
+        if (c >= G::P) return 0;
+        int x = c % S - 1, y = c / S - 1;
+        if (x < 0 || x >= N || y < 0 || y >= N) return 0;                     // :803
+        i = (x + 1) * S + (y + 1);
+        a = x * N + y;
+      }
       ka = a >> 6; abit = 1ull << (a & 63);
-      if (rl64(Bw | Ww, ka) & abit) return 0;                                 // :808 occupied
-      if (ko_pt == c && ko_age == 0 && ko_color == player) return 0;          // :234-240
+      if (!TRUSTED) {
+        if (rl64(Bw | Ww, ka) & abit) return 0;                               // :808 occupied
+        if (ko_pt == c && ko_age == 0 && ko_color == player) return 0;        // :234-240
+      }
       zi = zob[i];                                                            // issued now, hashed in after Play
       if (lane < 4) {                                                         // StoneLibertyAnalysis :161-199
         nv = L->pt[i + dl];
         nl = is_stone(nv) ? L->libs[nv & 0x7FFF] : 0;
       }
       emp4 = (u32)__ballot(lane < 4 && nv == 0);
-      if (emp4 == 0) {                                                        // isSuicideMove :201-232
+      if (!TRUSTED && emp4 == 0) {                                            // isSuicideMove :201-232
         const u32 pb = player == S_WHITE ? 0x8000u : 0u;
         const bool saves = lane < 4 && nv != PT_BORDER && (((nv & 0x8000u) == pb) ? nl > 1 : nl == 1);
         if (__ballot(saves) == 0) return 0;
