@@ -128,3 +128,14 @@ def test_reference_style_loop_reproduces_fixture(built):
     assert game.getLastMove() == chr(ord("A") + (x + 1 if x >= 8 else x)) + str(y + 1)
     sb = game.showBoard()
     assert sb.count("X") + sb.count("O") >= m - 2 and isinstance(game.getScore(), float) and game.getLastScore() == 0.0
+
+
+def test_gtp_coordinate_letters(built):
+    """console_lib.py:12-29: GTP letters skip 'I'; round trip over the whole 19x19 board"""
+    from elf_amd.gtp import move2xy, xy2move
+    assert xy2move(0, 0) == "A1" and xy2move(7, 3) == "H4" and xy2move(8, 3) == "J4" and xy2move(18, 18) == "T19"
+    assert move2xy("pass") == (-1, -1) and xy2move(-1, -1) == "pass"
+    for x in range(19):
+        for y in range(19):
+            m = xy2move(x, y)
+            assert "I" not in m and move2xy(m) == (x, y) and move2xy(m.lower()) == (x, y)
