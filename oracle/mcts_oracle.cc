@@ -1,0 +1,435 @@
+// TEST INFRASTRUCTURE ONLY -- not part of the product path.
+//
+// CPU restatement of the search half of the self-play hot path, serial and as plain as possible,
+// over the C restatement of the board engine (go_oracle.c).  Every function cites the reference lines it follows
+// (paths relative to /root/reference/src_cpp).  It is built into oracle/libgo_oracle{19,9}.so from source that travels with the
+// repository, so it exists wherever g++ does -- also where neither /root/reference nor a prebuilt oracle/_ref is present.
+//
+// Pinned: tests/test_oracle_mcts.py runs it against every MCTS golden fixture that the REAL reference stack produced
+// (tests/golden/mcts_*.npz, records_*.npz: root edges in iteration order, priors, visit counts, rewards, moves), bit for bit.
+//
+// What makes the result implementation-defined in the reference is taken from the same libstdc++ here, not re-derived:
+// std::unordered_map<unsigned short, ...> iteration order, std::sort tie order, std::gamma_distribution,
+// std::uniform_real_distribution, std::mt19937.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <random>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+extern "C" {
+typedef struct OrcState OrcState;
+OrcState* orc_new(void);
+OrcState* orc_clone(const OrcState*);
+void orc_free(OrcState*);
+void orc_reset(OrcState*);
+int orc_board_size(void);
+int orc_forward(OrcState*, int c);
+int orc_check_move(OrcState*, int c);
+int orc_terminated(const OrcState*);
+int orc_ply(const OrcState*);
+int orc_next_player(const OrcState*);
+int orc_last_move(const OrcState*);
+uint64_t orc_hash(const OrcState*);
+float orc_evaluate(const OrcState*, float komi);
+void orc_extract_agz(const OrcState*, int d4, float* out);
+void orc_stub_net(const float* s, int batch, uint32_t salt, int tie_levels, float* pi, float* v);
+}
+
+namespace {
+
+typedef unsigned short Coord;   // elfgames/go/base/common.h:20
+enum { M_PASS = 0, M_INVALID = 3, S_BLACK = 1, S_WHITE = 2 };
+
+// same layout as RefSpConfig / RefSpSearch in oracle/ref_selfplay.cc (one ctypes definition serves both)
+struct SpConfig {
+  int32_t num_games, batchsize, mcts_threads, rollouts_per_thread, rollouts_per_batch, virtual_loss, persistent_tree, use_prior;
+  int32_t unexplored_q_zero, root_unexplored_q_zero;
+  float c_puct, root_epsilon, root_alpha;
+  uint32_t seed;
+  float komi;
+  int32_t ply_pass_enabled, policy_distri_cutoff, move_cutoff;
+  float resign_thres, never_resign_prob;
+  uint32_t net_salt;
+  int32_t net_tie_levels, max_searches, timeout_usec;
+};
+struct SpSearch {
+  int32_t game, move_played, best_action, total_visits, n_edges;
+  float root_value, max_score;
+  int32_t pad;
+};
+
+// elf/ai/tree_search/tree_search_base.h:102-157 EdgeInfo
+struct Edge {
+  float prior;
+  int child = -1;
+  float reward = 0;
+  int num_visits = 0;
+  float virtual_loss = 0;
+  explicit Edge(float p) : prior(p) {}
+};
+
+enum { NOT_VISITED = 0, EVAL_REQUESTED = 1, VISITED = 2 };
+
+// elf/ai/tree_search/tree_search_node.h:84-399 NodeT (the state is owned by the node, :62-82)
+struct Node {
+  int status = NOT_VISITED;
+  std::unordered_map<Coord, Edge> sa;   // stateActions_ :310
+  int num_visits = 0;
+  float V = 0, unsigned_mean_q, unsigned_parent_q;
+  bool flip = false;
+  OrcState* state = nullptr;
+  explicit Node(float upq) : unsigned_mean_q(upq), unsigned_parent_q(upq) {}   // :97-102
+  ~Node() { if (state) orc_free(state); }
+};
+
+// tree_search_node.h:401-562 SearchTreeT
+struct Tree {
+  std::unordered_map<int, std::unique_ptr<Node>> nodes;
+  int count = 0, root = -1;
+  Tree() { clear(); }
+  int add_node(float upq) { nodes[count].reset(new Node(upq)); return count++; }          // :447-451
+  Node* at(int id) { auto it = nodes.find(id); return it == nodes.end() ? nullptr : it->second.get(); }
+  void clear() { nodes.clear(); count = 0; root = -1; root = add_node(0.0f); }             // :411-416, allocateRoot :555-561
+  void recursive_free(int id) {                                                            // :457-467
+    if (id < 0) return;
+    Node* n = at(id);
+    for (const auto& p : n->sa) recursive_free(p.second.child);
+    nodes.erase(id);
+  }
+  void advance(Coord action) {                                                             // treeAdvance :420-436
+    int next_root = -1;
+    Node* r = at(root);
+    for (const auto& p : r->sa) {
+      if (p.first == action) next_root = p.second.child;
+      else recursive_free(p.second.child);
+    }
+    nodes.erase(root);
+    root = next_root;
+    if (root < 0) root = add_node(0.0f);
+  }
+};
+
+struct Response {   // NodeResponseT, tree_search_base.h:33-38
+  std::vector<std::pair<Coord, float>> pi;
+  float value = 0;
+  bool q_flip = false;
+};
+
+typedef void (*net_fn)(const float* s, int batch, float* pi, float* v, void* user);
+
+struct Actor {   // elfgames/go/mcts/mcts.h:40-333 MCTSActor
+  int n, na;
+  float komi;
+  int ply_pass_enabled;
+  std::mt19937 rng;
+  const SpConfig* cfg;
+  net_fn net;
+  void* user;
+  int64_t rows = 0, batches = 0;
+
+  // BoardFeature::action2Coord (base/board_feature.h:139-144) with InvTransform (:115-130)
+  Coord action2coord(int a, int d4) const {
+    if (a == n * n) return M_PASS;
+    int x = a / n, y = a % n;
+    if ((d4 >> 2) == 1) std::swap(x, y);
+    const int rot = d4 % 4;
+    int ox = x, oy = y;
+    if (rot == 1) { ox = n - y - 1; oy = x; }
+    else if (rot == 2) { ox = n - x - 1; oy = n - y - 1; }
+    else if (rot == 3) { ox = y; oy = n - x - 1; }
+    return (Coord)((oy + 1) * (n + 2) + (ox + 1));
+  }
+
+  // pi2response :256-332 + normalize :244-254
+  void pi2response(const OrcState* s, int d4, const float* pi, bool pass_enabled, std::vector<std::pair<Coord, float>>* out) {
+    out->clear();
+    if (orc_terminated(s)) return;
+    for (int i = 0; i < na; ++i) out->push_back(std::make_pair(action2coord(i, d4), pi[i]));
+    typedef std::pair<Coord, float> D;
+    std::sort(out->begin(), out->end(), [](const D& a, const D& b) { return a.second > b.second; });
+    std::vector<D> tmp;
+    for (const D& v : *out) {
+      const bool valid = (v.first == M_PASS && pass_enabled) || (v.first != M_PASS && orc_check_move(const_cast<OrcState*>(s), v.first));
+      if (valid) tmp.push_back(v);
+    }
+    if (tmp.empty() && !pass_enabled) tmp.push_back(std::make_pair((Coord)M_PASS, 1.0f));
+    *out = tmp;
+    float total = 1e-10;
+    for (const D& p : *out) total += p.second;
+    for (D& p : *out) p.second /= total;
+  }
+
+  // evaluate :73-121 (batch): pre_evaluate :185-207, get_extractor :175-183, post_nn_result :209-230
+  void evaluate(const std::vector<const OrcState*>& states, std::vector<Response>* resps) {
+    if (states.empty()) return;
+    resps->assign(states.size(), Response());
+    std::vector<size_t> sel;
+    std::vector<int> d4s;
+    for (size_t i = 0; i < states.size(); ++i) {
+      Response& r = (*resps)[i];
+      const OrcState* s = states[i];
+      r.q_flip = orc_next_player(s) == S_WHITE;
+      if (orc_terminated(s)) {
+        r.value = orc_evaluate(s, komi) > 0 ? 1.0f : -1.0f;
+        r.pi.clear();
+      } else {
+        sel.push_back(i);
+        d4s.push_back((int)(rng() % 8));   // BoardFeature::RandomShuffle, base/board_feature.h:74-78
+      }
+    }
+    if (sel.empty()) return;
+    const int b = (int)sel.size(), fs = 18 * n * n;
+    std::vector<float> feat((size_t)b * fs), pi((size_t)b * na), v(b);
+    for (int j = 0; j < b; ++j) orc_extract_agz(states[sel[j]], d4s[j], &feat[(size_t)j * fs]);
+    if (net) net(feat.data(), b, pi.data(), v.data(), user);
+    else orc_stub_net(feat.data(), b, cfg->net_salt, cfg->net_tie_levels, pi.data(), v.data());
+    rows += b; batches++;
+    for (int j = 0; j < b; ++j) {
+      Response& r = (*resps)[sel[j]];
+      const OrcState* s = states[sel[j]];
+      r.value = v[j];
+      bool pass_enabled = orc_ply(s) >= ply_pass_enabled;
+      if (pass_enabled && orc_last_move(s) != M_PASS) {   // remove_pass_if_dangerous :232-242 (params default true)
+        const bool black_win = orc_evaluate(s, komi) > 0;
+        if ((black_win && orc_next_player(s) == S_WHITE) || (!black_win && orc_next_player(s) == S_BLACK)) pass_enabled = false;
+      }
+      pi2response(s, d4s[j], &pi[(size_t)j * na], pass_enabled, &r.pi);
+    }
+  }
+};
+
+struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + TreeSearchT, one thread
+  Tree tree;
+  const SpConfig* cfg;
+  Actor* actor;
+
+  // EdgeInfo::getScore (tree_search_base.h:132-157) + NodeT::UCT :361-397 + BestAction :321-358 + findMove :205-231
+  bool find_move(Node* nd, int depth, Coord* action) {
+    if (nd->status != VISITED) return false;
+    if (nd->sa.empty()) return false;
+    if (cfg->unexplored_q_zero || (cfg->root_unexplored_q_zero && depth == 0)) nd->unsigned_mean_q = 0.0;
+    Coord best = M_INVALID;
+    float max_score = std::numeric_limits<float>::lowest(), total_unsigned_q = 0;
+    int total_visits = 0;
+    for (const auto& ap : nd->sa) {
+      const Edge& e = ap.second;
+      const int all_visits = nd->num_visits + 1;
+      float r = e.reward;
+      if (nd->flip) r = -r;
+      r -= e.virtual_loss;
+      const int nvl = e.num_visits + e.virtual_loss;   // int + float -> float -> int
+      const float q = nvl > 0 ? r / nvl : (nd->flip ? -nd->unsigned_mean_q : nd->unsigned_mean_q);
+      const float unsigned_q = e.num_visits > 0 ? e.reward / e.num_visits : nd->unsigned_mean_q;
+      const float prior = e.prior / (1 + e.num_visits) * std::sqrt(all_visits);   // float * double sqrt(int) -> float
+      const bool first_visit = nvl == 0;
+      const float score = cfg->use_prior ? (prior * cfg->c_puct + q) : q;
+      if (score > max_score) { max_score = score; best = ap.first; }
+      if (!first_visit) { total_unsigned_q += unsigned_q; total_visits++; }
+    }
+    *action = best;
+    nd->unsigned_mean_q = (nd->unsigned_parent_q + total_unsigned_q) / (total_visits + 1);
+    return true;
+  }
+
+  struct Traj {
+    std::vector<std::pair<Node*, Coord>> traj;
+    Node* leaf;
+  };
+
+  // single_rollout :264-322
+  Traj single_rollout() {
+    Node* node = tree.at(tree.root);
+    Traj t;
+    int depth = 0;
+    while (node->status == VISITED) {
+      Coord action;
+      if (!find_move(node, depth, &action)) break;
+      if (cfg->virtual_loss > 0) node->sa.find(action)->second.virtual_loss += cfg->virtual_loss;   // addVirtualLoss :233-251
+      t.traj.push_back(std::make_pair(node, action));
+      Edge& e = node->sa.find(action)->second;                                                      // followEdge :280-302
+      if (e.child < 0) e.child = tree.add_node(node->unsigned_mean_q);
+      Node* next = tree.at(e.child);
+      if (next == nullptr) break;
+      if (next->state == nullptr) {                                                                 // allocateState :174-190
+        OrcState* st = orc_clone(node->state);
+        if (!orc_forward(st, action)) { orc_free(st); break; }
+        next->state = st;
+      }
+      node = next;
+      ++depth;
+    }
+    t.leaf = node;
+    return t;
+  }
+
+  // batch_rollouts :200-262.  The reference walks `traj_counts` (keyed by node address) in hash order; this restatement backs
+  // the unique leaves up in first-occurrence order (with values on a 1/256 grid the sums are order-independent).
+  void batch_rollouts() {
+    std::vector<Traj> trajs;
+    for (int j = 0; j < cfg->rollouts_per_batch; ++j) trajs.push_back(single_rollout());
+    std::vector<Node*> locked;
+    std::vector<const OrcState*> states;
+    std::vector<std::pair<Node*, std::pair<Traj*, int>>> counts;
+    for (Traj& t : trajs) {
+      if (t.leaf->status == NOT_VISITED) {   // requestEvaluation :142-153
+        t.leaf->status = EVAL_REQUESTED;
+        locked.push_back(t.leaf);
+        states.push_back(t.leaf->state);
+      }
+      bool found = false;
+      for (auto& c : counts) if (c.first == t.leaf) { c.second.second++; found = true; break; }
+      if (!found) counts.push_back(std::make_pair(t.leaf, std::make_pair(&t, 1)));
+    }
+    std::vector<Response> resps;
+    actor->evaluate(states, &resps);
+    for (size_t j = 0; j < locked.size(); ++j) {   // setEvaluation :176-203
+      Node* nd = locked[j];
+      for (const auto& ap : resps[j].pi) nd->sa.insert(std::make_pair(ap.first, Edge(ap.second)));
+      nd->V = resps[j].value;
+      nd->flip = resps[j].q_flip;
+      nd->status = VISITED;
+    }
+    for (auto& c : counts) {
+      const float reward = c.first->V;   // MCTSActor::reward :163-165
+      for (const auto& p : c.second.first->traj) {   // updateEdgeStats :253-278
+        Edge& e = p.first->sa.find(p.second)->second;
+        p.first->num_visits++;
+        e.reward += reward;
+        e.num_visits++;
+        e.virtual_loss -= (float)(cfg->virtual_loss * c.second.second);
+      }
+    }
+  }
+
+  // TreeSearchT::run :410-426 (setRootNodeState :478-493, enhanceExploration tree_search_node.h:132-155, chooseAction :495-528)
+  bool run(const OrcState* root_state) {
+    Node* root = tree.at(tree.root);
+    if (root->state == nullptr) root->state = orc_clone(root_state);
+    if (orc_hash(root_state) != orc_hash(root->state)) return false;   // "Root state is not the same as the input state"
+    if (cfg->root_epsilon > 0.0f) {
+      std::gamma_distribution<> dis(cfg->root_alpha);
+      std::vector<float> etas(root->sa.size());
+      float Z = 1e-10;
+      for (size_t i = 0; i < root->sa.size(); ++i) { etas[i] = dis(actor->rng); Z += etas[i]; }
+      int i = 0;
+      for (auto& p : root->sa) {
+        p.second.prior = (1 - cfg->root_epsilon) * p.second.prior + cfg->root_epsilon * etas[i] / Z;
+        i++;
+      }
+    }
+    for (int idx = 0; idx < cfg->rollouts_per_thread; idx += cfg->rollouts_per_batch) batch_rollouts();   // tree_search.h:112-117
+    return true;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+// Self-play of one game slot with one MCTS AI: GoGameSelfPlay::act (elfgames/go/common/game_selfplay.cc:272-430) with
+// init_ai :30-78, mcts_make_diverse_move :80-95, mcts_update_info :97-119, finish_game :121-149, ResignCheck
+// (common/game_utils.h:14-54), MCTSAI_T::act / align_state / advanceMoves (elf/ai/tree_search/mcts.h:59-81,141-167).
+// Outputs as refsp_run of oracle/ref_selfplay.cc: one SpSearch per search + the root edges in iteration order.
+int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search, int32_t* out_coord, int32_t* out_visits,
+              float* out_prior, float* out_reward, int64_t* stats) {
+  const int n = orc_board_size(), na = n * n + 1, max_move = 2 * n * n;
+  std::mt19937 game_rng;
+  game_rng.seed(cfg->seed);                      // GoGameBase, common/game_base.h:32-38
+  Actor actor;
+  actor.n = n; actor.na = na; actor.komi = cfg->komi; actor.ply_pass_enabled = cfg->ply_pass_enabled;
+  actor.cfg = cfg; actor.net = net; actor.user = user;
+  actor.rng.seed(game_rng());                    // params.seed = _rng() :47, MCTSActor::rng_(params.seed) mcts.h:52
+  Search search;
+  search.cfg = cfg; search.actor = &actor;
+  OrcState* st = orc_new();
+  std::vector<Coord> moves;                      // GoState::_moves
+  size_t next_move_number = 0;                   // MCTSAI_T::nextMoveNumber_
+  bool never_resign = false, has_never = false;  // ResignCheck
+  int k = 0;
+  while (k < cfg->max_searches) {
+    // MCTSAI_T::act: align_state
+    if (!cfg->persistent_tree) { search.tree.clear(); next_move_number = 0; }
+    else if (next_move_number > moves.size()) { search.tree.clear(); next_move_number = 0; }   // moves_since fails -> resetTree
+    else {
+      for (size_t i = next_move_number; i < moves.size(); ++i) search.tree.advance(moves[i]);
+      next_move_number = moves.size();
+    }
+    if (!search.run(st)) { orc_free(st); return -2; }
+    // chooseAction / MCTSResultT::addActions (tree_search_base.h:237-294), MOST_VISITED
+    Node* root = search.tree.at(search.tree.root);
+    SpSearch& S = out_search[k];
+    memset(&S, 0, sizeof(S));
+    S.game = 0; S.best_action = M_INVALID; S.max_score = std::numeric_limits<float>::lowest(); S.root_value = root->V;
+    std::vector<std::pair<Coord, float>> policy;
+    const Edge* best_edge = nullptr;
+    int i = 0;
+    for (int j = 0; j < na; ++j) { out_coord[(size_t)k * na + j] = -1; out_visits[(size_t)k * na + j] = 0; out_prior[(size_t)k * na + j] = 0; out_reward[(size_t)k * na + j] = 0; }
+    for (const auto& ap : root->sa) {
+      const float score = (float)ap.second.num_visits;
+      policy.push_back(std::make_pair(ap.first, score));
+      S.total_visits += ap.second.num_visits;
+      if (score > S.max_score) { S.max_score = score; S.best_action = ap.first; best_edge = &ap.second; }
+      out_coord[(size_t)k * na + i] = ap.first; out_visits[(size_t)k * na + i] = ap.second.num_visits;
+      out_prior[(size_t)k * na + i] = ap.second.prior; out_reward[(size_t)k * na + i] = ap.second.reward;
+      ++i;
+    }
+    S.n_edges = i;
+    Coord c = (Coord)S.best_action;
+    // mcts_make_diverse_move: MCTSPolicy::normalize (t = 1) + sample_multinomial (elf/utils/utils.h:159-182)
+    if (orc_ply(st) <= cfg->policy_distri_cutoff) {
+      float exp_sum = 0;
+      for (auto& e : policy) { const float v = std::pow(e.second, 1.0 / 1.0f); e.second = v; exp_sum += v; }
+      for (auto& e : policy) e.second /= exp_sum;
+      float Z = 0.0;
+      for (const auto& e : policy) Z += e.second;
+      std::uniform_real_distribution<> dis(0, Z);
+      const float rd = dis(game_rng);
+      std::vector<float> accu(policy.size() + 1);
+      accu[0] = 0;
+      size_t pick = policy.size() - 1;
+      for (size_t t = 1; t < accu.size(); t++) {
+        accu[t] = policy[t - 1].second + accu[t - 1];
+        if (rd < accu[t]) { pick = t - 1; break; }
+      }
+      c = policy[pick].first;
+    }
+    // mcts_update_info: MCTSGoAI::getValue (go/mcts/mcts.h:358-365)
+    const float predicted = (S.total_visits == 0 || best_edge == nullptr) ? root->V : best_edge->reward / best_edge->num_visits;
+    S.move_played = c;
+    ++k;
+    // shouldResign (go_state_ext.h:207-214) -> ResignCheck::check
+    const bool black = orc_next_player(st) == S_BLACK;
+    const float value = black ? predicted : -predicted;
+    if (!has_never) {
+      std::uniform_real_distribution<> dis(0.0, 1.0);
+      never_resign = dis(game_rng) < cfg->never_resign_prob;
+      has_never = true;
+    }
+    const bool resign = !never_resign && !(value >= -1.0 + cfg->resign_thres);
+    bool finished = false;
+    if (resign && orc_ply(st) >= 50) finished = true;                                  // finish_game(FR_RESIGN) :387-390
+    else {
+      if (!orc_forward(st, c)) { orc_free(st); return -3; }                            // "Something is wrong! Move cannot be applied"
+      moves.push_back(c);
+      if (orc_terminated(st)) finished = true;                                         // :420-425
+      if (cfg->move_cutoff > 0 && orc_ply(st) >= cfg->move_cutoff) finished = true;    // :427-429
+      (void)max_move;
+    }
+    if (finished) {   // finish_game :121-149: _ai->endGame (resetTree), _state_ext.restart()
+      search.tree.clear(); next_move_number = 0;
+      orc_reset(st); moves.clear();
+      never_resign = false; has_never = false;
+    }
+  }
+  if (stats) { stats[0] = actor.batches; stats[1] = actor.rows; stats[2] = 0; }
+  orc_free(st);
+  return k;
+}
+
+}  // extern "C"

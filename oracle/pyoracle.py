@@ -318,6 +318,34 @@ class RefSelfPlay:
                     move_idx=mi.value, num_move=nm.value, aug_code=ac.value, selfplay_ver=sv.value)
 
 
+class PortSelfPlay:
+    """The CPU restatement of the search + self-play loop (oracle/mcts_oracle.cc over go_oracle.c); same run() interface and
+    result layout as RefSelfPlay, which it is pinned against (tests/test_oracle_mcts.py)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.na = n * n + 1
+        Port(n)   # loads the library's Zobrist table
+        self.L = C.CDLL(os.path.join(HERE, "libgo_oracle%d.so" % n))
+        self.L.orcsp_run.restype = C.c_int
+
+    def run(self, **kw):
+        cfg = dict(MCTS_DEFAULTS)
+        cfg.update(kw)
+        c = RefSpConfig(**cfg)
+        m, na = c.max_searches, self.na
+        S = (RefSpSearch * m)()
+        coord = np.full((m, na), -1, np.int32); visits = np.zeros((m, na), np.int32)
+        prior = np.zeros((m, na), np.float32); reward = np.zeros((m, na), np.float32)
+        stats = (C.c_int64 * 3)()
+        k = self.L.orcsp_run(C.byref(c), None, None, S, coord.ctypes.data_as(C.c_void_p), visits.ctypes.data_as(C.c_void_p),
+                             prior.ctypes.data_as(C.c_void_p), reward.ctypes.data_as(C.c_void_p), stats)
+        if k < 0:
+            raise RuntimeError("orcsp_run failed: %d" % k)
+        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
+                    batches=int(stats[0]), rows=int(stats[1]))
+
+
 def stub_net(n, s, salt=7, tie_levels=0):
     """oracle/stub_net.h through the port library: s [B,18,n,n] f32 -> (pi [B,n*n+1], v [B])"""
     L = C.CDLL(os.path.join(HERE, "libgo_oracle%d.so" % n))

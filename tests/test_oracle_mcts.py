@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from pyoracle import MCTS_DEFAULTS, RefSelfPlay, stub_net
+from pyoracle import MCTS_DEFAULTS, PortSelfPlay, RefSelfPlay, stub_net
 
 CASES = ["mcts_19_r8192", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512_client", "mcts_19_r128_fresh", "mcts_9_r512",
          "mcts_9_r64_ties", "mcts_19_r128_vl0", "mcts_19_r128_noprior", "mcts_9_r128_rootq0", "mcts_9_r96_bs4", "mcts_9_r128_bs64"]
@@ -60,3 +60,36 @@ def test_reference_reproduces_fixture(name):
     assert np.array_equal(r["prior"].view(np.uint32), g["prior"].view(np.uint32))
     assert np.array_equal(r["reward"].view(np.uint32), g["reward"].view(np.uint32))
     assert [s.move_played for s in r["search"]] == g["move_played"].tolist()
+
+
+RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_19_resign", "records_19_cutoff"]
+
+
+@pytest.mark.parametrize("name", CASES + RECORD_RUNS)
+def test_restatement_matches_reference_fixture(built, name):
+    """oracle/mcts_oracle.cc (the CPU restatement of MCTSActor, the tree search and the self-play loop over go_oracle.c) replays
+    the fixture's configuration and must give what the REAL reference gave: every search's root edges in iteration order,
+    priors, visit counts, accumulated rewards, most-visited action, move played and root value, bit for bit -- across Dirichlet
+    noise, move sampling, prior ties, pass rules, resignation, never-resign draws, game ends and restarts."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    n = int(g["board_size"])
+    fl = ("c_puct", "root_epsilon", "root_alpha", "komi", "resign_thres", "never_resign_prob")
+    kw = {k: (float(np.float32(v)) if k in fl else int(v)) for k, v in cfg.items()}
+    m = len(g["move_played"])
+    if name == "mcts_19_r8192":
+        m = 1                       # 8192 rollouts per search: one search keeps the CPU suite short
+    kw["max_searches"] = m
+    r = PortSelfPlay(n).run(**kw)
+    assert len(r["search"]) == m
+    for i in range(m):
+        ne = int(g["n_edges"][i])
+        S = r["search"][i]
+        ctx = "%s search %d" % (name, i)
+        assert S.n_edges == ne, ctx
+        assert np.array_equal(r["coord"][i, :ne], g["coord"][i, :ne].astype(np.int32)), ctx
+        assert np.array_equal(r["visits"][i, :ne], g["visits"][i, :ne]), ctx
+        assert np.array_equal(r["prior"][i, :ne].view(np.uint32), g["prior"][i, :ne].view(np.uint32)), ctx
+        assert np.array_equal(r["reward"][i, :ne].view(np.uint32), g["reward"][i, :ne].view(np.uint32)), ctx
+        assert S.move_played == int(g["move_played"][i]) and S.best_action == int(g["best_action"][i]), ctx
+        assert np.float32(S.root_value) == g["root_value"][i], ctx
