@@ -85,7 +85,19 @@ def cpu_baseline_mcts(n, rollouts_per_batch):
     except Exception as e:
         return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
     if not RefSelfPlay.available(n):
-        return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": "oracle/_ref/libelfsp%d.so not built" % n}
+        # no prebuilt reference here (fresh clone): time the CPU restatement (oracle/mcts_oracle.cc) instead, one core
+        try:
+            from pyoracle import PortSelfPlay
+            rollouts, moves = 1024, 3
+            t0 = time.time()
+            r = PortSelfPlay(n).run(num_games=1, mcts_threads=1, rollouts_per_thread=rollouts, rollouts_per_batch=rollouts_per_batch,
+                                    batchsize=rollouts_per_batch, max_searches=moves, seed=1234)
+            dt = time.time() - t0
+            return {"value": len(r["search"]) * rollouts / dt, "unit": "rollouts/s", "cores": 1, "kind": "port",
+                    "sample": "%d searches of %d rollouts (bs %d) by the single-threaded CPU restatement, stub net included, %.1f s"
+                              % (len(r["search"]), rollouts, rollouts_per_batch, dt)}
+        except Exception as e:
+            return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
     cores = max(1, min(len(os.sched_getaffinity(0)) // 2, 32))
     rollouts, moves = 2048, 2
     r = RefSelfPlay(n).run(num_games=cores, mcts_threads=1, rollouts_per_thread=rollouts, rollouts_per_batch=rollouts_per_batch,
