@@ -328,9 +328,18 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
   }
 };
 
+std::vector<Coord> g_preload;   // GameOptions.preload_sgf as Coords for the following orcsp_run calls
+int g_preload_move_to = -1;
+
 }  // namespace
 
 extern "C" {
+
+// GameOptions.preload_sgf / preload_sgf_move_to (game_selfplay.cc:202-219); n = 0 switches it off
+void orcsp_set_preload(const uint16_t* moves, int n, int move_to) {
+  g_preload.assign(moves, moves + (n > 0 ? n : 0));
+  g_preload_move_to = move_to;
+}
 
 // Self-play of one game slot with one MCTS AI: GoGameSelfPlay::act (elfgames/go/common/game_selfplay.cc:272-430) with
 // init_ai :30-78, mcts_make_diverse_move :80-95, mcts_update_info :97-119, finish_game :121-149, ResignCheck
@@ -351,6 +360,11 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
   std::vector<Coord> moves;                      // GoState::_moves
   size_t next_move_number = 0;                   // MCTSAI_T::nextMoveNumber_
   bool never_resign = false, has_never = false;  // ResignCheck
+  size_t sgf_iter = 0;                           // GoGameSelfPlay::restart :202-219: forward the first preload_sgf_move_to moves
+  for (int i = 0; sgf_iter < g_preload.size() && i < g_preload_move_to; ++i, ++sgf_iter) {
+    if (!orc_forward(st, g_preload[sgf_iter])) { orc_free(st); return -4; }   // "Preload sgf: move not valid!"
+    moves.push_back(g_preload[sgf_iter]);
+  }
   int k = 0;
   while (k < cfg->max_searches) {
     // MCTSAI_T::act: align_state
@@ -414,7 +428,9 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
     const bool resign = !never_resign && !(value >= -1.0 + cfg->resign_thres);
     bool finished = false;
     if (resign && orc_ply(st) >= 50) finished = true;                                  // finish_game(FR_RESIGN) :387-390
+    else if (!g_preload.empty() && sgf_iter >= g_preload.size()) finished = true;      // SGF exhausted: finish_game(FR_MAX_STEP) :392-396
     else {
+      if (!g_preload.empty()) c = g_preload[sgf_iter++];                               // "Move changes from {} to {}" :397-405
       if (!orc_forward(st, c)) { orc_free(st); return -3; }                            // "Something is wrong! Move cannot be applied"
       moves.push_back(c);
       if (orc_terminated(st)) finished = true;                                         // :420-425

@@ -329,6 +329,11 @@ class PortSelfPlay:
         self.L = C.CDLL(os.path.join(HERE, "libgo_oracle%d.so" % n))
         self.L.orcsp_run.restype = C.c_int
 
+    def set_preload(self, moves, move_to=-1):
+        """GameOptions.preload_sgf as Coords for the following run() calls (empty = off)"""
+        mv = np.ascontiguousarray(moves, dtype=np.uint16)
+        self.L.orcsp_set_preload(mv.ctypes.data_as(C.c_void_p), C.c_int(mv.size), C.c_int(move_to))
+
     def run(self, **kw):
         cfg = dict(MCTS_DEFAULTS)
         cfg.update(kw)

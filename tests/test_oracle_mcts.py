@@ -62,7 +62,8 @@ def test_reference_reproduces_fixture(name):
     assert [s.move_played for s in r["search"]] == g["move_played"].tolist()
 
 
-RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_19_resign", "records_19_cutoff"]
+RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
+               "records_19_cutoff"]
 
 
 @pytest.mark.parametrize("name", CASES + RECORD_RUNS)
@@ -80,7 +81,13 @@ def test_restatement_matches_reference_fixture(built, name):
     if name == "mcts_19_r8192":
         m = 1                       # 8192 rollouts per search: one search keeps the CPU suite short
     kw["max_searches"] = m
-    r = PortSelfPlay(n).run(**kw)
+    P = PortSelfPlay(n)
+    if "preload_moves" in g.files:
+        P.set_preload(g["preload_moves"], int(g["preload_move_to"]))
+    try:
+        r = P.run(**kw)
+    finally:
+        P.set_preload([], -1)
     assert len(r["search"]) == m
     for i in range(m):
         ne = int(g["n_edges"][i])
