@@ -327,7 +327,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "metric": "mcts_rollouts_per_sec (self-play, %dx%d Go, %d rollouts/move, bs %d)" % (n, n, args.rollouts, K),
         "value": roll_all / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 search statistics; net %s" % args.net_dtype, "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
                                "persistent tree, %s, %d games per GPU in %d lock-step group(s) pipelined against the net"
                                % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s%s; leaf features %s)"
@@ -335,6 +335,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                      {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl] + (", one HIP graph per net call" if args.net_graph else ""),
                                      feat_fmt)
                                   if net is not None else "NO conv net (--net %s: search kernels only)" % args.net, G, groups),
+                   "search_dtype": "f32 edge statistics (the reference's float), u16 board labels", "net_dtype": args.net_dtype if net is not None else None,
                    "games_per_gpu": G, "board_size": n, "rollouts_per_step": G * K, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
                    "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups,
