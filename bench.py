@@ -241,7 +241,8 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     groups = max(1, args.groups)
     Gg = G // groups
     G = Gg * groups
-    sp = PipelinedSelfPlay(groups=groups, seed=1234 + 1000 * rank, board_size=n, num_games=Gg, device=local_rank,
+    sp = PipelinedSelfPlay(groups=groups, seed=1234, game_idx_base=rank * G, wait_rows=bool(args.wait_rows), board_size=n, num_games=Gg,
+                           device=local_rank,
                            mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1,
                            mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0,
                            policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt)
@@ -308,12 +309,12 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     dt = time.perf_counter() - t0
     sp.timing = False
     my_rollouts = G * K * steps
-    my_rows = int(sum(rows_log[warmup:]))
+    st = sp.stats()
+    my_rows = int(sum(rows_log[warmup:])) if args.wait_rows else int(st["rows"] * steps / max(st["steps"] / groups, 1))
     sel_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_select])) / steps
     exp_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_expand])) / steps
     net_ms = float(np.mean([a.elapsed_time(b) for a, b in sp.t_net])) if sp.t_net else 0.0   # per net call (one group)
     dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
-    st = sp.stats()
     sp.close()
     if rank != 0:
         return None
@@ -424,7 +425,7 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                               feature_format="f16_nhwc" if args.features in ("auto", "f16") else "f32_nchw")
     recs_json = []
     L = elf_amd.lib()
-    opt = SpOptions(n, 1, 1024, 1600, 1, 0.25, 0.03, 0, 30, -1, 0.0, 0.0, 0, 1, 1, 0, MctsOptions(16, 1, 1, 0, 0, 1.5, 7.5, 0, 1, 1))
+    opt = SpOptions(n, 1, 1024, 1600, 1, 0.25, 0.03, 0, 30, -1, 0.0, 0.0, 0, 1, 1, 0, 0, 0, MctsOptions(16, 1, 1, 0, 0, 1.5, 7.5, 0, 1, 1, 1, 0, -1))
     for r in range(R):
         pol = np.zeros((plies, P), np.uint8)                       # policy_distri_training_for_all: one policy per ply
         idx = rng.integers(0, P, size=(plies, 24))
@@ -516,6 +517,7 @@ def main():
     ap.add_argument("--net-graph", type=int, default=1, help="1: replay each group's net call as one HIP graph; 0: eager launches")
     ap.add_argument("--features", choices=["auto", "f32", "f16"], default="auto",
                     help="leaf feature rows: f32 NCHW (reference layout) or f16 channels_last (auto: f16 when the net is fp16)")
+    ap.add_argument("--wait-rows", type=int, default=0, help="1: the host waits for the row count of every step (drop-in path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

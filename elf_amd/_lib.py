@@ -40,7 +40,7 @@ SIGNATURES = {
     "elfmcts_set_d4": (_i, [_vp, _vp, _vp]),
     "elfmcts_dirichlet": (_i, [_vp, _vp, _vp, _f, _vp]),
     "elfmcts_select": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    "elfmcts_expand": (_i, [_vp, _vp, _i64, _vp, _i, _vp]),
+    "elfmcts_expand": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "elfmcts_root": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "elfmcts_advance": (_i, [_vp, _vp, _vp]),
     "elfmcts_node_visits": (_i, [_vp, _vp]),
@@ -50,7 +50,10 @@ SIGNATURES = {
     "elfsp_mcts": (_vp, [_vp]),
     "elfsp_max_rows": (_i, [_vp]),
     "elfsp_begin_step": (_i, [_vp, _vp, _i64, C.POINTER(_i), _vp]),
-    "elfsp_end_step": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "elfsp_end_step": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "elfsp_last_rows": (_i, [_vp, C.POINTER(_i)]),
+    "elfsp_set_request": (_i, [_vp, _i64, _i64, _f, _f, _i]),
+    "elfsp_take_game_starts": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "elfsp_stats": (_i, [_vp, _vp]),
     "elfsp_games_finished": (_i64, [_vp]),
     "elfsp_search_log": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -74,6 +77,10 @@ SIGNATURES = {
     "elfrec_quantise_policy": (_i, [_i, _vp, _vp, _i, _vp]),
     "elfnet_bias_act_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfnet_bias_act_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "elfgo_set_device": (_i, [_i]),
+    "elfgo_pointer_kind": (_i, [_vp, C.POINTER(_i)]),
+    "elfgo_memcpy2d_async": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
+    "elfgo_stream_sync": (_i, [_vp]),
     "elfgo_malloc": (_i, [C.POINTER(_vp), _sz]),
     "elfgo_free": (_i, [_vp]),
     "elfgo_memcpy_h2d": (_i, [_vp, _vp, _sz]),

@@ -227,7 +227,10 @@ extern "C" {
 int elfgo_create(int board_size, int capacity, int device, const uint64_t* zobrist_host, ElfGoEngine** out) {
   if (!out || !zobrist_host || capacity <= 0) return ELFGO_E_BADARG;
   if (board_size != 19 && board_size != 9) return ELFGO_E_BADSIZE;
-  HIPCHK(hipSetDevice(device));
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return ELFGO_E_BADARG;
+  DevGuard _dg(device);   // the caller's current device is restored on return
   ElfGoEngine* e = new (std::nothrow) ElfGoEngine();
   if (!e) return ELFGO_E_NOMEM;
   e->n = board_size; e->capacity = capacity; e->device = device;
@@ -239,6 +242,7 @@ int elfgo_create(int board_size, int capacity, int device, const uint64_t* zobri
 
 int elfgo_destroy(ElfGoEngine* e) {
   if (!e) return ELFGO_E_BADARG;
+  DevGuard _dg(e->device);
   if (e->slots) (void)hipFree(e->slots);
   if (e->sk_hash) (void)hipFree(e->sk_hash);
   if (e->sk_img) (void)hipFree(e->sk_img);
@@ -253,6 +257,7 @@ size_t elfgo_slot_bytes(const ElfGoEngine* e) { return e ? e->slot_bytes : 0; }
 
 int elfgo_sync(ElfGoEngine* e, void* stream) {
   if (!e) return ELFGO_E_BADARG;
+  DevGuard _dg(e->device);
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
@@ -260,7 +265,8 @@ int elfgo_sync(ElfGoEngine* e, void* stream) {
 #define CHECK_N(e, ids, n)                                             \
   if (!(e) || (n) < 0) return ELFGO_E_BADARG;                          \
   if (!(ids) && (n) > (e)->capacity) return ELFGO_E_BADARG;            \
-  if ((n) == 0) return 0;
+  if ((n) == 0) return 0;                                              \
+  DevGuard _dg((e)->device);
 
 int elfgo_reset(ElfGoEngine* e, const int32_t* ids, int n, void* stream) {
   CHECK_N(e, ids, n);
@@ -272,6 +278,7 @@ int elfgo_reset(ElfGoEngine* e, const int32_t* ids, int n, void* stream) {
 int elfgo_copy(ElfGoEngine* e, const int32_t* dst_ids, const int32_t* src_ids, int n, void* stream) {
   if (!e || n < 0 || !dst_ids || !src_ids) return ELFGO_E_BADARG;
   if (n == 0) return 0;
+  DevGuard _dg(e->device);
   DISPATCH(e, hipLaunchKernelGGL(k_copy<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), dst_ids, src_ids, n));
   HIPCHK(hipGetLastError());
   return 0;
@@ -343,6 +350,31 @@ int elfgo_playout(ElfGoEngine* e, const int32_t* ids, const uint64_t* seeds, int
   return 0;
 }
 
+int elfgo_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
+int elfgo_pointer_kind(const void* p, int* device) {
+  if (device) *device = -1;
+  if (!p) return 0;
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();   // an address the runtime does not know is pageable host memory, not an error
+    return 0;
+  }
+  if (at.type == hipMemoryTypeDevice) { if (device) *device = at.device; return 2; }
+  if (at.type == hipMemoryTypeHost) return 1;
+  if (at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeUnified) { if (device) *device = at.device; return 2; }
+  return 0;
+}
+int elfgo_memcpy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, void* stream) {
+  if (rows == 0 || width_bytes == 0) return 0;
+  if (!dst || !src || dst_pitch < width_bytes || src_pitch < width_bytes) return ELFGO_E_BADARG;
+  if (dst_pitch == width_bytes && src_pitch == width_bytes)
+    HIPCHK(hipMemcpyAsync(dst, src, width_bytes * rows, hipMemcpyDefault, (hipStream_t)stream));
+  else
+    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDefault, (hipStream_t)stream));
+  return 0;
+}
+int elfgo_stream_sync(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 int elfgo_malloc(void** dptr, size_t bytes) { HIPCHK(hipMalloc(dptr, bytes)); return 0; }
 int elfgo_free(void* dptr) { HIPCHK(hipFree(dptr)); return 0; }
 int elfgo_memcpy_h2d(void* dst, const void* src_host, size_t bytes) {
@@ -358,8 +390,21 @@ const char* elfgo_error_string(int status) {
   if (status == ELFGO_E_BADARG) return "elfgo: bad argument";
   if (status == ELFGO_E_BADSIZE) return "elfgo: unsupported board size (19 or 9)";
   if (status == ELFGO_E_NOMEM) return "elfgo: out of host memory";
+  if (status <= ELFGO_E_MCTS_BASE && status > ELFGO_E_MCTS_BASE - 32) {
+    // ELFGO_E_MCTS_BASE - (OR of ELFMCTS_E_* bits)
+    static thread_local char buf[320];
+    const int bits = ELFGO_E_MCTS_BASE - status;
+    snprintf(buf, sizeof(buf), "elfmcts:%s%s%s%s%s",
+             (bits & ELFMCTS_E_POOL) ? " node pool of a game exhausted (raise nodes_per_game);" : "",
+             (bits & ELFMCTS_E_ROOT_HASH) ? " TreeSearch::Root state is not the same as the input state;" : "",
+             (bits & ELFMCTS_E_FORWARD) ? " a move could not be applied (illegal move / invalid preload or tree edge);" : "",
+             (bits & ELFMCTS_E_RNG) ? " more D4 draws requested than uploaded;" : "",
+             (bits & ELFMCTS_E_VERSION) ? " model version of a reply and required version are not consistent;" : "");
+    return buf;
+  }
+  if (status < 0) return "elfgo: unknown status";
   return hipGetErrorString((hipError_t)status);
 }
-const char* elfgo_version(void) { return "elf_amd 0.2 (gfx950)"; }
+const char* elfgo_version(void) { return "elf_amd 0.3 (gfx950)"; }
 
 }  // extern "C"

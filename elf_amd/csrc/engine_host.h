@@ -27,6 +27,19 @@ struct ElfGoEngine {
   size_t slot_bytes = 0;
 };
 
+// Every ABI entry that touches the device runs on the engine's device, whatever the calling thread's current device is, and
+// leaves the caller's current device as it found it (several engines on different GPUs may live in one process).
+struct DevGuard {
+  int prev = -1;
+  explicit DevGuard(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+  }
+  ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
+
 #define HIPCHK(x)                         \
   do {                                    \
     hipError_t _e = (x);                  \

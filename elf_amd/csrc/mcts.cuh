@@ -13,6 +13,10 @@
 // sequential fp32 sums (FPU running mean, prior normalisation), virtual loss, duplicate-leaf handling.
 // One documented canonicalisation: leaves of a batch are backed up in first-occurrence order (the reference
 // iterates an unordered_map keyed by heap addresses, tree_search.h:216,245).
+// num_threads = T > 1 (TreeSearchT's thread pool, tree_search.h:345-368): one step runs the batch_rollouts of T search
+// threads back to back on the shared tree -- thread t's K descents see the virtual losses of threads < t, leaves are
+// de-duplicated per thread (traj_counts is per batch_rollouts call), evaluation and backup follow in thread order.  That is
+// one of the interleavings the reference's racing threads can produce; T x num_rollouts_per_thread rollouts per move.
 //
 // HBM layout (sized for 288 GB): per game a pool of C fixed-size node records (12 KiB at 19x19):
 //   [64 B header][368 x 16 B edge stats {prior, reward, visits, vloss}][368 x i32 child][368 x u16 coord][board slot 3840 B]
@@ -26,8 +30,8 @@ namespace elfgo {
 
 enum { NS_NOT_VISITED = 0, NS_EVAL_REQUESTED = 1, NS_VISITED = 2 };   // NodeT::VisitType
 enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2 };
-enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8 };
-constexpr int MCTS_KMAX = 64;   // max rollouts per batch (one lane per unique leaf)
+enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8, MCTS_ERR_VERSION = 16 };
+constexpr int MCTS_KMAX = 64;   // max rollouts per step = num_threads x rollouts_per_batch (one lane per unique leaf)
 
 struct NodeHdr {          // 64 B
   int parent;             // node id, -1 for the root
@@ -40,9 +44,7 @@ struct NodeHdr {          // 64 B
   int status;             // NS_*
   int flip;               // flipQSign_
   int has_state;          // stateType_ == NODE_STATE_SET
-  int alive;
-  int mark;
-  int pad[4];
+  int pad[6];
 };
 static_assert(sizeof(NodeHdr) == 64, "NodeHdr must be 64 bytes");
 
@@ -68,6 +70,8 @@ struct TreeCfg {          // TSOptions / SearchAlgoOptions (tree_search_options.
   int ply_pass_enabled;
   int remove_pass_if_dangerous;
   int rotation_flip;
+  int num_threads;        // TSOptions.num_threads (search threads per game, emulated in sequence)
+  long long required_version;   // MCTSActorParams.required_version (< 0: no check)
 };
 
 struct GameState {        // 64 B per game
@@ -91,7 +95,8 @@ struct LeafRec {          // 32 B
   int d4;
   float value;
   int nn_index;
-  int pad[2];
+  int depth;              // edges between the root and this leaf (length of the trajectory)
+  int pad;
 };
 
 struct RowRec { int game, node, d4, pad; };
@@ -100,6 +105,8 @@ template <int N>
 struct TreePool {
   NodeRec<N>* nodes;      // [G][C]
   int* free_stack;        // [G][C]
+  int* parent_of;         // [G][C] dense copy of NodeHdr.parent for the tree sweeps: -2 free slot, -1 root, else parent id
+  unsigned char* keep;    // [G][C] scratch of treeAdvance (reachable from the next root)
   GameState* gs;          // [G]
   LeafRec* leaves;        // [G][MCTS_KMAX]
   unsigned char* d4buf;   // [G][W]  pre-drawn rng() % 8 of the actor's mt19937 (go/mcts/mcts.h:175-183)
@@ -111,6 +118,9 @@ struct TreePool {
 
 __device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ void mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// monotone float -> u32 key (ascending with the value) and back
+__device__ __forceinline__ u32 f2ukey(float p) { const u32 b = __float_as_uint(p); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ukey2f(u32 k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
 // wave-uniform copy of a node header
 struct HdrU {
@@ -170,34 +180,59 @@ struct TreeSK {
 // tree bookkeeping
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ void node_init(NodeRec<N>* nd, int parent, int parent_edge, float parent_q, int lane) {
+__device__ __forceinline__ void node_init(const TreePool<N>& tp, int g, int id, int parent, int parent_edge, float parent_q, int lane) {
+  NodeRec<N>* nd = tp.game_nodes(g) + id;
   if (lane < 16) {
     int v = 0;
     if (lane == 0) v = parent;
     else if (lane == 1) v = parent_edge;
     else if (lane == 5 || lane == 6) v = __float_as_int(parent_q);   // NodeT ctor: unsignedMeanQ_ = unsignedParentQ_ (:99-103)
-    else if (lane == 10) v = 1;                                        // alive
     reinterpret_cast<int*>(&nd->h)[lane] = v;
   }
+  if (lane == 0) tp.parent_of[(size_t)g * tp.C + id] = parent;
 }
 
-// SearchTreeT::clear (:411-416): every id free, then allocateRoot -> addNode(0.0)
+// wave-wide maximum of a u32 on the DPP network (no LDS crossbar round trips): butterflies inside each 16-lane row
+// (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8), then row_bcast:15 into rows 1/3 and row_bcast:31 into rows 2/3;
+// lane 63 ends up with the maximum over all 64 lanes.  EXEC must be full.
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#define ELF_DPP_MAX(ctrl, rmask)                                                                       \
+  {                                                                                                    \
+    const u32 o = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false);           \
+    v = o > v ? o : v;                                                                                 \
+  }
+  ELF_DPP_MAX(0xB1, 0xf)
+  ELF_DPP_MAX(0x4E, 0xf)
+  ELF_DPP_MAX(0x124, 0xf)
+  ELF_DPP_MAX(0x128, 0xf)
+  ELF_DPP_MAX(0x142, 0xa)
+  ELF_DPP_MAX(0x143, 0xc)
+#undef ELF_DPP_MAX
+  return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// SearchTreeT::clear (:411-416) for game g: every id free, then allocateRoot -> addNode(0.0)
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_clear(TreePool<N> tp) {
-  const int g = blockIdx.x, lane = threadIdx.x;
-  NodeRec<N>* nodes = tp.game_nodes(g);
+__device__ __forceinline__ void tree_clear(const TreePool<N>& tp, int g, int lane) {
   int* fs = tp.free_stack + (size_t)g * tp.C;
+  int* po = tp.parent_of + (size_t)g * tp.C;
   for (int i = lane; i < tp.C; i += 64) {
     fs[i] = tp.C - 1 - i;   // pops hand out 0, 1, 2, ...
-    nodes[i].h.alive = 0;
+    po[i] = -2;
   }
   mem_sync();
-  node_init(&nodes[0], -1, -1, 0.0f, lane);
+  node_init(tp, g, 0, -1, -1, 0.0f, lane);
   if (lane == 0) {
     GameState& s = tp.gs[g];
     s.root = 0; s.free_top = tp.C - 1; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
-    s.node_visits = 0;
+    // node_visits is a lifetime counter (statistics): not reset with the tree
   }
+}
+
+// games == nullptr: game blockIdx.x
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_clear(TreePool<N> tp, const int32_t* games) {
+  tree_clear(tp, games ? games[blockIdx.x] : (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // TreeSearchT::setRootNodeState (tree_search.h:478-493): give the root a copy of the game's state if it
@@ -222,13 +257,15 @@ __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool
 }
 
 // ------------------------------------------------------------------------------------------------
-// select: rollouts_per_batch sequential descents per game (TreeSearchSingleThreadT::batch_rollouts, first half)
+// select: num_threads x rollouts_per_batch sequential descents per game (TreeSearchSingleThreadT::batch_rollouts, first
+// half, once per search thread)
 // ------------------------------------------------------------------------------------------------
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
   using NR = NodeRec<N>;
   constexpr int R = (N * N + 1 + 63) / 64;
   __shared__ Slot<N> lds;
+  __shared__ __attribute__((aligned(16))) float uqs[NR::NE + 16];   // unsigned child Qs of the visited edges, compacted in edge order
   const int g = blockIdx.x, lane = threadIdx.x;
   NR* nodes = tp.game_nodes(g);
   int* fs = tp.free_stack + (size_t)g * tp.C;
@@ -239,15 +276,19 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   const int root_sk_len = rfl((int)nodes[root].board.h.sk_len);
   Board<N> bd;
   bd.init(&lds, pool.zob, nullptr, nullptr);
+  const u64 lt_mask = (1ull << lane) - 1ull;
 
-  // lane u holds the u-th unique leaf of this batch
-  int my_leaf = -1, my_count = 0, my_kind = 0, my_d4 = 0, my_nn = 0;
+  // lane u holds the u-th unique leaf of this step (unique per search thread)
+  int my_leaf = -1, my_count = 0, my_kind = 0, my_d4 = 0, my_nn = 0, my_depth = 0;
   float my_value = 0.0f;
-  int n_unique = 0, n_nn = 0;
+  int n_unique = 0, n_nn = 0, thread_start = 0;
   const float vl_f = (float)cfg.virtual_loss;
   int visited_nodes = 0;
+  const int K = cfg.rollouts_per_batch, KT = K * cfg.num_threads;
 
-  for (int j = 0; j < cfg.rollouts_per_batch; ++j) {
+  for (int j = 0, jk = 0; j < KT; ++j, ++jk) {
+    if (jk == K) jk = 0;
+    if (jk == 0) thread_start = n_unique;   // traj_counts is per batch_rollouts call, i.e. per search thread
     int node = root, depth = 0;
     bool board_in_lds = false;   // LDS holds the state of `node`
     HdrU h;
@@ -279,10 +320,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       if (cfg.unexplored_q_zero || (cfg.root_unexplored_q_zero && depth == 0)) umq = 0.0f;
       const int all_visits = h.num_visits + 1;
       const double sq = all_visits < tp.sqrt_n ? tp.sqrt_tab[all_visits] : sqrt((double)all_visits);
-      float best_s = -__builtin_huge_valf();
-      int best_e = 0x7FFFFFFF;
       float uq[R];
       u64 vmask[R];
+      u32 skey[R];               // monotone key of the edge's score, 0 = not a candidate
+      u32 lmax = 0;
+      int tv = 0;
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         const int e = k * 64 + lane;
@@ -297,28 +339,52 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         const float pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);   // float / int, then * double sqrt, stored to float
         const float score = cfg.use_prior ? __fadd_rn(__fmul_rn(pp, cfg.c_puct), q) : q;
         vmask[k] = __ballot(valid && nvl != 0);                              // !first_visit
-        if (valid && score > best_s) { best_s = score; best_e = e; }         // strict >: first in iteration order wins
+        tv += __popcll(vmask[k]);
+        // strict '>' in iteration order = the lowest edge index among the maxima.  Keys compare like the floats do
+        // (-0.0 == +0.0: canonicalised by + 0.0f; NaN never wins a '>': key 0).
+        skey[k] = (valid && score == score) ? f2ukey(__fadd_rn(score, 0.0f)) : 0u;
+        lmax = skey[k] > lmax ? skey[k] : lmax;
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float os = __shfl_xor(best_s, o, 64);
-        const int oe = __shfl_xor(best_e, o, 64);
-        if (os > best_s || (os == best_s && oe < best_e)) { best_s = os; best_e = oe; }
-      }
-      best_e = rfl(best_e);
-      if (best_e == 0x7FFFFFFF) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
-      // BestAction::addAction :333-347: sequential fp32 sum of unsigned_q over edges that are not first visits
-      float tq = 0.0f;
-      int tv = 0;
+      const u32 kmax = wave_max_u32(lmax);
+      if (kmax == 0) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
+      int best_e = -1;
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        u64 m = vmask[k];
-        while (m) {
-          const int l = (int)__builtin_ctzll(m);
-          m &= m - 1;
-          tq = __fadd_rn(tq, rlf(uq[k], l));
-          ++tv;
+        const u64 b = __ballot(skey[k] == kmax);
+        if (best_e < 0 && b) best_e = k * 64 + (int)__builtin_ctzll(b);
+      }
+      // BestAction::addAction :333-347: sequential fp32 sum of unsigned_q over edges that are not first visits, in edge order
+      float tq = 0.0f;
+      if (tv <= 8) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          u64 m = vmask[k];
+          while (m) {
+            const int l = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            tq = __fadd_rn(tq, rlf(uq[k], l));
+          }
         }
+      } else {
+        // many visited edges (the nodes near the root): compact the values into LDS in edge order, then every lane runs the
+        // dependent chain on broadcast 16-B reads (issued ahead of the adds) instead of one readlane per element.  The tail is
+        // padded with +0.0f: the running sum starts at +0.0f and can never be -0.0f, so x + 0.0f == x bit for bit.
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const u64 m = vmask[k];
+          if ((m >> lane) & 1) uqs[base + __popcll(m & lt_mask)] = uq[k];
+          base += __popcll(m);
+        }
+        if (lane < 4) uqs[tv + lane] = 0.0f;
+        Board<N>::wsync();
+        const float4* u4 = reinterpret_cast<const float4*>(uqs);
+        const int n4 = (tv + 3) >> 2;
+        for (int c = 0; c < n4; ++c) {
+          const float4 q4 = u4[c];
+          tq = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(tq, q4.x), q4.y), q4.z), q4.w);
+        }
+        Board<N>::wsync();
       }
       const float new_umq = __fdiv_rn(__fadd_rn(h.upq, tq), (float)(tv + 1));   // :227-228
       // ---- addVirtualLoss :233-251; chosen edge's child / coord straight from the registers
@@ -339,7 +405,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         if (free_top <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
         child = rfl(fs[free_top - 1]);
         --free_top;
-        node_init(&nodes[child], node, best_e, new_umq, lane);
+        node_init(tp, g, child, node, best_e, new_umq, lane);
         if (lane == 0) nd.child[best_e] = child;
         // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
         bd.load(&nd.board);
@@ -356,8 +422,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       request(node);             // existing children always own a state (created together with the node)
     }
     visited_nodes += depth;
-    // ---- leaf bookkeeping: batch_rollouts :211-233 (requestEvaluation, duplicate leaves)
-    const u64 dup = __ballot(lane < n_unique && my_leaf == node);
+    // ---- leaf bookkeeping: batch_rollouts :211-233 (requestEvaluation, duplicate leaves of THIS thread's batch)
+    const u64 dup = __ballot(lane >= thread_start && lane < n_unique && my_leaf == node);
     if (dup) {
       if (lane == (int)__builtin_ctzll(dup)) ++my_count;
     } else {
@@ -379,7 +445,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         if (lane == 0) nodes[node].h.status = NS_EVAL_REQUESTED;
       }
       if (lane == n_unique) {
-        my_leaf = node; my_count = 1; my_kind = kind; my_d4 = d4; my_value = value; my_nn = n_nn;
+        my_leaf = node; my_count = 1; my_kind = kind; my_d4 = d4; my_value = value; my_nn = n_nn; my_depth = depth;
       }
       ++n_unique;
       if (kind == LK_NN) ++n_nn;
@@ -389,10 +455,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   if (lane < n_unique) {
     LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + lane];
     lr.node = my_leaf; lr.count = my_count; lr.kind = my_kind; lr.d4 = my_d4; lr.value = my_value; lr.nn_index = my_nn;
+    lr.depth = my_depth;
   }
   if (lane == 0) {
     gs.free_top = free_top; gs.rng_pos = rng_pos; gs.n_unique = n_unique; gs.n_nn = n_nn;
-    gs.rollouts_done += cfg.rollouts_per_batch;
+    gs.rollouts_done += KT;
     gs.node_visits += visited_nodes;
     if (err) gs.err |= err;
   }
@@ -402,7 +469,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
 // One wave per (game, unique leaf); the wave of (G-1, 0) also publishes the total row count.
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, void* __restrict__ s_out, int64_t stride, int fmt, RowRec* rowmap,
-                                                       int32_t* counts /* [0]=rows [1]=err-or */) {
+                                                       int32_t* counts /* [0]=rows [1]=err-or [2..3]=u64 running total of rows */) {
   using G = Geo<N>;
   __shared__ u64 hist[HIST][2][G::R];
   __shared__ u64 tpl[18][G::R];
@@ -417,7 +484,11 @@ __global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, voi
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { base += __shfl_xor(base, o, 64); eor |= __shfl_xor(eor, o, 64); }
-  if (last && lane == 0) { counts[0] = base + gs.n_nn; counts[1] = eor; }
+  if (last && lane == 0) {                      // single writer per launch
+    const int rows = base + gs.n_nn;
+    counts[0] = rows; counts[1] = eor;
+    *reinterpret_cast<unsigned long long*>(counts + 2) += (unsigned long long)rows;   // running total (statistics)
+  }
   if (u == 0 && lane == 0) tp.gs[g].row_base = base;
   if (u >= rfl(gs.n_unique)) return;
   const LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + u];
@@ -562,9 +633,6 @@ __device__ __forceinline__ void bitonic_sort512(u64 (&sx)[8], int lane) {
   }
 }
 
-// monotone float -> u32 key (ascending with the value) and back
-__device__ __forceinline__ u32 f2ukey(float p) { const u32 b = __float_as_uint(p); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
-__device__ __forceinline__ float ukey2f(u32 k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
 // The introsort loop of std::sort(pairs, a.second > b.second) over L.key / L.prob [0, n), wave-parallel and exact: the
 // pairing formulation of stl_emul.h (sort_desc_pairing, checked against libstdc++ on the host).  One partition = flags + ranks by
@@ -656,15 +724,22 @@ __device__ unsigned long long g_expand_rowmax[65536];     // per block id: longe
 
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* zob, const RowRec* rowmap, const float* __restrict__ pi,
-                                                     int64_t pi_stride, const float* __restrict__ value, int n_rows, TreeCfg cfg) {
+                                                     int64_t pi_stride, const float* __restrict__ value, const int64_t* __restrict__ rv,
+                                                     int n_rows_host, const int32_t* __restrict__ counts, TreeCfg cfg) {
   using G = Geo<N>;
   using NR = NodeRec<N>;
   constexpr int NA = N * N + 1, R = (NA + 63) / 64;
   __shared__ ExpandLds<N> L;
   const int row = blockIdx.x, lane = threadIdx.x;
+  // n_rows_host < 0: the row count of the last select stays on the device (no host round trip per step); the grid then
+  // covers the maximum and surplus blocks leave here
+  const int n_rows = n_rows_host >= 0 ? n_rows_host : rfl(counts[0]);
   if (row >= n_rows) return;
   const int g = rowmap[row].game, node = rowmap[row].node, d4 = rowmap[row].d4;
   NR& nd = tp.game_nodes(g)[node];
+  // MCTSActor::post_nn_result :210-217: the reply's model version must be the requested one (the reference throws)
+  if (rv != nullptr && cfg.required_version >= 0 && lane == 0 && rv[row] != cfg.required_version)
+    atomicOr(&tp.gs[g].err, MCTS_ERR_VERSION);
 #ifdef ELF_PROFILE_EXPAND
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -828,41 +903,70 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
 }
 
 // ------------------------------------------------------------------------------------------------
-// backup: batch_rollouts :245-259, one wave per game, leaves in first-occurrence order
+// backup: batch_rollouts :245-259, one wave per game, one LANE per unique leaf.
+// The trajectories are walked level by level from the deepest leaf's level up to the root's children, every lane at the
+// ancestor of its leaf on that level (the leaf's depth comes from select, so all lanes sit on the same tree level at the same
+// time).  Lanes whose trajectories have merged (same node) form a group; the edge above the group receives the group's rewards
+// in leaf order -- the order of the serial loop, which for fp32 sums is the result -- by every member running the same
+// readlane chain redundantly; the lowest lane of the group stores.  Visit counts are integers (order-free): one atomic add
+// per group on the parent node.
 // ------------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg) {
   using NR = NodeRec<N>;
   const int g = blockIdx.x, lane = threadIdx.x;
   NR* nodes = tp.game_nodes(g);
-  const GameState& gs = tp.gs[g];
-  const int nu = rfl(gs.n_unique);
-  if (lane != 0) return;   // pointer chase: serial by nature; edge statistics are 16-B records
-  for (int u = 0; u < nu; ++u) {
-    const LeafRec lr = tp.leaves[(size_t)g * MCTS_KMAX + u];
-    NR& leaf = nodes[lr.node];
-    if (lr.kind == LK_TERMINAL) {            // pre_evaluate result -> setEvaluation with an empty pi
-      leaf.h.V = lr.value;
-      leaf.h.flip = leaf.board.h.next_player == S_WHITE;
-      leaf.h.n_edges = 0;
-      leaf.h.status = NS_VISITED;
+  const int nu = rfl(tp.gs[g].n_unique);
+  if (nu == 0) return;
+  const bool have = lane < nu;
+  int c = 0, d = 0, count = 0, kind = LK_REVISIT;
+  float lvalue = 0.0f;
+  if (have) {
+    const LeafRec lr = tp.leaves[(size_t)g * MCTS_KMAX + lane];
+    c = lr.node; d = lr.depth; count = lr.count; kind = lr.kind; lvalue = lr.value;
+  }
+  if (have && kind == LK_TERMINAL) {         // pre_evaluate result -> setEvaluation with an empty pi
+    NR& leaf = nodes[c];
+    leaf.h.V = lvalue;
+    leaf.h.flip = leaf.board.h.next_player == S_WHITE;
+    leaf.h.n_edges = 0;
+    leaf.h.status = NS_VISITED;
+  }
+  mem_sync();                                // a terminal leaf may be another search thread's revisited leaf in this step
+  const float reward = have ? nodes[c].h.V : 0.0f;   // MCTSActor::reward (go/mcts/mcts.h:163-165)
+  const float vsub = (float)(cfg.virtual_loss * count);
+  const int maxd = (int)wave_max_u32((u32)d);
+  for (int lvl = maxd; lvl >= 1; --lvl) {    // updateEdgeStats :253-278 along the trajectories
+    const bool act = have && d >= lvl;
+    const u64 am = __ballot(act);
+    int p = 0, e = 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+      p = nodes[c].h.parent;
+      e = nodes[c].h.parent_edge;
+      s = nodes[p].stat[e];
     }
-    const float reward = leaf.h.V;           // MCTSActor::reward (go/mcts/mcts.h:163-165)
-    const float vsub = (float)(cfg.virtual_loss * lr.count);
-    int c = lr.node;
-    for (;;) {                               // updateEdgeStats :253-278 along the trajectory
-      const int p = nodes[c].h.parent;
-      if (p < 0) break;
-      const int e = nodes[c].h.parent_edge;
-      NR& pn = nodes[p];
-      pn.h.num_visits += 1;
-      float4 s = pn.stat[e];
-      s.y = __fadd_rn(s.y, reward);
-      s.z = __int_as_float(__float_as_int(s.z) + 1);
-      s.w = __fsub_rn(s.w, vsub);
-      pn.stat[e] = s;
-      c = p;
+    bool leader = true;
+    int zc = 0;
+    u64 m = am;
+    while (m) {
+      const int jl = (int)__builtin_ctzll(m);
+      m &= m - 1;
+      const int cj = rl(c, jl);
+      const float rj = rlf(reward, jl), vj = rlf(vsub, jl);
+      if (c == cj) {
+        if (jl < lane) leader = false;
+        s.y = __fadd_rn(s.y, rj);
+        s.w = __fsub_rn(s.w, vj);
+        ++zc;
+      }
     }
+    if (act && leader) {
+      s.z = __int_as_float(__float_as_int(s.z) + zc);
+      nodes[p].stat[e] = s;
+      atomicAdd(&nodes[p].h.num_visits, zc);
+    }
+    if (act) c = p;
   }
 }
 
@@ -925,17 +1029,11 @@ __global__ __launch_bounds__(64) void k_mcts_root(TreePool<N> tp, RootInfo* info
 }
 
 // SearchTreeT::treeAdvance :420-436: the child reached by `move` becomes the root, everything else is freed.
-// Reachability by walking parent links (depth-bounded), then a sweep that pushes dead ids on the free stack.
+// Two launches over the dense parent array (135 KB per game at 33 792 nodes: L2-resident, coalesced):
+//   k_mcts_advance_mark   G x MB waves: keep[id] = the parent chain of id reaches the next root
+//   k_mcts_advance_sweep  one wave per game: dead ids go back on the free stack in id order (deterministic), re-root.
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_advance(TreePool<N> tp, const int32_t* moves) {
-  using NR = NodeRec<N>;
-  const int g = blockIdx.x, lane = threadIdx.x;
-  NR* nodes = tp.game_nodes(g);
-  int* fs = tp.free_stack + (size_t)g * tp.C;
-  GameState& gs = tp.gs[g];
-  const int old_root = rfl(gs.root), mv = rfl(moves[g]);
-  if (mv < 0) return;                        // no move for this game (elfsp_play with a partial move list)
-  const NR& r = nodes[old_root];
+__device__ __forceinline__ int advance_next_root(const NodeRec<N>& r, int mv, int lane) {
   const int n = rfl(r.h.n_edges);
   int next_root = -1;
   for (int base = 0; base < n; base += 64) {
@@ -943,28 +1041,54 @@ __global__ __launch_bounds__(64) void k_mcts_advance(TreePool<N> tp, const int32
     const u64 b = __ballot(i < n && r.coord[i] == mv);
     if (b) next_root = rfl(r.child[base + (int)__builtin_ctzll(b)]);
   }
-  // keep[id]: alive and the parent chain reaches next_root
-  for (int base = 0; base < tp.C; base += 64) {
+  return next_root;
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_advance_mark(TreePool<N> tp, const int32_t* moves, int MB) {
+  const int g = blockIdx.x / MB, part = blockIdx.x % MB, lane = threadIdx.x;
+  const int mv = rfl(moves[g]);
+  if (mv < 0) return;                        // no move for this game (elfsp_play with a partial move list)
+  const NodeRec<N>* nodes = tp.game_nodes(g);
+  const int* po = tp.parent_of + (size_t)g * tp.C;
+  unsigned char* keep = tp.keep + (size_t)g * tp.C;
+  const int next_root = advance_next_root<N>(nodes[rfl(tp.gs[g].root)], mv, lane);
+  const int per = ((tp.C + MB - 1) / MB + 63) & ~63;
+  const int lo = part * per, hi = lo + per < tp.C ? lo + per : tp.C;
+  for (int base = lo; base < hi; base += 64) {
     const int id = base + lane;
-    int keep = 0;
-    if (nodes[id].h.alive) {
-      int a = id;
+    if (id >= hi) continue;
+    int a = id, k = 0;
+    if (po[id] != -2 && next_root >= 0) {
       for (;;) {
-        if (a == next_root) { keep = 1; break; }
-        a = nodes[a].h.parent;
+        if (a == next_root) { k = 1; break; }
+        a = po[a];
         if (a < 0) break;
       }
-      nodes[id].h.mark = keep;
     }
+    keep[id] = (unsigned char)k;
   }
-  mem_sync();
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_advance_sweep(TreePool<N> tp, const int32_t* moves) {
+  using NR = NodeRec<N>;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  NR* nodes = tp.game_nodes(g);
+  int* fs = tp.free_stack + (size_t)g * tp.C;
+  int* po = tp.parent_of + (size_t)g * tp.C;
+  const unsigned char* keep = tp.keep + (size_t)g * tp.C;
+  GameState& gs = tp.gs[g];
+  const int mv = rfl(moves[g]);
+  if (mv < 0) return;
+  int next_root = advance_next_root<N>(nodes[rfl(gs.root)], mv, lane);
   int free_top = rfl(gs.free_top);
   for (int base = 0; base < tp.C; base += 64) {
     const int id = base + lane;
-    const bool dead = nodes[id].h.alive && !nodes[id].h.mark;
+    const bool dead = id < tp.C && po[id] != -2 && !keep[id];
     const u64 b = __ballot(dead);
     if (dead) {
-      nodes[id].h.alive = 0;
+      po[id] = -2;
       fs[free_top + __popcll(b & ((1ull << lane) - 1))] = id;
     }
     free_top += __popcll(b);
@@ -973,10 +1097,11 @@ __global__ __launch_bounds__(64) void k_mcts_advance(TreePool<N> tp, const int32
   if (next_root < 0) {                       // allocateRoot -> addNode(0.0)
     next_root = rfl(fs[free_top - 1]);
     --free_top;
-    node_init(&nodes[next_root], -1, -1, 0.0f, lane);
+    node_init(tp, g, next_root, -1, -1, 0.0f, lane);
   } else if (lane == 0) {
     nodes[next_root].h.parent = -1;
     nodes[next_root].h.parent_edge = -1;
+    po[next_root] = -1;
   }
   if (lane == 0) { gs.root = next_root; gs.free_top = free_top; }
 }

@@ -12,13 +12,15 @@ struct ElfMcts {
   int G = 0, C = 0, W = 0, NE = 0;
   void* nodes = nullptr;
   int* free_stack = nullptr;
+  int* parent_of = nullptr;
+  unsigned char* keep = nullptr;
   GameState* gs = nullptr;
   LeafRec* leaves = nullptr;
   unsigned char* d4buf = nullptr;
   double* sqrt_tab = nullptr;
   int sqrt_n = 0;
   RowRec* rowmap = nullptr;
-  int32_t* all_games = nullptr;
+  int32_t* last_counts = nullptr;   // counts pointer of the last elfmcts_select (device), for elfmcts_expand(n_rows < 0)
   TreeCfg cfg;
   size_t node_bytes = 0;
   int feat_fmt = ELFGO_FEAT_F32_NCHW;
@@ -29,6 +31,8 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   TreePool<N> t;
   t.nodes = reinterpret_cast<NodeRec<N>*>(m->nodes);
   t.free_stack = m->free_stack;
+  t.parent_of = m->parent_of;
+  t.keep = m->keep;
   t.gs = m->gs;
   t.leaves = m->leaves;
   t.d4buf = m->d4buf;
@@ -38,27 +42,11 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   return t;
 }
 
-// per-game variant of k_mcts_clear for a list of games
-template <int N>
-__global__ __launch_bounds__(64) void k_mcts_clear_list(TreePool<N> tp, const int32_t* games) {
-  const int g = games[blockIdx.x], lane = threadIdx.x;
-  NodeRec<N>* nodes = tp.game_nodes(g);
-  int* fs = tp.free_stack + (size_t)g * tp.C;
-  for (int i = lane; i < tp.C; i += 64) {
-    fs[i] = tp.C - 1 - i;
-    nodes[i].h.alive = 0;
-  }
-  mem_sync();
-  node_init(&nodes[0], -1, -1, 0.0f, lane);
-  if (lane == 0) {
-    GameState& s = tp.gs[g];
-    s.root = 0; s.free_top = tp.C - 1; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
-    // node_visits is a lifetime counter (statistics): not reset with the tree
-  }
-}
-
 static int cfg_from(const ElfMctsOptions* o, TreeCfg* c) {
-  if (!o || o->num_rollouts_per_batch <= 0 || o->num_rollouts_per_batch > MCTS_KMAX) return ELFGO_E_BADARG;
+  // one lane per unique leaf of a step: num_threads x num_rollouts_per_batch <= 64 (larger products are rejected, not truncated)
+  if (!o || o->num_rollouts_per_batch <= 0 || o->num_threads <= 0 ||
+      (int64_t)o->num_rollouts_per_batch * o->num_threads > MCTS_KMAX)
+    return ELFGO_E_BADARG;
   c->rollouts_per_batch = o->num_rollouts_per_batch;
   c->virtual_loss = o->virtual_loss;
   c->use_prior = o->use_prior;
@@ -69,6 +57,8 @@ static int cfg_from(const ElfMctsOptions* o, TreeCfg* c) {
   c->ply_pass_enabled = o->ply_pass_enabled;
   c->remove_pass_if_dangerous = o->remove_pass_if_dangerous;
   c->rotation_flip = o->rotation_flip;
+  c->num_threads = o->num_threads;
+  c->required_version = o->required_version;
   return 0;
 }
 
@@ -81,7 +71,7 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
   if (!m) return ELFGO_E_NOMEM;
   int rc = cfg_from(opt, &m->cfg);
   if (rc) { delete m; return rc; }
-  HIPCHK(hipSetDevice(e->device));
+  DevGuard _dg(e->device);
   m->eng = e; m->G = num_games; m->C = nodes_per_game; m->W = d4_window;
   m->node_bytes = e->n == 19 ? sizeof(NodeRec<19>) : sizeof(NodeRec<9>);
   m->NE = e->n == 19 ? NodeRec<19>::NE : NodeRec<9>::NE;
@@ -89,18 +79,14 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
 #define MCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { elfmcts_destroy(m); return (int)_e; } } while (0)
   MCHK(hipMalloc(&m->nodes, G * C * m->node_bytes));
   MCHK(hipMalloc((void**)&m->free_stack, G * C * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->parent_of, G * C * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->keep, G * C));
   MCHK(hipMalloc((void**)&m->gs, G * sizeof(GameState)));
   MCHK(hipMemset(m->gs, 0, G * sizeof(GameState)));
   MCHK(hipMalloc((void**)&m->leaves, G * MCTS_KMAX * sizeof(LeafRec)));
   MCHK(hipMalloc((void**)&m->d4buf, G * (size_t)d4_window));
   MCHK(hipMemset(m->d4buf, 0, G * (size_t)d4_window));
   MCHK(hipMalloc((void**)&m->rowmap, G * MCTS_KMAX * sizeof(RowRec)));
-  MCHK(hipMalloc((void**)&m->all_games, G * sizeof(int32_t)));
-  {
-    std::vector<int32_t> ids(G);
-    for (size_t i = 0; i < G; ++i) ids[i] = (int32_t)i;
-    MCHK(hipMemcpy(m->all_games, ids.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
   // std::sqrt(int) of the reference (tree_search_base.h:153) tabulated with the host libm
   m->sqrt_n = 1 << 17;
   {
@@ -119,14 +105,16 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
 
 int elfmcts_destroy(ElfMcts* m) {
   if (!m) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
   if (m->nodes) (void)hipFree(m->nodes);
   if (m->free_stack) (void)hipFree(m->free_stack);
+  if (m->parent_of) (void)hipFree(m->parent_of);
+  if (m->keep) (void)hipFree(m->keep);
   if (m->gs) (void)hipFree(m->gs);
   if (m->leaves) (void)hipFree(m->leaves);
   if (m->d4buf) (void)hipFree(m->d4buf);
   if (m->sqrt_tab) (void)hipFree(m->sqrt_tab);
   if (m->rowmap) (void)hipFree(m->rowmap);
-  if (m->all_games) (void)hipFree(m->all_games);
   delete m;
   return 0;
 }
@@ -147,14 +135,16 @@ size_t elfmcts_node_bytes(const ElfMcts* m) { return m ? m->node_bytes : 0; }
 int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream) {
   if (!m || n < 0 || n > m->G) return ELFGO_E_BADARG;
   if (n == 0) return 0;
-  const int32_t* list = games ? games : m->all_games;
-  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_clear_list<N>, dim3(n), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), list));
+  if (!games && n != m->G) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_clear<N>, dim3(n), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), games));
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int elfmcts_set_root(ElfMcts* m, const int32_t* board_ids, void* stream) {
   if (!m) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
   DISPATCH(m->eng, {
     hipLaunchKernelGGL((k_mcts_set_root<N, Pool<N>>), dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
                        board_ids);
@@ -165,37 +155,44 @@ int elfmcts_set_root(ElfMcts* m, const int32_t* board_ids, void* stream) {
 
 int elfmcts_set_d4(ElfMcts* m, const uint8_t* d4_host, void* stream) {
   if (!m || !d4_host) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
   HIPCHK(hipMemcpyAsync(m->d4buf, d4_host, (size_t)m->G * m->W, hipMemcpyHostToDevice, (hipStream_t)stream));
   return 0;
 }
 
 int elfmcts_dirichlet(ElfMcts* m, const float* etas, const float* Z, float epsilon, void* stream) {
   if (!m || !etas || !Z) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
   DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_dirichlet<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), etas, Z, epsilon));
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-int elfmcts_select(ElfMcts* m, const int32_t* board_ids, float* s_dst, int64_t stride_floats, int32_t* counts, void* stream) {
-  if (!m || !s_dst || !counts || stride_floats < (int64_t)18 * m->eng->n * m->eng->n) return ELFGO_E_BADARG;
-  const int K = m->cfg.rollouts_per_batch;
+int elfmcts_select(ElfMcts* m, const int32_t* board_ids, void* s_dst, int64_t stride_elems, int32_t* counts, void* stream) {
+  if (!m || !s_dst || !counts || stride_elems < (int64_t)18 * m->eng->n * m->eng->n) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
+  const int KT = m->cfg.rollouts_per_batch * m->cfg.num_threads;
   DISPATCH(m->eng, {
     hipLaunchKernelGGL((k_mcts_select<N, Pool<N>>), dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
                        board_ids, m->cfg);
-    hipLaunchKernelGGL(k_mcts_features<N>, dim3(m->G * K), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), K, s_dst, stride_floats,
+    hipLaunchKernelGGL(k_mcts_features<N>, dim3(m->G * KT), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), KT, s_dst, stride_elems,
                        m->feat_fmt, m->rowmap, counts);
   });
   HIPCHK(hipGetLastError());
+  m->last_counts = counts;
   return 0;
 }
 
-int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const float* value, int n_rows, void* stream) {
-  if (!m || n_rows < 0 || n_rows > m->G * MCTS_KMAX) return ELFGO_E_BADARG;
-  if (n_rows > 0 && (!pi || !value || pi_stride_floats < (int64_t)m->eng->n * m->eng->n + 1)) return ELFGO_E_BADARG;
+int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const float* value, const int64_t* rv, int n_rows, void* stream) {
+  if (!m || n_rows > m->G * MCTS_KMAX) return ELFGO_E_BADARG;
+  if (n_rows < 0 && !m->last_counts) return ELFGO_E_BADARG;
+  if (n_rows != 0 && (!pi || !value || pi_stride_floats < (int64_t)m->eng->n * m->eng->n + 1)) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
+  const int grid = n_rows >= 0 ? n_rows : m->G * m->cfg.rollouts_per_batch * m->cfg.num_threads;
   DISPATCH(m->eng, {
-    if (n_rows > 0)
-      hipLaunchKernelGGL(k_mcts_expand<N>, dim3(n_rows), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (const u64*)m->eng->zob,
-                         (const RowRec*)m->rowmap, pi, pi_stride_floats, value, n_rows, m->cfg);
+    if (grid > 0)
+      hipLaunchKernelGGL(k_mcts_expand<N>, dim3(grid), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (const u64*)m->eng->zob,
+                         (const RowRec*)m->rowmap, pi, pi_stride_floats, value, rv, n_rows, (const int32_t*)m->last_counts, m->cfg);
     hipLaunchKernelGGL(k_mcts_backup<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), m->cfg);
   });
   HIPCHK(hipGetLastError());
@@ -221,6 +218,7 @@ extern "C" int elfprof_expand_rowmax(unsigned long long* out65536) {
 
 int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, float* prior, float* reward, int32_t* child, void* stream) {
   if (!m || !info) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
   static_assert(sizeof(RootInfo) == ELFMCTS_ROOT_WORDS * 4, "RootInfo layout");
   DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_root<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (RootInfo*)info, coord,
                                       visits, prior, reward, child));
@@ -230,6 +228,7 @@ int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, flo
 
 int elfmcts_node_visits(ElfMcts* m, int64_t* out_host) {
   if (!m || !out_host) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
   std::vector<GameState> gs(m->G);
   HIPCHK(hipMemcpy(gs.data(), m->gs, sizeof(GameState) * m->G, hipMemcpyDeviceToHost));
   long long t = 0;
@@ -240,7 +239,15 @@ int elfmcts_node_visits(ElfMcts* m, int64_t* out_host) {
 
 int elfmcts_advance(ElfMcts* m, const int32_t* moves, void* stream) {
   if (!m || !moves) return ELFGO_E_BADARG;
-  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_advance<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), moves));
+  DevGuard _dg(m->eng->device);
+  // enough marking waves to fill the chip whatever the number of games; each covers >= 64 node ids
+  int MB = (2048 + m->G - 1) / m->G;
+  if (MB > m->C / 64) MB = m->C / 64;
+  if (MB < 1) MB = 1;
+  DISPATCH(m->eng, {
+    hipLaunchKernelGGL(k_mcts_advance_mark<N>, dim3(m->G * MB), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), moves, MB);
+    hipLaunchKernelGGL(k_mcts_advance_sweep<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), moves);
+  });
   HIPCHK(hipGetLastError());
   return 0;
 }

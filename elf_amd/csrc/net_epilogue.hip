@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "../../include/elf_amd.h"
+#include "engine_host.h"
 
 namespace {
 
@@ -64,6 +65,10 @@ static int launch_bias_act(void* x, const void* bias, const void* res, int64_t r
   const int64_t n8 = rows * (int64_t)(channels / 8);
   if (n8 == 0) return 0;
   const int c8 = channels / 8;
+  // no handle here: the pass runs on the device that owns x (the caller's stream must belong to it)
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, x) != hipSuccess) { (void)hipGetLastError(); return ELFGO_E_BADARG; }
+  DevGuard _dg(at.device);
   int64_t blocks = (n8 + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;   // 256 CUs x 32 resident waves / 4 waves per block, x4 oversubscription
   dim3 g((unsigned)blocks), b(256);

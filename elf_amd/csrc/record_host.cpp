@@ -202,7 +202,7 @@ inline int Y(int c, int S) { return c / S - 1; }
 SpRecordMeta elfrec_meta_from_options(const ElfSpOptions& o) {
   SpRecordMeta m{};
   m.board_size = o.board_size; m.black_ver = o.model_ver; m.white_ver = -1;   // self-play: one AI plays both colours
-  m.num_threads = 1; m.num_rollouts_per_thread = o.num_rollouts_per_thread; m.num_rollouts_per_batch = o.mcts.num_rollouts_per_batch;
+  m.num_threads = o.mcts.num_threads > 0 ? o.mcts.num_threads : 1; m.num_rollouts_per_thread = o.num_rollouts_per_thread; m.num_rollouts_per_batch = o.mcts.num_rollouts_per_batch;
   m.virtual_loss = o.mcts.virtual_loss; m.persistent_tree = o.persistent_tree != 0; m.use_prior = o.mcts.use_prior != 0;
   m.unexplored_q_zero = o.mcts.unexplored_q_zero != 0; m.root_unexplored_q_zero = o.mcts.root_unexplored_q_zero != 0;
   m.c_puct = o.mcts.c_puct; m.root_epsilon = o.root_epsilon; m.root_alpha = o.root_alpha;

@@ -47,11 +47,11 @@ struct ElfSelfPlay {
   ElfSpOptions opt;
   ElfGoEngine* eng = nullptr;
   ElfMcts* mcts = nullptr;
-  int G = 0, NE = 0, NA = 0, K = 0, steps_per_move = 0, step_in_move = 0, W = 0;
+  int G = 0, NE = 0, NA = 0, K = 0, T = 1, KT = 0, steps_per_move = 0, step_in_move = 0, W = 0;
   hipStream_t stream = nullptr;
   std::vector<SpGame> games;
   // device scratch
-  int32_t* d_counts = nullptr;   // [2]
+  int32_t* d_counts = nullptr;   // [4]: rows, error bits, running total of rows (u64)
   int32_t* d_info = nullptr;     // [G][8]
   int32_t *d_coord = nullptr, *d_visits = nullptr, *d_moves = nullptr, *d_ids = nullptr, *d_binfo = nullptr;
   float *d_prior = nullptr, *d_reward = nullptr, *d_etas = nullptr, *d_Z = nullptr, *d_val = nullptr;
@@ -61,8 +61,14 @@ struct ElfSelfPlay {
   std::vector<float> h_prior, h_reward, h_etas, h_Z, h_val;
   std::vector<uint8_t> h_d4, h_ok;
   int32_t h_counts[2] = {0, 0};
-  int last_rows = 0;
+  int last_rows = 0;             // rows of the last begin_step, -1 = left on the device (begin_step without n_rows)
   bool search_open = false;
+  // request state (MsgRequest, common/record.h): versions + client_ctrl of the current and of a pending request
+  int64_t black_ver = 0, white_ver = -1;
+  bool have_pending = false, pending_async = false, cur_async = false;
+  int64_t pend_black = 0, pend_white = -1;
+  float pend_thres = 0.f, pend_never = 0.f;
+  int game_starts = 0;
   // statistics / capture
   int64_t n_moves = 0, n_games = 0, n_rollouts = 0, n_rows = 0, n_steps = 0;
   double sum_final = 0.0;
@@ -74,6 +80,7 @@ struct ElfSelfPlay {
   std::deque<std::string> records;
   SpRecordMeta meta{};
   std::vector<int32_t> sgf;   // GameOptions.preload_sgf as reference Coords (elfsp_preload)
+  int sgf_move_to = -1;       // GameOptions.preload_sgf_move_to
 };
 
 static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int final_ply) {
@@ -99,10 +106,63 @@ static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int fina
     if (_rc != 0) return _rc;     \
   } while (0)
 
+// GoGameSelfPlay::restart :202-219: forward the first preload_sgf_move_to moves of the preloaded SGF on every (fresh) game board
+static int sp_forward_preload(ElfSelfPlay* sp) {
+  const int G = sp->G, n = (int)sp->sgf.size();
+  int fwd = 0;
+  for (; fwd < n && fwd < sp->sgf_move_to; ++fwd) {            // while (!_sgf_iter.done() && i < preload_sgf_move_to)
+    std::vector<int32_t> mv(G, (int32_t)sp->sgf[fwd]);
+    HIPCHK(hipMemcpyAsync(sp->d_moves, mv.data(), 4 * G, hipMemcpyHostToDevice, sp->stream));
+    SPCHK(elfgo_forward(sp->eng, nullptr, sp->d_moves, G, sp->d_ok, sp->stream));
+    HIPCHK(hipMemcpyAsync(sp->h_ok.data(), sp->d_ok, G, hipMemcpyDeviceToHost, sp->stream));
+    HIPCHK(hipStreamSynchronize(sp->stream));
+    for (int g = 0; g < G; ++g)
+      if (sp->h_ok[g] != 1) return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD;   // "Preload sgf: move not valid!" :211-215
+    for (int g = 0; g < G; ++g) {
+      sp->games[g].ply++;
+      if (sp->opt.keep_records > 0) sp->games[g].rec.moves.push_back((uint16_t)sp->sgf[fwd]);
+    }
+  }
+  for (int g = 0; g < G; ++g) sp->games[g].sgf_iter = fwd;
+  return 0;
+}
+
+// GoGameSelfPlay::OnReceive (game_selfplay.cc:222-270) at a move boundary: new versions -> restart() of every game (board,
+// tree, record, resign check; a fresh MCTS actor seeded with the next draw of the game's generator, init_ai :45-47); same
+// versions (or async) -> only the request (thresholds) changes.
+static int sp_apply_request(ElfSelfPlay* sp) {
+  sp->have_pending = false;
+  const bool same_vers = sp->pend_black == sp->black_ver && sp->pend_white == sp->white_ver;
+  sp->opt.resign_thres = sp->pend_thres;            // (black + white) / 2 with both equal (go_state_ext.h:62-66)
+  sp->opt.never_resign_prob = sp->pend_never;
+  sp->cur_async = sp->pending_async;
+  if (!(same_vers || sp->pending_async)) {
+    const int G = sp->G;
+    SPCHK(elfgo_reset(sp->eng, nullptr, G, sp->stream));
+    SPCHK(elfmcts_clear(sp->mcts, nullptr, G, sp->stream));
+    for (int g = 0; g < G; ++g) {
+      SpGame& gm = sp->games[g];
+      gm.actor_rng.seed(gm.rng());
+      gm.ply = 1; gm.never_resign = false; gm.has_calculated_never_resign = false; gm.last_predicted = 0.0f;
+      gm.seq++; gm.sgf_iter = 0;
+      gm.rec = SpRecord();
+    }
+    if (!sp->sgf.empty()) SPCHK(sp_forward_preload(sp));
+    sp->game_starts++;
+  }
+  sp->black_ver = sp->pend_black; sp->white_ver = sp->pend_white;
+  sp->opt.model_ver = (int32_t)sp->black_ver;
+  sp->meta = elfrec_meta_from_options(sp->opt);
+  sp->opt.mcts.required_version = sp->cur_async ? -1 : sp->black_ver;
+  SPCHK(elfmcts_set_options(sp->mcts, &sp->opt.mcts));
+  return 0;
+}
+
 static int sp_begin_search(ElfSelfPlay* sp) {
   // MCTSAI_T::act -> align_state (mcts.h:141-167) happened at the end of the previous move (treeAdvance) or is a
   // clear when the tree is not persistent; then TreeSearchT::run :410-417
   const int G = sp->G;
+  if (sp->have_pending) SPCHK(sp_apply_request(sp));
   if (!sp->opt.persistent_tree) SPCHK(elfmcts_clear(sp->mcts, nullptr, G, sp->stream));
   SPCHK(elfmcts_set_root(sp->mcts, nullptr, sp->stream));
   SPCHK(elfmcts_root(sp->mcts, sp->d_info, nullptr, nullptr, nullptr, nullptr, nullptr, sp->stream));
@@ -315,7 +375,12 @@ static int sp_finish_move(ElfSelfPlay* sp) {
 extern "C" {
 
 int elfsp_create(const ElfSpOptions* o, int device, const uint64_t* zobrist_host, ElfSelfPlay** out) {
-  if (!o || !out || !zobrist_host || o->num_games <= 0 || o->num_rollouts_per_thread <= 0) return ELFGO_E_BADARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return ELFGO_E_BADARG;
+  DevGuard _dg(device);
+  if (!o || !out || !zobrist_host || o->num_games <= 0 || o->num_rollouts_per_thread <= 0 || o->mcts.num_threads <= 0 ||
+      o->mcts.num_rollouts_per_batch <= 0)
+    return ELFGO_E_BADARG;
   ElfSelfPlay* sp = new (std::nothrow) ElfSelfPlay();
   if (!sp) return ELFGO_E_NOMEM;
   sp->opt = *o;
@@ -323,22 +388,31 @@ int elfsp_create(const ElfSpOptions* o, int device, const uint64_t* zobrist_host
   int rc = elfgo_create(o->board_size, G, device, zobrist_host, &sp->eng);
   if (rc) { delete sp; return rc; }
   sp->K = o->mcts.num_rollouts_per_batch;
-  sp->steps_per_move = (o->num_rollouts_per_thread + sp->K - 1) / sp->K;   // for (idx = 0; idx < num_rollout; idx += batch) tree_search.h:112-117
-  sp->W = sp->steps_per_move * sp->K;
+  sp->T = o->mcts.num_threads;
+  sp->KT = sp->K * sp->T;
+  sp->steps_per_move = (o->num_rollouts_per_thread + sp->K - 1) / sp->K;   // for (idx = 0; idx < num_rollout; idx += batch) tree_search.h:112-117, in every search thread
+  sp->W = sp->steps_per_move * sp->KT;
+  sp->black_ver = o->model_ver; sp->white_ver = -1;
   rc = elfmcts_create(sp->eng, G, o->nodes_per_game, sp->W, &o->mcts, &sp->mcts);
   if (rc) { elfgo_destroy(sp->eng); delete sp; return rc; }
   sp->G = G; sp->NE = elfmcts_edge_stride(sp->mcts); sp->NA = o->board_size * o->board_size + 1;
   sp->games.resize(G);
+  const uint64_t now_ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(
+                              std::chrono::system_clock::now().time_since_epoch()).count();
   for (int g = 0; g < G; ++g) {
-    // GoGameBase ctor: _rng.seed(options.seed) (game_base.h:32-38); restart() -> init_ai: params.seed = _rng() (game_selfplay.cc:47)
-    const uint32_t seed = o->seed + (G > 1 ? (uint32_t)g : 0u);
-    sp->games[g].rng.seed(seed);
+    // GoGameBase ctor: _rng.seed(_seed) (game_base.h:32-38); restart() -> init_ai: params.seed = _rng() (game_selfplay.cc:47).
+    // Per-game seed rule: include/elf_amd.h (ElfSpOptions).
+    const uint64_t gi = (uint64_t)(uint32_t)(o->game_idx_base + g);
+    uint64_t seed;
+    if (o->seed != 0) seed = (uint64_t)o->seed + gi;
+    else seed = ((now_ms / 1000) * 1000 + now_ms + (uint64_t)(int)(gi ^ o->job_hash) * 2341479ull) % 100000000ull;
+    sp->games[g].rng.seed((std::mt19937::result_type)seed);
     const uint64_t aseed = sp->games[g].rng();
     sp->games[g].actor_rng.seed(aseed);
   }
 #define A(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { elfsp_destroy(sp); return (int)_e; } } while (0)
   const size_t GE = (size_t)G * sp->NE;
-  A(sp->d_counts, 8); A(sp->d_info, sizeof(int32_t) * G * ELFMCTS_ROOT_WORDS);
+  A(sp->d_counts, 16); A(sp->d_info, sizeof(int32_t) * G * ELFMCTS_ROOT_WORDS);
   A(sp->d_coord, 4 * GE); A(sp->d_visits, 4 * GE); A(sp->d_prior, 4 * GE); A(sp->d_reward, 4 * GE); A(sp->d_etas, 4 * GE);
   A(sp->d_Z, 4 * G); A(sp->d_moves, 4 * G); A(sp->d_ids, 4 * G); A(sp->d_val, 4 * G); A(sp->d_ok, G);
   A(sp->d_binfo, sizeof(int32_t) * G * ELFGO_INFO_WORDS);
@@ -346,6 +420,7 @@ int elfsp_create(const ElfSpOptions* o, int device, const uint64_t* zobrist_host
   sp->h_info.resize(G * ELFMCTS_ROOT_WORDS); sp->h_coord.resize(GE); sp->h_visits.resize(GE); sp->h_prior.resize(GE);
   sp->h_reward.resize(GE); sp->h_etas.assign(GE, 0.f); sp->h_Z.resize(G); sp->h_moves.resize(G); sp->h_val.resize(G);
   sp->h_ok.resize(G); sp->h_binfo.resize(G * ELFGO_INFO_WORDS); sp->h_d4.resize((size_t)G * sp->W);
+  if (hipMemset(sp->d_counts, 0, 16) != hipSuccess) { elfsp_destroy(sp); return ELFGO_E_NOMEM; }
   sp->log_cap = o->log_searches;
   sp->meta = elfrec_meta_from_options(*o);
   *out = sp;
@@ -354,6 +429,7 @@ int elfsp_create(const ElfSpOptions* o, int device, const uint64_t* zobrist_host
 
 int elfsp_destroy(ElfSelfPlay* sp) {
   if (!sp) return ELFGO_E_BADARG;
+  DevGuard _dg(sp->eng ? sp->eng->device : 0);
   void* ptrs[] = {sp->d_counts, sp->d_info, sp->d_coord, sp->d_visits, sp->d_prior, sp->d_reward, sp->d_etas, sp->d_Z,
                   sp->d_moves, sp->d_ids, sp->d_val, sp->d_ok, sp->d_binfo};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -365,13 +441,18 @@ int elfsp_destroy(ElfSelfPlay* sp) {
 
 ElfGoEngine* elfsp_engine(ElfSelfPlay* sp) { return sp ? sp->eng : nullptr; }
 ElfMcts* elfsp_mcts(ElfSelfPlay* sp) { return sp ? sp->mcts : nullptr; }
-int elfsp_max_rows(const ElfSelfPlay* sp) { return sp ? sp->G * sp->K : ELFGO_E_BADARG; }
+int elfsp_max_rows(const ElfSelfPlay* sp) { return sp ? sp->G * sp->KT : ELFGO_E_BADARG; }
 
-int elfsp_begin_step(ElfSelfPlay* sp, float* s_dst, int64_t stride_floats, int* n_rows, void* stream) {
-  if (!sp || !s_dst || !n_rows) return ELFGO_E_BADARG;
+int elfsp_begin_step(ElfSelfPlay* sp, void* s_dst, int64_t stride_elems, int* n_rows, void* stream) {
+  if (!sp || !s_dst) return ELFGO_E_BADARG;
+  DevGuard _dg(sp->eng->device);
   sp->stream = (hipStream_t)stream;
   if (!sp->search_open) SPCHK(sp_begin_search(sp));
-  SPCHK(elfmcts_select(sp->mcts, nullptr, s_dst, stride_floats, sp->d_counts, sp->stream));
+  SPCHK(elfmcts_select(sp->mcts, nullptr, s_dst, stride_elems, sp->d_counts, sp->stream));
+  if (!n_rows) {          // row count and error word stay on the device until the move boundary
+    sp->last_rows = -1;
+    return 0;
+  }
   HIPCHK(hipMemcpyAsync(sp->h_counts, sp->d_counts, 8, hipMemcpyDeviceToHost, sp->stream));
   HIPCHK(hipStreamSynchronize(sp->stream));
   if (sp->h_counts[1]) return ELFGO_E_MCTS_BASE - sp->h_counts[1];
@@ -380,21 +461,51 @@ int elfsp_begin_step(ElfSelfPlay* sp, float* s_dst, int64_t stride_floats, int* 
   return 0;
 }
 
-int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, void* stream) {
+int elfsp_last_rows(ElfSelfPlay* sp, int* n_rows) {
+  if (!sp || !n_rows) return ELFGO_E_BADARG;
+  DevGuard _dg(sp->eng->device);
+  HIPCHK(hipMemcpyAsync(sp->h_counts, sp->d_counts, 8, hipMemcpyDeviceToHost, sp->stream));
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  if (sp->h_counts[1]) return ELFGO_E_MCTS_BASE - sp->h_counts[1];
+  *n_rows = sp->h_counts[0];
+  return 0;
+}
+
+int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, const int64_t* rv, void* stream) {
   if (!sp || !sp->search_open) return ELFGO_E_BADARG;
+  DevGuard _dg(sp->eng->device);
   sp->stream = (hipStream_t)stream;
-  SPCHK(elfmcts_expand(sp->mcts, pi, pi_stride_floats, value, sp->last_rows, sp->stream));
-  sp->n_rows += sp->last_rows;
-  sp->n_rollouts += (int64_t)sp->G * sp->K;
+  SPCHK(elfmcts_expand(sp->mcts, pi, pi_stride_floats, value, rv, sp->last_rows, sp->stream));
+  sp->n_rollouts += (int64_t)sp->G * sp->KT;
   sp->n_steps++;
   if (++sp->step_in_move >= sp->steps_per_move) SPCHK(sp_finish_move(sp));
   return 0;
+}
+
+int elfsp_set_request(ElfSelfPlay* sp, int64_t black_ver, int64_t white_ver, float resign_thres, float never_resign_prob, int async) {
+  if (!sp || black_ver < 0) return ELFGO_E_BADARG;     // black_ver < 0 is the reference's "wait" request: nothing to play
+  if (white_ver >= 0) return ELFGO_E_BADARG;           // second AI for White: not supported (out of scope)
+  sp->have_pending = true;
+  sp->pend_black = black_ver; sp->pend_white = white_ver;
+  sp->pend_thres = resign_thres; sp->pend_never = never_resign_prob;
+  sp->pending_async = async != 0;
+  return 0;
+}
+
+int elfsp_take_game_starts(ElfSelfPlay* sp, int64_t* black_ver, int64_t* white_ver) {
+  if (!sp) return ELFGO_E_BADARG;
+  const int n = sp->game_starts;
+  sp->game_starts = 0;
+  if (black_ver) *black_ver = sp->black_ver;
+  if (white_ver) *white_ver = sp->white_ver;
+  return n;
 }
 
 // the human half of GoGameSelfPlay::act (game_selfplay.cc:290-330): an externally chosen move is forwarded on the game board,
 // the tree follows at the next search (MCTSAI_T::align_state -> advanceMoves, mcts.h:141-167).  moves_host[g] < 0 = no move.
 int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream) {
   if (!sp || !moves_host || sp->search_open) return ELFGO_E_BADARG;
+  DevGuard _dg(sp->eng->device);
   sp->stream = (hipStream_t)stream;
   const int G = sp->G;
   std::vector<int32_t> ids, mv;
@@ -435,30 +546,17 @@ int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream) {
 // (:392-405) and the game is finished (FR_MAX_STEP) by the search that finds the list exhausted.
 int elfsp_preload(ElfSelfPlay* sp, const uint16_t* moves_host, int n, int move_to, void* stream) {
   if (!sp || n < 0 || (n > 0 && !moves_host) || sp->search_open || sp->n_moves != 0) return ELFGO_E_BADARG;
+  DevGuard _dg(sp->eng->device);
   sp->stream = (hipStream_t)stream;
   sp->sgf.assign(moves_host, moves_host + n);
-  const int G = sp->G;
-  int fwd = 0;
-  for (; fwd < n && fwd < move_to; ++fwd) {            // while (!_sgf_iter.done() && i < preload_sgf_move_to)
-    std::vector<int32_t> mv(G, (int32_t)sp->sgf[fwd]);
-    HIPCHK(hipMemcpyAsync(sp->d_moves, mv.data(), 4 * G, hipMemcpyHostToDevice, sp->stream));
-    SPCHK(elfgo_forward(sp->eng, nullptr, sp->d_moves, G, sp->d_ok, sp->stream));
-    HIPCHK(hipMemcpyAsync(sp->h_ok.data(), sp->d_ok, G, hipMemcpyDeviceToHost, sp->stream));
-    HIPCHK(hipStreamSynchronize(sp->stream));
-    for (int g = 0; g < G; ++g)
-      if (sp->h_ok[g] != 1) return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD;   // "Preload sgf: move not valid!" :211-215
-    for (int g = 0; g < G; ++g) {
-      sp->games[g].ply++;
-      if (sp->opt.keep_records > 0) sp->games[g].rec.moves.push_back(sp->sgf[fwd]);
-    }
-  }
-  for (int g = 0; g < G; ++g) sp->games[g].sgf_iter = fwd;
-  return 0;
+  sp->sgf_move_to = move_to;
+  return sp_forward_preload(sp);
 }
 
 // finish_game(FR_CLEAR) + restart (game_selfplay.cc:121-149,302-307): the listed games start over from the empty board
 int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* stream) {
   if (!sp || n < 0 || n > sp->G || (n > 0 && !games_host) || sp->search_open) return ELFGO_E_BADARG;
+  DevGuard _dg(sp->eng->device);
   if (n == 0) return 0;
   sp->stream = (hipStream_t)stream;
   for (int j = 0; j < n; ++j) if (games_host[j] < 0 || games_host[j] >= sp->G) return ELFGO_E_BADARG;
@@ -503,7 +601,11 @@ int64_t elfsp_games_finished(const ElfSelfPlay* sp) { return sp ? sp->n_games : 
 
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out) {
   if (!sp || !out) return ELFGO_E_BADARG;
-  SPCHK(elfmcts_node_visits(sp->mcts, &out[8]));
+  DevGuard _dg(sp->eng->device);
+  SPCHK(elfmcts_node_visits(sp->mcts, &out[8]));      // synchronises the device
+  uint64_t total_rows = 0;
+  HIPCHK(hipMemcpy(&total_rows, sp->d_counts + 2, 8, hipMemcpyDeviceToHost));
+  sp->n_rows = (int64_t)total_rows;
   out[0] = sp->n_moves; out[1] = sp->n_games; out[2] = sp->n_rollouts; out[3] = sp->n_rows; out[4] = sp->n_steps;
   out[5] = (int64_t)sp->log_search.size(); out[6] = sp->steps_per_move; out[7] = sp->step_in_move;
   return 0;

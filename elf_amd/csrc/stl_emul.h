@@ -23,7 +23,7 @@
 #include <vector>
 #endif
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define STL_HD __host__ __device__ __forceinline__
 #else
 #define STL_HD static inline

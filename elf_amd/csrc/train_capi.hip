@@ -31,7 +31,7 @@ int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_polici
   r->P = (e->n + 2) * (e->n + 2);
   ReplayStore& st = r->st;
   st.capacity = capacity; st.max_moves = max_moves;
-  HIPCHK(hipSetDevice(e->device));
+  DevGuard _dg(e->device);
   const size_t cm = (size_t)capacity * max_moves;
 #define A(ptr, bytes) do { hipError_t _e = hipMalloc((void**)&(ptr), (bytes)); if (_e != hipSuccess) { elftrain_destroy(r); return (int)_e; } \
                            _e = hipMemset((ptr), 0, (bytes)); if (_e != hipSuccess) { elftrain_destroy(r); return (int)_e; } } while (0)
@@ -49,6 +49,7 @@ int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_polici
 
 int elftrain_destroy(ElfReplay* r) {
   if (!r) return ELFGO_E_BADARG;
+  DevGuard _dg(r->eng->device);
   void* ptrs[] = {r->st.moves, r->st.num_moves, r->st.winner, r->st.black_ver, r->st.pol, r->st.num_pol, r->st.values, r->st.num_values};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete r;
@@ -65,6 +66,7 @@ int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_mov
   if ((num_moves > 0 && !moves_host) || num_policies < 0 || num_policies > r->st.max_moves || num_values < 0 ||
       num_values > r->st.max_moves) return ELFGO_E_BADARG;
   if ((num_policies > 0 && (!policies_host || !r->st.pol)) || (num_values > 0 && !values_host)) return ELFGO_E_BADARG;
+  DevGuard _dg(r->eng->device);
   ReplayStore& st = r->st;
   const size_t base = (size_t)slot * st.max_moves;
   if (num_moves) HIPCHK(hipMemcpy(st.moves + base, moves_host, sizeof(u16) * num_moves, hipMemcpyHostToDevice));
@@ -91,6 +93,7 @@ int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec_dev,
   bool any = false;
   for (int32_t s : r->filled) any = any || r->h_num_moves[s] > num_future_actions - 1;
   if (!any) return ELFGO_E_BADARG;
+  DevGuard _dg(r->eng->device);
   r->h_draw.resize((size_t)3 * n);
   for (int i = 0; i < n; ++i) {
     int32_t slot;
@@ -110,6 +113,7 @@ int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec_dev,
 int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, const int32_t* d4, int n, const ElfTrainBatch* b, void* stream) {
   if (!r || !rec || !move_to || !b || n < 0 || n > r->eng->capacity) return ELFGO_E_BADARG;
   if (n == 0) return 0;
+  DevGuard _dg(r->eng->device);
   const int nn = r->eng->n;
   if (!b->s || b->s_stride < (int64_t)18 * nn * nn || (b->s_format != ELFGO_FEAT_F32_NCHW && b->s_format != ELFGO_FEAT_F16_NHWC)) return ELFGO_E_BADARG;
   if (b->offline_a && b->num_future_actions < 1) return ELFGO_E_BADARG;

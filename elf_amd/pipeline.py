@@ -1,7 +1,18 @@
-"""Two lock-step game groups pipelined over two HIP streams: while the net evaluates the leaves of one group
-(stream `net`), the other group's expand/backup/select/feature kernels run on stream `search`.  This is the
-device-side analogue of the reference's double-buffered batches (`num_recv = 2` SharedMem per actor group,
-src_py/elfgames/go/game.py:428, src_py/elf/utils_elf.py:82-97): the net never waits for the search.
+"""Lock-step game groups pipelined against the net: while the net evaluates the leaves of one group (stream `net`), the other
+groups' expand/backup/select/feature kernels run on their own streams.  This is the device-side analogue of the reference's
+double-buffered batches (`num_recv = 2` SharedMem per actor group, src_py/elfgames/go/game.py:428,
+src_py/elf/utils_elf.py:82-97).
+
+Per group i and step, in stream order:
+    search[i]:  wait(net done i) -> expand + backup (end_step) -> select + leaf features (begin_step) -> record(sel i)
+    net:        wait(sel i) -> net(s_i) -> record(net done i)
+so a group's search work never sits between two net calls of the net stream, and the net stream only ever waits for the features
+of the group it is about to evaluate.  With wait_rows=False (default) no host synchronisation happens inside a move: the row count
+of a step stays on the device (elfsp_begin_step with n_rows = NULL), the net evaluates the fixed-shape tensor, the expansion kernel
+reads the count.  Host work remains at move boundaries (Dirichlet draws, move choice, records).
+
+Seeds: every group gets the same GameOptions.seed and a distinct game_idx_base, so game g of group i is the job-wide game
+game_idx_base + i * num_games + g of the per-game seed rule (include/elf_amd.h, ElfSpOptions).
 """
 import torch
 
@@ -9,48 +20,58 @@ from .selfplay import SelfPlay
 
 
 class PipelinedSelfPlay:
-    def __init__(self, groups=2, seed=0, **kw):
-        self.groups = [SelfPlay(seed=seed + 7919 * i if seed else 0, **kw) for i in range(groups)]
+    def __init__(self, groups=2, seed=0, game_idx_base=0, wait_rows=False, **kw):
+        ng = int(kw["num_games"])
+        self.groups = [SelfPlay(seed=seed, game_idx_base=game_idx_base + i * ng, **kw) for i in range(groups)]
         dev = self.groups[0].device
         self.device = dev
-        self.search_stream = torch.cuda.Stream(device=dev)
+        self.wait_rows = bool(wait_rows)
+        self.search_streams = [torch.cuda.Stream(device=dev) for _ in range(groups)]
         self.net_stream = torch.cuda.Stream(device=dev)
+        self._ev_sel = [None] * groups
         self._rows = [0] * groups
         self._primed = False
         self.num_games = sum(g.num_games for g in self.groups)
         self.timing = False
-        self.t_select, self.t_expand = [], []   # (start, end) HIP event pairs on the search stream
+        self.t_select, self.t_expand = [], []   # (start, end) HIP event pairs on the groups' search streams
         self.t_net = []                         # (start, end) pairs around the net callback on the net stream
 
     def close(self):
         for g in self.groups:
             g.close()
 
+    def _pair(self):
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     def _begin(self, i):
-        with torch.cuda.stream(self.search_stream):
+        st = self.search_streams[i]
+        with torch.cuda.stream(st):
             if self.timing:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(self.search_stream)
-            self._rows[i] = self.groups[i].begin_step()     # select + features on `search`; host waits for the row count
+                e0, e1 = self._pair()
+                e0.record(st)
+            self._rows[i] = self.groups[i].begin_step(wait_rows=self.wait_rows)   # select + features
             if self.timing:
-                e1.record(self.search_stream)
+                e1.record(st)
                 self.t_select.append((e0, e1))
+            ev = torch.cuda.Event()
+            ev.record(st)                       # right behind this group's feature kernel
+            self._ev_sel[i] = ev
 
     def step(self, net_fn):
-        """One batch for every group. net_fn(s_tensor, rows) -> (pi, V) is enqueued on the net stream."""
-        if not self._primed:
-            self._begin(0)
-            self._primed = True
+        """One batch for every group. net_fn(s_tensor, rows) -> (pi, V) is enqueued on the net stream; rows is None when the
+        count stays on the device.  Returns the number of net rows of the step (None with wait_rows=False)."""
         n = len(self.groups)
+        if not self._primed:
+            for i in range(n):
+                self._begin(i)
+            self._primed = True
         total = 0
         for i in range(n):
             g = self.groups[i]
-            ev_sel = torch.cuda.Event()
-            ev_sel.record(self.search_stream)
             with torch.cuda.stream(self.net_stream):
-                self.net_stream.wait_event(ev_sel)          # features of group i are in g.s
+                self.net_stream.wait_event(self._ev_sel[i])          # features of group i are in g.s
                 if self.timing:
-                    n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    n0, n1 = self._pair()
                     n0.record(self.net_stream)
                 pi, v = net_fn(g.s, self._rows[i])
                 if self.timing:
@@ -58,24 +79,28 @@ class PipelinedSelfPlay:
                     self.t_net.append((n0, n1))
                 ev_net = torch.cuda.Event()
                 ev_net.record(self.net_stream)
-            # next group's select overlaps this group's net
-            self._begin((i + 1) % n) if n > 1 else None
-            with torch.cuda.stream(self.search_stream):
-                self.search_stream.wait_event(ev_net)
+            st = self.search_streams[i]
+            with torch.cuda.stream(st):
+                st.wait_event(ev_net)
                 if self.timing:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(self.search_stream)
-                g.end_step(pi, v)                           # expand + backup of group i
+                    e0, e1 = self._pair()
+                    e0.record(st)
+                g.end_step(pi, v)                                    # expand + backup of group i (+ the move boundary)
                 if self.timing:
-                    e1.record(self.search_stream)
+                    e1.record(st)
                     self.t_expand.append((e0, e1))
                 if pi is not None:
-                    pi.record_stream(self.search_stream)
-                    v.record_stream(self.search_stream)
-            total += self._rows[i]
-            if n == 1:
-                self._begin(0)
-        return total
+                    pi.record_stream(st)
+                    v.record_stream(st)
+            if self._rows[i] is not None:
+                total += self._rows[i]
+            self._begin(i)                                           # next step's select, behind the expansion on the same stream
+        return total if self.wait_rows else None
+
+    def synchronize(self):
+        for st in self.search_streams:
+            st.synchronize()
+        self.net_stream.synchronize()
 
     def stats(self):
         out = {}
@@ -83,4 +108,5 @@ class PipelinedSelfPlay:
             for k, v in g.stats().items():
                 out[k] = out.get(k, 0) + v
         out["steps_per_move"] = self.groups[0].stats()["steps_per_move"]
+        out["step_in_move"] = self.groups[0].stats()["step_in_move"]
         return out

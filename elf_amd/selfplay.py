@@ -21,7 +21,8 @@ class MctsOptions(C.Structure):
     _fields_ = [("num_rollouts_per_batch", C.c_int32), ("virtual_loss", C.c_int32), ("use_prior", C.c_int32),
                 ("unexplored_q_zero", C.c_int32), ("root_unexplored_q_zero", C.c_int32), ("c_puct", C.c_float),
                 ("komi", C.c_float), ("ply_pass_enabled", C.c_int32), ("remove_pass_if_dangerous", C.c_int32),
-                ("rotation_flip", C.c_int32)]
+                ("rotation_flip", C.c_int32), ("num_threads", C.c_int32), ("reserved0", C.c_int32),
+                ("required_version", C.c_int64)]
 
 
 class SpOptions(C.Structure):
@@ -31,13 +32,20 @@ class SpOptions(C.Structure):
                 ("root_alpha", C.c_float), ("seed", C.c_uint32), ("policy_distri_cutoff", C.c_int32),
                 ("move_cutoff", C.c_int32), ("resign_thres", C.c_float), ("never_resign_prob", C.c_float),
                 ("log_searches", C.c_int32), ("keep_records", C.c_int32), ("policy_distri_training_for_all", C.c_int32),
-                ("model_ver", C.c_int32), ("mcts", MctsOptions)]
+                ("model_ver", C.c_int32), ("game_idx_base", C.c_int32), ("job_hash", C.c_uint64), ("mcts", MctsOptions)]
 
 
 class SpSearch(C.Structure):
     """ElfSpSearch"""
     _fields_ = [("game", C.c_int32), ("move_played", C.c_int32), ("best_action", C.c_int32), ("total_visits", C.c_int32),
                 ("n_edges", C.c_int32), ("root_value", C.c_float), ("max_score", C.c_float), ("predicted_value", C.c_float)]
+
+
+def job_hash(job_id):
+    """64-bit hash of ContextOptions.job_id for the seed == 0 rule (the reference uses std::hash<std::string>; any stable
+    64-bit hash serves: the seeds of that rule are time-based anyway)"""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b((job_id or "").encode(), digest_size=8).digest(), "little")
 
 
 STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_per_move", "step_in_move", "node_visits")
@@ -51,7 +59,8 @@ class SelfPlay:
                  mcts_alpha=0.0, mcts_unexplored_q_zero=False, mcts_root_unexplored_q_zero=False, komi=7.5,
                  ply_pass_enabled=0, policy_distri_cutoff=0, move_cutoff=-1, resign_thres=0.0, never_resign_prob=0.0,
                  seed=0, nodes_per_game=None, log_searches=0, rotation_flip=True, remove_pass_if_dangerous=True,
-                 feature_format="f32_nchw", keep_records=0, policy_distri_training_for_all=False, model_ver=0):
+                 feature_format="f32_nchw", keep_records=0, policy_distri_training_for_all=False, model_ver=0,
+                 mcts_threads=1, game_idx_base=0, job_id="", required_version=-1):
         if not torch.cuda.is_available():
             raise RuntimeError("elf_amd.SelfPlay needs a ROCm GPU (no CPU fallback exists)")
         self.L = _lib.lib()
@@ -61,14 +70,15 @@ class SelfPlay:
         self.num_action = self.n * self.n + 1
         if nodes_per_game is None:
             # one node per rollout of the current search + the subtree kept from the previous ones
-            nodes_per_game = 4 * mcts_rollout_per_thread + 1024
+            nodes_per_game = 4 * mcts_rollout_per_thread * mcts_threads + 1024
         nodes_per_game = (int(nodes_per_game) + 63) // 64 * 64
         mo = MctsOptions(mcts_rollout_per_batch, mcts_virtual_loss, int(mcts_use_prior), int(mcts_unexplored_q_zero),
                          int(mcts_root_unexplored_q_zero), mcts_puct, komi, ply_pass_enabled, int(remove_pass_if_dangerous),
-                         int(rotation_flip))
+                         int(rotation_flip), int(mcts_threads), 0, int(required_version))
         self.opt = SpOptions(self.n, self.num_games, nodes_per_game, mcts_rollout_per_thread, int(mcts_persistent_tree),
                              mcts_epsilon, mcts_alpha, seed, policy_distri_cutoff, move_cutoff, resign_thres, never_resign_prob,
-                             log_searches, int(keep_records), int(policy_distri_training_for_all), int(model_ver), mo)
+                             log_searches, int(keep_records), int(policy_distri_training_for_all), int(model_ver), int(game_idx_base),
+                             job_hash(job_id), mo)
         z = np.fromfile(_lib.ZOBRIST_BIN, dtype="<u8")
         zz = np.ascontiguousarray(z[: (self.n + 2) ** 2])
         torch.cuda.set_device(self.device)
@@ -89,6 +99,7 @@ class SelfPlay:
             raise ValueError("feature_format must be 'f32_nchw' or 'f16_nhwc'")
         self.feature_format = feature_format
         self._rows = C.c_int(0)
+        self._waited = True
         self._cb = {}
 
     def close(self):
@@ -106,13 +117,20 @@ class SelfPlay:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- batch interface
-    def begin_step(self):
-        check(self.L.elfsp_begin_step(self._h, C.c_void_p(self.s.data_ptr()), 18 * self.n * self.n, C.byref(self._rows),
-                                      self._stream()))
+    def begin_step(self, wait_rows=True):
+        """select + leaf features into self.s.  wait_rows=False: nothing is waited for (the row count stays on the device, the
+        net evaluates all max_rows rows, end_step expands the counted ones); returns None then."""
+        rows = C.byref(self._rows) if wait_rows else None
+        check(self.L.elfsp_begin_step(self._h, C.c_void_p(self.s.data_ptr()), 18 * self.n * self.n, rows, self._stream()))
+        self._waited = wait_rows
+        return self._rows.value if wait_rows else None
+
+    def last_rows(self):
+        check(self.L.elfsp_last_rows(self._h, C.byref(self._rows)))
         return self._rows.value
 
-    def end_step(self, pi, v):
-        rows = self._rows.value
+    def end_step(self, pi, v, rv=None):
+        rows = self._rows.value if self._waited else self.max_rows
         if rows:
             if pi.dtype != torch.float32 or not pi.is_contiguous():
                 pi = pi.float().contiguous()
@@ -121,9 +139,19 @@ class SelfPlay:
             v = v.reshape(-1)
             if pi.shape[0] < rows or pi.shape[1] != self.num_action or v.shape[0] < rows:
                 raise ValueError("reply shapes do not match the batch")
-            check(self.L.elfsp_end_step(self._h, C.c_void_p(pi.data_ptr()), pi.stride(0), C.c_void_p(v.data_ptr()), self._stream()))
+            rvp = None
+            if rv is not None:
+                rv = rv.to(device=self.device, dtype=torch.int64).reshape(-1).contiguous()
+                if rv.shape[0] < rows:
+                    raise ValueError("reply shapes do not match the batch")
+                rvp = C.c_void_p(rv.data_ptr())
+            check(self.L.elfsp_end_step(self._h, C.c_void_p(pi.data_ptr()), pi.stride(0), C.c_void_p(v.data_ptr()), rvp, self._stream()))
         else:
-            check(self.L.elfsp_end_step(self._h, None, 0, None, self._stream()))
+            check(self.L.elfsp_end_step(self._h, None, 0, None, None, self._stream()))
+
+    def set_request(self, black_ver, white_ver=-1, resign_thres=0.0, never_resign_prob=0.0, async_=False):
+        """Client::setRequest (train/distri_client.h:318-331); takes effect at the next move boundary"""
+        check(self.L.elfsp_set_request(self._h, int(black_ver), int(white_ver), float(resign_thres), float(never_resign_prob), int(async_)))
 
     def reg_callback(self, key, cb):
         """GCWrapper.reg_callback (utils_elf.py:340-359): cb(batch) -> dict(pi=..., V=...)"""
@@ -136,7 +164,7 @@ class SelfPlay:
         if rows:
             cb = self._cb.get("actor_black") or self._cb.get("actor")
             reply = cb({"s": self.s[:rows]})
-        self.end_step(reply["pi"], reply["V"])
+        self.end_step(reply["pi"], reply["V"], reply.get("rv"))
         return rows
 
     # ---- results

@@ -14,6 +14,9 @@
  *    in _host; `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue
  *    work and return; use elfgo_sync() or your own stream sync before reading results.
  *  - `ids` may be NULL, meaning slots [0, n).
+ *  - devices: a handle belongs to the HIP device it was created on; every call switches to that device for its duration and
+ *    restores the calling thread's current device on return, so handles on different GPUs can be driven from one process.
+ *    `stream` must be a stream of the handle's device (NULL = that device's default stream).
  *  - threading: a handle (engine, search, self-play context, replay store) may be driven by one host thread at a time; different
  *    handles are independent.  Calls on one handle are ordered by the stream they are given; results written by a call on
  *    stream A may be consumed by a call on stream B only after the caller has ordered the streams (event / sync).
@@ -107,12 +110,19 @@ typedef struct ElfMctsOptions {
   int32_t ply_pass_enabled;         /* MCTSActorParams.ply_pass_enabled */
   int32_t remove_pass_if_dangerous; /* MCTSActorParams.remove_pass_if_dangerous */
   int32_t rotation_flip;            /* MCTSActorParams.rotation_flip */
+  int32_t num_threads;              /* TSOptions.num_threads: search threads per game (tree_search.h:345-368), >= 1; one step runs
+                                     * their batch_rollouts in sequence on the shared tree, so a move costs
+                                     * num_threads x num_rollouts_per_thread rollouts (tree_search.h:472-476).
+                                     * num_threads x num_rollouts_per_batch must be <= 64 (ELFGO_E_BADARG otherwise) */
+  int32_t reserved0;
+  int64_t required_version;         /* MCTSActorParams.required_version: < 0 = replies of any model version are accepted */
 } ElfMctsOptions;
 
 #define ELFMCTS_E_POOL 1      /* node pool of some game exhausted (raise nodes_per_game) */
 #define ELFMCTS_E_ROOT_HASH 2 /* TreeSearch::Root state is not the same as the input state (tree_search.h:488-492) */
 #define ELFMCTS_E_FORWARD 4   /* a tree edge could not be played */
 #define ELFMCTS_E_RNG 8       /* more D4 draws requested than uploaded with elfmcts_set_d4 */
+#define ELFMCTS_E_VERSION 16  /* a reply row's model version ("rv") differs from required_version (go/mcts/mcts.h:209-217) */
 
 #define ELFMCTS_ROOT_WORDS 8
 /* per-game record of elfmcts_root (int32 words): 0 n_edges 1 num_visits 2 status 3 root id 4 V (float bits)
@@ -138,12 +148,15 @@ int elfmcts_set_d4(ElfMcts* m, const uint8_t* d4_host, void* stream);
 /* NodeT::enhanceExploration (tree_search_node.h:132-155): etas device f32 [num_games][edge_stride] in edge
  * iteration order, Z device f32 [num_games] (= 1e-10 + sum of etas, accumulated in fp32 on the host) */
 int elfmcts_dirichlet(ElfMcts* m, const float* etas, const float* Z, float epsilon, void* stream);
-/* first half of batch_rollouts (:205-233): num_rollouts_per_batch descents per game, then the features of
- * every leaf that needs the net into s_dst (row r at s_dst + r*stride_floats, rows game-major);
- * counts (device int32[2]) <- {rows, OR of error bits}. */
-int elfmcts_select(ElfMcts* m, const int32_t* board_ids, float* s_dst, int64_t stride_floats, int32_t* counts, void* stream);
-/* second half (:235-259): pi2response + setEvaluation for the n_rows leaves of the last select, then backup */
-int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const float* value, int n_rows, void* stream);
+/* first half of batch_rollouts (:205-233): num_threads x num_rollouts_per_batch descents per game, then the features of
+ * every leaf that needs the net into s_dst (row r at s_dst + r*stride_elems elements of the feature format, rows game-major);
+ * counts (device int32[4], 8-byte aligned): [0] <- rows, [1] <- OR of error bits, [2..3] += rows (u64 running total). */
+int elfmcts_select(ElfMcts* m, const int32_t* board_ids, void* s_dst, int64_t stride_elems, int32_t* counts, void* stream);
+/* second half (:235-259): pi2response + setEvaluation for the n_rows leaves of the last select, then backup.
+ * rv (device int64 [n_rows], may be NULL) = the "rv" reply column, checked against required_version.
+ * n_rows < 0: use the row count the last select left in its `counts` buffer on the device (no host round trip). */
+int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const float* value, const int64_t* rv, int n_rows,
+                   void* stream);
 /* root edges in the reference's iteration order (what MCTSResultT::addActions walks, tree_search_base.h:237-294);
  * info device int32 [num_games][ELFMCTS_ROOT_WORDS]; the per-edge outputs ([num_games][edge_stride]) may be NULL */
 int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, float* prior, float* reward, int32_t* child, void* stream);
@@ -171,7 +184,7 @@ typedef struct ElfSpOptions {
   int32_t num_rollouts_per_thread;  /* TSOptions.num_rollouts_per_thread; one search thread per game */
   int32_t persistent_tree;          /* TSOptions.persistent_tree */
   float root_epsilon, root_alpha;   /* TSOptions.root_epsilon / root_alpha */
-  uint32_t seed;                    /* GameOptions.seed; game g uses seed + g when num_games > 1 */
+  uint32_t seed;                    /* GameOptions.seed; per-game rule below */
   int32_t policy_distri_cutoff;     /* GameOptions.policy_distri_cutoff */
   int32_t move_cutoff;              /* GameOptions.move_cutoff */
   float resign_thres;               /* ClientCtrl.{black,white}_resign_thres */
@@ -180,8 +193,18 @@ typedef struct ElfSpOptions {
   int32_t keep_records;             /* > 0: keep the Record JSON of the last N finished games for elfsp_pop_record */
   int32_t policy_distri_training_for_all; /* GameOptions.policy_distri_training_for_all: record the MCTS policy of every move */
   int32_t model_ver;                /* Record.request.vers.black_ver (the self-play model version; white_ver = -1) */
+  int32_t game_idx_base;            /* global index of this context's game 0 in the whole job (rank x games + group offset) */
+  uint64_t job_hash;                /* std::hash of ContextOptions.job_id, only used by the seed == 0 rule below */
   ElfMctsOptions mcts;
 } ElfSpOptions;
+/* Per-game RNG seeds.  The reference seeds every GoGameBase with GameOptions.seed itself (common/game_base.h:32-38), so with a
+ * non-zero seed and a deterministic net all its games are identical; its time-seeded default (seed == 0) is what production
+ * runs use.  Here game g (global index i = game_idx_base + g) is seeded
+ *   seed != 0:  seed + i            (the rule of this repository's reference harness, oracle/ref_selfplay.cc: distinct,
+ *                                    reproducible games; i is unique over groups and ranks, so no two games of a job collide)
+ *   seed == 0:  (unix_seconds*1000 + unix_milliseconds + (i ^ job_hash) * 2341479) % 100000000
+ *                                   (elf_utils::get_seed, elf/utils/utils.h:50-57, as GoGameBase calls it)
+ * and the MCTS actor seed is the first draw of that generator (game_selfplay.cc:45-47). */
 
 /* what GameNotifierBase::OnMCTSResult (common/notifier.h:13) sees after one search */
 typedef struct ElfSpSearch {
@@ -193,10 +216,28 @@ int elfsp_create(const ElfSpOptions* opt, int device, const uint64_t* zobrist_ho
 int elfsp_destroy(ElfSelfPlay* sp);
 ElfGoEngine* elfsp_engine(ElfSelfPlay* sp);
 ElfMcts* elfsp_mcts(ElfSelfPlay* sp);
-int elfsp_max_rows(const ElfSelfPlay* sp);   /* num_games * num_rollouts_per_batch */
-/* s_dst device f32, rows stride_floats apart; *n_rows (host) <- rows that need the net this step */
-int elfsp_begin_step(ElfSelfPlay* sp, float* s_dst, int64_t stride_floats, int* n_rows, void* stream);
-int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, void* stream);
+int elfsp_max_rows(const ElfSelfPlay* sp);   /* num_games * num_threads * num_rollouts_per_batch */
+/* s_dst: device rows in the context's feature format (elfmcts_set_feature_format: fp32 [18][N][N] or fp16 [N][N][18]), rows
+ * stride_elems elements apart.  n_rows != NULL: the call waits for the device and stores the number of rows that need the net.
+ * n_rows == NULL: nothing is waited for inside a move -- the row count stays on the device, the net evaluates elfsp_max_rows()
+ * rows (surplus rows hold stale features and are ignored) and elfsp_end_step expands exactly the counted ones; errors raised by
+ * the kernels surface at the next move boundary.  Host work (Dirichlet draws, move choice, records) happens at move boundaries
+ * either way. */
+int elfsp_begin_step(ElfSelfPlay* sp, void* s_dst, int64_t stride_elems, int* n_rows, void* stream);
+/* pi device f32 [rows][N*N+1] (rows pi_stride_floats apart), value device f32 [rows], rv device int64 [rows] or NULL (the reply's
+ * model version, checked against the requested one: elfsp_set_request) */
+int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, const int64_t* rv, void* stream);
+/* rows of the last begin_step (synchronises the stream of that call) */
+int elfsp_last_rows(ElfSelfPlay* sp, int* n_rows);
+/* Client::setRequest / GameContext::setRequest (train/distri_client.h:318-331, inference/game_context.h:76-88): model versions
+ * and resign threshold for the games from the next move boundary on.  A new black_ver restarts every game from the empty board
+ * without a record (GoGameSelfPlay::OnReceive -> restart, game_selfplay.cc:222-270) and becomes the version replies must carry
+ * ("rv"; async != 0 switches the check off, setAsync :150-156) and records report.  white_ver >= 0 (a second AI for White,
+ * game_selfplay.cc:171-185) is not supported: ELFGO_E_BADARG. */
+int elfsp_set_request(ElfSelfPlay* sp, int64_t black_ver, int64_t white_ver, float resign_thres, float never_resign_prob, int async);
+/* number of times the games were (re)started by a request since the last call (each is one "game_start" batch of the reference,
+ * common/dispatcher_callback.h:86-88); *black_ver / *white_ver <- the versions of the current request */
+int elfsp_take_game_starts(ElfSelfPlay* sp, int64_t* black_ver, int64_t* white_ver);
 /* out[9]: moves played, games finished, rollouts, net rows, steps, searches logged, steps per move, step in move,
  * tree nodes descended through (synchronises the device) */
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
@@ -300,7 +341,16 @@ int elfnet_bias_act_f16(void* x, const void* bias, const void* res, int64_t rows
 /* the same pass for a bfloat16 activation (round to nearest even) */
 int elfnet_bias_act_bf16(void* x, const void* bias, const void* res, int64_t rows, int channels, int relu, void* stream);
 
-/* convenience for callers without a HIP runtime of their own (tests, cgo/ctypes stubs) */
+/* convenience for callers without a HIP runtime of their own (tests, the pybind11/cgo/ctypes side); these act on the calling
+ * thread's current device unless a device is named */
+int elfgo_set_device(int device);
+/* what kind of memory a caller-provided address is: 0 = pageable host (or unknown), 1 = page-locked (pinned) host, 2 = device;
+ * *device (may be NULL) <- the owning device for kind 2 */
+int elfgo_pointer_kind(const void* p, int* device);
+/* 2-D copy between any two of {device, pinned host, pageable host} (hipMemcpyDefault), `rows` rows of width_bytes, row pitches
+ * in bytes; asynchronous on `stream` when the host side is pinned */
+int elfgo_memcpy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, void* stream);
+int elfgo_stream_sync(void* stream);
 int elfgo_malloc(void** dptr, size_t bytes);
 int elfgo_free(void* dptr);
 int elfgo_memcpy_h2d(void* dst, const void* src_host, size_t bytes);

@@ -270,32 +270,44 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
 
   // batch_rollouts :200-262.  The reference walks `traj_counts` (keyed by node address) in hash order; this restatement backs
   // the unique leaves up in first-occurrence order (with values on a 1/256 grid the sums are order-independent).
-  void batch_rollouts() {
+  // mcts_threads = T > 1 (TreeSearchT's thread pool, tree_search.h:345-368) is restated as ONE of the interleavings the
+  // reference's racing threads can produce: the T batch_rollouts calls of a round run their descents back to back (thread t
+  // sees the virtual losses of threads < t; a leaf another thread has already requested is not requested again, :142-153),
+  // then every thread evaluates its own locked leaves (all threads draw from the one actor stream here: the reference's
+  // actors are seeded alike, game_selfplay.cc:45-47,77), then every thread backs up its own trajectories (waitEvaluation :250).
+  struct Batch {
     std::vector<Traj> trajs;
-    for (int j = 0; j < cfg->rollouts_per_batch; ++j) trajs.push_back(single_rollout());
     std::vector<Node*> locked;
     std::vector<const OrcState*> states;
     std::vector<std::pair<Node*, std::pair<Traj*, int>>> counts;
-    for (Traj& t : trajs) {
+  };
+  void descend(Batch& b) {
+    b.trajs.reserve(cfg->rollouts_per_batch);
+    for (int j = 0; j < cfg->rollouts_per_batch; ++j) b.trajs.push_back(single_rollout());
+    for (Traj& t : b.trajs) {
       if (t.leaf->status == NOT_VISITED) {   // requestEvaluation :142-153
         t.leaf->status = EVAL_REQUESTED;
-        locked.push_back(t.leaf);
-        states.push_back(t.leaf->state);
+        b.locked.push_back(t.leaf);
+        b.states.push_back(t.leaf->state);
       }
       bool found = false;
-      for (auto& c : counts) if (c.first == t.leaf) { c.second.second++; found = true; break; }
-      if (!found) counts.push_back(std::make_pair(t.leaf, std::make_pair(&t, 1)));
+      for (auto& c : b.counts) if (c.first == t.leaf) { c.second.second++; found = true; break; }
+      if (!found) b.counts.push_back(std::make_pair(t.leaf, std::make_pair(&t, 1)));
     }
+  }
+  void evaluate(Batch& b) {
     std::vector<Response> resps;
-    actor->evaluate(states, &resps);
-    for (size_t j = 0; j < locked.size(); ++j) {   // setEvaluation :176-203
-      Node* nd = locked[j];
+    actor->evaluate(b.states, &resps);
+    for (size_t j = 0; j < b.locked.size(); ++j) {   // setEvaluation :176-203
+      Node* nd = b.locked[j];
       for (const auto& ap : resps[j].pi) nd->sa.insert(std::make_pair(ap.first, Edge(ap.second)));
       nd->V = resps[j].value;
       nd->flip = resps[j].q_flip;
       nd->status = VISITED;
     }
-    for (auto& c : counts) {
+  }
+  void backup(Batch& b) {
+    for (auto& c : b.counts) {
       const float reward = c.first->V;   // MCTSActor::reward :163-165
       for (const auto& p : c.second.first->traj) {   // updateEdgeStats :253-278
         Edge& e = p.first->sa.find(p.second)->second;
@@ -305,6 +317,13 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
         e.virtual_loss -= (float)(cfg->virtual_loss * c.second.second);
       }
     }
+  }
+  void batch_rollouts() {
+    const int T = cfg->mcts_threads > 1 ? cfg->mcts_threads : 1;
+    std::vector<Batch> bs(T);
+    for (int t = 0; t < T; ++t) descend(bs[t]);
+    for (int t = 0; t < T; ++t) evaluate(bs[t]);
+    for (int t = 0; t < T; ++t) backup(bs[t]);
   }
 
   // TreeSearchT::run :410-426 (setRootNodeState :478-493, enhanceExploration tree_search_node.h:132-155, chooseAction :495-528)

@@ -92,13 +92,14 @@ struct Capture : public GameNotifierBase {
   int game_of_thread(const std::thread::id&) { return 0; }
 
   int total_calls = 0;   // every search, recorded or not
-  void OnMCTSResult(Coord c, const MCTSResult& r) override {
+  void OnMCTSResult(Coord c, const MCTSResult& r) override { add(0, c, r); }
+  void add(int game, Coord c, const MCTSResult& r) {
     std::lock_guard<std::mutex> l(m);
     ++total_calls;
     if ((int)searches.size() >= max_searches) return;
     RefSpSearch s;
     memset(&s, 0, sizeof(s));
-    s.game = current_game;
+    s.game = game;
     s.move_played = c;
     s.best_action = r.best_action;
     s.total_visits = r.total_visits;
@@ -121,7 +122,6 @@ struct Capture : public GameNotifierBase {
     }
     count++;
   }
-  int current_game = 0;   // parity runs use num_games == 1
   std::vector<std::string> records;   // Record JSON of every finished game, in completion order
   void OnGameEnd(const GoStateExt& s) override {
     std::lock_guard<std::mutex> l(m);
@@ -132,6 +132,14 @@ struct Capture : public GameNotifierBase {
     s.dumpRecord().setJsonFields(j);
     records.push_back(j.dump());
   }
+};
+
+// one notifier per game thread: GameNotifierBase callbacks carry no game index (common/notifier.h:13), the search log needs one
+struct GameCapture : public GameNotifierBase {
+  Capture* cap = nullptr;
+  int game = 0;
+  void OnMCTSResult(Coord c, const MCTSResult& r) override { cap->add(game, c, r); }
+  void OnGameEnd(const GoStateExt& s) override { cap->OnGameEnd(s); }
 };
 
 std::string g_preload_sgf;     // GameOptions.preload_sgf for the next refsp_run ("" = none)
@@ -197,10 +205,12 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     Capture cap;
     cap.max_searches = cfg->max_searches;
     std::vector<std::unique_ptr<GoGameSelfPlay>> games;
+    std::vector<GameCapture> gcaps(n);
     for (int i = 0; i < n; ++i) {
       GameOptions gopt = opt;
-      if (n > 1 && cfg->seed != 0) gopt.seed = cfg->seed + i;   // distinct games in throughput runs
-      games.emplace_back(new GoGameSelfPlay(i, ctx.getClient(), co, gopt, &disp, &cap));
+      if (n > 1 && cfg->seed != 0) gopt.seed = cfg->seed + i;   // distinct games (the reference proper seeds them all alike)
+      gcaps[i].cap = &cap; gcaps[i].game = i;
+      games.emplace_back(new GoGameSelfPlay(i, ctx.getClient(), co, gopt, &disp, &gcaps[i]));
     }
     ctx.setStartCallback(n, [&](int i, elf::GameClient*) {
       disp.RegGame(i);

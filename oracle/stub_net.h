@@ -10,6 +10,7 @@
  *  - V is a multiple of 1/256 in [-1,1]: sums of <= 2^15 such values are exact in fp32, so the
  *    reference's heap-address-dependent backup order (tree_search.h:216,245)
  *    cannot change any edge statistic;
+ *    (salt bit 31 switches this off for the order-sensitivity test, see below);
  *  - tie_levels > 0 quantises the priors to that many distinct values, forcing equal priors
  *    (exercises std::sort tie order, go/mcts/mcts.h:292-297).
  */
@@ -47,6 +48,13 @@ static inline void stubnet_eval1(const float* s, int n, uint32_t salt, int tie_l
   }
   for (int a = 0; a < na; ++a) pi[a] = pi[a] / sum;
   uint64_t hv = stubnet_mix(seed ^ 0xA5A5A5A5DEADBEEFULL);
+  if (salt & 0x80000000u) {
+    /* un-quantised value head (salt bit 31): an arbitrary fp32 in (-1, 1).  fp32 sums of such values depend on the backup
+     * order, so this mode is only comparable between engines that share one order (the HIP search and oracle/mcts_oracle.cc
+     * both use first occurrence; the reference's own order follows heap addresses) */
+    *v = (float)((double)(hv >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0);
+    return;
+  }
   *v = (float)((int)((hv >> 20) % 513u) - 256) * (1.0f / 256.0f);
 }
 

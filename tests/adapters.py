@@ -83,3 +83,28 @@ class GpuState:
 
     def legal_mask(self):
         return self.E.legal_mask([self.slot]).cpu().numpy()[0]
+
+
+class HashNet:
+    """A deterministic policy/value function evaluated by torch ON THE GPU whose result depends only on the logical 0/1 content of
+    the feature rows -- not on their dtype (fp32 / fp16) or memory layout (NCHW / channels_last): integer hashing of the planes,
+    then a fixed elementwise map.  Lets serial fp32-NCHW self-play be compared bit for bit with the pipelined, HIP-graph-replayed,
+    fp16 channels_last path (tests only)."""
+
+    def __init__(self, n, device, salt=12345):
+        import torch
+        self.n, self.na = n, n * n + 1
+        g = torch.Generator().manual_seed(salt)
+        self.w = torch.randint(1, 2 ** 31 - 1, (18 * n * n,), generator=g, dtype=torch.int64).to(device)
+        self.a = (torch.arange(self.na, dtype=torch.int64, device=device) + 1) * 2654435761
+
+    def __call__(self, s):
+        import torch
+        b = s.shape[0]
+        x = (s != 0).reshape(b, -1).to(torch.int64)          # logical NCHW order whatever the strides
+        h = (x * self.w).sum(1) & 0x7FFFFFFF                  # exact integer arithmetic
+        z = ((h[:, None] * 40503 + self.a[None, :]) >> 7) & 0xFFFF
+        wgt = ((z + 1).to(torch.float32) * (1.0 / 65536.0)) ** 8   # peaky, like a trained policy
+        pi = wgt / wgt.sum(1, keepdim=True)
+        v = ((h % 513) - 256).to(torch.float32) * (1.0 / 256.0)
+        return pi, v

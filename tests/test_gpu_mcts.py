@@ -143,3 +143,196 @@ def test_live_differential_against_the_reference_stack(elf, case):
         assert rec[i].move_played == S[i].move_played and rec[i].best_action == S[i].best_action, ctx
         assert np.float32(rec[i].root_value) == np.float32(S[i].root_value), ctx
     sp.close()
+
+
+# ---- the benchmarked configuration, pinned (VERDICT r1 "next round" item 1) --------------------------------------------------
+def _sp_from_cfg(elf, n, cfg, **over):
+    kw = dict(board_size=n, device=0, mcts_rollout_per_thread=cfg["rollouts_per_thread"], mcts_rollout_per_batch=cfg["rollouts_per_batch"],
+              mcts_puct=cfg["c_puct"], mcts_virtual_loss=cfg["virtual_loss"], mcts_use_prior=bool(cfg["use_prior"]),
+              mcts_persistent_tree=bool(cfg["persistent_tree"]), mcts_epsilon=cfg["root_epsilon"], mcts_alpha=cfg["root_alpha"],
+              mcts_unexplored_q_zero=bool(cfg["unexplored_q_zero"]), mcts_root_unexplored_q_zero=bool(cfg["root_unexplored_q_zero"]),
+              komi=cfg["komi"], ply_pass_enabled=cfg["ply_pass_enabled"], policy_distri_cutoff=cfg["policy_distri_cutoff"],
+              move_cutoff=cfg["move_cutoff"], resign_thres=cfg["resign_thres"], never_resign_prob=cfg["never_resign_prob"],
+              seed=cfg["seed"], mcts_threads=cfg["mcts_threads"], num_games=cfg["num_games"], nodes_per_game=4096)
+    kw.update(over)
+    return elf.SelfPlay(**kw)
+
+
+def _drive_stub(sp, n, cfg, searches, wait_rows=True):
+    import torch
+    while sp.stats()["logged"] < searches:
+        rows = sp.begin_step(wait_rows=wait_rows)
+        k = rows if wait_rows else sp.max_rows          # without the wait every row is evaluated; stale ones are ignored
+        if k:
+            pi, v = stub_net(n, sp.s[:k].cpu().numpy(), cfg["net_salt"], cfg["net_tie_levels"])
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        else:
+            sp.end_step(None, None)
+
+
+def _per_game(rec, coord, visits, prior, reward, games):
+    out = {g: [] for g in range(games)}
+    for i, r in enumerate(rec):
+        ne = r.n_edges
+        out[r.game].append((ne, r.move_played, r.best_action, r.total_visits, np.float32(r.root_value).tobytes(),
+                            coord[i, :ne].tobytes(), visits[i, :ne].tobytes(), prior[i, :ne].tobytes(), reward[i, :ne].tobytes()))
+    return out
+
+
+@pytest.mark.parametrize("n,G,roll,per_game", [(19, 8, 64, 4), (9, 16, 48, 10)])
+def test_multi_game_context_equals_the_reference_game_by_game(elf, n, G, roll, per_game):
+    """A G-game context (the benchmarked shape) against the reference stack running G game threads: game g of the context must
+    reproduce, search for search, the reference's game g, which the reference harness seeds with seed + g
+    (oracle/ref_selfplay.cc; the per-game seed rule of include/elf_amd.h).  Where the prebuilt reference is absent its CPU
+    restatement plays the G games one by one with the same seeds."""
+    from pyoracle import MCTS_DEFAULTS, PortSelfPlay, RefSelfPlay
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=G, rollouts_per_thread=roll, seed=9001, net_salt=311, policy_distri_cutoff=6, move_cutoff=30 if n == 9 else -1)
+    want = {}
+    if RefSelfPlay.available(n):
+        # the G reference game threads finish searches at their own pace: run long enough for `per_game` searches of every game
+        r = RefSelfPlay(n).run(max_searches=G * per_game * 3, **{k: v for k, v in cfg.items() if k != "max_searches"})
+        want = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)
+    else:
+        for g in range(G):
+            c1 = dict(cfg)
+            c1.update(num_games=1, seed=cfg["seed"] + g, max_searches=per_game)
+            r = PortSelfPlay(n).run(**c1)
+            for x in r["search"]:
+                x.game = g
+            want.update({g: _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)[g]})
+    assert all(len(want[g]) >= per_game for g in range(G)), [len(want[g]) for g in range(G)]
+    sp = _sp_from_cfg(elf, n, cfg, log_searches=G * per_game)
+    _drive_stub(sp, n, cfg, G * per_game)
+    rec, coord, visits, prior, reward = sp.search_log()
+    na = n * n + 1
+    got = _per_game(rec, coord[:, :na], visits[:, :na], prior[:, :na], reward[:, :na], G)
+    for g in range(G):
+        assert len(got[g]) == per_game
+        for k in range(per_game):
+            assert got[g][k] == want[g][k], "game %d search %d" % (g, k)
+    sp.close()
+
+
+def test_step_without_host_wait_equals_step_with_it(elf):
+    """elfsp_begin_step(n_rows = NULL): the row count stays on the device and the expansion kernel reads it there.  Same search
+    logs as the path that waits for the count."""
+    from pyoracle import MCTS_DEFAULTS
+    n, G, m = 19, 6, 3
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=G, rollouts_per_thread=96, seed=515, net_salt=99, policy_distri_cutoff=2)
+    logs = []
+    for wait in (True, False):
+        sp = _sp_from_cfg(elf, n, cfg, log_searches=G * m)
+        _drive_stub(sp, n, cfg, G * m, wait_rows=wait)
+        rec, coord, visits, prior, reward = sp.search_log()
+        logs.append(_per_game(rec, coord, visits, prior, reward, G))
+        st = sp.stats()
+        assert st["rows"] > 0 and st["moves"] == G * m
+        sp.close()
+    assert logs[0] == logs[1]
+
+
+@pytest.mark.parametrize("n,T,K,roll", [(9, 2, 8, 64), (19, 2, 16, 96), (9, 4, 4, 32)])
+def test_search_threads_equal_their_restatement(elf, n, T, K, roll):
+    """TSOptions.num_threads = T > 1: T x num_rollouts_per_thread rollouts per move (tree_search.h:472-476), the T batch_rollouts
+    of a round run back to back on the shared tree.  The reference's racing threads are not deterministic; the
+    bar is the sequential interleaving restated in oracle/mcts_oracle.cc, bit for bit, plus the visit budget."""
+    from pyoracle import MCTS_DEFAULTS, PortSelfPlay
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=1, mcts_threads=T, rollouts_per_thread=roll, rollouts_per_batch=K, batchsize=K, seed=77 + T, net_salt=5,
+               max_searches=6, policy_distri_cutoff=3)
+    ref = PortSelfPlay(n).run(**cfg)
+    m = len(ref["search"])
+    assert m == 6
+    sp = _sp_from_cfg(elf, n, cfg, log_searches=m)
+    assert sp.max_rows == T * K
+    _drive_stub(sp, n, cfg, m)
+    rec, coord, visits, prior, reward = sp.search_log()
+    for i in range(m):
+        ne = ref["search"][i].n_edges
+        assert rec[i].n_edges == ne
+        assert np.array_equal(coord[i, :ne], ref["coord"][i, :ne]) and np.array_equal(visits[i, :ne], ref["visits"][i, :ne]), i
+        assert np.array_equal(reward[i, :ne].view(np.uint32), ref["reward"][i, :ne].view(np.uint32)), i
+        assert rec[i].move_played == ref["search"][i].move_played
+    # budget: every step adds at most T*K visits below the root; the first search loses its first round (the root is the leaf)
+    assert 0.5 * T * roll < rec[0].total_visits <= T * roll - T * K
+    assert sp.stats()["rollouts"] == m * T * ((roll + K - 1) // K) * K
+    sp.close()
+    with pytest.raises(Exception):     # one lane per unique leaf of a step: T x K <= 64, rejected loudly beyond
+        elf.SelfPlay(board_size=9, num_games=1, mcts_rollout_per_batch=16, mcts_threads=8)
+
+
+def test_backup_order_is_first_occurrence_with_unquantised_values(elf):
+    """fp32 reward sums depend on the order in which the leaves of a batch are backed up.  With a value head that is
+    NOT quantised (stub salt bit 31) the HIP search must still equal, bit for bit, a CPU search that uses the same documented
+    order (first occurrence: oracle/mcts_oracle.cc); the reference itself iterates heap addresses and may differ in the last
+    ulps of edges that received two backups from one batch."""
+    from pyoracle import MCTS_DEFAULTS, PortSelfPlay
+    n = 19
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=1, rollouts_per_thread=512, seed=4, net_salt=0x80000000 | 41, max_searches=4)
+    ref = PortSelfPlay(n).run(**cfg)
+    sp = _sp_from_cfg(elf, n, cfg, log_searches=4)
+    _drive_stub(sp, n, cfg, 4)
+    rec, coord, visits, prior, reward = sp.search_log()
+    inexact = 0
+    for i in range(4):
+        ne = ref["search"][i].n_edges
+        assert np.array_equal(visits[i, :ne], ref["visits"][i, :ne]), i
+        assert np.array_equal(reward[i, :ne].view(np.uint32), ref["reward"][i, :ne].view(np.uint32)), i
+        inexact += int(np.sum((reward[i, :ne] * 256.0) != np.round(reward[i, :ne] * 256.0)))
+    assert inexact > 0      # the sums really are off the 1/256 grid: the order was exercised
+    sp.close()
+
+
+def test_pipelined_graph_fp16_groups_equal_the_serial_fp32_loop(elf):
+    """The headline bench configuration's machinery -- PipelinedSelfPlay with two groups on their own streams, no host wait
+    inside a move, the net call replayed as a HIP graph, fp16 channels_last feature rows -- against the plain serial loop with
+    fp32 NCHW rows and an eager net: identical search logs, group by group and game by game."""
+    import torch
+    from adapters import HashNet
+    from elf_amd.pipeline import PipelinedSelfPlay
+    n, Gg, m, roll = 19, 4, 3, 128
+    kw = dict(board_size=n, num_games=Gg, mcts_rollout_per_thread=roll, mcts_rollout_per_batch=16, mcts_puct=1.5, mcts_virtual_loss=1,
+              mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, policy_distri_cutoff=30, nodes_per_game=2048,
+              log_searches=Gg * m)
+    net = HashNet(n, torch.device("cuda", 0))
+    steps = m * (roll // 16)
+    # serial reference loops, one per group, seeded as the pipeline seeds its groups
+    serial = []
+    for i in range(2):
+        sp = elf.SelfPlay(seed=1234, game_idx_base=i * Gg, feature_format="f32_nchw", **kw)
+        for _ in range(steps):
+            rows = sp.begin_step()
+            pi, v = net(sp.s[:rows])
+            sp.end_step(pi, v)
+        rec, coord, visits, prior, reward = sp.search_log()
+        serial.append(_per_game(rec, coord, visits, prior, reward, Gg))
+        assert len(rec) == Gg * m
+        sp.close()
+    pipe = PipelinedSelfPlay(groups=2, seed=1234, wait_rows=False, feature_format="f16_nhwc", **kw)
+    graphs, outs = {}, {}
+    side = torch.cuda.Stream()
+    for g in pipe.groups:                      # one captured graph per group, reading that group's own "s" tensor
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                net(g.s)
+        side.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            outs[g.s.data_ptr()] = net(g.s)
+        graphs[g.s.data_ptr()] = gr
+
+    def net_fn(s, rows):
+        graphs[s.data_ptr()].replay()
+        return outs[s.data_ptr()]
+
+    for _ in range(steps):
+        pipe.step(net_fn)
+    pipe.synchronize()
+    for i, g in enumerate(pipe.groups):
+        rec, coord, visits, prior, reward = g.search_log()
+        assert len(rec) == Gg * m
+        assert _per_game(rec, coord, visits, prior, reward, Gg) == serial[i], "group %d" % i
+    pipe.close()

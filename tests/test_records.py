@@ -17,10 +17,10 @@ CASES = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9
 def sp_options(elf_amd, n, cfg, num_games=1):
     from elf_amd.selfplay import MctsOptions, SpOptions
     mo = MctsOptions(int(cfg["rollouts_per_batch"]), int(cfg["virtual_loss"]), int(cfg["use_prior"]), int(cfg["unexplored_q_zero"]),
-                     int(cfg["root_unexplored_q_zero"]), float(cfg["c_puct"]), float(cfg["komi"]), int(cfg["ply_pass_enabled"]), 1, 1)
+                     int(cfg["root_unexplored_q_zero"]), float(cfg["c_puct"]), float(cfg["komi"]), int(cfg["ply_pass_enabled"]), 1, 1, 1, 0, -1)
     return SpOptions(n, num_games, 1024, int(cfg["rollouts_per_thread"]), int(cfg["persistent_tree"]), float(cfg["root_epsilon"]),
                      float(cfg["root_alpha"]), int(cfg["seed"]), int(cfg["policy_distri_cutoff"]), int(cfg["move_cutoff"]),
-                     float(cfg["resign_thres"]), float(cfg["never_resign_prob"]), 0, 1, 0, 0, mo)
+                     float(cfg["resign_thres"]), float(cfg["never_resign_prob"]), 0, 1, 0, 0, 0, 0, mo)
 
 
 def to_json(elf_amd, opt, p, j):
