@@ -60,7 +60,10 @@ SIGNATURES = {
     "elfsp_play": (_i, [_vp, _vp, _vp]),
     "elfsp_preload": (_i, [_vp, _vp, _i, _i, _vp]),
     "elfsp_restart": (_i, [_vp, _vp, _i, _vp]),
+    "elfsp_finish": (_i, [_vp, _vp, _i, _i, _vp]),
+    "elfsp_take_finished": (_i, [_vp, _vp, _i]),
     "elfsp_last_score": (_i, [_vp, _vp]),
+    "elfsp_last_moves": (_i, [_vp, _vp]),
     "elfsp_records_pending": (_i, [_vp]),
     "elfsp_pop_record": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "elftrain_create": (_i, [_vp, _i, _i, _i, C.c_uint32, C.POINTER(_vp)]),
@@ -78,6 +81,7 @@ SIGNATURES = {
     "elfnet_bias_act_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfnet_bias_act_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfgo_set_device": (_i, [_i]),
+    "elfgo_get_device": (_i, [C.POINTER(_i)]),
     "elfgo_pointer_kind": (_i, [_vp, C.POINTER(_i)]),
     "elfgo_memcpy2d_async": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
     "elfgo_stream_sync": (_i, [_vp]),

@@ -39,6 +39,7 @@ struct SpGame {
   int ply = 1;             // GoState::getPly of the game board
   int seq = 0;             // games finished by this slot
   float last_final = 0.0f; // GoStateExt::getLastGameFinalValue (go_state_ext.h:153-155)
+  int last_move = -1;      // what the last finished search of this game did: the Coord it forwarded, M_RESIGN, or -1 (none yet)
   int sgf_iter = 0;        // GoGameSelfPlay::_sgf_iter (game_selfplay.h): next move of the preloaded SGF
   SpRecord rec;            // GoStateExt::_mcts_policies / _predicted_values / the game's moves (go_state_ext.h:131-148)
 };
@@ -65,7 +66,7 @@ struct ElfSelfPlay {
   bool search_open = false;
   // request state (MsgRequest, common/record.h): versions + client_ctrl of the current and of a pending request
   int64_t black_ver = 0, white_ver = -1;
-  bool have_pending = false, pending_async = false, cur_async = false;
+  bool have_pending = false, pending_async = false, cur_async = false, had_request = false;
   int64_t pend_black = 0, pend_white = -1;
   float pend_thres = 0.f, pend_never = 0.f;
   int game_starts = 0;
@@ -78,6 +79,7 @@ struct ElfSelfPlay {
   int log_cap = 0;
   // finished-game records (GameNotifier::OnGameEnd -> GoStateExt::dumpRecord), newest at the back
   std::deque<std::string> records;
+  std::deque<float> finished_values;   // final value of every finished game not yet taken (GameStats::feedWinRate, game_stats.h:41-44)
   SpRecordMeta meta{};
   std::vector<int32_t> sgf;   // GameOptions.preload_sgf as reference Coords (elfsp_preload)
   int sgf_move_to = -1;       // GameOptions.preload_sgf_move_to
@@ -86,6 +88,8 @@ struct ElfSelfPlay {
 static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int final_ply) {
   SpGame& gm = sp->games[g];
   gm.last_final = final_value;
+  sp->finished_values.push_back(final_value);
+  if (sp->finished_values.size() > 65536) sp->finished_values.pop_front();
   if (sp->opt.keep_records > 0) {
     SpRecord& r = gm.rec;
     r.reward = final_value;                      // _state.getFinalValue()
@@ -132,7 +136,12 @@ static int sp_forward_preload(ElfSelfPlay* sp) {
 // versions (or async) -> only the request (thresholds) changes.
 static int sp_apply_request(ElfSelfPlay* sp) {
   sp->have_pending = false;
-  const bool same_vers = sp->pend_black == sp->black_ver && sp->pend_white == sp->white_ver;
+  // the first request is what starts the reference's games (they wait for it, game_selfplay.cc:277-279): elfsp_create has
+  // already done that restart (boards empty, actor seeded with the first draw), so it only counts as a game start here
+  const bool first = !sp->had_request;
+  sp->had_request = true;
+  const bool same_vers = first || (sp->pend_black == sp->black_ver && sp->pend_white == sp->white_ver);
+  if (first) sp->game_starts++;
   sp->opt.resign_thres = sp->pend_thres;            // (black + white) / 2 with both equal (go_state_ext.h:62-66)
   sp->opt.never_resign_prob = sp->pend_never;
   sp->cur_async = sp->pending_async;
@@ -293,6 +302,7 @@ static int sp_finish_move(ElfSelfPlay* sp) {
     }
     if (resign && gm.ply >= 50) {
       finished.push_back(g);
+      gm.last_move = M_RESIGN;
       sp->h_moves[g] = M_PASS;       // placeholder; the board is reset below
       const float fv = ((gm.ply & 1) == 1) ? -1.0f : 1.0f;   // setFinalValue FR_RESIGN (go_state_ext.h:83-85)
       sp->sum_final += fv;
@@ -304,6 +314,7 @@ static int sp_finish_move(ElfSelfPlay* sp) {
     } else {
       if (!sp->sgf.empty()) c = sp->sgf[gm.sgf_iter++];       // "Move changes from {} to {}" :397-405
       sp->h_moves[g] = c;
+      gm.last_move = c;
     }
   }
   if (!sgf_done.empty()) {
@@ -489,6 +500,10 @@ int elfsp_set_request(ElfSelfPlay* sp, int64_t black_ver, int64_t white_ver, flo
   sp->pend_black = black_ver; sp->pend_white = white_ver;
   sp->pend_thres = resign_thres; sp->pend_never = never_resign_prob;
   sp->pending_async = async != 0;
+  if (!sp->search_open) {                              // between two moves: the move boundary is now
+    DevGuard _dg(sp->eng->device);
+    return sp_apply_request(sp);
+  }
   return 0;
 }
 
@@ -531,13 +546,17 @@ int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream) {
   SPCHK(elfgo_info(sp->eng, nullptr, G, sp->d_binfo, sp->stream));
   HIPCHK(hipMemcpyAsync(sp->h_binfo.data(), sp->d_binfo, sizeof(int32_t) * G * ELFGO_INFO_WORDS, hipMemcpyDeviceToHost, sp->stream));
   HIPCHK(hipStreamSynchronize(sp->stream));
+  std::vector<int32_t> two_pass;
   for (int g = 0; g < G; ++g) {
     if (adv[g] < 0) continue;
     SpGame& gm = sp->games[g];
-    gm.ply = sp->h_binfo[g * ELFGO_INFO_WORDS];
+    const int32_t* bi = &sp->h_binfo[g * ELFGO_INFO_WORDS];
+    gm.ply = bi[0];
     if (sp->opt.keep_records > 0) gm.rec.moves.push_back((uint16_t)adv[g]);
+    if (bi[2] == M_PASS && bi[3] == M_PASS) two_pass.push_back(g);   // "If the human opponent pass, we pass as well" :319-322
   }
   sp->n_moves += k - bad;
+  if (!two_pass.empty()) SPCHK(elfsp_finish(sp, two_pass.data(), (int)two_pass.size(), ELFSP_FR_TWO_PASSES, stream));
   return bad ? ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD : 0;
 }
 
@@ -553,11 +572,13 @@ int elfsp_preload(ElfSelfPlay* sp, const uint16_t* moves_host, int n, int move_t
   return sp_forward_preload(sp);
 }
 
-// finish_game(FR_CLEAR) + restart (game_selfplay.cc:121-149,302-307): the listed games start over from the empty board
-int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* stream) {
+// finish_game(reason) + restart (game_selfplay.cc:121-149): the listed games are scored (setFinalValue, go_state_ext.h:76-103: FR_RESIGN
+// = the side to move loses, every other reason = GoState::evaluate(komi)), leave their record and start over from the empty board
+int elfsp_finish(ElfSelfPlay* sp, const int32_t* games_host, int n, int reason, void* stream) {
   if (!sp || n < 0 || n > sp->G || (n > 0 && !games_host) || sp->search_open) return ELFGO_E_BADARG;
-  DevGuard _dg(sp->eng->device);
+  if (reason < ELFSP_FR_RESIGN || reason > ELFSP_FR_ILLEGAL) return ELFGO_E_BADARG;
   if (n == 0) return 0;
+  DevGuard _dg(sp->eng->device);
   sp->stream = (hipStream_t)stream;
   for (int j = 0; j < n; ++j) if (games_host[j] < 0 || games_host[j] >= sp->G) return ELFGO_E_BADARG;
   HIPCHK(hipMemcpyAsync(sp->d_ids, games_host, 4 * n, hipMemcpyHostToDevice, sp->stream));
@@ -568,7 +589,10 @@ int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* strea
   HIPCHK(hipStreamSynchronize(sp->stream));
   for (int j = 0; j < n; ++j) {
     SpGame& gm = sp->games[games_host[j]];
-    sp_finish_record(sp, games_host[j], sp->h_val[j], gm.ply);
+    float fv = sp->h_val[j];
+    if (reason == ELFSP_FR_RESIGN) fv = ((gm.ply & 1) == 1) ? -1.0f : 1.0f;   // nextPlayer() == S_WHITE ? 1 : -1; ply 1 = Black to move
+    sp->sum_final += fv;
+    sp_finish_record(sp, games_host[j], fv, gm.ply);
     gm.ply = 1; gm.never_resign = false; gm.has_calculated_never_resign = false; gm.last_predicted = 0.0f;
     gm.seq++;
   }
@@ -576,10 +600,30 @@ int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* strea
   return 0;
 }
 
+int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* stream) {
+  return elfsp_finish(sp, games_host, n, ELFSP_FR_CLEAR, stream);
+}
+
+int elfsp_take_finished(ElfSelfPlay* sp, float* out_host, int cap) {
+  if (!sp || cap < 0 || (cap > 0 && !out_host)) return ELFGO_E_BADARG;
+  int k = 0;
+  while (k < cap && !sp->finished_values.empty()) {
+    out_host[k++] = sp->finished_values.front();
+    sp->finished_values.pop_front();
+  }
+  return k;
+}
+
 // GoGameSelfPlay::getLastScore (GoStateExt::getLastGameFinalValue): final value of the last finished game of each game slot
 int elfsp_last_score(const ElfSelfPlay* sp, float* out_host) {
   if (!sp || !out_host) return ELFGO_E_BADARG;
   for (int g = 0; g < sp->G; ++g) out_host[g] = sp->games[g].last_final;
+  return 0;
+}
+
+int elfsp_last_moves(const ElfSelfPlay* sp, int32_t* out_host) {
+  if (!sp || !out_host) return ELFGO_E_BADARG;
+  for (int g = 0; g < sp->G; ++g) out_host[g] = sp->games[g].last_move;
   return 0;
 }
 

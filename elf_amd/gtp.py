@@ -13,6 +13,8 @@ import inspect
 import sys
 
 from .engine import M_PASS
+
+M_RESIGN = 1   # base/common.h:44
 from .selfplay import SelfPlay
 
 
@@ -113,7 +115,9 @@ class GtpEngine:
         return True, None
 
     def on_clear_board(self, items):
-        self.sp.restart([0])
+        # M_CLEAR of the human actor (game_selfplay.cc:306-311): a game that has not started yet is left alone
+        if int(self._info()["ply"][0]) > 1:
+            self.sp.restart([0])
         return True, None
 
     def on_play(self, items):
@@ -131,13 +135,15 @@ class GtpEngine:
         ret, msg = self.check_player(items[1][0])
         if not ret:
             return False, msg
-        games = self.sp.games_finished()
         moves = self.sp.stats()["moves"]
         while self.sp.stats()["moves"] == moves:
             self.sp.run()
-        if self.sp.games_finished() != games:      # the engine's move ended the game (two passes / move limit): board was restarted
-            return True, "pass"
-        return True, self.coord2move(int(self._info()["last_move"][0]))
+        # what the search did -- not inferred from the game counter: the engine may have resigned (no move, board restarted), or
+        # its move may have ended the game (two passes / move limit), in which case the board shows the next game already
+        c = int(self.sp.last_moves()[0])
+        if c == M_RESIGN:
+            return True, "resign"
+        return True, self.coord2move(c)
 
     def on_showboard(self, items):
         return True, "\n" + self.showboard()

@@ -201,6 +201,17 @@ class SelfPlay:
         check(self.L.elfsp_last_score(self._h, out.ctypes.data))
         return out
 
+    def last_moves(self):
+        """per game: the Coord the last finished search forwarded, 1 (M_RESIGN) if the engine resigned, -1 if none yet"""
+        out = np.zeros(self.num_games, np.int32)
+        check(self.L.elfsp_last_moves(self._h, out.ctypes.data))
+        return out
+
+    def finish(self, games, reason):
+        """finish_game(reason) + restart for the listed games (FinishReason: 0 resign, 1 two passes, 2 max step, 3 clear, 4 illegal)"""
+        g = np.ascontiguousarray(games, dtype=np.int32)
+        check(self.L.elfsp_finish(self._h, g.ctypes.data, g.size, int(reason), self._stream()))
+
     def board_engine(self):
         """GoEngine view of the game boards (slot g = game g), for showBoard / getNextPlayer / getLastMove / getScore"""
         from .engine import GoEngine

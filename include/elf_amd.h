@@ -243,17 +243,33 @@ int elfsp_take_game_starts(ElfSelfPlay* sp, int64_t* black_ver, int64_t* white_v
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
 /* Interactive play (the human_actor half of GoGameSelfPlay::act, game_selfplay.cc:290-330, that the GTP console
  * drives): between two searches, forward externally chosen moves (moves_host[g] = reference Coord, < 0 = none) on the game boards;
- * the trees follow.  Refused moves leave their game untouched and make the call return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD. */
+ * the trees follow.  Refused moves leave their game untouched and make the call return ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD.
+ * A move that completes two consecutive passes finishes that game (finish_game(FR_TWO_PASSES), :319-322). */
 int elfsp_play(ElfSelfPlay* sp, const int32_t* moves_host, void* stream);
 /* GameOptions.preload_sgf / preload_sgf_move_to (GoGameSelfPlay::restart, game_selfplay.cc:202-219): before the first search,
  * make every game follow the move list moves_host[0..n) (reference Coords): the first move_to moves are forwarded at once, then
  * each search's move is replaced by the next listed move (:392-405); the search that finds the list exhausted finishes the game
  * (FR_MAX_STEP).  An illegal listed move returns ELFGO_E_MCTS_BASE - ELFMCTS_E_FORWARD ("Preload sgf: move not valid!"). */
 int elfsp_preload(ElfSelfPlay* sp, const uint16_t* moves_host, int n, int move_to, void* stream);
-/* finish_game(FR_CLEAR) + restart for the listed games (clear_board) */
+/* finish_game(reason) + restart (game_selfplay.cc:121-149) for the listed games between two searches: the game is scored
+ * (FR_RESIGN: the side to move loses; every other reason: GoState::evaluate(komi), go_state_ext.h:76-103), leaves its record and
+ * starts over from the empty board.  reason = FinishReason of common/go_state_ext.h:24-32. */
+#define ELFSP_FR_RESIGN 0
+#define ELFSP_FR_TWO_PASSES 1
+#define ELFSP_FR_MAX_STEP 2
+#define ELFSP_FR_CLEAR 3
+#define ELFSP_FR_ILLEGAL 4
+int elfsp_finish(ElfSelfPlay* sp, const int32_t* games_host, int n, int reason, void* stream);
+/* = elfsp_finish(..., ELFSP_FR_CLEAR, ...) (clear_board) */
 int elfsp_restart(ElfSelfPlay* sp, const int32_t* games_host, int n, void* stream);
+/* final values of the games finished since the last call, oldest first (what GameNotifier::OnGameEnd feeds to
+ * GameStats::feedWinRate, train/distri_client.h:228-240); returns the number stored (<= cap) */
+int elfsp_take_finished(ElfSelfPlay* sp, float* out_host, int cap);
 /* GoGameSelfPlay::getLastScore: final value of the last finished game of every game slot, host f32 [num_games] */
 int elfsp_last_score(const ElfSelfPlay* sp, float* out_host);
+/* what the last finished search of every game did: out_host[g] = the Coord it forwarded on the game board (after move sampling /
+ * preload substitution), 1 (M_RESIGN) if the engine resigned instead of moving, -1 if no search of that game has finished yet */
+int elfsp_last_moves(const ElfSelfPlay* sp, int32_t* out_host);
 /* Self-play records: with ElfSpOptions.keep_records > 0 every finished game leaves the Record the reference's
  * GameNotifier::OnGameEnd would send (GoStateExt::dumpRecord go_state_ext.h:131-148, Record::setJsonFields record.h:246-254),
  * as the JSON text nlohmann::json::dump() produces.  elfsp_pop_record copies the oldest pending record (NUL-terminated) into buf
@@ -344,6 +360,7 @@ int elfnet_bias_act_bf16(void* x, const void* bias, const void* res, int64_t row
 /* convenience for callers without a HIP runtime of their own (tests, the pybind11/cgo/ctypes side); these act on the calling
  * thread's current device unless a device is named */
 int elfgo_set_device(int device);
+int elfgo_get_device(int* device);
 /* what kind of memory a caller-provided address is: 0 = pageable host (or unknown), 1 = page-locked (pinned) host, 2 = device;
  * *device (may be NULL) <- the owning device for kind 2 */
 int elfgo_pointer_kind(const void* p, int* device);

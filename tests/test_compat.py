@@ -1,133 +1,41 @@
-"""The reference-named Python surface (elf_amd.compat): option structs, GameContext, GCWrapper, Batch.
-CPU part: names, defaults and error behaviour of the reference (utils_elf.py:340-359,406-414; game_context.h:38-40).
-GPU part: a reference-style self-play loop through GCWrapper reproduces a reference fixture."""
-import os
+"""The reference's module names resolve to this library's pybind11 extensions (elf_amd/compat.py); SGF main-line reader; GTP
+coordinate letters.  The boundary itself is exercised in tests/test_pybind_boundary.py."""
+import glob
 
-import numpy as np
 import pytest
 
-from conftest import GOLDEN
 
-
-def test_option_structs_carry_the_reference_field_names():
+def test_reference_module_names_resolve(built):
+    """the import lines of src_py/elfgames/go/game_inference.py:15, game.py:15 and src_py/elf/__init__.py:8"""
     from elf_amd import compat
-    ts = compat.TSOptions()
-    for f in ("max_num_moves", "num_threads", "num_rollouts_per_thread", "num_rollouts_per_batch", "verbose", "verbose_time", "seed",
-              "persistent_tree", "root_epsilon", "root_alpha", "log_prefix", "pick_method", "alg_opt", "virtual_loss"):
-        assert hasattr(ts, f)                      # tree_search_options.h:215-228
-    for f in ("use_prior", "c_puct", "unexplored_q_zero", "root_unexplored_q_zero"):
-        assert hasattr(ts.alg_opt, f)              # tree_search_options.h:70-74
-    assert (ts.num_threads, ts.num_rollouts_per_thread, ts.num_rollouts_per_batch, ts.alg_opt.c_puct) == (16, 100, 8, 5.0)
-    co = compat.ContextOptions()
-    for f in ("job_id", "batchsize", "num_games", "T", "mcts_options"):
-        assert hasattr(co, f)                      # python_options_utils_cpp.h:46
-    go = compat.GameOptions()
-    assert (go.komi, go.policy_distri_cutoff, go.resign_thres, go.move_cutoff) == (7.5, 20, 0.05, -1)
-
-
-def test_error_behaviour_matches_the_reference():
-    from elf_amd import compat
-    go = compat.GameOptions()
-    go.mode = "bogus"
-    with pytest.raises(ValueError):
-        compat.GameContext(compat.ContextOptions(), go)
-    go.mode = "selfplay"
-    gc = compat.GameContext(compat.ContextOptions(), go)
-    params = gc.getParams()
-    assert params["num_action"] == 362 and params["ACTION_PASS"] == -99 and params["num_planes"] == 18
-    w = compat.GCWrapper(gc, 16, {"actor_black": dict(input=["s"], reply=["pi", "V", "a", "rv"]), "game_end": dict(batchsize=1)})
-    with pytest.raises(ValueError):
-        w.reg_callback("no_such_key", lambda b: None)
-    assert w.reg_callback_if_exists("nope", None) is False
-    assert w.reg_callback("actor_black", lambda b: None)
-    with pytest.raises(ValueError):
-        w.start()                                  # game_end has no callback yet (utils_elf.py:416-424)
-    b = compat.Batch(s=np.zeros((4, 2)), last_r=np.arange(5))
-    assert b.first_k(2)["s"].shape == (2, 2) and "r" in b and len(b["r"]) == 4
-    with pytest.raises(KeyError):
-        b["zzz"]
+    mods = compat.install_reference_module_names()
+    import _elfgames_go as go2
+    import _elfgames_go_inference as go
+    from _elf import SearchAlgoOptions, TSOptions   # noqa: F401
+    assert [m.__name__ for m in mods] == ["_elf", "_elfgames_go_inference", "_elfgames_go"]
+    assert all(m.__file__.endswith(".so") for m in mods)          # real extensions, not Python shims
+    co, opt = go.ContextOptions(), go.GameOptions()
+    co.mcts_options.alg_opt.c_puct = 1.5
+    assert isinstance(co.mcts_options, TSOptions) and go2.ContextOptions is go.ContextOptions and go2.GameContext is not go.GameContext
+    co.batchsize, opt.mode = 8, "online"
+    co.mcts_options.num_threads = 1
+    GC = go.GameContext(co, opt)
+    assert GC.getParams()["num_action"] == 362 and GC.getParams()["ACTION_PASS"] == -99
 
 
 def test_sgf_main_line_matches_reference_loader(built):
-    """compat.sgf_main_line against the reference's own Sgf loader (via oracle/_ref) on ladder-suite files"""
-    import glob
+    """the preload_sgf reader of the boundary against the reference's own Sgf loader (via oracle/_ref) on ladder-suite files"""
     from elf_amd import compat
     from pyoracle import Ref
+    compat.install_reference_module_names()
+    import _elf
     files = sorted(glob.glob("/root/reference/ladder_suite/ladder/*.sgf"))[:25]
     if not files or not Ref.available(19):
         pytest.skip("reference tree / oracle/_ref not present")
     R = Ref(19)
     for f in files:
         mv, _ = R.sgf_moves(f)
-        assert compat.sgf_main_line(f, 19) == [int(c) for c in mv], f
-
-
-def test_reference_module_names_resolve(built):
-    """the import lines of src_py/elfgames/go/game_inference.py:15 and src_py/elf/__init__.py:8 work against the shim"""
-    from elf_amd import compat
-    compat.install_reference_module_names()
-    import _elfgames_go_inference as go
-    import _elfgames_go as go2
-    from _elf import TSOptions, SearchAlgoOptions   # noqa: F401
-    co, opt = go.ContextOptions(), go.GameOptions()
-    co.mcts_options.alg_opt.c_puct = 1.5
-    assert isinstance(co.mcts_options, TSOptions) and go2.GameContext is go.GameContext
-    GC = go.GameContext(co, opt)
-    assert GC.getParams()["num_action"] == 362 and GC.getParams()["ACTION_PASS"] == -99
-    assert compat.install_reference_module_names() is not None   # idempotent
-
-
-@pytest.mark.gpu
-def test_reference_style_loop_reproduces_fixture(built):
-    import torch
-    from elf_amd import compat
-    from pyoracle import stub_net
-    g = np.load(os.path.join(GOLDEN, "mcts_19_r256_dir.npz"))
-    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
-    co, opt = compat.ContextOptions(), compat.GameOptions()
-    co.num_games, co.batchsize = 1, 16
-    ts = co.mcts_options
-    ts.num_threads, ts.num_rollouts_per_thread, ts.num_rollouts_per_batch = 1, int(cfg["rollouts_per_thread"]), int(cfg["rollouts_per_batch"])
-    ts.virtual_loss, ts.persistent_tree = int(cfg["virtual_loss"]), bool(cfg["persistent_tree"])
-    ts.root_epsilon, ts.root_alpha = float(np.float32(cfg["root_epsilon"])), float(np.float32(cfg["root_alpha"]))
-    ts.alg_opt.c_puct = float(np.float32(cfg["c_puct"]))
-    opt.seed, opt.komi, opt.policy_distri_cutoff, opt.ply_pass_enabled = int(cfg["seed"]), 7.5, int(cfg["policy_distri_cutoff"]), 0
-    m = 8
-    opt.log_searches = m
-    GC = compat.GameContext(co, opt)
-    desc = {"actor_black": dict(input=["s"], reply=["pi", "V", "a", "rv"], batchsize=16, timeout_usec=10),
-            "game_end": dict(batchsize=1)}
-    gcw = compat.GCWrapper(GC, co.batchsize, desc, num_recv=2, gpu=0, params=GC.getParams())
-    calls = []
-
-    def actor(batch):                              # Evaluator.actor-shaped callback
-        s = batch["s"]
-        calls.append(batch.batchsize)
-        pi, v = stub_net(19, s.cpu().numpy(), int(cfg["net_salt"]), int(cfg["net_tie_levels"]))
-        return dict(pi=torch.from_numpy(pi).to(s.device), V=torch.from_numpy(v).to(s.device), rv=0)
-
-    gcw.reg_callback("actor_black", actor)
-    gcw.reg_callback("game_end", lambda batch: None)
-    gcw.start()
-    GC.getClient().setRequest(0, -1, 0.0, -1)
-    while GC._sp is None or GC._sp.stats()["logged"] < m:
-        gcw.run()
-    gcw.stop()
-    rec, coord, visits, _, _ = GC._sp.search_log()
-    for i in range(m):
-        ne = int(g["n_edges"][i])
-        assert np.array_equal(coord[i, :ne], g["coord"][i, :ne].astype(np.int32))
-        assert np.array_equal(visits[i, :ne], g["visits"][i, :ne])
-        assert rec[i].move_played == int(g["move_played"][i])
-    assert max(calls) <= 16
-    # GoGameSelfPlay accessors the console uses (inference/Pybind.cc:31-45)
-    game = GC.getGame(0)
-    assert game.getNextPlayer() in ("B", "W") and game.getNextPlayer() == ("B" if m % 2 == 0 else "W")
-    last = int(g["move_played"][m - 1])
-    x, y = last % 21 - 1, last // 21 - 1
-    assert game.getLastMove() == chr(ord("A") + (x + 1 if x >= 8 else x)) + str(y + 1)
-    sb = game.showBoard()
-    assert sb.count("X") + sb.count("O") >= m - 2 and isinstance(game.getScore(), float) and game.getLastScore() == 0.0
+        assert list(_elf._go.sgf_main_line(f, 19)) == [int(c) for c in mv], f
 
 
 def test_gtp_coordinate_letters(built):

@@ -77,9 +77,38 @@ def test_gtp_session(elf):
     assert int(eng.boards.info_host(n=1)["ply"][0]) == 1
     assert eng.command("final_score") == "= %s\n\n" % want          # getLastScore of the game just cleared
     recs = eng.sp.pop_records()
-    assert len(recs) == 2                                            # both clear_board calls finished a game (the first one empty)
+    assert len(recs) == 1                                            # the first clear_board found a game that had not started (:306-311)
     import json
-    j = json.loads(recs[1])
+    j = json.loads(recs[0])
     assert j["result"]["num_move"] == int(port.info(st)[0]) - 1 and abs(j["result"]["reward"] - score) < 1e-6
     assert eng.command("quit") == "= \n\n" and eng.exit
+    eng.close()
+
+
+def test_genmove_reports_a_resignation(elf):
+    """ResignCheck (game_utils.h:14-54) through the console: a value head that sees the side to move losing makes the engine
+    resign once ply >= 50; genmove must answer 'resign', not a move inferred from the restarted board."""
+    import torch
+    from elf_amd.gtp import GtpEngine
+    n = 9
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def actor(batch):
+        s = batch["s"]
+        b = s.shape[0]
+        pi = torch.softmax(2.0 * torch.randn((b, n * n + 1), device="cuda", generator=g), dim=1)
+        black_to_move = s[:, 16, 0, 0] > 0
+        v = torch.where(black_to_move, torch.full((b,), -0.96875, device="cuda"), torch.full((b,), 0.96875, device="cuda"))
+        return dict(pi=pi, V=v)
+
+    eng = GtpEngine(actor, board_size=n, mcts_rollout_per_thread=32, nodes_per_game=2048, resign_thres=0.1, ply_pass_enabled=200)
+    replies = []
+    for _ in range(80):
+        r = eng.command("genmove " + eng.next_player().lower())
+        assert r.startswith("= ")
+        replies.append(r[2:].strip())
+        if replies[-1] == "resign":
+            break
+    assert replies[-1] == "resign" and len(replies) >= 50
+    assert int(eng.boards.info_host(n=1)["ply"][0]) == 1          # finish_game(FR_RESIGN) restarted the board
     eng.close()
