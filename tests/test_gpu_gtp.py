@@ -86,8 +86,8 @@ def test_gtp_session(elf):
 
 
 def test_genmove_reports_a_resignation(elf):
-    """ResignCheck (game_utils.h:14-54) through the console: a value head that sees the side to move losing makes the engine
-    resign once ply >= 50; genmove must answer 'resign', not a move inferred from the restarted board."""
+    """ResignCheck (game_utils.h:14-54) through the console: a value head that sees Black losing makes the engine resign for
+    Black once ply >= 50 (ply 51, Black to move); genmove must answer 'resign', not a move inferred from the restarted board."""
     import torch
     from elf_amd.gtp import GtpEngine
     n = 9
@@ -97,8 +97,7 @@ def test_genmove_reports_a_resignation(elf):
         s = batch["s"]
         b = s.shape[0]
         pi = torch.softmax(2.0 * torch.randn((b, n * n + 1), device="cuda", generator=g), dim=1)
-        black_to_move = s[:, 16, 0, 0] > 0
-        v = torch.where(black_to_move, torch.full((b,), -0.96875, device="cuda"), torch.full((b,), 0.96875, device="cuda"))
+        v = torch.full((b,), -0.96875, device="cuda")        # values are Black-positive: Black is always seen losing
         return dict(pi=pi, V=v)
 
     eng = GtpEngine(actor, board_size=n, mcts_rollout_per_thread=32, nodes_per_game=2048, resign_thres=0.1, ply_pass_enabled=200)
@@ -109,6 +108,6 @@ def test_genmove_reports_a_resignation(elf):
         replies.append(r[2:].strip())
         if replies[-1] == "resign":
             break
-    assert replies[-1] == "resign" and len(replies) >= 50
+    assert replies[-1] == "resign" and len(replies) == 51 and "resign" not in replies[:-1]
     assert int(eng.boards.info_host(n=1)["ply"][0]) == 1          # finish_game(FR_RESIGN) restarted the board
     eng.close()

@@ -361,7 +361,8 @@ def test_gcwrapper_session_reproduces_the_reference_fixture(mods, device_residen
     x, y = last % 21 - 1, last // 21 - 1
     assert game.getLastMove() == chr(ord("A") + (x + 1 if x >= 8 else x)) + str(y + 1)
     sb = game.showBoard()
-    assert sb.count("X") + sb.count("O") >= m - 2 and sb.count(")") == 1 and "has captured" in sb
+    # m stones minus captures, the last move marked "X)" / "O)" once; the two caption lines carry "(X)" and "(O)" themselves
+    assert sb.count("X ") + sb.count("O ") + 1 >= m - 2 and sb.count("X)") + sb.count("O)") == 3 and "has captured" in sb
     assert isinstance(game.getScore(), float) and game.getLastScore() == 0.0
     assert GC.getClient().getGameStats().getWinRateStats().total_games == 0
     ev["gcw"].stop()
