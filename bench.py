@@ -1,24 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- driver contract.
 
-  python bench.py --gpus N --steps K --warmup W [--workload mcts|board]
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--workload mcts|board|train|feature|boundary|games|both]
 
-Default workload "mcts" = BASELINE.json configs[2], the configuration the headline metric is quoted on:
-MCTS self-play, 16 rollouts per batch per game, 8192 rollouts per move, puct 1.5, virtual loss 1, Dirichlet
-0.25/0.03, random-init 20-block/256-channel policy/value net on PyTorch-ROCm (fp16, channels_last), G games per
-GPU in lock-step.  One "step" = one batch of the reference's batch interface for every game: G*16 rollouts
-(select -> leaf features -> net -> expand -> backup).  value = rollouts/s summed over ranks.
+--gpus N > 1 without a launcher environment: the script re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1`, one process per GPU (under the driver's own torchrun launch RANK / WORLD_SIZE are
+already set and are used as they are).  Rank 0 prints ONE JSON line.
 
-Workload "board" = configs[1]: 4096 concurrent 19x19 boards per GPU played to game end by the config-2 policy,
-whole games inside one k_playout launch; value = board steps/s.  The default run also measures it and reports
-it under "board_step" in the same JSON line.
+Default workload = BASELINE.json configs[2], the configuration the headline metric is quoted on: MCTS self-play, 16 rollouts per
+batch per game, 8192 rollouts per move, puct 1.5, virtual loss 1, Dirichlet 0.25/0.03, random-init 20-block/256-channel
+policy/value net on PyTorch-ROCm (fp16, channels_last), G games per GPU in lock-step groups pipelined against the net.  One
+"step" = one batch of the reference's batch interface for every game: G*16 rollouts (select -> leaf features -> net -> expand ->
+backup).  value = rollouts/s summed over ranks.  The trees are grown in an UNTIMED prologue (cheap pseudo-random replies instead
+of the conv net) to the point where the timed steps run at the depth of a search in progress and CROSS A MOVE BOUNDARY (root
+statistics down, move choice, forward, treeAdvance, Dirichlet draws, next search).
 
+At N = 1 the same JSON line carries sub-results measured in the same run (each with its own roofline):
+  board_step      configs[1]: 4096 boards 19x19 played to the end by the config-2 policy in one k_playout launch, EVERY final
+                  (hash, ply, steps) compared with the reference (parity_checked_boards)
+  board_step_9x9  configs[4]: 65 536 boards 9x9, same protocol, same check
+  feature_extract extractAGZ rows per second, fp32 NCHW and fp16 NHWC, GB/s against the HBM roof
+  train_loader    SURVEY.md 8f-1 trainer input pipeline
+  boundary        the pybind11 drop-in boundary (_elf / _elfgames_go): rollouts/s with the batch tensors in pinned host memory
+                  (the reference's Allocator) and device-resident, serial wait()/step() loop
+  selfplay_games  whole self-play games per second on a SHORTENED configuration (few rollouts per move, move cutoff): the full
+                  game loop (moves, restarts, records) measured rather than estimated
 Weak scaling: every rank owns independent games/boards, no data-path collective.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,9 +41,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz max clock
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s = 1228.8
 STEP_BYTES = {19: 8730, 9: 4450}  # reference state in + out + legal mask, per board step
-# SURVEY.md 8d, algorithmic bytes of one MCTS rollout: per visited node 362 x 20 B edge read + 12 B vloss write + 12 B
-# backup write; per expansion 8368 B state copy + 7240 B edge init + 26728 B features + 1468 B reply read + 8730 B legality
+FEAT_BYTES = {("f32", 19): 26728, ("f32", 9): 6008, ("f16", 19): 13732, ("f16", 9): 3092}   # row written + 16 history bit-planes read
+# SURVEY.md 8d, algorithmic bytes of one MCTS rollout: per visited node 362 x 20 B edge read + 12 B vloss write + 12 B backup
+# write; per expansion 8368 B state copy + 7240 B edge init + 26728 B features + 1468 B reply read + 8730 B legality
 ROLLOUT_NODE_BYTES = 362 * 20 + 12 + 12
 ROLLOUT_EXPAND_BYTES = 8368 + 7240 + 26728 + 1468 + 8730
 
@@ -42,32 +57,68 @@ def seeds_for(rank, boards, rep):
     return b * np.uint64(0x9E3779B9) + np.uint64(1)
 
 
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/gpu_round.sh), committed under profiles/."""
+    return load_profile_json("pmc_traffic.json").get(kernel, {}).get("hbm_bytes_per_launch")
+
+
+def issue_roof(kernel, units_per_launch, kernel_s):
+    """Instruction-issue roof of a kernel that lives in LDS/registers (board engine): VALU wave-instructions per second against
+    what 1024 SIMD-32 can issue (one wave64 VALU op per 2 cycles at 2.4 GHz).  The per-unit VALU count comes from the committed
+    PMC pass (profiles/pmc_issue.json: SQ_INSTS_VALU / units); HBM bytes per launch are reported as `traffic`."""
+    per = load_profile_json("pmc_issue.json").get(kernel, {})
+    valu = per.get("valu_per_unit")
+    if not valu:
+        return None
+    ach = units_per_launch * valu / kernel_s / 1e9
+    return {"bound": "issue", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": ach / VALU_PEAK_GINST,
+            "traffic": load_traffic(kernel), "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "valu_per_unit": valu,
+            "salu_per_unit": per.get("salu_per_unit"), "lds_per_unit": per.get("lds_per_unit"), "profile": per.get("profile"),
+            "note": "the position never leaves LDS, so HBM is not the roof: frac = VALU wave-instructions/s (SQ_INSTS_VALU per unit from "
+                    "profiles/pmc_issue.json x units/s) / (1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 op), i.e. the VALU-pipe busy "
+                    "fraction at the maximum clock; traffic = PMC HBM bytes per launch"}
+
+
+# ------------------------------------------------------------------------------------------------------------------- CPU baselines
+def _oracle():
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import pyoracle
+    return pyoracle
+
+
 def cpu_baseline_board(n, budget_s=12.0):
     """Reference (oracle/_ref, the real ELF board engine) or port timed on the host cores, bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
-        from pyoracle import Port, Ref, playout_seeds
+        po = _oracle()
     except Exception as e:  # checker missing: report, never substitute
         return {"value": None, "unit": "board_steps/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
     cores = max(1, min(len(os.sched_getaffinity(0)), 64))
-    if Ref.available(n):
-        R = Ref(n)
+    if po.Ref.available(n):
+        R = po.Ref(n)
         t0 = time.time()
-        tot, _ = R.playout(playout_seeds(cores * 8), threads=cores)  # calibration
+        tot, _ = R.playout(po.playout_seeds(cores * 8), threads=cores)  # calibration
         rate = tot / max(time.time() - t0, 1e-6)
         games = int(max(cores * 4, min(65536, rate * budget_s / 455.0)))
         games -= games % cores
         t0 = time.time()
-        tot, _ = R.playout(playout_seeds(games), threads=cores)
+        tot, _ = R.playout(po.playout_seeds(games), threads=cores)
         dt = time.time() - t0
-        return {"value": tot / dt, "unit": "board_steps/s", "cores": cores, "kind": "reference",
-                "per_core": tot / dt / cores,
+        return {"value": tot / dt, "unit": "board_steps/s", "cores": cores, "kind": "reference", "per_core": tot / dt / cores,
                 "sample": "%d of the same %dx%d config-2 games (%d board steps) on %d host threads, %.1f s" % (games, n, n, tot, cores, dt)}
-    P = Port(n)
+    P = po.Port(n)
     t0, tot, games = time.time(), 0, 0
     while time.time() - t0 < budget_s:
         s = P.new()
-        tot += len(P.playout_moves(s, int(playout_seeds(1, base=games)[0])))
+        tot += len(P.playout_moves(s, int(po.playout_seeds(1, base=games)[0])))
         P.free(s)
         games += 1
     dt = time.time() - t0
@@ -75,23 +126,38 @@ def cpu_baseline_board(n, budget_s=12.0):
             "sample": "%d config-2 games (%d board steps), single thread, %.1f s" % (games, tot, dt)}
 
 
-def cpu_baseline_mcts(n, rollouts_per_batch):
-    """The REAL reference self-play stack (oracle/_ref/libelfsp: Context batcher + GoGameSelfPlay + MCTSGoAI) on the host
-    cores, one game thread + one search thread per core, net replaced by the stub (host-side ceiling of the reference:
-    its net time is excluded, ours is included)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+def reference_playout(n, seeds):
+    """(hash_lo, hash_hi, ply, steps) of every board from the CPU checker: the real reference where its prebuilt library is
+    present, its C restatement otherwise.  -> (uint32 [boards, 4], kind)"""
+    po = _oracle()
+    if po.Ref.available(n):
+        _, out = po.Ref(n).playout(seeds, threads=max(1, min(len(os.sched_getaffinity(0)), 64)))
+        return out, "reference"
+    P = po.Port(n)
+    out = np.zeros((len(seeds), 4), np.uint32)
+    for i, sd in enumerate(seeds):
+        s = P.new()
+        mv = P.playout_moves(s, int(sd))
+        h = P.hash(s)
+        out[i] = (h & 0xFFFFFFFF, h >> 32, int(P.info(s)[0]), len(mv))
+        P.free(s)
+    return out, "port"
+
+
+def cpu_baseline_mcts_stub(n, rollouts_per_batch):
+    """The REAL reference self-play stack (oracle/_ref/libelfsp: Context batcher + GoGameSelfPlay + MCTSGoAI) on the host cores,
+    one game thread + one search thread per core, net replaced by the stub: the host-side ceiling of the reference (its net time
+    is excluded, ours is included)."""
     try:
-        from pyoracle import RefSelfPlay
+        po = _oracle()
     except Exception as e:
         return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
-    if not RefSelfPlay.available(n):
-        # no prebuilt reference here (fresh clone): time the CPU restatement (oracle/mcts_oracle.cc) instead, one core
+    if not po.RefSelfPlay.available(n):
         try:
-            from pyoracle import PortSelfPlay
             rollouts, moves = 1024, 3
             t0 = time.time()
-            r = PortSelfPlay(n).run(num_games=1, mcts_threads=1, rollouts_per_thread=rollouts, rollouts_per_batch=rollouts_per_batch,
-                                    batchsize=rollouts_per_batch, max_searches=moves, seed=1234)
+            r = po.PortSelfPlay(n).run(num_games=1, mcts_threads=1, rollouts_per_thread=rollouts, rollouts_per_batch=rollouts_per_batch,
+                                       batchsize=rollouts_per_batch, max_searches=moves, seed=1234)
             dt = time.time() - t0
             return {"value": len(r["search"]) * rollouts / dt, "unit": "rollouts/s", "cores": 1, "kind": "port",
                     "sample": "%d searches of %d rollouts (bs %d) by the single-threaded CPU restatement, stub net included, %.1f s"
@@ -100,13 +166,74 @@ def cpu_baseline_mcts(n, rollouts_per_batch):
             return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
     cores = max(1, min(len(os.sched_getaffinity(0)) // 2, 32))
     rollouts, moves = 2048, 2
-    r = RefSelfPlay(n).run(num_games=cores, mcts_threads=1, rollouts_per_thread=rollouts, rollouts_per_batch=rollouts_per_batch,
-                           batchsize=rollouts_per_batch, max_searches=cores * moves, seed=1234)
+    r = po.RefSelfPlay(n).run(num_games=cores, mcts_threads=1, rollouts_per_thread=rollouts, rollouts_per_batch=rollouts_per_batch,
+                              batchsize=rollouts_per_batch, max_searches=cores * moves, seed=1234)
     dt = r["usec"] / 1e6
     done = len(r["search"]) * rollouts
     return {"value": done / dt, "unit": "rollouts/s", "cores": cores * 2, "kind": "reference",
             "sample": "%d searches of %d rollouts (bs %d) by %d reference game threads + %d search threads, stub net (net time "
                       "excluded), %.1f s" % (len(r["search"]), rollouts, rollouts_per_batch, cores, cores, dt)}
+
+
+def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=20.0):
+    """SURVEY.md 8d / BASELINE.md: the reference stack (its TreeSearchT + batcher, oracle/_ref/libelfsp) driving the SAME
+    PyTorch-ROCm net through its batch interface (`refsp_net_fn` plays GCWrapper's part: pinned-host rows -> GPU -> net -> host),
+    mcts_threads = 2, batchsize = 16 as in start_selfplay.sh, game threads sized to the host cores.  Bounded sample."""
+    try:
+        po = _oracle()
+    except Exception as e:
+        return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
+    if not po.RefSelfPlay.available(n) or net is None:
+        return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": "oracle/_ref/libelfsp%d.so not built" % n}
+    host = len(os.sched_getaffinity(0))
+    games = max(1, min(host // 3, 32))          # one game thread + two search threads each
+    calls = [0, 0]
+
+    def net_fn(s):
+        with torch.no_grad():
+            x = torch.from_numpy(s).to(dev, non_blocking=True)
+            out = net({"s": x.to(dtype).contiguous(memory_format=torch.channels_last)})
+            calls[0] += 1
+            calls[1] += s.shape[0]
+            return out["pi"].float().cpu().numpy(), out["V"].float().cpu().numpy()
+
+    R = po.RefSelfPlay(n)
+    rollouts = 256
+    # calibrate on one search per game, then size the sample to the budget
+    t0 = time.time()
+    r = R.run(net=net_fn, num_games=games, mcts_threads=2, rollouts_per_thread=rollouts // 2, rollouts_per_batch=rollouts_per_batch,
+              batchsize=rollouts_per_batch, max_searches=games, seed=1234, timeout_usec=10)
+    dt0 = max(r["usec"] / 1e6, 1e-3)
+    per = dt0 / max(len(r["search"]), 1)
+    searches = int(max(games, min(64 * games, (budget_s - (time.time() - t0)) / max(per, 1e-4))))
+    calls[0] = calls[1] = 0
+    r = R.run(net=net_fn, num_games=games, mcts_threads=2, rollouts_per_thread=rollouts // 2, rollouts_per_batch=rollouts_per_batch,
+              batchsize=rollouts_per_batch, max_searches=searches, seed=1234, timeout_usec=10)
+    dt = r["usec"] / 1e6
+    done = len(r["search"]) * rollouts       # 2 search threads x rollouts/2 each (tree_search.h:472-476)
+    return {"value": done / dt, "unit": "rollouts/s", "cores": games * 3, "kind": "reference",
+            "sample": "%d searches of %d rollouts (2 search threads x %d, bs %d) by %d reference game threads, the same %s net on the "
+                      "GPU through the reference's batch interface (%d net calls, mean %.1f rows), net time INCLUDED, %.1f s"
+                      % (len(r["search"]), rollouts, rollouts // 2, rollouts_per_batch, games, str(dtype).replace("torch.", ""), calls[0],
+                         calls[1] / max(calls[0], 1), dt)}
+
+
+# ------------------------------------------------------------------------------------------------------------------- distributed
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_spawn(n):
+    """python bench.py --gpus N (no launcher environment): become `torch.distributed.run` with N workers, one per GPU."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def init_dist(args):
@@ -140,16 +267,58 @@ def reduce_max_sum(dist, dev, dt, count):
     return float(t_all.item()), int(s_all.item())
 
 
-def run_board(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
+def gather_per_rank(dist, dev, value, world):
+    if dist is None:
+        return [value]
+    t = torch.zeros(world, dtype=torch.float64, device=dev)
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def make_barrier(dist):
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    return barrier
+
+
+def run_stub(args, rank, local_rank, world, dist, steps, warmup):
+    """CPU stand-in workload for the N > 1 plumbing test (tests/test_dist_gloo.py): no GPU, no library -- each rank "processes"
+    1000 + rank units per step; the report must carry the slowest rank's time and the sum of the units."""
+    dev = torch.device("cpu")
+    barrier = make_barrier(dist)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        time.sleep(0.002 * (rank + 1))
+    barrier()
+    dt = time.perf_counter() - t0
+    dt_max, total = reduce_max_sum(dist, dev, dt, (1000 + rank) * steps)
+    per_rank = gather_per_rank(dist, dev, float((1000 + rank) * steps), world)
+    if rank != 0:
+        return None
+    return {"metric": "stub_units_per_sec", "value": total / dt_max, "unit": "units/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+            "data": "synthetic", "config": {"workload": "CPU stub (plumbing test of the N-rank path)", "per_rank_units": per_rank, "units": total}}
+
+
+# ------------------------------------------------------------------------------------------------------------------- board step
+def run_board(args, rank, local_rank, world, dist, steps, warmup, with_cpu, n=None, boards=None):
     import elf_amd
-    n, boards = args.board_size, args.boards
+    n = n or args.board_size
+    boards = boards or args.boards
     eng = elf_amd.GoEngine(n, boards, local_rank)
     dev = eng.device
     out = torch.empty((boards, 4), dtype=torch.int32, device=dev)
     total = warmup + steps
-    seeds = [torch.from_numpy(seeds_for(rank, boards, r).view(np.int64)).to(dev) for r in range(total)]  # resident in HBM
+    host_seeds = [seeds_for(rank, boards, r) for r in range(total)]
+    seeds = [torch.from_numpy(s.view(np.int64)).to(dev) for s in host_seeds]  # resident in HBM
     step_counts = torch.zeros(total, dtype=torch.int64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(total)]
+    keep = torch.empty((boards, 4), dtype=torch.int32, device=dev)   # results of the first timed pass, for the parity check
 
     def one(r):
         eng.reset()                       # GoState::reset for every board
@@ -157,12 +326,10 @@ def run_board(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         eng.playout(seeds[r], out=out)    # the dominant kernel, on torch's current stream
         ev[r][1].record()
         step_counts[r] = out[:, 3].to(torch.int64).sum()
+        if r == warmup:
+            keep.copy_(out)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier = make_barrier(dist)
     for r in range(warmup):
         one(r)
     barrier()
@@ -175,97 +342,163 @@ def run_board(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     my_steps = int(counts[warmup:].sum())
     kern_ms = [ev[r][0].elapsed_time(ev[r][1]) for r in range(warmup, total)]
     dt_max, steps_all = reduce_max_sum(dist, dev, dt, my_steps)
+    got = keep.cpu().numpy().astype(np.uint32)
     eng.close()
     if rank != 0:
         return None
     avg_kernel_s = float(np.mean(kern_ms)) / 1e3
     steps_per_launch = my_steps / steps
-    achieved = steps_per_launch * STEP_BYTES[n] / avg_kernel_s / 1e9
-    traffic = load_traffic("k_playout<%d>" % n)
+    kname = "k_playout<%d>" % n
+    # wave-lifetime utilisation: every board is one wave resident from t = 0; the launch lasts as long as the longest game
+    lens = got[:, 3].astype(np.float64)
+    life = float(lens.mean() / max(lens.max(), 1.0))
     res = {
         "metric": "board_steps_per_sec (%dx%d GoState::forward + legal-move mask, random legal play to game end)" % (n, n),
         "value": steps_all / dt_max, "unit": "board_steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %d concurrent %dx%d boards per GPU, config-2 random legal non-eye play "
-                               "to game end, board-step kernel only (no net)" % (boards, n, n),
+        "config": {"workload": "BASELINE configs[%d]: %d concurrent %dx%d boards per GPU, config-2 random legal non-eye play "
+                               "to game end, board-step kernel only (no net)" % (1 if n == 19 else 4, boards, n, n),
                    "boards_per_gpu": boards, "board_size": n, "board_steps_per_pass": steps_per_launch,
+                   "mean_game_length": float(lens.mean()), "longest_game": int(lens.max()),
+                   "wave_lifetime_utilisation": life,
+                   "wave_lifetime_note": "mean game length / longest game: one wave per board, all resident from the start, the launch "
+                                         "ends with the longest game -- the share of wave-slot time that holds a live game",
+                   "algorithmic_GBps": steps_per_launch * STEP_BYTES[n] / avg_kernel_s / 1e9,
+                   "algorithmic_note": "SURVEY.md 8d bytes (reference Board in+out + legal mask = %d B per step) x steps/s: the data "
+                                       "movement the reference's formulation would need; NOT this kernel's roof" % STEP_BYTES[n],
                    "parallelism": "independent boards per GPU, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_playout<%d>" % n, "avg_kernel_ms": avg_kernel_s * 1e3,
-                     "algorithmic_bytes_per_step": STEP_BYTES[n],
-                     "note": "algorithmic bytes = reference Board in+out + legal mask per step (SURVEY.md 8d); the kernel "
-                             "keeps the position in LDS for the whole game, so this is a rate against the HBM roof; "
-                             "traffic = PMC HBM bytes per launch from profiles/ (FETCH_SIZE x2 + WRITE_SIZE, KiB)"},
     }
+    roof = issue_roof(kname, steps_per_launch, avg_kernel_s)
+    if roof is None:
+        roof = {"bound": "issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
+                "traffic": load_traffic(kname), "kernel": kname, "avg_kernel_ms": avg_kernel_s * 1e3,
+                "note": "profiles/pmc_issue.json has no VALU count for this kernel"}
+    res["roofline"] = roof
+    # parity: EVERY board of the first timed pass against the CPU checker (final hash + ply of every board)
+    mismatch = None
+    try:
+        t0 = time.time()
+        want, kind = reference_playout(n, host_seeds[warmup])
+        ok = int(np.sum(np.all(got == want, axis=1)))
+        res["parity_checked_boards"] = int(boards)
+        res["parity_mismatches"] = int(boards) - ok
+        res["parity_checker"] = "%s, %.1f s" % (kind, time.time() - t0)
+        if ok != boards:
+            mismatch = "bench: %d of %d boards differ from the %s -- results are invalid" % (boards - ok, boards, kind)
+    except Exception as e:
+        res["parity_checked_boards"] = 0
+        res["parity_checker"] = "unavailable: %r" % (e,)
+    if mismatch:
+        raise SystemExit(mismatch)
     res["cpu_baseline"] = cpu_baseline_board(n) if with_cpu else None
     return res
 
 
-def load_traffic(kernel):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/gpu_round.sh), committed under profiles/."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        return json.load(open(p)).get(kernel, {}).get("hbm_bytes_per_launch")
-    except Exception:
+# ------------------------------------------------------------------------------------------------------------------- features
+def run_feature(args, rank, local_rank, world, dist, steps, warmup):
+    """extractAGZ alone (north_star: HBM GB/s on feature extraction): rows boards in mid-game positions, random D4 codes, one
+    launch writes every row.  fp32 NCHW (the reference's "s" layout) and fp16 NHWC."""
+    import elf_amd
+    n, rows = args.board_size, args.feature_rows
+    dev = torch.device("cuda", local_rank)
+    eng = elf_amd.GoEngine(n, rows, local_rank)
+    # positions: 60 plies of the config-2 policy (8 history planes filled, stones on the board)
+    out4 = torch.empty((rows, 4), dtype=torch.int32, device=dev)
+    eng.playout(torch.from_numpy(seeds_for(rank, rows, 777).view(np.int64)).to(dev), max_steps=60, out=out4)
+    d4 = torch.randint(0, 8, (rows,), device=dev, dtype=torch.int32)
+    res = {}
+    for fmt, key in (("f32_nchw", "f32"), ("f16_nhwc", "f16")):
+        dst = None
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for _ in range(warmup):
+            dst = eng.extract_agz(d4=d4, out=dst, fmt=fmt)
+        torch.cuda.synchronize()
+        for i in range(steps):
+            ev[i][0].record()
+            dst = eng.extract_agz(d4=d4, out=dst, fmt=fmt)
+            ev[i][1].record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        per = FEAT_BYTES[(key, n)]
+        gbs = rows * per / (ms / 1e3) / 1e9
+        res[key] = {"rows_per_sec": rows / (ms / 1e3), "avg_kernel_ms": ms,
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "traffic": load_traffic("k_extract_agz<%d>:%s" % (n, key)), "kernel": "k_extract_agz<%d> (%s)" % (n, fmt),
+                                 "algorithmic_bytes_per_row": per}}
+    eng.close()
+    if rank != 0:
         return None
+    return {"metric": "feature_rows_per_sec (extractAGZ 18 planes, random D4)", "rows": rows, "board_size": n, **res,
+            "note": "one wave per row; fp32 row = 25 992 B written + 736 B of history bit-planes read (SURVEY.md 8d); measured "
+                    "achievable HBM copy bandwidth on this part is ~6.3 TB/s (MI355X_MICROARCH.md)"}
 
 
-def mcts_traffic(n, rollouts_per_step):
-    """PMC HBM bytes of the four search kernels per step, scaled per rollout from the profiled run (profiles/pmc_traffic.json)."""
-    try:
-        per = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["k_mcts_search<%d>" % n]["hbm_bytes_per_rollout"]
-        return per * rollouts_per_step
-    except Exception:
-        return None
+# ------------------------------------------------------------------------------------------------------------------- MCTS
+class RandomReplies:
+    """Pseudo-random policy/value replies drawn on the GPU (no conv net): a peaky policy grows deep, narrow trees like a trained
+    net does.  Used for --net random and for the untimed tree-growing prologue of the headline."""
+
+    def __init__(self, rows, na, dev, seed):
+        self.rows, self.na, self.dev = rows, na, dev
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+
+    def __call__(self, s=None, rows=None):
+        return (torch.softmax(4.0 * torch.randn((self.rows, self.na), device=self.dev, generator=self.gen), dim=1),
+                torch.tanh(0.5 * torch.randn((self.rows,), device=self.dev, generator=self.gen)))
+
+
+def build_net(args, n, dev):
+    from elf_amd.net import make_net
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.net_dtype]
+    if args.net != "resnet":
+        return None, dtype
+    torch.backends.cudnn.benchmark = True
+    net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0, fold_bn=not args.no_fold_bn)
+    if args.no_fold_bn or dtype == torch.float32:
+        args.net_impl = "eager"   # the fused epilogue is an fp16/bf16, BN-folded inference path
+    if args.net_impl != "eager":
+        from elf_amd.net import FusedInferenceNet
+        net = FusedInferenceNet(net)
+    return net, dtype
+
+
+def net_flops_per_position(args, n):
+    d = n * n
+    return 2.0 * d * 9 * (18 * args.net_dim + 2 * args.net_blocks * args.net_dim * args.net_dim) \
+        + 2.0 * d * args.net_dim * 3 + 2.0 * (2 * d * (d + 1) + d * 256 + 256)
 
 
 def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
-    import elf_amd
-    from elf_amd.net import make_net
+    import elf_amd  # noqa: F401
+    from elf_amd.pipeline import PipelinedSelfPlay
     n, G, K = args.board_size, args.games, args.rollouts_per_batch
     dev = torch.device("cuda", local_rank)
-    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.net_dtype]
-    net = None
-    if args.net == "resnet":
-        torch.backends.cudnn.benchmark = True
-        net = make_net(n, args.net_blocks, args.net_dim, dev, dtype, channels_last=True, seed=0, fold_bn=not args.no_fold_bn)
-        if args.no_fold_bn or dtype == torch.float32:
-            args.net_impl = "eager"   # the fused epilogue is an fp16, BN-folded inference path
-        if args.net_impl != "eager":
-            from elf_amd.net import FusedInferenceNet
-            net = FusedInferenceNet(net)
+    net, dtype = build_net(args, n, dev)
     feat_fmt = "f16_nhwc" if (args.features == "f16" or (args.features == "auto" and net is not None and dtype == torch.float16)) else "f32_nchw"
-    from elf_amd.pipeline import PipelinedSelfPlay
     groups = max(1, args.groups)
     Gg = G // groups
     G = Gg * groups
     sp = PipelinedSelfPlay(groups=groups, seed=1234, game_idx_base=rank * G, wait_rows=bool(args.wait_rows), board_size=n, num_games=Gg,
-                           device=local_rank,
-                           mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1,
-                           mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0,
-                           policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt)
+                           device=local_rank, mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5,
+                           mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5,
+                           ply_pass_enabled=0, policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt,
+                           mcts_threads=args.mcts_threads)
     na = n * n + 1
     rows_max = sp.groups[0].max_rows
-    # --net random: a peaky pseudo-random policy and a random value drawn on the GPU by torch (no conv net): isolates the
-    # search kernels while still growing deep, narrow trees like a trained net does.  --net null: uniform prior, V = 0.
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(99 + rank)
+    rnd = RandomReplies(rows_max, na, dev, 99 + rank)
     uni_pi = torch.full((rows_max, na), 1.0 / na, dtype=torch.float32, device=dev)
     zero_v = torch.zeros(rows_max, dtype=torch.float32, device=dev)
-    rows_log = []
     if net is not None:
         # initialisation, not a step: the first call of each convolution shape runs MIOpen's find (tens of seconds on a fresh box).
-        # Done here so that even --warmup 0 times steady-state steps only.
         with torch.no_grad():
             net({"s": sp.groups[0].s})
         torch.cuda.synchronize()
     graphs = {}
     if net is not None and args.net_graph:
-        # one HIP graph per game group (PyTorch's CUDAGraph on ROCm): the ~85 kernel launches of a net call (41 convolutions, 41
-        # epilogue passes, heads) become one graph launch; the graph reads the group's own "s" tensor, which is where the select
-        # kernel writes the leaf features, and its output tensors are what the expand kernel reads
+        # one HIP graph per game group (PyTorch's CUDAGraph on ROCm): the ~85 kernel launches of a net call become one graph launch;
+        # the graph reads the group's own "s" tensor, where the select kernel writes the leaf features
         from elf_amd.net import GraphedNet
         try:
             for g in sp.groups:
@@ -283,93 +516,272 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                 out = gn()
                 return out["pi"], out["V"]
             with torch.no_grad():
-                out = net({"s": s})   # fixed shape [Gg*K, 18, N, N]: rows >= `rows` are stale and ignored (no MIOpen re-tuning)
+                out = net({"s": s})   # fixed shape [Gg*K, 18, N, N]: rows beyond the count are stale and ignored
             return out["pi"], out["V"]
         if args.net == "random":
-            return (torch.softmax(4.0 * torch.randn((rows_max, na), device=dev, generator=gen), dim=1),
-                    torch.tanh(0.5 * torch.randn((rows_max,), device=dev, generator=gen)))
+            return rnd()
         return uni_pi, zero_v
 
-    def one(i):
-        rows_log.append(sp.step(net_fn))   # every group: select -> leaf features -> net -> expand -> backup
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier = make_barrier(dist)
+    # ---- untimed prologue: grow every tree with cheap pseudo-random replies so that the timed window is a search IN PROGRESS that
+    # ends its move inside the window (the move boundary falls in the middle of the timed steps)
+    spm = sp.groups[0].stats()["steps_per_move"]
+    if args.pregrow < 0:
+        pregrow = max(0, spm - warmup - max(1, steps // 2)) if steps + warmup < spm else 0
+    else:
+        pregrow = args.pregrow
+    for _ in range(pregrow):
+        sp.step(lambda s, rows: rnd())
+    sp.synchronize()
     for i in range(warmup):
-        one(i)
+        sp.step(net_fn)
+    sp.synchronize()
     barrier()
+    st0 = sp.stats()
     sp.timing = True
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        one(i)
+    for i in range(steps):
+        sp.step(net_fn)   # every group: net -> expand -> backup -> select -> leaf features
+    sp.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     sp.timing = False
-    my_rollouts = G * K * steps
-    st = sp.stats()
-    my_rows = int(sum(rows_log[warmup:])) if args.wait_rows else int(st["rows"] * steps / max(st["steps"] / groups, 1))
+    st1 = sp.stats()
+    T = max(1, args.mcts_threads)
+    my_rollouts = G * K * T * steps
+    d = {k: st1[k] - st0[k] for k in ("moves", "games", "rollouts", "rows", "steps", "node_visits", "boundary_ns", "boundaries")}
+    my_rows = d["rows"]
     sel_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_select])) / steps
     exp_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_expand])) / steps
     net_ms = float(np.mean([a.elapsed_time(b) for a, b in sp.t_net])) if sp.t_net else 0.0   # per net call (one group)
     dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
+    per_rank = gather_per_rank(dist, dev, my_rollouts / dt, world)
     sp.close()
     if rank != 0:
         return None
     step_ms = dt_max / steps * 1e3
-    # roofline of the search kernels (select+features / expand+backup), SURVEY.md 8d bytes with a depth estimate
-    depth = st["node_visits"] / max(st["rollouts"], 1)   # measured mean descent depth (select kernel counter)
-    bytes_per_step = G * K * depth * ROLLOUT_NODE_BYTES + my_rows / steps * ROLLOUT_EXPAND_BYTES
+    depth = d["node_visits"] / max(d["rollouts"], 1)   # measured mean descent depth over the timed window
+    bytes_per_step = (d["node_visits"] * ROLLOUT_NODE_BYTES + my_rows * ROLLOUT_EXPAND_BYTES) / steps
     search_s = (sel_ms + exp_ms) / 1e3
-    achieved = bytes_per_step / search_s / 1e9
+    achieved = bytes_per_step / search_s / 1e9 if search_s > 0 else None
+    # the select kernel alone: per visited node the header + edge statistics + child ids + coords it really loads, per new node
+    # the parent's board slot in and the child's out
+    sel_bytes = (d["node_visits"] * (64 + 368 * 22) + my_rows * (2 * 3840 + 64)) / steps if n == 19 else None
+    net_desc = ("random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s%s; leaf features %s)"
+                % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs",
+                   {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl]
+                   + (", one HIP graph per net call" if args.net_graph else ""), feat_fmt)
+                if net is not None else "NO conv net (--net %s: search kernels only)" % args.net)
+    moves_per_game = 250.0
     res = {
-        "metric": "mcts_rollouts_per_sec (self-play, %dx%d Go, %d rollouts/move, bs %d)" % (n, n, args.rollouts, K),
+        "metric": "mcts_rollouts_per_sec (self-play, %dx%d Go, %d rollouts/move, bs %d)" % (n, n, args.rollouts * T, K),
         "value": roll_all / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
-                               "persistent tree, %s, %d games per GPU in %d lock-step group(s) pipelined against the net"
-                               % (K, args.rollouts, "random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s%s; leaf features %s)"
-                                  % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs",
-                                     {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl] + (", one HIP graph per net call" if args.net_graph else ""),
-                                     feat_fmt)
-                                  if net is not None else "NO conv net (--net %s: search kernels only)" % args.net, G, groups),
+                               "persistent tree, %s, %d games per GPU in %d lock-step group(s) pipelined against the net; trees grown for %d "
+                               "untimed steps so that the timed window is a search in progress that crosses a move boundary"
+                               % (K, args.rollouts * T, net_desc, G, groups, pregrow),
                    "search_dtype": "f32 edge statistics (the reference's float), u16 board labels", "net_dtype": args.net_dtype if net is not None else None,
-                   "games_per_gpu": G, "board_size": n, "rollouts_per_step": G * K, "net_rows_per_step": my_rows / steps,
+                   "games_per_gpu": G, "board_size": n, "mcts_threads": T, "rollouts_per_step": G * K * T, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
-                   "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups,
-                   "moves_per_sec": roll_all / dt_max / args.rollouts,
-                   "games_per_sec_est": roll_all / dt_max / args.rollouts / 250.0,
-                   "games_per_sec_note": "rollouts/s / (rollouts per move x 250 moves per game); a full game does not fit a bench run",
+                   "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups, "pregrow_steps": pregrow,
+                   "host_wait_per_step": bool(args.wait_rows),
+                   "mean_depth": depth, "moves_in_window": d["moves"], "games_finished_in_window": d["games"],
+                   "move_boundaries_in_window": d["boundaries"],
+                   "move_boundary_ms": (d["boundary_ns"] / 1e6 / d["boundaries"]) if d["boundaries"] else None,
+                   "move_boundary_note": "wall time of one group's move boundary (root edge statistics of its %d games to the host, "
+                                         "chooseAction / move sampling / resign check, forward on the game boards, treeAdvance, "
+                                         "Dirichlet + D4 draws for the next search, device waits included); it is inside ms_per_step" % Gg,
+                   "moves_per_sec": roll_all / dt_max / (args.rollouts * T),
+                   "games_per_sec_estimated": roll_all / dt_max / (args.rollouts * T) / moves_per_game,
+                   "games_per_sec_note": "ESTIMATED, not measured: rollouts/s / (rollouts per move x 250 moves per game) -- a 19x19 game at "
+                                         "8192 rollouts/move takes hours; measured games/s on a shortened configuration: selfplay_games",
+                   "per_rank_rollouts_per_sec": per_rank,
                    "parallelism": "independent games per GPU, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": mcts_traffic(n, G * K),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                      "kernel": "k_mcts_select+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
-                     "algorithmic_bytes_per_rollout": bytes_per_step / (G * K),
-                     "note": "search kernels only (HIP events around begin_step/end_step on the launch stream); bytes per rollout = "
-                             "depth x (362x20 B edge read + 24 B writes) + per expansion 52534 B (SURVEY.md 8d) with depth %.1f; "
-                             "the path is latency-bound (pointer chasing down the tree), not HBM-bound -- see DESIGN.md" % depth,
+                     "algorithmic_bytes_per_rollout": bytes_per_step / (G * K * T),
+                     "select_kernel": {"achieved_GBps": (sel_bytes / (sel_ms / 1e3) / 1e9) if (sel_bytes and sel_ms > 0) else None,
+                                       "bytes_per_visited_node": 64 + 368 * 22, "bytes_per_new_node": 2 * 3840 + 64,
+                                       "note": "select + leaf-feature launches (HIP events around begin_step); bytes = what the kernel loads "
+                                               "per visited node (header, 368 x 16 B statistics, child ids, coords) and moves per new node"},
+                     "note": "search kernels of this library (HIP events around begin_step / end_step on the groups' launch streams); bytes per "
+                             "rollout = measured depth %.2f x (362 x 20 B edge read + 24 B writes) + per expansion 52534 B (SURVEY.md 8d). The "
+                             "descent is a dependent pointer chase (one memory round trip per level, one wave per game): latency shares the roof "
+                             "with bandwidth -- DESIGN.md section 3" % depth,
                      "mean_depth": depth},
-        "selfplay_stats": st,
+        "selfplay_stats_window": d,
     }
     if net is not None:
         # the kernel that dominates the timed region is not this library's: PyTorch-ROCm's convolution (north_star leaves the
         # net on PyTorch).  Reported for transparency: algorithmic flops of the 20x256 net per position / measured call time.
-        d = n * n
-        flops_pos = 2.0 * d * 9 * (18 * args.net_dim + 2 * args.net_blocks * args.net_dim * args.net_dim) \
-            + 2.0 * d * args.net_dim * 3 + 2.0 * (2 * d * (d + 1) + d * 256 + 256)
-        rows_call = Gg * K
+        flops_pos = net_flops_per_position(args, n)
+        rows_call = Gg * K * T
         ach = flops_pos * rows_call / (net_ms / 1e3) / 1e12 if net_ms > 0 else None
         res["net_roofline"] = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None,
                                "traffic": None, "kernel": "PyTorch-ROCm net call (MIOpen CK implicit-GEMM 3x3 conv x41 + elfnet_bias_act_f16 epilogues)",
                                "avg_call_ms": net_ms, "rows_per_call": rows_call, "flops_per_position": flops_pos,
                                "note": "not a kernel of this library; dense fp16/bf16 MFMA peak from MI355X_MICROARCH.md"}
-    res["cpu_baseline"] = cpu_baseline_mcts(n, K) if with_cpu else None
+    if with_cpu:
+        base = cpu_baseline_mcts_with_net(n, K, net, dev, dtype) if net is not None else cpu_baseline_mcts_stub(n, K)
+        if base.get("value") is None and net is not None:
+            base = cpu_baseline_mcts_stub(n, K)
+        res["cpu_baseline"] = base
+        if net is not None:
+            res["cpu_baseline_stub_net"] = cpu_baseline_mcts_stub(n, K)
+    else:
+        res["cpu_baseline"] = None
     return res
 
 
+def run_games(args, rank, local_rank, world, dist):
+    """Whole self-play games per second, MEASURED, on a shortened configuration of the headline (same net, same kernels, same host
+    loop): few rollouts per move and a move cutoff, so that several generations of games finish inside the run -- exercises what
+    the headline window cannot hold: game ends (Tromp-Taylor scoring), restarts, Record assembly."""
+    from elf_amd.pipeline import PipelinedSelfPlay
+    n, K = args.board_size, args.rollouts_per_batch
+    dev = torch.device("cuda", local_rank)
+    net, dtype = build_net(args, n, dev)
+    G, groups = args.games, max(1, args.groups)
+    Gg = G // groups
+    feat_fmt = "f16_nhwc" if (net is not None and dtype == torch.float16) else "f32_nchw"
+    roll, cutoff = args.games_rollouts, args.games_cutoff
+    sp = PipelinedSelfPlay(groups=groups, seed=4321, game_idx_base=rank * G, wait_rows=False, board_size=n, num_games=Gg, device=local_rank,
+                           mcts_rollout_per_thread=roll, mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1, mcts_persistent_tree=True,
+                           mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, policy_distri_cutoff=30, move_cutoff=cutoff, resign_thres=0.05,
+                           nodes_per_game=4096, feature_format=feat_fmt, keep_records=8)
+    rnd = RandomReplies(sp.groups[0].max_rows, n * n + 1, dev, 5 + rank)
+    graphs = {}
+    if net is not None:
+        with torch.no_grad():
+            net({"s": sp.groups[0].s})
+        from elf_amd.net import GraphedNet
+        try:
+            for g in sp.groups:
+                graphs[g.s.data_ptr()] = GraphedNet(net, g.s)
+        except Exception:
+            graphs = {}
+
+    def net_fn(s, rows):
+        if net is None:
+            return rnd()
+        gn = graphs.get(s.data_ptr())
+        if gn is not None:
+            o = gn()
+        else:
+            with torch.no_grad():
+                o = net({"s": s})
+        return o["pi"], o["V"]
+
+    barrier = make_barrier(dist)
+    spm = sp.groups[0].stats()["steps_per_move"]
+    want_moves = (cutoff - 1) * args.games_generations     # a game ends when ply reaches the cutoff
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(want_moves * spm):
+        sp.step(net_fn)
+    sp.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = sp.stats()
+    recs = sum(len(g.pop_records()) for g in sp.groups)
+    dt_max, games_all = reduce_max_sum(dist, dev, dt, st["games"])
+    sp.close()
+    if rank != 0:
+        return None
+    return {"metric": "selfplay_games_per_sec (MEASURED, shortened configuration)", "value": games_all / dt_max, "unit": "games/s",
+            "games_finished": games_all, "seconds": dt_max, "moves": st["moves"], "records_kept": recs,
+            "config": {"workload": "the headline's self-play loop with %d rollouts/move (bs %d) and move_cutoff %d: %d games per GPU, "
+                                   "%d generations of games played to the cutoff, scored, recorded and restarted" % (roll, K, cutoff, G, args.games_generations),
+                       "rollouts_per_move": roll, "move_cutoff": cutoff, "games_per_gpu": G, "net": "resnet" if net is not None else args.net}}
+
+
+def run_boundary(args, rank, local_rank, world, dist, steps, warmup):
+    """The pybind11 drop-in boundary (_elf / _elfgames_go) in a serial wait()/step() loop, as src_py/elf/utils_elf.py drives it:
+    once with the batch tensors in pinned host memory (what the reference's Allocator makes: s rows D2H, replies H2D, every step),
+    once device-resident.  One SharedMem buffer holds a whole device step (batchsize = games x 16)."""
+    from elf_amd import compat
+    compat.install_reference_module_names()
+    import _elfgames_go as go
+    n, K = args.board_size, args.rollouts_per_batch
+    dev = torch.device("cuda", local_rank)
+    net, dtype = build_net(args, n, dev)
+    G = args.boundary_games
+    B = G * K
+    na = n * n + 1
+    rnd = RandomReplies(B, na, dev, 17)
+    out = {}
+    for mode in ("pinned_host", "device_resident"):
+        co, opt = go.ContextOptions(), go.GameOptions()
+        co.num_games, co.batchsize, co.job_id = G, B, "bench"
+        ts = co.mcts_options
+        ts.num_threads, ts.num_rollouts_per_thread, ts.num_rollouts_per_batch = 1, args.rollouts, K
+        ts.virtual_loss, ts.persistent_tree, ts.root_epsilon, ts.root_alpha = 1, True, 0.25, 0.03
+        ts.alg_opt.c_puct = 1.5
+        opt.mode, opt.seed, opt.board_size, opt.gpu, opt.policy_distri_cutoff = "selfplay", 1234, n, local_rank, 30
+        opt.nodes_per_game = 4 * K * (steps + warmup + 8) + 1024
+        GC = go.GameContext(co, opt)
+        ctx = GC.ctx()
+        o = ctx.createSharedMemOptions("actor_black", B)
+        sm = ctx.allocateSharedMem(o, ["s", "pi", "V", "rv"])
+        tens = {}
+        for key in ("s", "pi", "V", "rv"):
+            f = sm[key].field()
+            dt_ = {"float": torch.float32, "int64_t": torch.int64}[f.type_name()]
+            if mode == "pinned_host":
+                t = torch.zeros(tuple(f.sz().vec()), dtype=dt_).pin_memory()
+            else:
+                t = torch.zeros(tuple(f.sz().vec()), dtype=dt_, device=dev)
+            sm[key].set(t.data_ptr(), [s_ * t.element_size() for s_ in t.stride()])
+            tens[key] = t
+        ctx.start()
+        GC.getClient().setRequest(0, -1, 0.0, -1)
+
+        def one():
+            smem = ctx.wait()
+            k = smem.effective_batchsize()
+            s = tens["s"][:k]
+            if mode == "pinned_host":
+                s = s.to(dev, non_blocking=True)               # Batch.cpu2gpu (utils_elf.py:243-250)
+            if net is not None:
+                with torch.no_grad():
+                    r = net({"s": s.to(dtype).contiguous(memory_format=torch.channels_last)})
+                pi, v = r["pi"], r["V"]
+            else:
+                pi, v = rnd()
+                pi, v = pi[:k], v[:k]
+            tens["pi"][:k].copy_(pi)                           # Batch.copy_from (utils_elf.py:184-222): D2H when pinned
+            tens["V"][:k].copy_(v)
+            tens["rv"][:k].zero_()
+            torch.cuda.synchronize()
+            ctx.step()
+            return k
+
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rows = 0
+        for _ in range(steps):
+            rows += one()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[mode] = {"rollouts_per_sec": G * K * steps / dt, "ms_per_step": dt / steps * 1e3, "rows_per_step": rows / steps}
+        ctx.stop()
+        del sm, ctx, GC
+    if rank != 0:
+        return None
+    pcie = G * K * (18 * n * n * 4 + na * 4 + 4 + 8)
+    out["note"] = ("serial loop, no pipelining, %d games x %d rollouts per step, %s; pinned_host moves %d bytes per step over PCIe (s rows down, "
+                   "pi/V/rv up); the difference between the two modes is the cost of the reference's memory contract"
+                   % (G, K, "same net as the headline" if net is not None else "--net %s" % args.net, pcie))
+    out["pcie_bytes_per_step"] = pcie
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------- trainer
 def synth_games(n, games, plies, dev, local_rank, seed):
     """Random legal play on the product board engine (legal mask -> torch.multinomial -> forward), `games` games of up to `plies`
     plies; pass when nothing is legal.  -> int64 tensor [games, plies] of reference Coords."""
@@ -394,15 +806,14 @@ def synth_games(n, games, plies, dev, local_rank, seed):
 def cpu_baseline_train(n, records_json, nfa):
     """The reference's per-sample trainer work (GoGameTrain::act: fromRecord, switchRandomMove, generateD4Code + every "train"
     extractor; oracle/_ref, the real reference) on the host cores, same records."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
-        from pyoracle import RefSelfPlay
+        po = _oracle()
     except Exception as e:
         return {"value": None, "unit": "samples/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
-    if not RefSelfPlay.available(n):
+    if not po.RefSelfPlay.available(n):
         return {"value": None, "unit": "samples/s", "cores": 0, "kind": "unavailable", "sample": "oracle/_ref/libelfsp%d.so not built" % n}
     cores = max(1, min(len(os.sched_getaffinity(0)), 64))
-    R = RefSelfPlay(n)
+    R = po.RefSelfPlay(n)
     samples = 4000 * cores
     steps, sec = R.train_bench(records_json, samples, cores, nfa)
     return {"value": samples / sec, "unit": "samples/s", "cores": cores, "kind": "reference", "board_steps_per_sec": steps / sec,
@@ -443,12 +854,7 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     out = ld._alloc(B)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     mt_sum = torch.zeros((), dtype=torch.int64, device=dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier = make_barrier(dist)
     d = ld._draw
     for i in range(warmup):
         ld.sample(B, out=out)
@@ -470,7 +876,7 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     if rank != 0:
         return None
     per_sample = replayed / (B * steps) * STEP_BYTES[n] + (26728 if n == 19 else 6008) + P + 4 * (n * n + 1) + 40
-    achieved = B * per_sample / (kern_ms / 1e3) / 1e9
+    kname = "k_replay_extract<%d>" % n
     res = {
         "metric": "train_samples_per_sec (%dx%d replay to a random ply + every field of the reference's train batch)" % (n, n),
         "value": samples_all / dt_max, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -479,14 +885,18 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "config": {"workload": "SURVEY.md 8f-1 trainer input pipeline: batch %d, %d records of %d plies (random legal play on the device "
                                "engine), one MCTS policy per ply, num_future_actions %d, s rows %s" % (B, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
                    "batch": B, "records": R, "board_size": n, "mean_replayed_plies": replayed / (B * steps),
-                   "replayed_board_steps_per_sec": replayed / dt, "parallelism": "independent samples per GPU, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": load_traffic("k_replay_extract<%d>" % n), "kernel": "k_replay_extract<%d>" % n, "avg_kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_sample": per_sample,
-                     "note": "bytes per sample = replayed plies x 8730 B (reference Board in+out+mask per forward, SURVEY.md 8d) + 26728 B "
-                             "features + 441 B policy row + 362 x 4 B scores + scalars; the replay itself runs in LDS, so like k_playout "
-                             "this is a rate against the HBM roof, not HBM traffic"},
+                   "replayed_board_steps_per_sec": replayed / dt,
+                   "algorithmic_GBps": B * per_sample / (kern_ms / 1e3) / 1e9,
+                   "algorithmic_note": "SURVEY.md 8d bytes per sample (replayed plies x 8730 B + features + policy row + scores): the data "
+                                       "movement of the reference's formulation; NOT this kernel's roof (the replay runs in LDS)",
+                   "parallelism": "independent samples per GPU, no collective"},
     }
+    roof = issue_roof(kname, replayed / steps, kern_ms / 1e3)   # unit = one replayed board step
+    if roof is None:
+        roof = {"bound": "issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
+                "traffic": load_traffic(kname), "kernel": kname, "avg_kernel_ms": kern_ms,
+                "note": "profiles/pmc_issue.json has no VALU count for this kernel"}
+    res["roofline"] = roof
     res["cpu_baseline"] = cpu_baseline_train(n, "[" + ",".join(recs_json) + "]", nfa) if with_cpu else None
     return res
 
@@ -496,17 +906,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["mcts", "board", "train", "both"], default="both",
-                    help="both (default) = mcts headline + board_step + train_loader sub-results")
+    ap.add_argument("--workload", choices=["mcts", "board", "train", "feature", "boundary", "games", "both", "stub"], default="both",
+                    help="both (default) = mcts headline + every sub-result at N = 1")
     ap.add_argument("--train-batch", type=int, default=2048)
     ap.add_argument("--train-records", type=int, default=256)
     ap.add_argument("--boards", type=int, default=4096)
+    ap.add_argument("--boards9", type=int, default=65536)
     ap.add_argument("--board-size", type=int, default=19)
+    ap.add_argument("--feature-rows", type=int, default=16384)
     ap.add_argument("--games", type=int, default=256, help="games per GPU (split over --groups)")
     ap.add_argument("--groups", type=int, default=2, help="lock-step game groups pipelined against the net (1 = serial)")
-    ap.add_argument("--rollouts", type=int, default=8192)
+    ap.add_argument("--rollouts", type=int, default=8192, help="TSOptions.num_rollouts_per_thread")
     ap.add_argument("--rollouts-per-batch", type=int, default=16)
+    ap.add_argument("--mcts-threads", type=int, default=1, help="TSOptions.num_threads (search threads per game)")
     ap.add_argument("--nodes-per-game", type=int, default=None)
+    ap.add_argument("--pregrow", type=int, default=-1, help="untimed tree-growing steps before the warm-up (-1: so that the move ends mid-window)")
     ap.add_argument("--net", choices=["resnet", "random", "null"], default="resnet")
     ap.add_argument("--no-fold-bn", action="store_true")
     ap.add_argument("--net-blocks", type=int, default=20)
@@ -518,34 +932,69 @@ def main():
     ap.add_argument("--features", choices=["auto", "f32", "f16"], default="auto",
                     help="leaf feature rows: f32 NCHW (reference layout) or f16 channels_last (auto: f16 when the net is fp16)")
     ap.add_argument("--wait-rows", type=int, default=0, help="1: the host waits for the row count of every step (drop-in path)")
+    ap.add_argument("--boundary-games", type=int, default=128)
+    ap.add_argument("--games-rollouts", type=int, default=32)
+    ap.add_argument("--games-cutoff", type=int, default=40)
+    ap.add_argument("--games-generations", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="headline only (no sub-results)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_spawn(args.gpus)      # does not return
 
     rank, local_rank, world, dist = init_dist(args)
     with_cpu = (not args.no_cpu_baseline) and world == 1
+    sub = args.workload == "both" and world == 1 and not args.no_sub
     res = None
+    if args.workload == "stub":
+        res = run_stub(args, rank, local_rank, world, dist, args.steps or 5, args.warmup or 0)
     if args.workload in ("mcts", "both"):
         steps = args.steps if args.steps is not None else 40
         warmup = args.warmup if args.warmup is not None else 8
         res = run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu)
-    if args.workload in ("board", "both"):
-        bsteps = args.steps if (args.steps is not None and args.workload == "board") else 20
-        bwarm = args.warmup if (args.warmup is not None and args.workload == "board") else 3
-        b = run_board(args, rank, local_rank, world, dist, bsteps, bwarm, with_cpu)
+
+    def own(name, dflt):      # --steps/--warmup belong to the headline unless a single sub-workload was asked for
+        v = getattr(args, name)
+        return v if (v is not None and args.workload != "both") else dflt
+
+    if args.workload == "board" or sub:
+        b = run_board(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3), with_cpu)
         if args.workload == "board":
             res = b
         elif rank == 0:
             res["board_step"] = b
-    if args.workload in ("train", "both"):
-        tsteps = args.steps if (args.steps is not None and args.workload == "train") else 20
-        twarm = args.warmup if (args.warmup is not None and args.workload == "train") else 3
-        t = run_train(args, rank, local_rank, world, dist, tsteps, twarm, with_cpu)
+    if sub and args.board_size == 19:
+        b9 = run_board(args, rank, local_rank, world, dist, 8, 2, with_cpu, n=9, boards=args.boards9)
+        if rank == 0:
+            res["board_step_9x9"] = b9
+    if args.workload == "feature" or sub:
+        f = run_feature(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3))
+        if args.workload == "feature":
+            res = f
+        elif rank == 0:
+            res["feature_extract"] = f
+    if args.workload == "train" or sub:
+        t = run_train(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3), with_cpu)
         if args.workload == "train":
             res = t
         elif rank == 0:
             res["train_loader"] = t
+    if args.workload == "boundary" or sub:
+        bd = run_boundary(args, rank, local_rank, world, dist, own("steps", 10), own("warmup", 3))
+        if args.workload == "boundary":
+            res = bd
+        elif rank == 0:
+            res["boundary"] = bd
+    if args.workload == "games" or sub:
+        gm = run_games(args, rank, local_rank, world, dist)
+        if args.workload == "games":
+            res = gm
+        elif rank == 0:
+            res["selfplay_games"] = gm
     if rank == 0:
         print(json.dumps(res))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

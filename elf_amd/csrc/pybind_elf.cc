@@ -603,7 +603,7 @@ class Context {
   py::list searchLog() {
     py::list out;
     if (!sp_) return out;
-    int64_t st[9];
+    int64_t st[12];
     chk(elfsp_stats(sp_, st), "elfsp_stats");
     const int n = (int)st[5], NE = elfmcts_edge_stride(elfsp_mcts(sp_));
     if (n == 0) return out;
@@ -740,7 +740,7 @@ class Context {
 
   void finish_search_step() {
     const int64_t games_before = elfsp_games_finished(sp_);
-    int64_t st0[9];
+    int64_t st0[12];
     chk(elfsp_stats(sp_, st0), "elfsp_stats");
     const int rc = step_rows_ > 0
         ? elfsp_end_step(sp_, (const float*)d_pi_, NA_, (const float*)d_v_, have_rv_ ? (const int64_t*)d_rv_ : nullptr, stream_)
@@ -749,7 +749,7 @@ class Context {
       throw std::runtime_error("model version of a reply (rv) and required version " + std::to_string(black_ver_) +
                                " are not consistent");                                   // go/mcts/mcts.h:210-217
     chk(rc, "elfsp_end_step");
-    int64_t st1[9];
+    int64_t st1[12];
     chk(elfsp_stats(sp_, st1), "elfsp_stats");
     if (st1[0] != st0[0]) search_running_ = false;   // a move was played: the search of this move is over
     const int64_t done = elfsp_games_finished(sp_) - games_before;

@@ -72,6 +72,7 @@ struct ElfSelfPlay {
   int game_starts = 0;
   // statistics / capture
   int64_t n_moves = 0, n_games = 0, n_rollouts = 0, n_rows = 0, n_steps = 0;
+  int64_t boundary_ns = 0, n_boundaries = 0;   // wall time of the move boundaries (sp_finish_move + sp_begin_search, incl. device waits)
   double sum_final = 0.0;
   std::vector<ElfSpSearchRec> log_search;
   std::vector<int32_t> log_coord, log_visits;
@@ -458,7 +459,11 @@ int elfsp_begin_step(ElfSelfPlay* sp, void* s_dst, int64_t stride_elems, int* n_
   if (!sp || !s_dst) return ELFGO_E_BADARG;
   DevGuard _dg(sp->eng->device);
   sp->stream = (hipStream_t)stream;
-  if (!sp->search_open) SPCHK(sp_begin_search(sp));
+  if (!sp->search_open) {
+    const auto t0 = std::chrono::steady_clock::now();
+    SPCHK(sp_begin_search(sp));
+    sp->boundary_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
   SPCHK(elfmcts_select(sp->mcts, nullptr, s_dst, stride_elems, sp->d_counts, sp->stream));
   if (!n_rows) {          // row count and error word stay on the device until the move boundary
     sp->last_rows = -1;
@@ -489,7 +494,12 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
   SPCHK(elfmcts_expand(sp->mcts, pi, pi_stride_floats, value, rv, sp->last_rows, sp->stream));
   sp->n_rollouts += (int64_t)sp->G * sp->KT;
   sp->n_steps++;
-  if (++sp->step_in_move >= sp->steps_per_move) SPCHK(sp_finish_move(sp));
+  if (++sp->step_in_move >= sp->steps_per_move) {
+    const auto t0 = std::chrono::steady_clock::now();
+    SPCHK(sp_finish_move(sp));
+    sp->boundary_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    sp->n_boundaries++;
+  }
   return 0;
 }
 
@@ -652,6 +662,7 @@ int elfsp_stats(ElfSelfPlay* sp, int64_t* out) {
   sp->n_rows = (int64_t)total_rows;
   out[0] = sp->n_moves; out[1] = sp->n_games; out[2] = sp->n_rollouts; out[3] = sp->n_rows; out[4] = sp->n_steps;
   out[5] = (int64_t)sp->log_search.size(); out[6] = sp->steps_per_move; out[7] = sp->step_in_move;
+  out[9] = sp->boundary_ns; out[10] = sp->n_boundaries; out[11] = 0;
   return 0;
 }
 

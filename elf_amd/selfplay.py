@@ -48,7 +48,8 @@ def job_hash(job_id):
     return int.from_bytes(hashlib.blake2b((job_id or "").encode(), digest_size=8).digest(), "little")
 
 
-STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_per_move", "step_in_move", "node_visits")
+STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_per_move", "step_in_move", "node_visits", "boundary_ns",
+               "boundaries", "reserved")
 
 
 class SelfPlay:
@@ -169,7 +170,7 @@ class SelfPlay:
 
     # ---- results
     def stats(self):
-        out = (C.c_int64 * 9)()
+        out = (C.c_int64 * 12)()
         check(self.L.elfsp_stats(self._h, out))
         return dict(zip(STAT_FIELDS, [int(x) for x in out]))
 

@@ -31,3 +31,20 @@ def test_world_size_2_gloo():
     rep = json.loads([l for l in outs[0][0].strip().splitlines() if l.startswith("{")][-1])
     assert rep["world"] == 2 and rep["total"] == 2001 and abs(rep["dt_max"] - 0.1) < 1e-9
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 reports
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run with two workers
+    (one per GPU on a real node; the CPU stub workload over gloo here) and rank 0 prints one JSON line with n_gpus = 2, the
+    slowest rank's time and the sum over ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ELF_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "5", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 2 and rep["steps"] == 5 and rep["scaling"] == "weak"
+    assert rep["config"]["units"] == 5 * (1000 + 1001) and rep["config"]["per_rank_units"] == [5000.0, 5005.0]
+    assert rep["ms_per_step"] >= 4.0        # rank 1 sleeps 4 ms per step: the report carries the slowest rank
