@@ -549,7 +549,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     st1 = sp.stats()
     T = max(1, args.mcts_threads)
     my_rollouts = G * K * T * steps
-    d = {k: st1[k] - st0[k] for k in ("moves", "games", "rollouts", "rows", "steps", "node_visits", "boundary_ns", "boundaries")}
+    d = {k: st1[k] - st0[k] for k in ("moves", "games", "rollouts", "rows", "steps", "node_visits", "boundary_ns", "boundaries", "boundary_wait_ns")}
     my_rows = d["rows"]
     sel_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_select])) / steps
     exp_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_expand])) / steps
@@ -590,9 +590,12 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "mean_depth": depth, "moves_in_window": d["moves"], "games_finished_in_window": d["games"],
                    "move_boundaries_in_window": d["boundaries"],
                    "move_boundary_ms": (d["boundary_ns"] / 1e6 / d["boundaries"]) if d["boundaries"] else None,
-                   "move_boundary_note": "wall time of one group's move boundary (root edge statistics of its %d games to the host, "
-                                         "chooseAction / move sampling / resign check, forward on the game boards, treeAdvance, "
-                                         "Dirichlet + D4 draws for the next search, device waits included); it is inside ms_per_step" % Gg,
+                   "move_boundary_queue_drain_ms": (d["boundary_wait_ns"] / 1e6 / d["boundaries"]) if d["boundaries"] else None,
+                   "move_boundary_note": "move_boundary_ms = host + kernel time of one group's move boundary after its stream has drained "
+                                         "(chooseAction / move sampling / resign check for its %d games, forward on the game boards, treeAdvance, "
+                                         "game ends, Dirichlet + D4 draws and root set-up of the next search); queue_drain = how long the boundary "
+                                         "first waited for the steps the host had queued ahead (pipeline depth; the GPU is busy meanwhile). Both "
+                                         "are inside ms_per_step" % Gg,
                    "moves_per_sec": roll_all / dt_max / (args.rollouts * T),
                    "games_per_sec_estimated": roll_all / dt_max / (args.rollouts * T) / moves_per_game,
                    "games_per_sec_note": "ESTIMATED, not measured: rollouts/s / (rollouts per move x 250 moves per game) -- a 19x19 game at "

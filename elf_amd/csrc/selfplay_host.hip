@@ -70,9 +70,12 @@ struct ElfSelfPlay {
   int64_t pend_black = 0, pend_white = -1;
   float pend_thres = 0.f, pend_never = 0.f;
   int game_starts = 0;
+  std::chrono::steady_clock::time_point t_after_drain;
   // statistics / capture
   int64_t n_moves = 0, n_games = 0, n_rollouts = 0, n_rows = 0, n_steps = 0;
-  int64_t boundary_ns = 0, n_boundaries = 0;   // wall time of the move boundaries (sp_finish_move + sp_begin_search, incl. device waits)
+  // move boundaries: boundary_wait_ns = the first wait of sp_finish_move (the stream drains whatever the host had queued ahead:
+  // pipeline depth, not boundary work); boundary_ns = everything after it up to the end of the next sp_begin_search
+  int64_t boundary_ns = 0, boundary_wait_ns = 0, n_boundaries = 0;
   double sum_final = 0.0;
   std::vector<ElfSpSearchRec> log_search;
   std::vector<int32_t> log_coord, log_visits;
@@ -218,6 +221,7 @@ static int sp_finish_move(ElfSelfPlay* sp) {
   HIPCHK(hipMemcpyAsync(sp->h_prior.data(), sp->d_prior, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
   HIPCHK(hipMemcpyAsync(sp->h_reward.data(), sp->d_reward, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
   HIPCHK(hipStreamSynchronize(sp->stream));
+  sp->t_after_drain = std::chrono::steady_clock::now();
   std::vector<int> finished, sgf_done;
   for (int g = 0; g < G; ++g) {
     SpGame& gm = sp->games[g];
@@ -497,7 +501,9 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
   if (++sp->step_in_move >= sp->steps_per_move) {
     const auto t0 = std::chrono::steady_clock::now();
     SPCHK(sp_finish_move(sp));
-    sp->boundary_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    const auto t1 = std::chrono::steady_clock::now();
+    sp->boundary_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(sp->t_after_drain - t0).count();
+    sp->boundary_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - sp->t_after_drain).count();
     sp->n_boundaries++;
   }
   return 0;
@@ -662,7 +668,7 @@ int elfsp_stats(ElfSelfPlay* sp, int64_t* out) {
   sp->n_rows = (int64_t)total_rows;
   out[0] = sp->n_moves; out[1] = sp->n_games; out[2] = sp->n_rollouts; out[3] = sp->n_rows; out[4] = sp->n_steps;
   out[5] = (int64_t)sp->log_search.size(); out[6] = sp->steps_per_move; out[7] = sp->step_in_move;
-  out[9] = sp->boundary_ns; out[10] = sp->n_boundaries; out[11] = 0;
+  out[9] = sp->boundary_ns; out[10] = sp->n_boundaries; out[11] = sp->boundary_wait_ns;
   return 0;
 }
 

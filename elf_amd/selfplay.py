@@ -49,7 +49,7 @@ def job_hash(job_id):
 
 
 STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_per_move", "step_in_move", "node_visits", "boundary_ns",
-               "boundaries", "reserved")
+               "boundaries", "boundary_wait_ns")
 
 
 class SelfPlay:

@@ -239,8 +239,9 @@ int elfsp_set_request(ElfSelfPlay* sp, int64_t black_ver, int64_t white_ver, flo
  * common/dispatcher_callback.h:86-88); *black_ver / *white_ver <- the versions of the current request */
 int elfsp_take_game_starts(ElfSelfPlay* sp, int64_t* black_ver, int64_t* white_ver);
 /* out[12]: 0 moves played, 1 games finished, 2 rollouts, 3 net rows, 4 steps, 5 searches logged, 6 steps per move, 7 step in
- * move, 8 tree nodes descended through, 9 wall nanoseconds spent in move boundaries (root statistics down, move choice,
- * forward + treeAdvance, Dirichlet / D4 draws up; device waits included), 10 move boundaries, 11 reserved.
+ * move, 8 tree nodes descended through, 9 wall nanoseconds of move-boundary work (move choice, forward + treeAdvance, game
+ * ends, Dirichlet / D4 draws up, root of the next search), 10 move boundaries, 11 wall nanoseconds the boundaries first waited
+ * for the stream to drain what the host had queued ahead (pipeline depth, not boundary work).
  * Synchronises the device. */
 int elfsp_stats(ElfSelfPlay* sp, int64_t* out);
 /* Interactive play (the human_actor half of GoGameSelfPlay::act, game_selfplay.cc:290-330, that the GTP console
