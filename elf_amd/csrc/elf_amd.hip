@@ -26,7 +26,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(Pool<N> pool, const int32_t* ids
   __shared__ Slot<N> lds;
   int b = slot_of(ids, blockIdx.x);
   Board<N> bd;
-  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.init(&lds, pool.zob, pool.skr(b));
   bd.reset();
   bd.store(&pool.slots[b]);
 }
@@ -41,9 +41,7 @@ __global__ __launch_bounds__(WAVE) void k_copy(Pool<N> pool, const int32_t* dst,
   uint4* dp = reinterpret_cast<uint4*>(&pool.slots[d]);
   for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += WAVE) dp[j] = sp[j];
   int len = pool.slots[s].h.sk_len;
-  const u64* sh = pool.skh(s); u64* dh = pool.skh(d);
-  for (int j = lane; j < len; j += WAVE) dh[j] = sh[j];
-  const u64* si = pool.ski(s); u64* di = pool.ski(d);
+  const u64* si = pool.skr(s); u64* di = pool.skr(d);
   for (int j = lane; j < len * G::SKW; j += WAVE) di[j] = si[j];
 }
 
@@ -57,7 +55,7 @@ __global__ __launch_bounds__(WAVE) void k_forward(Pool<N> pool, const int32_t* i
     return;
   }
   Board<N> bd;
-  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.init(&lds, pool.zob, pool.skr(b));
   bd.load(&pool.slots[b]);
   int r = bd.forward(c);
   if (r) bd.store(&pool.slots[b]);
@@ -70,7 +68,7 @@ __global__ __launch_bounds__(WAVE) void k_legal_mask(Pool<N> pool, const int32_t
   __shared__ Slot<N> lds;
   int b = slot_of(ids, blockIdx.x);
   Board<N> bd;
-  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.init(&lds, pool.zob, pool.skr(b));
   bd.load(&pool.slots[b]);
   u64 legal, cand;
   bd.template legal_moves<false>(legal, cand);
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(WAVE) void k_evaluate(Pool<N> pool, const int32_t* 
   __shared__ Slot<N> lds;
   int b = slot_of(ids, blockIdx.x);
   Board<N> bd;
-  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.init(&lds, pool.zob, pool.skr(b));
   bd.load(&pool.slots[b]);
   float v = bd.evaluate(komi);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
@@ -148,8 +146,9 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
   __shared__ Slot<N> lds;
   int b = slot_of(ids, blockIdx.x);
   Board<N> bd;
-  bd.init(&lds, pool.zob, pool.skh(b), pool.ski(b));
+  bd.init(&lds, pool.zob, pool.skr(b));
   bd.load(&pool.slots[b]);
+  const GameSK<N> sk{pool.skr(b)};
   const u64 seed = seeds[blockIdx.x];
   int steps = 0;
   ELF_PHASE(bd, 7);
@@ -166,7 +165,14 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
     const int total = pre[G::R];
     int pick_a = -1;   // action id of the chosen candidate, -1 = pass
     if (total > 0) {
-      const int r = (int)(playout_rng(seed, (u32)bd.ply) % (u32)total);
+      // rng % total without a runtime division: floor(2^32 / total) comes from a table behind the Zobrist constants through the
+      // scalar cache (issued now, it arrives while the counter RNG's multiplies run); the estimate is at most one too small
+      const u64 magic = sload_u64(pool.zob + G::ZOBW + 4 * G::R, total);
+      const u32 x = playout_rng(seed, (u32)bd.ply);
+      const u32 q = __umulhi(x, (u32)sload_wait(magic));
+      u32 rr = x - q * (u32)total;
+      if (rr >= (u32)total) rr -= (u32)total;
+      const int r = (int)rr;
       int kw = 0;
 #pragma unroll
       for (int k = 1; k < G::R; ++k) kw += r >= pre[k];
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
     }
     ELF_PHASE(bd, 1);   // pick the k-th candidate
     // a candidate comes from the legal mask of this very position: forward_legal_action skips TryPlay's re-check
-    if (!(pick_a >= 0 ? bd.forward_legal_action(pick_a) : bd.forward(M_PASS))) break;
+    if (!(pick_a >= 0 ? bd.forward_legal_action(pick_a, sk) : bd.forward(M_PASS, sk))) break;
     ++steps;
   }
   ELF_PHASE_END(bd);
@@ -200,11 +206,15 @@ static int create_impl(ElfGoEngine* e, const uint64_t* zob_host) {
   using G = Geo<N>;
   e->slot_bytes = sizeof(Slot<N>);
   HIPCHK(hipMalloc(&e->slots, (size_t)e->capacity * sizeof(Slot<N>)));
-  HIPCHK(hipMalloc((void**)&e->sk_hash, (size_t)e->capacity * (G::MAXMOVE + 2) * sizeof(u64)));
-  HIPCHK(hipMalloc((void**)&e->sk_img, (size_t)e->capacity * (G::MAXMOVE + 2) * G::SKW * sizeof(u64)));
-  HIPCHK(hipMalloc((void**)&e->zob, (size_t)(G::ZOBW + 4 * G::R) * sizeof(u64)));
-  // reference Coord order -> internal (transposed) index order, followed by the per-word geometry masks
-  std::vector<u64> z(G::ZOBW + 4 * G::R, 0);
+  HIPCHK(hipMalloc((void**)&e->sk_rec, (size_t)e->capacity * (G::MAXMOVE + 2) * G::SKW * sizeof(u64)));
+  HIPCHK(hipMalloc((void**)&e->zob, (size_t)(G::ZOBW + 4 * G::R + G::NP + 2) * sizeof(u64)));
+  // reference Coord order -> internal (transposed) index order, followed by the per-word geometry masks and by the table
+  // floor(2^32 / d), d <= N*N, that k_playout's "rng % candidates" uses instead of a runtime division
+  std::vector<u64> z(G::ZOBW + 4 * G::R + G::NP + 2, 0);
+  for (int d = 1; d <= G::NP + 1; ++d) {
+    const u64 m = (1ull << 32) / (u64)d;
+    z[G::ZOBW + 4 * G::R + d] = m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m;
+  }
   for (int i = 0; i < G::P; ++i) z[i] = zob_host[(i % G::S) * G::S + i / G::S];
   for (int a = 0; a < G::NP; ++a) {
     const int k = a >> 6, y = a % N;
@@ -244,8 +254,7 @@ int elfgo_destroy(ElfGoEngine* e) {
   if (!e) return ELFGO_E_BADARG;
   DevGuard _dg(e->device);
   if (e->slots) (void)hipFree(e->slots);
-  if (e->sk_hash) (void)hipFree(e->sk_hash);
-  if (e->sk_img) (void)hipFree(e->sk_img);
+  if (e->sk_rec) (void)hipFree(e->sk_rec);
   if (e->zob) (void)hipFree(e->zob);
   delete e;
   return 0;

@@ -11,18 +11,15 @@ using namespace elfgo;
 template <int N>
 struct Pool {
   Slot<N>* slots;
-  u64* sk_hash;   // [capacity][MAXMOVE+2]
-  u64* sk_img;    // [capacity][MAXMOVE+2][SKW]
+  u64* sk_rec;    // [capacity][MAXMOVE+2][SKW]  superko records {hash, black words, white words}
   const u64* zob; // internal index order
-  __device__ __forceinline__ u64* skh(int b) const { return sk_hash + (size_t)b * (Geo<N>::MAXMOVE + 2); }
-  __device__ __forceinline__ u64* ski(int b) const { return sk_img + (size_t)b * (Geo<N>::MAXMOVE + 2) * Geo<N>::SKW; }
+  __device__ __forceinline__ u64* skr(int b) const { return sk_rec + (size_t)b * (Geo<N>::MAXMOVE + 2) * Geo<N>::SKW; }
 };
 
 struct ElfGoEngine {
   int n = 0, capacity = 0, device = 0;
   void* slots = nullptr;
-  u64* sk_hash = nullptr;
-  u64* sk_img = nullptr;
+  u64* sk_rec = nullptr;
   u64* zob = nullptr;
   size_t slot_bytes = 0;
 };
@@ -50,8 +47,7 @@ template <int N>
 static Pool<N> pool_of(const ElfGoEngine* e) {
   Pool<N> p;
   p.slots = reinterpret_cast<Slot<N>*>(e->slots);
-  p.sk_hash = e->sk_hash;
-  p.sk_img = e->sk_img;
+  p.sk_rec = e->sk_rec;
   p.zob = e->zob;
   return p;
 }

@@ -69,7 +69,7 @@ struct Geo {
   static constexpr int R = (NP + 63) / 64;        // rounds of 64 lanes / u64 words per bitboard
   static constexpr int PP = (P + 7) & ~7;         // u16 arrays padded to 16 B
   static constexpr int MAXMOVE = 2 * NP;          // BOARD_MAX_MOVE (go_common.h:15)
-  static constexpr int SKW = 2 * R;               // u64 words per superko image (black, white)
+  static constexpr int SKW = 2 * R + 1;           // u64 words per superko record: hash, black words, white words
   static constexpr int BLOOM = N > 9 ? 256 : 64;  // u32 words of the superko Bloom filter
   static constexpr int ZOBW = PP;                 // zobrist table words; geometry masks follow it
 };
@@ -118,14 +118,42 @@ __device__ __forceinline__ void set_lane64(u64& X, int k, u64 val) {
   X = ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ bool lane_bit(u64 uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
+// XOR over the 64 lanes on the DPP network (same butterfly as wave_max_u32 in mcts.cuh: no LDS crossbar round trips);
+// every lane of the last row -- and lane 63 in particular -- ends with the total, returned wave-uniform.  EXEC must be full.
 __device__ __forceinline__ u64 wave_xor64(u64 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
-  return v;
+  u32 lo = (u32)v, hi = (u32)(v >> 32);
+#define ELF_DPP_XOR(ctrl, rmask)                                                     \
+  lo ^= (u32)__builtin_amdgcn_update_dpp(0, (int)lo, ctrl, rmask, 0xf, false);       \
+  hi ^= (u32)__builtin_amdgcn_update_dpp(0, (int)hi, ctrl, rmask, 0xf, false);
+  ELF_DPP_XOR(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  ELF_DPP_XOR(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  ELF_DPP_XOR(0x124, 0xf)   // row_ror:4
+  ELF_DPP_XOR(0x128, 0xf)   // row_ror:8   -> every lane of a row holds the row's XOR
+  ELF_DPP_XOR(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+  ELF_DPP_XOR(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> row 3 holds the total
+#undef ELF_DPP_XOR
+  lo = (u32)__builtin_amdgcn_readlane((int)lo, 63);
+  hi = (u32)__builtin_amdgcn_readlane((int)hi, 63);
+  return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ bool is_stone(u32 v) { return v != 0 && v != PT_BORDER; }
 // base/board.cc:24-36 transform_hash
 __device__ __forceinline__ u64 zob_col(u64 h, int s) { return s == S_BLACK ? h : ((h >> 32) | (h << 32)); }
+
+// Scalar (SMEM) load of a 64-bit table entry at a wave-uniform index.  The played point's Zobrist constant is read this way:
+// SMEM completion is tracked by lgkmcnt, so consuming it does not have to wait on vmcnt -- and on gfx9 vmcnt also counts the
+// fire-and-forget superko record STORES issued in between (an `s_waitcnt vmcnt(0)` for a vector load of this constant was found
+// to stall ~1 200 cycles per board step behind those stores).  The value must pass through sload_wait() before its first use:
+// inline asm is invisible to the compiler's own waitcnt insertion.
+__device__ __forceinline__ u64 sload_u64(const u64* base, int uniform_index) {
+  u64 v;
+  asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(v) : "s"(base), "s"(uniform_index * 8) : "memory");
+  return v;
+}
+__device__ __forceinline__ u64 sload_wait(u64 v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+  return v;
+}
 
 // config-2 counter RNG; the CPU checkers under oracle/ restate the same function
 __device__ __forceinline__ u32 playout_rng(u64 seed, u32 t) {
@@ -136,35 +164,50 @@ __device__ __forceinline__ u32 playout_rng(u64 seed, u32 t) {
   return (u32)(z >> 32);
 }
 
-// Superko record store of a GAME board (GoState::_board_hashes, go_state.h:218): every pre-move position
-// of the game so far, (hash, black/white bitboards) per record, in HBM.
+// Superko record store of a GAME board (GoState::_board_hashes, go_state.h:218): every pre-move position of the game so far,
+// one record per non-pass forward, in HBM: rec[MAXMOVE+2][SKW] u64 = {hash, black words [R], white words [R]} -- 104 B at
+// 19x19, contiguous, so one record is ONE store instruction (lanes 0..2R) and a run of records is one contiguous block.
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+  u32 lo = __builtin_amdgcn_update_dpp(0u, (u32)v, CTRL, 0xf, 0xf, true);
+  u32 hi = __builtin_amdgcn_update_dpp(0u, (u32)(v >> 32), CTRL, 0xf, 0xf, true);
+  return ((u64)hi << 32) | lo;
+}
+// the record as one word per lane: lane 0 hash, lanes 1..R black words, lanes R+1..2R white words (bitboards are
+// lane-distributed over lanes 0..R-1 and zero elsewhere: row_shr:1 / row_shr:R+1 move them into place)
+template <int N>
+__device__ __forceinline__ u64 sk_record_word(u64 hash, u64 Bw, u64 Ww, int lane) {
+  constexpr int R = Geo<N>::R;
+  const u64 w = dpp_u64<0x110 + 1>(Bw) | dpp_u64<0x110 + R + 1>(Ww);
+  return lane == 0 ? hash : w;
+}
+
 template <int N>
 struct GameSK {
   using G = Geo<N>;
-  u64* sk_hash;   // [MAXMOVE+2]
-  u64* sk_img;    // [MAXMOVE+2][SKW]
+  u64* rec;   // [MAXMOVE+2][SKW]
   __device__ __forceinline__ void record(int sk_len, u64 hash, u64 Bw, u64 Ww, int lane) const {
-    if (lane < G::R) {
-      sk_img[(size_t)sk_len * G::SKW + lane] = Bw;
-      sk_img[(size_t)sk_len * G::SKW + G::R + lane] = Ww;
-    }
-    if (lane == 0) sk_hash[sk_len] = hash;
+    const u64 w = sk_record_word<N>(hash, Bw, Ww, lane);
+    if (lane < G::SKW) rec[(size_t)sk_len * G::SKW + lane] = w;
   }
-  // go_state.cc:96-111: hash match, then full image compare, over records [0, sk_len)
-  __device__ __forceinline__ bool exact_hit(int sk_len, u64 hash, u64 Bw, u64 Ww, int lane) const {
+  // go_state.cc:96-111: hash match, then full image compare, over `cnt` records starting at `base`
+  __device__ __forceinline__ static bool scan(const u64* base, int cnt, u64 hash, u64 w, int lane) {
     bool hit = false;
-    for (int base = 0; base < sk_len; base += 64) {
-      int t = base + lane;
-      u64 bal = __ballot(t < sk_len && sk_hash[t] == hash);
+    for (int b0 = 0; b0 < cnt; b0 += 64) {
+      const int t = b0 + lane;
+      u64 bal = __ballot(t < cnt && base[(size_t)t * G::SKW] == hash);
       while (bal) {
-        int tt = base + (int)__builtin_ctzll(bal);
+        const int tt = b0 + (int)__builtin_ctzll(bal);
         bal &= bal - 1;
         bool same = true;
-        if (lane < G::R) same = sk_img[(size_t)tt * G::SKW + lane] == Bw && sk_img[(size_t)tt * G::SKW + G::R + lane] == Ww;
+        if (lane >= 1 && lane < G::SKW) same = base[(size_t)tt * G::SKW + lane] == w;
         if (__all(same)) hit = true;
       }
     }
     return hit;
+  }
+  __device__ __forceinline__ bool exact_hit(int sk_len, u64 hash, u64 Bw, u64 Ww, int lane) const {
+    return scan(rec, sk_len, hash, sk_record_word<N>(hash, Bw, Ww, lane), lane);
   }
 };
 
@@ -175,8 +218,7 @@ struct Board {
 
   Slot<N>* L;          // LDS image of this wave's board
   const u64* zob;      // Zobrist constants in INTERNAL index order (global memory) + geometry masks
-  u64* sk_hash;        // this board's superko hashes   [MAXMOVE+2]        (HBM)
-  u64* sk_img;         // this board's superko images   [MAXMOVE+2][SKW]   (HBM)
+  u64* sk_rec;         // this board's superko records  [MAXMOVE+2][SKW]   (HBM)
   int lane;
   int idx[R];          // LDS index of this lane's point in round k (clamped for invalid lanes)
   int dl4;             // lanes 0..3: LDS offset of the neighbour in delta4 order (dir4(lane & 3))
@@ -202,8 +244,8 @@ struct Board {
   // no s_waitcnt vmcnt(0) behind the fire-and-forget superko stores to HBM.
   __device__ __forceinline__ static void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
-  __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skh, u64* ski) {
-    L = lds; zob = z; sk_hash = skh; sk_img = ski;
+  __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skr) {
+    L = lds; zob = z; sk_rec = skr;
     lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -305,9 +347,10 @@ struct Board {
 
   __device__ __forceinline__ static void atomic_inc_u16(u16* p) {
     // LDS has no 16-bit atomic add: add into the containing dword (never carries: liberties < 2^15)
-    size_t a = reinterpret_cast<size_t>(p);
-    u32* w = reinterpret_cast<u32*>(a & ~size_t(3));
-    atomicAdd(w, (a & 2) ? 0x10000u : 1u);
+    // the slot pointer is generic: say "LDS" explicitly so that this is a ds_add_u32, not a flat atomic
+    const u32 a = (u32)reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)p);
+    __attribute__((address_space(3))) u32* w = (__attribute__((address_space(3))) u32*)(size_t)(a & ~3u);
+    __hip_atomic_fetch_add(w, (a & 2) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __device__ __forceinline__ int popc_lanes(u64 X) const {   // population of a lane-distributed bitboard
     int c = __popcll(X), t = 0;
@@ -319,7 +362,7 @@ struct Board {
   // ---- GoState::forward (go_state.cc:74-94). c = reference Coord, wave-uniform. ---------------
   // returns 1 played, 0 refused (terminated / illegal). M_INVALID is rejected by the caller.
   __device__ int forward(int c) {
-    GameSK<N> sk{sk_hash, sk_img};
+    GameSK<N> sk{sk_rec};
     return forward(c, sk);
   }
   template <class SK>
@@ -327,10 +370,8 @@ struct Board {
   // a move the caller took from legal_moves() of THIS position (k_playout): action id a, neither pass nor resign.  TryPlay's
   // verdict is known, so the Coord decode, the occupancy / simple-ko / suicide tests and the terminated() test are skipped;
   // the neighbour analysis that Play needs is not.
-  __device__ int forward_legal_action(int a) {
-    GameSK<N> sk{sk_hash, sk_img};
-    return forward_impl<true>(tr(a2i(a)), a, sk);
-  }
+  template <class SK>
+  __device__ int forward_legal_action(int a, const SK& sk) { return forward_impl<true>(tr(a2i(a)), a, sk); }
   template <bool TRUSTED, class SK>
   __device__ int forward_impl(int c, int a_trusted, const SK& sk) {
     c = rfl(c);
@@ -360,7 +401,7 @@ struct Board {
         if (rl64(Bw | Ww, ka) & abit) return 0;                               // :808 occupied
         if (ko_pt == c && ko_age == 0 && ko_color == player) return 0;        // :234-240
       }
-      zi = zob[i];                                                            // issued now, hashed in after Play
+      zi = sload_u64(zob, i);                                                 // issued now (scalar cache), hashed in after Play
       if (lane < 4) {                                                         // StoneLibertyAnalysis :161-199
         nv = L->pt[i + dl];
         nl = is_stone(nv) ? L->libs[nv & 0x7FFF] : 0;
@@ -497,7 +538,7 @@ struct Board {
       }
       newlibs = rfl(newlibs);
       if (lane == 0) L->libs[root] = (u16)newlibs;
-      hash ^= zob_col(zi, player);
+      hash ^= zob_col(sload_wait(zi), player);
       new_ko = (m == 0 && total_cap == 1 && newlibs == 1);                    // :1386
     }
     ELF_PHASE(*this, 5);   // liberties of the mover's group

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   int free_top = rfl(gs.free_top), rng_pos = rfl(gs.rng_pos), err = 0;
   const int root_sk_len = rfl((int)nodes[root].board.h.sk_len);
   Board<N> bd;
-  bd.init(&lds, pool.zob, nullptr, nullptr);
+  bd.init(&lds, pool.zob, nullptr);
   const u64 lt_mask = (1ull << lane) - 1ull;
 
   // lane u holds the u-th unique leaf of this step (unique per search thread)
@@ -331,14 +331,24 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         const bool valid = e < h.n_edges;
         const float prior = st[k].x, reward = st[k].y, vl = st[k].w;
         const int nv = __float_as_int(st[k].z);
-        float r = h.flip ? -reward : reward;
-        r = __fsub_rn(r, vl);
-        const int nvl = (int)__fadd_rn((float)nv, vl);                       // int + float -> float -> int
-        const float q = nvl > 0 ? __fdiv_rn(r, (float)nvl) : (h.flip ? -umq : umq);
-        uq[k] = nv > 0 ? __fdiv_rn(reward, (float)nv) : umq;
-        const float pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);   // float / int, then * double sqrt, stored to float
+        float q, pp;
+        if (__ballot(valid && (nv != 0 || vl != 0.0f)) == 0) {
+          // no edge of this round of 64 carries statistics (most rounds of most nodes): N = 0 and vl = 0 make nvl = 0, Q the
+          // first-play urgency, and prior / (1 + 0) the prior itself -- the same values as below without the three divisions
+          q = h.flip ? -umq : umq;
+          uq[k] = umq;
+          pp = (float)((double)prior * sq);
+          vmask[k] = 0;
+        } else {
+          float r = h.flip ? -reward : reward;
+          r = __fsub_rn(r, vl);
+          const int nvl = (int)__fadd_rn((float)nv, vl);                       // int + float -> float -> int
+          q = nvl > 0 ? __fdiv_rn(r, (float)nvl) : (h.flip ? -umq : umq);
+          uq[k] = nv > 0 ? __fdiv_rn(reward, (float)nv) : umq;
+          pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);       // float / int, then * double sqrt, stored to float
+          vmask[k] = __ballot(valid && nvl != 0);                              // !first_visit
+        }
         const float score = cfg.use_prior ? __fadd_rn(__fmul_rn(pp, cfg.c_puct), q) : q;
-        vmask[k] = __ballot(valid && nvl != 0);                              // !first_visit
         tv += __popcll(vmask[k]);
         // strict '>' in iteration order = the lowest edge index among the maxima.  Keys compare like the floats do
         // (-0.0 == +0.0: canonicalised by + 0.0f; NaN never wins a '>': key 0).
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         if (lane == 0) nd.child[best_e] = child;
         // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
         bd.load(&nd.board);
-        TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skh(bslot), pool.ski(bslot)}, root_sk_len};
+        TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skr(bslot)}, root_sk_len};
         if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; --depth; break; }
         bd.store(&nodes[child].board);
         if (lane == 0) nodes[child].h.has_state = 1;
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
 #endif
   Board<N> bd;
-  bd.init(&L.board, zob, nullptr, nullptr);
+  bd.init(&L.board, zob, nullptr);
   bd.load(&nd.board);
   EXP_PHASE(0);   // row map + board load
   // ---- post_nn_result :209-230

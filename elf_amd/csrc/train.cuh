@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void k_replay_extract(PoolT pool, ReplayStore s
   if (mt > nm) mt = nm;   // the reference asserts move_to < size (go_state_ext.h:284)
   const u16* mv = st.moves + (size_t)r * st.max_moves;
   Board<N> bd;
-  bd.init(&lds, pool.zob, pool.skh(i), pool.ski(i));
+  bd.init(&lds, pool.zob, pool.skr(i));
   bd.reset();                                   // _state.reset()
   for (int t = 0; t < mt; ++t) {                // switchBeforeMove: for (i < move_to) _state.forward(moves[i])
     const int c = rfl((int)mv[t]);

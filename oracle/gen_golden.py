@@ -5,7 +5,8 @@ The GPU box has no /root/reference; tests read the committed .npz files.
 Fixtures
   sgf_406844.npz   BASELINE config 1: ladder_suite/ladder/406844.sgf, per ply: Zobrist hash, info
                    record, legal mask (bit-packed), Tromp-Taylor value; AGZ planes for all 8 D4 codes
-                   (bit-packed) on every 10th ply and the last one.
+                   (bit-packed) on EVERY ply (201 x 8 rows), plus the SHA-256 of each fp32 row (`feat_sha`, what a
+                   consumer that only sees the batch tensor can check).
   ladder_suite.npz every SGF in ladder_suite/ladder that replays legally: move list, final hash/ply,
                    final legal mask, final AGZ planes (code 3).
   playout_19.npz / playout_9.npz   config 2/5 protocol: seeds -> (final hash, ply, steps) per board.
@@ -13,6 +14,7 @@ Fixtures
                    tests/test_reference_known_answers.py (not generated here).
 """
 import glob
+import hashlib
 import os
 import sys
 
@@ -48,18 +50,19 @@ def main():
     # ---- config 1
     mv, pl = R.sgf_moves(os.path.join(SUITE, "406844.sgf"))
     s = R.new()
-    hashes, infos, masks, vals, feat_ply, feats = [], [], [], [], [], []
+    hashes, infos, masks, vals, feat_ply, feats, shas = [], [], [], [], [], [], []
     for i in range(len(mv) + 1):
         hashes.append(R.hash(s)); infos.append(R.info(s)); masks.append(pack(R.legal_mask(s)))
         vals.append(R.evaluate(s, 7.5))
-        if i % 10 == 0 or i == len(mv):
-            feat_ply.append(i)
-            feats.append(np.stack([pack(R.extract_agz(s, d)) for d in range(8)]))
+        feat_ply.append(i)
+        rows = [R.extract_agz(s, d) for d in range(8)]
+        feats.append(np.stack([pack(r) for r in rows]))
+        shas.append(np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(r, np.float32).tobytes()).digest(), np.uint8) for r in rows]))
         if i < len(mv):
             assert pl[i] == R.info(s)[1] and R.forward(s, mv[i]) == 1
     np.savez_compressed(os.path.join(OUT, "sgf_406844.npz"), moves=mv.astype(np.int16), hash=np.array(hashes, np.uint64),
                         info=np.stack(infos).astype(np.int32), mask=np.stack(masks), value=np.array(vals, np.float32),
-                        feat_ply=np.array(feat_ply, np.int32), feat=np.stack(feats))
+                        feat_ply=np.array(feat_ply, np.int32), feat=np.stack(feats), feat_sha=np.stack(shas))
     print("sgf_406844: %d moves, final hash %016x" % (len(mv), hashes[-1]))
     # ---- ladder suite
     names, allmv, offs, fh, fp, fm, ff = [], [], [0], [], [], [], []
