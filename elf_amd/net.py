@@ -52,6 +52,42 @@ class PolicyValueNet(nn.Module):
         return dict(pi=pi, V=v)
 
 
+def map_reference_state_dict(sd):
+    """Keys of a reference Model_PolicyValue checkpoint (src_py/elfgames/go/df_model3.py:113-313, saved by
+    rlpytorch/model_base.py:83-109 as {"state_dict", "step", "options"}) -> keys of PolicyValueNet.  Same tensors, other names:
+        [init_conv|pi_final_conv|value_final_conv](.module)?.{0,1}.*   -> unchanged (DataParallel's ".module" dropped)
+        resnet(.module)?.resnet.{i}.conv_lower.{0,1}.*                  -> resnet.{i}.lower.{0,1}.*
+        resnet(.module)?.resnet.{i}.conv_upper.{0,1}.*                  -> resnet.{i}.upper.{0,1}.*
+        pi_linear.* / value_linear1.* / value_linear2.*                 -> unchanged
+    Raises KeyError on a key it does not know (nothing is dropped silently)."""
+    import re
+    sd = sd.get("state_dict", sd) if isinstance(sd, dict) and "state_dict" in sd else sd
+    out = {}
+    for k, v in sd.items():
+        k2 = k.replace(".module.", ".")
+        m = re.match(r"^resnet\.resnet\.(\d+)\.conv_(lower|upper)\.(.+)$", k2)
+        if m:
+            out["resnet.%s.%s.%s" % (m.group(1), m.group(2), m.group(3))] = v
+        elif re.match(r"^(init_conv|pi_final_conv|value_final_conv)\.[01]\.", k2) or re.match(r"^(pi_linear|value_linear1|value_linear2)\.", k2):
+            out[k2] = v
+        else:
+            raise KeyError("unknown key in a Model_PolicyValue state_dict: " + k)
+    return out
+
+
+def load_reference_checkpoint(path_or_state, board_size=19, device="cpu"):
+    """A PolicyValueNet (eval mode) with the weights of a reference checkpoint (save-*.bin) or of its state_dict.  Block count and
+    width are read from the checkpoint itself."""
+    sd = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, str) else path_or_state
+    sd = map_reference_state_dict(sd)
+    blocks = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("resnet."))
+    dim = sd["init_conv.0.weight"].shape[0]
+    planes = sd["init_conv.0.weight"].shape[1]
+    net = PolicyValueNet(board_size, planes, blocks, dim)
+    net.load_state_dict(sd, strict=True)
+    return net.eval().to(device)
+
+
 def fold_batchnorm(net):
     """Inference-time algebra, not a different net: every Conv2d+BatchNorm2d(eval) pair becomes one Conv2d with
     w' = w * gamma / sqrt(var + eps), b' = (b - mean) * gamma / sqrt(var + eps) + beta (torch.nn.utils.fusion)."""
