@@ -436,17 +436,20 @@ def run_feature(args, rank, local_rank, world, dist, steps, warmup):
 
 # ------------------------------------------------------------------------------------------------------------------- MCTS
 class RandomReplies:
-    """Pseudo-random policy/value replies drawn on the GPU (no conv net): a peaky policy grows deep, narrow trees like a trained
-    net does.  Used for --net random and for the untimed tree-growing prologue of the headline."""
+    """Pseudo-random policy/value replies (no conv net): a peaky policy grows deep, narrow trees like a trained net does.  Used
+    for --net random and for the untimed tree-growing prologue of the headline.  A pool of replies is drawn once on the GPU and
+    cycled through, so that a search-only measurement times the search kernels and not torch's random-number kernels."""
 
-    def __init__(self, rows, na, dev, seed):
-        self.rows, self.na, self.dev = rows, na, dev
-        self.gen = torch.Generator(device=dev)
-        self.gen.manual_seed(seed)
+    def __init__(self, rows, na, dev, seed, pool=8):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        self.pool = [(torch.softmax(4.0 * torch.randn((rows, na), device=dev, generator=gen), dim=1),
+                      torch.tanh(0.5 * torch.randn((rows,), device=dev, generator=gen))) for _ in range(pool)]
+        self.i = 0
 
     def __call__(self, s=None, rows=None):
-        return (torch.softmax(4.0 * torch.randn((self.rows, self.na), device=self.dev, generator=self.gen), dim=1),
-                torch.tanh(0.5 * torch.randn((self.rows,), device=self.dev, generator=self.gen)))
+        self.i = (self.i + 1) % len(self.pool)
+        return self.pool[self.i]
 
 
 def build_net(args, n, dev):

@@ -494,3 +494,61 @@ def test_online_mode_human_actor(mods):
     assert game.getNextPlayer() == "W" and game.getLastMove() == "C3"        # prompt 6 played action 2*9+2
     assert GC.ctx().version().startswith("elf_amd")
     gcw.stop()
+
+
+@pytest.mark.gpu
+def test_new_request_restarts_the_games_at_the_next_move_boundary(mods):
+    """Client::setRequest with a new model version while a search is running (GoGameSelfPlay::OnReceive, game_selfplay.cc:222-270):
+    the search in progress finishes with the old version; at the move boundary every game restarts from the empty board, one
+    game_start batch carries the new versions, and from then on replies must carry the new version in rv."""
+    import contextlib
+    import io
+    import torch
+    import gcwrapper_restated as mod
+    from pyoracle import MCTS_DEFAULTS, stub_net
+    _elf, go, _ = mods
+    n = 9
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=2, rollouts_per_thread=32, seed=66, net_salt=2, policy_distri_cutoff=4)
+    co, opt = options_from_cfg(go, cfg, n=n, log_searches=64)
+    GC = go.GameContext(co, opt)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gcw = mod.GCWrapper(GC, co.batchsize, game_py_desc(co.batchsize), num_recv=2, gpu=0, params=GC.getParams())
+    state = dict(rv=0, starts=[], rows=0)
+
+    def actor(batch):
+        s = batch["s"]
+        k = s.shape[0]
+        state["rows"] += k
+        pi, v = stub_net(n, s.cpu().numpy(), 2, 0)
+        return dict(pi=torch.from_numpy(pi).cuda(), V=torch.from_numpy(v).cuda(), a=torch.zeros(k, dtype=torch.int64).cuda(),
+                    rv=torch.full((k,), state["rv"], dtype=torch.int64).cuda())
+
+    gcw.reg_callback("actor_black", actor)
+    gcw.reg_callback("actor_white", actor)
+    gcw.reg_callback("game_start", lambda b: state["starts"].append((int(b["black_ver"][0]), int(b["white_ver"][0]))))
+    gcw.reg_callback("game_end", lambda b: None)
+    gcw.start()
+    client = GC.getClient()
+    client.setRequest(0, -1, 0.0, -1)
+    while len(GC.ctx().searchLog()) < 2 * 3:          # three moves per game under version 0
+        gcw.run()
+    assert state["starts"] == [(0, -1)] and GC.getGame(0).getNextPlayer() == "W"
+    gcw.run()                                          # a batch of the 4th search: that search is now open
+    client.setRequest(7, -1, 0.0, -1)                  # new model while the search runs
+    moves_before = len(GC.ctx().searchLog())
+    while len(GC.ctx().searchLog()) == moves_before:   # the running search completes under version 0 (rv = 0 still accepted)
+        gcw.run()
+    state["rv"] = 7
+    for _ in range(6):
+        gcw.run()
+    assert state["starts"] == [(0, -1), (7, -1)]
+    g = GC.getGame(0)
+    assert g.getNextPlayer() == "B" or len(GC.ctx().searchLog()) > moves_before + 2    # restarted from the empty board
+    state["rv"] = 0                                    # the old model's replies are now refused
+    with pytest.raises(RuntimeError):
+        for _ in range(8):
+            gcw.run()
+    with pytest.raises(ValueError):
+        client.setRequest(1, 2, 0.0, -1)               # a second AI for White is not supported: said loudly
+    gcw.stop()
