@@ -19,7 +19,11 @@
 // one of the interleavings the reference's racing threads can produce; T x num_rollouts_per_thread rollouts per move.
 //
 // HBM layout (sized for 288 GB): per game a pool of C fixed-size node records (12 KiB at 19x19):
-//   [64 B header][368 x 16 B edge stats {prior, reward, visits, vloss}][368 x i32 child][368 x u16 coord][board slot 3840 B]
+//   [64 B header][368 x 16 B edge stats {prior, reward, visits, vloss}][368 x i32 child][368 x u16 coord][368 x u16 perm][board slot 3840 B]
+// `perm` lists the edge indices in SCORING order: first the edges that have been followed at least once (sorted by index), then
+// the never-followed ones by descending prior.  A never-followed edge has N = 0, vl = 0, so its PUCT score is a monotone function
+// of its prior: select scores the followed edges and the head of the prior-sorted run -- one round of 64 lanes for almost every
+// node instead of all 362 edges -- and still returns the reference's arg-max (ties -> lowest index), see k_mcts_select.
 // The board slot is the same LDS image the board engine uses, so "allocateState" (tree_search.h:174-190)
 // is: 16-B/lane coalesced load of the parent's slot -> Board::forward in LDS -> coalesced store.
 #pragma once
@@ -44,7 +48,8 @@ struct NodeHdr {          // 64 B
   int status;             // NS_*
   int flip;               // flipQSign_
   int has_state;          // stateType_ == NODE_STATE_SET
-  int pad[6];
+  int n_touched;          // edges followed at least once = length of the index-sorted prefix of NodeRec::perm
+  int pad[5];
 };
 static_assert(sizeof(NodeHdr) == 64, "NodeHdr must be 64 bytes");
 
@@ -55,9 +60,10 @@ struct alignas(256) NodeRec {
   float4 stat[NE];   // x prior_probability, y reward, z num_visits (int bits), w virtual_loss  (EdgeInfo, tree_search_base.h:102-124)
   int child[NE];
   u16 coord[NE];
+  u16 perm[NE];      // edge indices in scoring order: [followed edges, ascending index | never-followed edges, descending prior]
   Slot<N> board;
 };
-static_assert(sizeof(NodeRec<19>) == 12032, "19x19 node record");
+static_assert(sizeof(NodeRec<19>) == 12800, "19x19 node record");
 
 struct TreeCfg {          // TSOptions / SearchAlgoOptions (tree_search_options.h:23-229) + MCTSActorParams (go/mcts/mcts.h:17-37)
   int rollouts_per_batch;
@@ -124,7 +130,7 @@ __device__ __forceinline__ float ukey2f(u32 k) { return __uint_as_float((k & 0x8
 
 // wave-uniform copy of a node header
 struct HdrU {
-  int parent, parent_edge, n_edges, num_visits, status, flip, has_state;
+  int parent, parent_edge, n_edges, num_visits, status, flip, has_state, n_touched;
   float V, umq, upq;
   __device__ __forceinline__ void load(const NodeHdr* h, int lane) {
     set(lane < 16 ? reinterpret_cast<const int*>(h)[lane] : 0);
@@ -132,7 +138,7 @@ struct HdrU {
   __device__ __forceinline__ void set(int w) {
     parent = rl(w, 0); parent_edge = rl(w, 1); n_edges = rl(w, 2); num_visits = rl(w, 3);
     V = __int_as_float(rl(w, 4)); umq = __int_as_float(rl(w, 5)); upq = __int_as_float(rl(w, 6));
-    status = rl(w, 7); flip = rl(w, 8); has_state = rl(w, 9);
+    status = rl(w, 7); flip = rl(w, 8); has_state = rl(w, 9); n_touched = rl(w, 10);
   }
 };
 
@@ -210,6 +216,25 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 #undef ELF_DPP_MAX
   return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
+// the same butterfly for a 64-bit key (hi word decides, lo word breaks ties)
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#define ELF_DPP_MAX64(ctrl, rmask)                                                                             \
+  {                                                                                                            \
+    const u32 olo = (u32)__builtin_amdgcn_update_dpp((int)(u32)v, (int)(u32)v, ctrl, rmask, 0xf, false);        \
+    const u32 ohi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(v >> 32), (int)(u32)(v >> 32), ctrl, rmask, 0xf, false); \
+    const u64 o = ((u64)ohi << 32) | olo;                                                                      \
+    v = o > v ? o : v;                                                                                         \
+  }
+  ELF_DPP_MAX64(0xB1, 0xf)
+  ELF_DPP_MAX64(0x4E, 0xf)
+  ELF_DPP_MAX64(0x124, 0xf)
+  ELF_DPP_MAX64(0x128, 0xf)
+  ELF_DPP_MAX64(0x142, 0xa)
+  ELF_DPP_MAX64(0x143, 0xc)
+#undef ELF_DPP_MAX64
+  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63);
+  return ((u64)hi << 32) | lo;
+}
 
 // SearchTreeT::clear (:411-416) for game g: every id free, then allocateRoot -> addNode(0.0)
 template <int N>
@@ -259,14 +284,35 @@ __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool
 // ------------------------------------------------------------------------------------------------
 // select: num_threads x rollouts_per_batch sequential descents per game (TreeSearchSingleThreadT::batch_rollouts, first
 // half, once per search thread)
+//
+// findMove/UCT over a node WITHOUT touching all of its edges.  The reference scores every edge and keeps the first maximum in
+// iteration order.  An edge that was never followed has N = 0, vl = 0, reward = 0: its Q is the node's first-play urgency and
+// its U = (float)((double)(prior / 1) * sqrt) * c_puct is a monotone non-decreasing function of the prior (every rounding step
+// is monotone, c_puct >= 0), so among the never-followed edges the maxima are the HEAD of the list sorted by descending prior --
+// exactly the run whose score equals the score of its first element.  `perm` keeps [followed edges by ascending index | the
+// rest by descending prior]; one round of 64 lanes scores the followed edges plus the head of that run, further rounds are
+// read only while followed edges remain or the run of equal scores continues (uniform priors).  The maximum is taken over
+// (score, lowest index), which is the reference's result; the FPU running mean sums the followed edges in index order, which is
+// lane order.
 // ------------------------------------------------------------------------------------------------
+// phase markers for cycle attribution (tools/select_phases.sh builds with -DELF_PROFILE_SELECT; compiled out of the library)
+#ifdef ELF_PROFILE_SELECT
+__device__ unsigned long long g_select_phase[4096][8];   // per block id: no atomics, summed on the host
+#define SEL_PHASE(k) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); sel_acc[k] += _t - sel_t; sel_t = _t; } while (0)
+#else
+#define SEL_PHASE(k)
+#endif
+
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
   using NR = NodeRec<N>;
-  constexpr int R = (N * N + 1 + 63) / 64;
   __shared__ Slot<N> lds;
-  __shared__ __attribute__((aligned(16))) float uqs[NR::NE + 16];   // unsigned child Qs of the visited edges, compacted in edge order
+  __shared__ __attribute__((aligned(16))) float uqs[64 + 8];   // unsigned child Qs of one round's visited edges, compacted
   const int g = blockIdx.x, lane = threadIdx.x;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+#ifdef ELF_PROFILE_SELECT
+  unsigned long long sel_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sel_t = __builtin_amdgcn_s_memtime();
+#endif
   NR* nodes = tp.game_nodes(g);
   int* fs = tp.free_stack + (size_t)g * tp.C;
   GameState& gs = tp.gs[g];
@@ -276,7 +322,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   const int root_sk_len = rfl((int)nodes[root].board.h.sk_len);
   Board<N> bd;
   bd.init(&lds, pool.zob, nullptr);
-  const u64 lt_mask = (1ull << lane) - 1ull;
 
   // lane u holds the u-th unique leaf of this step (unique per search thread)
   int my_leaf = -1, my_count = 0, my_kind = 0, my_d4 = 0, my_nn = 0, my_depth = 0;
@@ -292,124 +337,114 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     int node = root, depth = 0;
     bool board_in_lds = false;   // LDS holds the state of `node`
     HdrU h;
-    // One memory round trip per tree level: the header, the edge statistics, the child ids and the coords of a node are
-    // requested together (speculatively: a leaf's edge arrays are never used), so the only dependent load of a level is
-    // the one of the chosen child.
+    // first memory round trip of a level: the header and the first 64 entries of the scoring order, requested together
     int hw;
-    float4 st[R];
-    int chv[R];
-    u32 cdv[R];
+    u32 pm0;
     auto request = [&](int nid) {
       const NR& q = nodes[nid];
       hw = lane < 16 ? reinterpret_cast<const int*>(&q.h)[lane] : 0;
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const int e = k * 64 + lane, ec = e < NR::NE ? e : NR::NE - 1;
-        st[k] = q.stat[ec];
-        chv[k] = q.child[ec];
-        cdv[k] = q.coord[ec];
-      }
+      pm0 = q.perm[lane];
     };
     request(node);
     for (;;) {                   // single_rollout, tree_search.h:264-322
       h.set(hw);
+      SEL_PHASE(0);   // header + scoring order arrive
       if (h.status != NS_VISITED || h.n_edges == 0) break;
       NR& nd = nodes[node];
       // ---- findMove :205-231 + UCT :361-397 + EdgeInfo::getScore (tree_search_base.h:132-157)
       float umq = h.umq;
       if (cfg.unexplored_q_zero || (cfg.root_unexplored_q_zero && depth == 0)) umq = 0.0f;
+      const float fpu = h.flip ? -umq : umq;
       const int all_visits = h.num_visits + 1;
-      const double sq = all_visits < tp.sqrt_n ? tp.sqrt_tab[all_visits] : sqrt((double)all_visits);
-      float uq[R];
-      u64 vmask[R];
-      u32 skey[R];               // monotone key of the edge's score, 0 = not a candidate
-      u32 lmax = 0;
+      // sqrt(N + 1) from the host-libm table through the SCALAR cache: a vector load here would sit in vmcnt between the scoring
+      // order and the statistics gather and serialise a third memory round trip into every level (measured)
+      const bool sq_tab = all_visits < tp.sqrt_n;
+      u64 sq_bits = sq_tab ? sload_u64(reinterpret_cast<const u64*>(tp.sqrt_tab), all_visits) : 0ull;
+      const int ne = h.n_edges, nt = h.n_touched;
+      bool sq_ready = false;
+      double sq = 0.0;
+      u32 best_key = 0, unt_key0 = 0;
+      int best_e = 0x7FFFFFFF, best_pos = 0, best_child = -1, best_mv = 0;
+      float best_vl = 0.0f, tq = 0.0f;
       int tv = 0;
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const int e = k * 64 + lane;
-        const bool valid = e < h.n_edges;
-        const float prior = st[k].x, reward = st[k].y, vl = st[k].w;
-        const int nv = __float_as_int(st[k].z);
-        float q, pp;
-        if (__ballot(valid && (nv != 0 || vl != 0.0f)) == 0) {
-          // no edge of this round of 64 carries statistics (most rounds of most nodes): N = 0 and vl = 0 make nvl = 0, Q the
-          // first-play urgency, and prior / (1 + 0) the prior itself -- the same values as below without the three divisions
-          q = h.flip ? -umq : umq;
-          uq[k] = umq;
-          pp = (float)((double)prior * sq);
-          vmask[k] = 0;
-        } else {
-          float r = h.flip ? -reward : reward;
-          r = __fsub_rn(r, vl);
-          const int nvl = (int)__fadd_rn((float)nv, vl);                       // int + float -> float -> int
-          q = nvl > 0 ? __fdiv_rn(r, (float)nvl) : (h.flip ? -umq : umq);
-          uq[k] = nv > 0 ? __fdiv_rn(reward, (float)nv) : umq;
-          pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);       // float / int, then * double sqrt, stored to float
-          vmask[k] = __ballot(valid && nvl != 0);                              // !first_visit
+      for (int base = 0; base < ne; base += 64) {
+        const int pos = base + lane;
+        const bool in = pos < ne;
+        const int e = in ? (int)(base == 0 ? pm0 : (u32)nd.perm[pos]) : 0;
+        // second round trip: the statistics, child id and coord of the listed edges
+        const float4 st = nd.stat[e];
+        const int ch = nd.child[e];
+        const u32 cd = nd.coord[e];
+        const float prior = st.x, reward = st.y, vl = st.w;
+        const int nv = __float_as_int(st.z);
+        if (!sq_ready) {
+          sq = sq_tab ? __longlong_as_double((long long)sload_wait(sq_bits)) : sqrt((double)all_visits);
+          sq_ready = true;
         }
+        // one formula for both kinds of edge: with N = 0, vl = 0, reward = 0 it yields nvl = 0, Q = first-play urgency,
+        // unsigned_q = umq and prior / 1 = prior
+        float r = h.flip ? -reward : reward;
+        r = __fsub_rn(r, vl);
+        const int nvl = (int)__fadd_rn((float)nv, vl);                       // int + float -> float -> int
+        const float q = nvl > 0 ? __fdiv_rn(r, (float)nvl) : fpu;
+        const float uq = nv > 0 ? __fdiv_rn(reward, (float)nv) : umq;
+        const float pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);   // float / int, then * double sqrt, stored to float
         const float score = cfg.use_prior ? __fadd_rn(__fmul_rn(pp, cfg.c_puct), q) : q;
-        tv += __popcll(vmask[k]);
-        // strict '>' in iteration order = the lowest edge index among the maxima.  Keys compare like the floats do
-        // (-0.0 == +0.0: canonicalised by + 0.0f; NaN never wins a '>': key 0).
-        skey[k] = (valid && score == score) ? f2ukey(__fadd_rn(score, 0.0f)) : 0u;
-        lmax = skey[k] > lmax ? skey[k] : lmax;
-      }
-      const u32 kmax = wave_max_u32(lmax);
-      if (kmax == 0) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
-      int best_e = -1;
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const u64 b = __ballot(skey[k] == kmax);
-        if (best_e < 0 && b) best_e = k * 64 + (int)__builtin_ctzll(b);
-      }
-      // BestAction::addAction :333-347: sequential fp32 sum of unsigned_q over edges that are not first visits, in edge order
-      float tq = 0.0f;
-      if (tv <= 8) {
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          u64 m = vmask[k];
-          while (m) {
-            const int l = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            tq = __fadd_rn(tq, rlf(uq[k], l));
+        // keys compare like the floats do (-0.0 == +0.0: canonicalised by + 0.0f; NaN never wins a '>': key 0)
+        const u32 key = (in && score == score) ? f2ukey(__fadd_rn(score, 0.0f)) : 0u;
+        // BestAction::addAction :333-347: sequential fp32 sum of unsigned_q over edges that are not first visits, in edge order
+        u64 vm = __ballot(in && nvl != 0);
+        const int tvr = __popcll(vm);
+        tv += tvr;
+        if (tvr <= 6) {
+          while (vm) {
+            const int l = (int)__builtin_ctzll(vm);
+            vm &= vm - 1;
+            tq = __fadd_rn(tq, rlf(uq, l));
+          }
+        } else {
+          // many visited edges (the nodes near the root): the values go to LDS compacted in lane (= edge) order and every lane
+          // runs the dependent chain on broadcast 16-B reads instead of one readlane per element.  The tail is padded with
+          // +0.0f: the running sum starts at +0.0f and can never be -0.0f, so x + 0.0f == x bit for bit.
+          if ((vm >> lane) & 1) uqs[__popcll(vm & lt_mask)] = uq;
+          if (lane < 4) uqs[tvr + lane] = 0.0f;
+          Board<N>::wsync();
+          const float4* u4 = reinterpret_cast<const float4*>(uqs);
+          const int n4 = (tvr + 3) >> 2;
+          for (int c4 = 0; c4 < n4; ++c4) {
+            const float4 q4 = u4[c4];
+            tq = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(tq, q4.x), q4.y), q4.z), q4.w);
+          }
+          Board<N>::wsync();
+        }
+        // strict '>' in iteration order = the lowest edge index among the maxima: one maximum of (score key, ~index)
+        const u64 k64 = ((u64)key << 32) | (u32)(0xFFFF - e);
+        const u64 kmax64 = wave_max_u64(k64);
+        const u32 kmax = (u32)(kmax64 >> 32);
+        if (kmax != 0 && kmax >= best_key) {
+          const int emin = 0xFFFF - (int)(u32)kmax64;
+          if (kmax > best_key || emin < best_e) {
+            const int bl = (int)__builtin_ctzll(__ballot(k64 == kmax64));
+            best_key = kmax; best_e = emin; best_pos = base + bl;
+            best_child = rl(ch, bl); best_mv = rl((int)cd, bl); best_vl = rlf(vl, bl);
           }
         }
-      } else {
-        // many visited edges (the nodes near the root): compact the values into LDS in edge order, then every lane runs the
-        // dependent chain on broadcast 16-B reads (issued ahead of the adds) instead of one readlane per element.  The tail is
-        // padded with +0.0f: the running sum starts at +0.0f and can never be -0.0f, so x + 0.0f == x bit for bit.
-        int base = 0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const u64 m = vmask[k];
-          if ((m >> lane) & 1) uqs[base + __popcll(m & lt_mask)] = uq[k];
-          base += __popcll(m);
-        }
-        if (lane < 4) uqs[tv + lane] = 0.0f;
-        Board<N>::wsync();
-        const float4* u4 = reinterpret_cast<const float4*>(uqs);
-        const int n4 = (tv + 3) >> 2;
-        for (int c = 0; c < n4; ++c) {
-          const float4 q4 = u4[c];
-          tq = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(tq, q4.x), q4.y), q4.z), q4.w);
-        }
-        Board<N>::wsync();
+        if (base + 64 >= ne) break;                          // every edge has been scored
+        if (base + 64 <= nt) continue;                       // followed edges (or the first never-followed one) are still ahead
+        if (nt >= base) unt_key0 = (u32)rl((int)key, nt - base);   // this round holds the head of the prior-sorted run
+        if ((u32)rl((int)key, 63) != unt_key0) break;        // the run of maximal never-followed scores ends inside this round
       }
+      SEL_PHASE(1);   // statistics gather, scores, reductions, FPU sum
+      if (best_e == 0x7FFFFFFF) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
       const float new_umq = __fdiv_rn(__fadd_rn(h.upq, tq), (float)(tv + 1));   // :227-228
-      // ---- addVirtualLoss :233-251; chosen edge's child / coord straight from the registers
-      const int bk = best_e >> 6, bl = best_e & 63;
-      float cur_vl = 0.0f;
-      int child = 0, mv = 0;
-#pragma unroll
-      for (int k = 0; k < R; ++k)
-        if (k == bk) { cur_vl = st[k].w; child = chv[k]; mv = (int)cdv[k]; }
-      cur_vl = rlf(cur_vl, bl); child = rl(child, bl); mv = rl(mv, bl);
+      // ---- addVirtualLoss :233-251
       if (lane == 0) {
         nd.h.unsigned_mean_q = new_umq;
-        if (cfg.virtual_loss > 0) nd.stat[best_e].w = __fadd_rn(cur_vl, vl_f);
+        if (cfg.virtual_loss > 0) nd.stat[best_e].w = __fadd_rn(best_vl, vl_f);
       }
       ++depth;
+      int child = best_child;
+      const int mv = best_mv;
       if (child < 0) {
         // ---- followEdge :280-302 -> SearchTreeT::addNode(unsignedMeanQ_) :439-443
         if (free_top <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
@@ -417,10 +452,28 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         --free_top;
         node_init(tp, g, child, node, best_e, new_umq, lane);
         if (lane == 0) nd.child[best_e] = child;
+        // the edge joins the index-sorted prefix of the scoring order: entries [p, best_pos) move up by one
+        int p = 0;
+        for (int b2 = 0; b2 < nt; b2 += 64) {
+          const int pos = b2 + lane;
+          const bool t = pos < nt;
+          const int v = t ? (int)nd.perm[pos] : 0;
+          p += __popcll(__ballot(t && v < best_e));
+        }
+        for (int b2 = best_pos & ~63; b2 >= (p & ~63); b2 -= 64) {   // high rounds first: a round's loads precede its stores
+          const int pos = b2 + lane;
+          const bool mvd = pos >= p && pos < best_pos;
+          const u16 v = mvd ? nd.perm[pos] : (u16)0;
+          if (mvd) nd.perm[pos + 1] = v;
+        }
+        if (lane == 0) { nd.perm[p] = (u16)best_e; nd.h.n_touched = nt + 1; }
+        SEL_PHASE(2);   // new node: id, header, scoring-order insertion
         // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
         bd.load(&nd.board);
+        SEL_PHASE(3);   // parent's board slot to LDS
         TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skr(bslot)}, root_sk_len};
         if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; --depth; break; }
+        SEL_PHASE(4);   // Board::forward
         bd.store(&nodes[child].board);
         if (lane == 0) nodes[child].h.has_state = 1;
         board_in_lds = true;
@@ -432,6 +485,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       request(node);             // existing children always own a state (created together with the node)
     }
     visited_nodes += depth;
+    SEL_PHASE(5);   // slot store issue, loop exit
     // ---- leaf bookkeeping: batch_rollouts :211-233 (requestEvaluation, duplicate leaves of THIS thread's batch)
     const u64 dup = __ballot(lane >= thread_start && lane < n_unique && my_leaf == node);
     if (dup) {
@@ -460,8 +514,15 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       ++n_unique;
       if (kind == LK_NN) ++n_nn;
     }
+    SEL_PHASE(6);   // leaf bookkeeping (terminal test, D4 draw)
     mem_sync();
+    SEL_PHASE(7);   // fence: this rollout's stores are visible to the next descent
   }
+#ifdef ELF_PROFILE_SELECT
+  if (lane < 8 && g < 4096)
+    g_select_phase[g][lane] += lane == 0 ? sel_acc[0] : lane == 1 ? sel_acc[1] : lane == 2 ? sel_acc[2] : lane == 3 ? sel_acc[3]
+                             : lane == 4 ? sel_acc[4] : lane == 5 ? sel_acc[5] : lane == 6 ? sel_acc[6] : sel_acc[7];
+#endif
   if (lane < n_unique) {
     LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + lane];
     lr.node = my_leaf; lr.count = my_count; lr.kind = my_kind; lr.d4 = my_d4; lr.value = my_value; lr.nn_index = my_nn;
@@ -898,8 +959,10 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
     nd.stat[jn] = make_float4(L.sprob[src], 0.0f, __int_as_float(0), 0.0f);
     nd.child[jn] = -1;
     nd.coord[jn] = L.skey[src];
+    nd.perm[src] = (u16)jn;   // scoring order of a fresh node: no edge followed yet, the rest by descending prior = pi2response's sort
   }
   if (lane == 0) {
+    nd.h.n_touched = 0;
     nd.h.n_edges = n;
     nd.h.V = value[row];                                  // resp->value = reply.value :222
     nd.h.flip = bd.next_player == S_WHITE;                // pre_evaluate :186
@@ -995,6 +1058,25 @@ __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const flo
     const float p = r.stat[i].x;
     // (1 - epsilon) * p + epsilon * etas[i] / Z, left to right, no contraction
     r.stat[i].x = __fadd_rn(__fmul_rn(ome, p), __fdiv_rn(__fmul_rn(epsilon, etas[(size_t)g * NodeRec<N>::NE + i]), z));
+  }
+  // the never-followed part of the scoring order follows the NEW priors: descending prior (ties: ascending index)
+  mem_sync();
+  const int nt = rfl(r.h.n_touched);
+  u64 sx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int pos = nt + k * 64 + lane;
+    sx[k] = ~0ull;
+    if (pos < n) {
+      const u32 e = r.perm[pos];
+      sx[k] = ((u64)(~f2ukey(r.stat[e].x)) << 32) | e;
+    }
+  }
+  bitonic_sort512(sx, lane);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = k * 64 + lane;
+    if (nt + i < n) r.perm[nt + i] = (u16)(sx[k] & 0xFFFFu);
   }
 }
 

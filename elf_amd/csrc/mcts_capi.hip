@@ -59,6 +59,7 @@ static int cfg_from(const ElfMctsOptions* o, TreeCfg* c) {
   c->rotation_flip = o->rotation_flip;
   c->num_threads = o->num_threads;
   c->required_version = o->required_version;
+  if (!(c->c_puct >= 0.0f)) return ELFGO_E_BADARG;   // the scoring order of never-followed edges relies on U growing with the prior
   return 0;
 }
 
@@ -198,6 +199,18 @@ int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const 
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+#ifdef ELF_PROFILE_SELECT
+// profile builds only: accumulated s_memtime ticks per k_mcts_select phase (see SEL_PHASE in mcts.cuh)
+extern "C" int elfprof_select_phases(unsigned long long* out8) {
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<unsigned long long> all((size_t)4096 * 8);
+  HIPCHK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(elfgo::g_select_phase), all.size() * sizeof(unsigned long long)));
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (size_t i = 0; i < all.size(); ++i) out8[i & 7] += all[i];
+  return 0;
+}
+#endif
 
 #ifdef ELF_PROFILE_EXPAND
 // profile builds only: accumulated s_memtime ticks per k_mcts_expand phase (see EXP_PHASE in mcts.cuh)
