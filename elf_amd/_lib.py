@@ -43,6 +43,7 @@ SIGNATURES = {
     "elfmcts_expand": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "elfmcts_root": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "elfmcts_advance": (_i, [_vp, _vp, _vp]),
+    "elfmcts_validate": (_i, [_vp, _vp]),
     "elfmcts_node_visits": (_i, [_vp, _vp]),
     "elfsp_create": (_i, [_vp, _i, _vp, C.POINTER(_vp)]),
     "elfsp_destroy": (_i, [_vp]),

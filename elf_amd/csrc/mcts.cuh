@@ -19,11 +19,15 @@
 // one of the interleavings the reference's racing threads can produce; T x num_rollouts_per_thread rollouts per move.
 //
 // HBM layout (sized for 288 GB): per game a pool of C fixed-size node records (12 KiB at 19x19):
-//   [64 B header][368 x 16 B edge stats {prior, reward, visits, vloss}][368 x i32 child][368 x u16 coord][368 x u16 perm][board slot 3840 B]
-// `perm` lists the edge indices in SCORING order: first the edges that have been followed at least once (sorted by index), then
-// the never-followed ones by descending prior.  A never-followed edge has N = 0, vl = 0, so its PUCT score is a monotone function
-// of its prior: select scores the followed edges and the head of the prior-sorted run -- one round of 64 lanes for almost every
-// node instead of all 362 edges -- and still returns the reference's arg-max (ties -> lowest index), see k_mcts_select.
+//   [64 B header][368 x 16 B edge stats {prior, reward, visits, vloss}][368 x i32 child][368 x u16 coord][368 x u16 orig][board slot 3840 B]
+// The edge arrays are kept in SCORING order: first the edges that have been followed at least once, sorted by their index in the
+// reference's unordered_map iteration order (`orig`), then the never-followed ones by descending prior.  A never-followed edge
+// has N = 0, vl = 0, so its PUCT score is a monotone function of its prior: select scores the followed edges and the head of the
+// prior-sorted run -- ONE coalesced round of 64 entries for almost every node instead of all 362 edges -- and still returns the
+// reference's arg-max (ties -> lowest `orig`), see k_mcts_select.  Every order-dependent rule of the reference (PUCT ties,
+// Dirichlet eta_i <-> i-th edge, most-visited ties, MCTSPolicy order) goes through `orig`.  An entry moves only when an edge is
+// followed for the first time (it joins the sorted prefix; the entries it passes shift up by one and their child nodes'
+// `parent_edge` follows), so a child's `parent_edge` is always the current position of its edge.
 // The board slot is the same LDS image the board engine uses, so "allocateState" (tree_search.h:174-190)
 // is: 16-B/lane coalesced load of the parent's slot -> Board::forward in LDS -> coalesced store.
 #pragma once
@@ -48,7 +52,7 @@ struct NodeHdr {          // 64 B
   int status;             // NS_*
   int flip;               // flipQSign_
   int has_state;          // stateType_ == NODE_STATE_SET
-  int n_touched;          // edges followed at least once = length of the index-sorted prefix of NodeRec::perm
+  int n_touched;          // edges followed at least once = length of the orig-sorted prefix of the edge arrays
   int pad[5];
 };
 static_assert(sizeof(NodeHdr) == 64, "NodeHdr must be 64 bytes");
@@ -60,7 +64,7 @@ struct alignas(256) NodeRec {
   float4 stat[NE];   // x prior_probability, y reward, z num_visits (int bits), w virtual_loss  (EdgeInfo, tree_search_base.h:102-124)
   int child[NE];
   u16 coord[NE];
-  u16 perm[NE];      // edge indices in scoring order: [followed edges, ascending index | never-followed edges, descending prior]
+  u16 orig[NE];      // index of the edge in the reference's unordered_map iteration order (the arrays themselves are in scoring order)
   Slot<N> board;
 };
 static_assert(sizeof(NodeRec<19>) == 12800, "19x19 node record");
@@ -337,13 +341,19 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     int node = root, depth = 0;
     bool board_in_lds = false;   // LDS holds the state of `node`
     HdrU h;
-    // first memory round trip of a level: the header and the first 64 entries of the scoring order, requested together
+    // the one memory round trip of a level: the header and the first 64 entries of the scoring order, requested together
+    // (speculatively: a leaf's edge arrays are never used), all coalesced
     int hw;
-    u32 pm0;
+    float4 st0;
+    int ch0;
+    u32 cd0, og0;
     auto request = [&](int nid) {
       const NR& q = nodes[nid];
       hw = lane < 16 ? reinterpret_cast<const int*>(&q.h)[lane] : 0;
-      pm0 = q.perm[lane];
+      st0 = q.stat[lane];
+      ch0 = q.child[lane];
+      cd0 = q.coord[lane];
+      og0 = q.orig[lane];
     };
     request(node);
     for (;;) {                   // single_rollout, tree_search.h:264-322
@@ -356,31 +366,28 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       if (cfg.unexplored_q_zero || (cfg.root_unexplored_q_zero && depth == 0)) umq = 0.0f;
       const float fpu = h.flip ? -umq : umq;
       const int all_visits = h.num_visits + 1;
-      // sqrt(N + 1) from the host-libm table through the SCALAR cache: a vector load here would sit in vmcnt between the scoring
-      // order and the statistics gather and serialise a third memory round trip into every level (measured)
+      // sqrt(N + 1) from the host-libm table through the SCALAR cache (a vector load would queue behind the edge entries in vmcnt).
+      // A constant-address-space load with a wave-uniform index: the compiler emits s_load_dwordx2 and tracks its lgkmcnt itself.
       const bool sq_tab = all_visits < tp.sqrt_n;
-      u64 sq_bits = sq_tab ? sload_u64(reinterpret_cast<const u64*>(tp.sqrt_tab), all_visits) : 0ull;
+      typedef const __attribute__((address_space(4))) u64 cu64;
+      const u64 sq_bits = reinterpret_cast<cu64*>(reinterpret_cast<uintptr_t>(tp.sqrt_tab))[rfl(sq_tab ? all_visits : 0)];
       const int ne = h.n_edges, nt = h.n_touched;
-      bool sq_ready = false;
-      double sq = 0.0;
+      const double sq = sq_tab ? __longlong_as_double((long long)sq_bits) : sqrt((double)all_visits);
       u32 best_key = 0, unt_key0 = 0;
       int best_e = 0x7FFFFFFF, best_pos = 0, best_child = -1, best_mv = 0;
-      float best_vl = 0.0f, tq = 0.0f;
+      float best_vl = 0.0f, best_prior_v = 0.0f, tq = 0.0f;
       int tv = 0;
       for (int base = 0; base < ne; base += 64) {
         const int pos = base + lane;
         const bool in = pos < ne;
-        const int e = in ? (int)(base == 0 ? pm0 : (u32)nd.perm[pos]) : 0;
-        // second round trip: the statistics, child id and coord of the listed edges
-        const float4 st = nd.stat[e];
-        const int ch = nd.child[e];
-        const u32 cd = nd.coord[e];
+        const int pc = in ? pos : 0;
+        // further rounds (nodes with more than ~60 followed edges, or a long run of equal priors) are read on demand
+        const float4 st = base == 0 ? st0 : nd.stat[pc];
+        const int ch = base == 0 ? ch0 : nd.child[pc];
+        const u32 cd = base == 0 ? cd0 : (u32)nd.coord[pc];
+        const int e = (int)(base == 0 ? og0 : (u32)nd.orig[pc]);
         const float prior = st.x, reward = st.y, vl = st.w;
         const int nv = __float_as_int(st.z);
-        if (!sq_ready) {
-          sq = sq_tab ? __longlong_as_double((long long)sload_wait(sq_bits)) : sqrt((double)all_visits);
-          sq_ready = true;
-        }
         // one formula for both kinds of edge: with N = 0, vl = 0, reward = 0 it yields nvl = 0, Q = first-play urgency,
         // unsigned_q = umq and prior / 1 = prior
         float r = h.flip ? -reward : reward;
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           if (kmax > best_key || emin < best_e) {
             const int bl = (int)__builtin_ctzll(__ballot(k64 == kmax64));
             best_key = kmax; best_e = emin; best_pos = base + bl;
-            best_child = rl(ch, bl); best_mv = rl((int)cd, bl); best_vl = rlf(vl, bl);
+            best_child = rl(ch, bl); best_mv = rl((int)cd, bl); best_vl = rlf(vl, bl); best_prior_v = rlf(prior, bl);
           }
         }
         if (base + 64 >= ne) break;                          // every edge has been scored
@@ -437,10 +444,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       SEL_PHASE(1);   // statistics gather, scores, reductions, FPU sum
       if (best_e == 0x7FFFFFFF) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
       const float new_umq = __fdiv_rn(__fadd_rn(h.upq, tq), (float)(tv + 1));   // :227-228
-      // ---- addVirtualLoss :233-251
+      // ---- addVirtualLoss :233-251 (an edge followed for the first time gets it together with its move into the prefix below)
+      const float new_vl = cfg.virtual_loss > 0 ? __fadd_rn(best_vl, vl_f) : best_vl;
       if (lane == 0) {
         nd.h.unsigned_mean_q = new_umq;
-        if (cfg.virtual_loss > 0) nd.stat[best_e].w = __fadd_rn(best_vl, vl_f);
+        if (cfg.virtual_loss > 0 && best_child >= 0) nd.stat[best_pos].w = new_vl;
       }
       ++depth;
       int child = best_child;
@@ -450,23 +458,33 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         if (free_top <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
         child = rfl(fs[free_top - 1]);
         --free_top;
-        node_init(tp, g, child, node, best_e, new_umq, lane);
-        if (lane == 0) nd.child[best_e] = child;
-        // the edge joins the index-sorted prefix of the scoring order: entries [p, best_pos) move up by one
+        // the edge joins the orig-sorted prefix of the scoring order at position p: entries [p, best_pos) move up by one and
+        // the child nodes of the moved edges learn their new position
         int p = 0;
         for (int b2 = 0; b2 < nt; b2 += 64) {
           const int pos = b2 + lane;
           const bool t = pos < nt;
-          const int v = t ? (int)nd.perm[pos] : 0;
+          const int v = t ? (int)(b2 == 0 ? og0 : (u32)nd.orig[pos]) : 0;
           p += __popcll(__ballot(t && v < best_e));
         }
         for (int b2 = best_pos & ~63; b2 >= (p & ~63); b2 -= 64) {   // high rounds first: a round's loads precede its stores
           const int pos = b2 + lane;
           const bool mvd = pos >= p && pos < best_pos;
-          const u16 v = mvd ? nd.perm[pos] : (u16)0;
-          if (mvd) nd.perm[pos + 1] = v;
+          const int pc = mvd ? pos : 0;
+          const float4 ms = nd.stat[pc];
+          const int mc = nd.child[pc];
+          const u16 md = nd.coord[pc], mo = nd.orig[pc];
+          if (mvd) {
+            nd.stat[pos + 1] = ms; nd.child[pos + 1] = mc; nd.coord[pos + 1] = md; nd.orig[pos + 1] = mo;
+            if (mc >= 0) nodes[mc].h.parent_edge = pos + 1;
+          }
         }
-        if (lane == 0) { nd.perm[p] = (u16)best_e; nd.h.n_touched = nt + 1; }
+        node_init(tp, g, child, node, p, new_umq, lane);
+        if (lane == 0) {
+          nd.stat[p] = make_float4(best_prior_v, 0.0f, __int_as_float(0), new_vl);
+          nd.child[p] = child; nd.coord[p] = (u16)mv; nd.orig[p] = (u16)best_e;
+          nd.h.n_touched = nt + 1;
+        }
         SEL_PHASE(2);   // new node: id, header, scoring-order insertion
         // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
         bd.load(&nd.board);
@@ -954,12 +972,14 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
   // ---- setEvaluation :176-203: insert in this order; store edges in the map's ITERATION order
   umap_order_wave<N>(L, n, lane);
   EXP_PHASE(6);   // unordered_map iteration order
+  // the edges are stored in scoring order: no edge followed yet, all of them by descending prior = pi2response's sorted order;
+  // `orig` carries each edge's index in the map's iteration order
   for (int jn = lane; jn < n; jn += 64) {
     const int src = L.seq[jn];
-    nd.stat[jn] = make_float4(L.sprob[src], 0.0f, __int_as_float(0), 0.0f);
-    nd.child[jn] = -1;
-    nd.coord[jn] = L.skey[src];
-    nd.perm[src] = (u16)jn;   // scoring order of a fresh node: no edge followed yet, the rest by descending prior = pi2response's sort
+    nd.stat[src] = make_float4(L.sprob[src], 0.0f, __int_as_float(0), 0.0f);
+    nd.child[src] = -1;
+    nd.coord[src] = L.skey[src];
+    nd.orig[src] = (u16)jn;
   }
   if (lane == 0) {
     nd.h.n_touched = 0;
@@ -1056,10 +1076,12 @@ __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const flo
   const float z = Z[g], ome = __fsub_rn(1.0f, epsilon);
   for (int i = lane; i < n; i += 64) {
     const float p = r.stat[i].x;
-    // (1 - epsilon) * p + epsilon * etas[i] / Z, left to right, no contraction
-    r.stat[i].x = __fadd_rn(__fmul_rn(ome, p), __fdiv_rn(__fmul_rn(epsilon, etas[(size_t)g * NodeRec<N>::NE + i]), z));
+    const int o = r.orig[i];   // eta_o belongs to the o-th edge of the map's iteration order
+    // (1 - epsilon) * p + epsilon * etas[o] / Z, left to right, no contraction
+    r.stat[i].x = __fadd_rn(__fmul_rn(ome, p), __fdiv_rn(__fmul_rn(epsilon, etas[(size_t)g * NodeRec<N>::NE + o]), z));
   }
-  // the never-followed part of the scoring order follows the NEW priors: descending prior (ties: ascending index)
+  // the never-followed part of the scoring order follows the NEW priors: descending prior (ties: ascending orig).  Those
+  // entries carry no statistics and no child: sort (prior, position) keys, then move prior / coord / orig accordingly.
   mem_sync();
   const int nt = rfl(r.h.n_touched);
   u64 sx[8];
@@ -1067,16 +1089,30 @@ __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const flo
   for (int k = 0; k < 8; ++k) {
     const int pos = nt + k * 64 + lane;
     sx[k] = ~0ull;
-    if (pos < n) {
-      const u32 e = r.perm[pos];
-      sx[k] = ((u64)(~f2ukey(r.stat[e].x)) << 32) | e;
-    }
+    if (pos < n) sx[k] = ((u64)(~f2ukey(r.stat[pos].x)) << 32) | ((u32)r.orig[pos] << 16) | (u32)(pos - nt);
   }
   bitonic_sort512(sx, lane);
+  float np[8];
+  u16 nc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int i = k * 64 + lane;
-    if (nt + i < n) r.perm[nt + i] = (u16)(sx[k] & 0xFFFFu);
+    np[k] = 0.0f; nc[k] = 0;
+    if (nt + i < n) {
+      const int src = nt + (int)(sx[k] & 0xFFFFu);
+      np[k] = r.stat[src].x;
+      nc[k] = r.coord[src];
+    }
+  }
+  mem_sync();   // every source entry has been read before any destination is written
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = k * 64 + lane;
+    if (nt + i < n) {
+      r.stat[nt + i] = make_float4(np[k], 0.0f, __int_as_float(0), 0.0f);
+      r.coord[nt + i] = nc[k];
+      r.orig[nt + i] = (u16)((sx[k] >> 16) & 0xFFFFu);
+    }
   }
 }
 
@@ -1101,22 +1137,64 @@ __global__ __launch_bounds__(64) void k_mcts_root(TreePool<N> tp, RootInfo* info
     ri.rng_pos = gs.rng_pos; ri.err = gs.err; ri.free_top = gs.free_top;
     info[g] = ri;
   }
-  for (int i = lane; i < NE; i += 64) {
+  // the arrays are in scoring order; the caller gets them in the map's iteration order (entry -> slot orig)
+  for (int i = n + lane; i < NE; i += 64) {
     const size_t o = (size_t)g * NE + i;
-    if (i < n) {
+    if (coord) coord[o] = -1;
+    if (visits) visits[o] = 0;
+    if (prior) prior[o] = 0.f;
+    if (reward) reward[o] = 0.f;
+    if (child) child[o] = -1;
+  }
+  for (int i = lane; i < n; i += 64) {
+    const size_t o = (size_t)g * NE + r.orig[i];
+    const float4 s = r.stat[i];
+    if (coord) coord[o] = r.coord[i];
+    if (visits) visits[o] = __float_as_int(s.z);
+    if (prior) prior[o] = s.x;
+    if (reward) reward[o] = s.y;
+    if (child) child[o] = r.child[i];
+  }
+}
+
+// Invariants of the node records (test / debug service, elfmcts_validate): for every live node that has been expanded
+//   entries [0, n_touched): child >= 0, the child's header points back (parent, parent_edge == position), orig ascending
+//   entries [n_touched, n_edges): no child, no statistics, priors descending
+// out[0] = number of violations, out[1..4] = code, game, node, position of one of them.
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_validate(TreePool<N> tp, int32_t* out) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const NodeRec<N>* nodes = tp.game_nodes(g);
+  const int* po = tp.parent_of + (size_t)g * tp.C;
+  auto fail = [&](int code, int node, int pos) {
+    if (atomicAdd(&out[0], 1) == 0) { out[1] = code; out[2] = g; out[3] = node; out[4] = pos; }
+  };
+  for (int id = blockIdx.y; id < tp.C; id += gridDim.y) {
+    if (po[id] == -2) continue;
+    const NodeRec<N>& r = nodes[id];
+    if (r.h.status != NS_VISITED) continue;
+    const int n = r.h.n_edges, nt = r.h.n_touched;
+    if (nt < 0 || nt > n) { if (lane == 0) fail(1, id, nt); continue; }
+    int visits = 0;
+    for (int i = lane; i < n; i += 64) {
       const float4 s = r.stat[i];
-      if (coord) coord[o] = r.coord[i];
-      if (visits) visits[o] = __float_as_int(s.z);
-      if (prior) prior[o] = s.x;
-      if (reward) reward[o] = s.y;
-      if (child) child[o] = r.child[i];
-    } else {
-      if (coord) coord[o] = -1;
-      if (visits) visits[o] = 0;
-      if (prior) prior[o] = 0.f;
-      if (reward) reward[o] = 0.f;
-      if (child) child[o] = -1;
+      const int ch = r.child[i];
+      visits += __float_as_int(s.z);
+      if (i < nt) {
+        if (ch < 0 || ch >= tp.C) { fail(2, id, i); continue; }
+        if (nodes[ch].h.parent != id || po[ch] != id) fail(3, id, i);
+        if (nodes[ch].h.parent_edge != i) fail(4, id, i);
+        if (i + 1 < nt && r.orig[i] >= r.orig[i + 1]) fail(5, id, i);
+      } else {
+        if (ch != -1) fail(6, id, i);
+        if (__float_as_int(s.z) != 0 || s.y != 0.0f || s.w != 0.0f) fail(7, id, i);
+        if (i + 1 < n && !(s.x >= r.stat[i + 1].x)) fail(8, id, i);
+      }
+      if (r.orig[i] >= n) fail(9, id, i);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) visits += __shfl_xor(visits, o, 64);
+    if (lane == 0 && visits != r.h.num_visits) fail(10, id, visits);
   }
 }
 

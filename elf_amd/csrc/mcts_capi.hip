@@ -239,6 +239,23 @@ int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, flo
   return 0;
 }
 
+int elfmcts_validate(ElfMcts* m, int32_t* out5_host) {
+  if (!m || !out5_host) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
+  HIPCHK(hipDeviceSynchronize());
+  int32_t* d = nullptr;
+  HIPCHK(hipMalloc(&d, 5 * sizeof(int32_t)));
+  HIPCHK(hipMemset(d, 0, 5 * sizeof(int32_t)));
+  int gy = 4096 / m->G;
+  if (gy < 1) gy = 1;
+  if (gy > m->C) gy = m->C;
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_validate<N>, dim3(m->G, gy), dim3(64), 0, (hipStream_t)0, tree_of<N>(m), d));
+  hipError_t e = hipMemcpy(out5_host, d, 5 * sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIPCHK(e);
+  return 0;
+}
+
 int elfmcts_node_visits(ElfMcts* m, int64_t* out_host) {
   if (!m || !out_host) return ELFGO_E_BADARG;
   DevGuard _dg(m->eng->device);

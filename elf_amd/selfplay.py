@@ -208,6 +208,12 @@ class SelfPlay:
         check(self.L.elfsp_last_moves(self._h, out.ctypes.data))
         return out
 
+    def validate_trees(self):
+        """elfmcts_validate: (violations, code, game, node, position) of the node-record invariants; synchronises (tests / debugging)"""
+        out = np.zeros(5, np.int32)
+        check(self.L.elfmcts_validate(self.L.elfsp_mcts(self._h), out.ctypes.data))
+        return tuple(int(x) for x in out)
+
     def finish(self, games, reason):
         """finish_game(reason) + restart for the listed games (FinishReason: 0 resign, 1 two passes, 2 max step, 3 clear, 4 illegal)"""
         g = np.ascontiguousarray(games, dtype=np.int32)

@@ -160,6 +160,10 @@ int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const 
 /* root edges in the reference's iteration order (what MCTSResultT::addActions walks, tree_search_base.h:237-294);
  * info device int32 [num_games][ELFMCTS_ROOT_WORDS]; the per-edge outputs ([num_games][edge_stride]) may be NULL */
 int elfmcts_root(ElfMcts* m, int32_t* info, int32_t* coord, int32_t* visits, float* prior, float* reward, int32_t* child, void* stream);
+/* Test / debug service: checks the invariants of every live node record (scoring-order prefix sorted and linked to its child
+   nodes, never-followed tail without statistics and by descending prior, visit counts add up).  Synchronises the device.
+   out5_host: 0 number of violations, 1 code, 2 game, 3 node, 4 position of one of them.  No counterpart in the reference. */
+int elfmcts_validate(ElfMcts* m, int32_t* out5_host);
 /* statistics: total number of tree nodes descended through by all rollouts so far (mean depth = this / rollouts); synchronous */
 int elfmcts_node_visits(ElfMcts* m, int64_t* out_host);
 /* SearchTreeT::treeAdvance (tree_search_node.h:420-436), moves device int32 [num_games] (reference Coords) */

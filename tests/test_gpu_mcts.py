@@ -39,6 +39,8 @@ def run_case(elf_amd, name, max_searches=None):
             sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
         else:
             sp.end_step(None, None)
+        if rows_total < 4096:   # the node records' own invariants (scoring order, child back links, visit sums) after every step
+            assert sp.validate_trees()[0] == 0, "%s: node record invariants %s" % (name, sp.validate_trees())
     rec, coord, visits, prior, reward = sp.search_log()
     na = n * n + 1
     for i in range(m):

@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=gpurun_out/r02d
+OUT=gpurun_out/r02e
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
