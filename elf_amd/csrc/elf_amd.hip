@@ -154,15 +154,17 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
   ELF_PHASE(bd, 7);
   while (steps < max_steps && !bd.terminated()) {
     u64 legal, cand;
-    bd.template legal_moves<true>(legal, cand);
+    bd.template legal_moves<true, true>(legal, cand);
     ELF_PHASE(bd, 0);   // legal mask + true eyes
-    // uniformly random candidate: r-th set bit of the lane-distributed candidate bitboard
+    // uniformly random candidate: r-th set bit of the lane-distributed candidate bitboard (words in lanes 0..R-1, 0 elsewhere)
     const int cnt = __popcll(cand);
-    int pre[G::R + 1];
-    pre[0] = 0;
-#pragma unroll
-    for (int k = 0; k < G::R; ++k) pre[k + 1] = pre[k] + rl(cnt, k);
-    const int total = pre[G::R];
+    // inclusive prefix sum over the lanes of row 0 on the DPP network (row_shr with zero fill): lane k < R ends with the
+    // number of candidates in words 0..k, lanes R..15 with the total
+    int inc = cnt;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+    if (G::R > 4) inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+    const int total = rl(inc, G::R - 1);
     int pick_a = -1;   // action id of the chosen candidate, -1 = pass
     if (total > 0) {
       // rng % total without a runtime division: floor(2^32 / total) comes from a table behind the Zobrist constants through the
@@ -172,16 +174,13 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
       const u32 q = __umulhi(x, (u32)sload_wait(magic));
       u32 rr = x - q * (u32)total;
       if (rr >= (u32)total) rr -= (u32)total;
-      const int r = (int)rr;
-      int kw = 0;
-#pragma unroll
-      for (int k = 1; k < G::R; ++k) kw += r >= pre[k];
-      int base = 0;
-#pragma unroll
-      for (int k = 1; k < G::R; ++k) base = (kw == k) ? pre[k] : base;
+      // the word that holds the r-th candidate: the prefix sums are non-decreasing, so it is the number of words whose
+      // inclusive count is <= r; its exclusive count is the rank base
+      const int kw = __popc((u32)bal_le((u32)inc, rr) & ((1u << G::R) - 1u));
+      const int base = rl(inc - cnt, kw);
       const u64 wk = rl64(cand, kw);
-      const int rank = __builtin_amdgcn_mbcnt_hi((u32)(wk >> 32), __builtin_amdgcn_mbcnt_lo((u32)wk, 0));
-      const u64 sel = __ballot(lane_bit(wk) && rank == r - base);
+      const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(wk >> 32), __builtin_amdgcn_mbcnt_lo((u32)wk, 0));
+      const u64 sel = bal_eq(rank, rr - (u32)base) & wk;
       pick_a = kw * 64 + (int)__builtin_ctzll(sel);
     }
     ELF_PHASE(bd, 1);   // pick the k-th candidate

@@ -13,9 +13,10 @@
 //  * points live in LDS on a padded (N+2)^2 grid in x-major order so that NN action ids
 //    (a = x*N + y, board.h:189) map to consecutive LDS addresses: idx = (x+1)*(N+2) + (y+1).
 //    The reference Coord is the transpose, c = (y+1)*(N+2) + (x+1) (board.h:183); i<->c is an involution.
-//  * pt[idx] (u16): 0 empty, 0xFFFF border, else (white?0x8000:0) | root, root = idx of the group's
-//    representative point.  libs[root] (u16) = liberties of that group.  Lane l owns points
-//    a = 64*k + l, k < R (R = 6 for 19x19, 2 for 9x9).
+//  * pt[idx] (u16): 0 empty, 0x8000 border ("white, root 0"), else (white?0x8000:0) | root, root = idx of the
+//    group's representative point (never 0).  libs[root] (u16) = liberties of that group; libs[0] stays 0, so
+//    "libs[label & 0x7FFF]" is a valid, branch-free read for empty and border points too (it yields 0).
+//    Lane l owns points a = 64*k + l, k < R (R = 6 for 19x19, 2 for 9x9).
 //  * captures / merges / liberty recounts are wave-parallel scans over the R rounds with __ballot +
 //    __popcll; liberty give-back after a capture uses LDS atomics.
 //  * history = ring of 8 x {black,white} bitboards in action order (W u64 words each); superko keeps
@@ -39,7 +40,7 @@ typedef unsigned long long u64;
 
 enum { S_EMPTY = 0, S_BLACK = 1, S_WHITE = 2 };                       // base/common.h:36-38
 enum { M_PASS = 0, M_RESIGN = 1, M_SKIP = 2, M_INVALID = 3, M_CLEAR = 4 };  // base/common.h:43-47
-constexpr u16 PT_BORDER = 0xFFFF;
+constexpr u16 PT_BORDER = 0x8000;  // colour bit with root 0: no stone ever carries it
 constexpr int HIST = 8;  // base/board_feature.h:39 MAX_NUM_AGZ_HISTORY
 
 // 64-byte header, wave-uniform; lives at the front of every board slot.
@@ -72,7 +73,19 @@ struct Geo {
   static constexpr int SKW = 2 * R + 1;           // u64 words per superko record: hash, black words, white words
   static constexpr int BLOOM = N > 9 ? 256 : 64;  // u32 words of the superko Bloom filter
   static constexpr int ZOBW = PP;                 // zobrist table words; geometry masks follow it
+  // floor(v / N) = (v * DN_M) >> DN_S for 0 <= v < 64*R, floor(v / S) = (v * DS_M) >> DS_S for 0 <= v < PP (exhaustively
+  // checked by static_assert below): a wave-uniform multiply + shift instead of the compiler's general 32-bit sequences
+  static constexpr int DN_M = N == 19 ? 27 : 57, DN_S = 9;
+  static constexpr int DS_M = N == 19 ? 781 : 187, DS_S = N == 19 ? 14 : 11;
 };
+template <int N>
+constexpr bool geo_div_ok() {
+  using G = Geo<N>;
+  for (int v = 0; v < 64 * G::R; ++v) if (((v * G::DN_M) >> G::DN_S) != v / N) return false;
+  for (int v = 0; v < G::PP; ++v) if (((v * G::DS_M) >> G::DS_S) != v / G::S) return false;
+  return true;
+}
+static_assert(geo_div_ok<19>() && geo_div_ok<9>(), "small-range division constants");
 
 // One board slot = the LDS image, also the HBM image (copied 16 B per lane).
 template <int N>
@@ -136,7 +149,14 @@ __device__ __forceinline__ u64 wave_xor64(u64 v) {
   hi = (u32)__builtin_amdgcn_readlane((int)hi, 63);
   return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ bool is_stone(u32 v) { return v != 0 && v != PT_BORDER; }
+__device__ __forceinline__ bool is_stone(u32 v) { return (v & 0x7FFFu) != 0; }   // neither empty (0) nor border (0x8000)
+// Wave masks straight from a vector compare (v_cmp -> SGPR pair).  __ballot(a && b) makes the compiler rebuild the mask through
+// v_cndmask + v_cmp_ne; "bal_xx(..) & bal_yy(..)" is two v_cmp and one s_and_b64.  Inactive lanes contribute 0, like __ballot.
+__device__ __forceinline__ u64 bal_eq(u32 a, u32 b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+__device__ __forceinline__ u64 bal_ne(u32 a, u32 b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+__device__ __forceinline__ u64 bal_gt(u32 a, u32 b) { return __builtin_amdgcn_uicmp(a, b, 34); }   // unsigned a > b
+__device__ __forceinline__ u64 bal_le(u32 a, u32 b) { return __builtin_amdgcn_uicmp(a, b, 37); }   // unsigned a <= b
+__device__ __forceinline__ u64 bal_ne64(u64 a, u64 b) { return __builtin_amdgcn_uicmpl(a, b, 33); }   // 64-bit operands: uicmpl (uicmp would truncate)
 // base/board.cc:24-36 transform_hash
 __device__ __forceinline__ u64 zob_col(u64 h, int s) { return s == S_BLACK ? h : ((h >> 32) | (h << 32)); }
 
@@ -226,10 +246,21 @@ struct Board {
                        // jj-th side not facing it (MergeToGroup liberty test)
   // lane-distributed bitboards in NN action order: lane k < R holds bits [64k, 64k+64); other lanes 0
   u64 Bw, Ww;          // black / white stones of the current position
-  u64 mTop, mBot, mValid, mEdge;  // per-lane geometry masks: y != 0, y != N-1, a < N*N, point on the first/last line
+  u64 mValid, mEdge;   // per-lane geometry masks (lanes 0..R-1, 0 elsewhere): a < N*N, point on the first/last line
+  // y != 0, y != N-1, a < N*N for the shifts.  These live in lanes 0..R-1 AND again in lanes 8..8+R-1: a second bitboard parked
+  // in lanes 8.. of the same row rides through dilate / the shifts for free (dilate2, eye test); the DPP row shifts never mix
+  // the two because lanes R..7 and 8+R..15 hold 0
+  u64 mTop, mBot, pValid;
   // wave-uniform copy of the header (SGPRs); LDS/HBM copy is refreshed by store_hdr()
   u64 hash;
   int ply, next_player, ko_pt, ko_age, ko_color, lm0, lm1, lm2, lm3, b_cap, w_cap, hist_cnt, sk_len, superko;
+  int ko_a;            // action id of ko_pt (derived; valid whenever ko_pt != 0)
+  // k_playout only: the atari set of the current position (stones of groups with exactly one liberty), carried from one
+  // legal_moves to the next; forward_legal_action updates it in place when the move changed it by at most the played stone
+  // and marks it dirty otherwise (a capture, a neighbour group falling to one liberty, the mover's group changing status)
+  u64 at_cache;
+  int at_dirty;
+  int nb_addr, t12_off;   // per-lane LDS byte offsets for the neighbour reads of forward (see init)
 #ifdef ELF_PROFILE
   unsigned long long ph_t, ph_acc[16];   // tools/playout_phases.hip
 #endif
@@ -237,6 +268,12 @@ struct Board {
   __device__ __forceinline__ static int a2i(int a) { return a + S + 1 + 2 * (a / N); }
   __device__ __forceinline__ static int tr(int i) { return (i % S) * S + i / S; }  // idx <-> reference Coord
   __device__ __forceinline__ static int i2a(int i) { return (i / S - 1) * N + (i % S - 1); }
+  // the same maps for wave-uniform in-range arguments, division by multiply + shift (Geo::DN_M / DS_M)
+  __device__ __forceinline__ static int div_n(int a) { return (int)(((u32)a * (u32)G::DN_M) >> G::DN_S); }   // a / N, 0 <= a < 64 R
+  __device__ __forceinline__ static int div_s(int i) { return (int)(((u32)i * (u32)G::DS_M) >> G::DS_S); }   // i / S, 0 <= i < PP
+  __device__ __forceinline__ static int a2i_u(int a) { return a + S + 1 + 2 * div_n(a); }
+  __device__ __forceinline__ static int a2c_u(int a) { const int x = div_n(a), y = a - x * N; return (y + 1) * S + (x + 1); }   // action -> reference Coord
+  __device__ __forceinline__ static int c2a_u(int c) { const int y1 = div_s(c), x1 = c - y1 * S; return (x1 - 1) * N + (y1 - 1); }  // on-board Coord -> action
   // reference delta4 order L,T,R,B = x-1,y-1,x+1,y+1 (board.h:220) -> internal -S,-1,+S,+1
   __device__ __forceinline__ static int dir4(int q) { return (q & 1) ? ((q & 2) ? 1 : -1) : ((q & 2) ? S : -S); }
   // single-wave workgroup: LDS ops of one wave execute in order, so a wavefront-scope fence (no
@@ -255,9 +292,19 @@ struct Board {
     dl4 = dir4(lane & 3);
     kk3 = (lane < 12 ? lane : 0) / 3;
     off12 = dir4(kk3) + dir4((kk3 + 3 + ((lane < 12 ? lane : 0) - 3 * kk3)) & 3);
+    // branch-free neighbour reads of the played point i (all 64 lanes issue the read, no EXEC games):
+    //   lanes 0..3  : pt[i + dir4(lane)]              byte offset = pt + 2 i + nb_addr
+    //   lanes >= 4  : libs[0], which is always 0      ("an empty non-neighbour": label 0, liberties 0)
+    //   lanes 0..11 : pt[i + off12] for the MergeToGroup test; other lanes re-read pt[i]
+    nb_addr = 2 * dl4;
+    t12_off = lane < 12 ? 2 * off12 : 0;
+    ko_a = 0; at_cache = 0; at_dirty = 1;
     const u64* geo = z + G::ZOBW;
-    mTop = lane < R ? geo[lane * 4 + 0] : 0ull;
-    mBot = lane < R ? geo[lane * 4 + 1] : 0ull;
+    const int gl = lane & 7;
+    const bool g2 = lane < 16 && gl < R;
+    mTop = g2 ? geo[gl * 4 + 0] : 0ull;
+    mBot = g2 ? geo[gl * 4 + 1] : 0ull;
+    pValid = g2 ? geo[gl * 4 + 2] : 0ull;
     mValid = lane < R ? geo[lane * 4 + 2] : 0ull;
     mEdge = lane < R ? geo[lane * 4 + 3] : 0ull;
     Bw = Ww = 0;
@@ -270,14 +317,20 @@ struct Board {
     d |= ((X >> 1) | (n << 63)) & mBot;             // a+1 in X
     d |= (X << N) | (p >> (64 - N));                // a-N in X
     d |= (X >> N) | (n << (64 - N));                // a+N in X
-    return d & mValid;
+    return d & pValid;
+  }
+  // two dilations for the price of one: B rides in lanes 8..8+R-1.  dA is valid in lanes 0..R-1 (its lanes 8.. hold dilate(B):
+  // AND it with a lanes-0..R-1 bitboard before use); dB is clean.
+  __device__ __forceinline__ void dilate2(u64 A, u64 B, u64& dA, u64& dB) const {
+    dA = dilate(A | dpp_u64<0x118>(B));   // row_shr:8
+    dB = dpp_u64<0x108>(dA);              // row_shl:8
   }
 
   // single-direction shifts of a lane-distributed bitboard: result bit a = X bit (a -/+ 1) within the column run, (a -/+ N)
   __device__ __forceinline__ u64 sh_m1(u64 X) const { const u64 p = dpp_prev(X); return ((X << 1) | (p >> 63)) & mTop; }
   __device__ __forceinline__ u64 sh_p1(u64 X) const { const u64 n = dpp_next(X); return ((X >> 1) | (n << 63)) & mBot; }
   __device__ __forceinline__ u64 sh_mN(u64 X) const { const u64 p = dpp_prev(X); return (X << N) | (p >> (64 - N)); }
-  __device__ __forceinline__ u64 sh_pN(u64 X) const { const u64 n = dpp_next(X); return ((X >> N) | (n << (64 - N))) & mValid; }
+  __device__ __forceinline__ u64 sh_pN(u64 X) const { const u64 n = dpp_next(X); return ((X >> N) | (n << (64 - N))) & pValid; }
 
   __device__ __forceinline__ void load_hdr() {
     u32 w = lane < 16 ? reinterpret_cast<const u32*>(&L->h)[lane] : 0u;
@@ -291,6 +344,8 @@ struct Board {
     w_cap = w6 & 0xFFFF; hist_cnt = w6 >> 16;
     sk_len = w7 & 0xFFFF; next_player = (w7 >> 16) & 0xFF; ko_color = w7 >> 24;
     superko = w8 & 0xFF;
+    ko_a = ko_pt ? c2a_u(ko_pt) : 0;
+    at_dirty = 1;
   }
   __device__ __forceinline__ void store_hdr() {
     if (lane == 0) {
@@ -336,6 +391,7 @@ struct Board {
     }
     hash = 0; ply = 1; next_player = S_BLACK; ko_pt = 0; ko_age = 0; ko_color = 0;
     lm0 = lm1 = lm2 = lm3 = M_INVALID; b_cap = w_cap = 0; hist_cnt = 0; sk_len = 0; superko = 0;
+    ko_a = 0; at_cache = 0; at_dirty = 1;
     Bw = Ww = 0;
     wsync();
   }
@@ -351,6 +407,11 @@ struct Board {
     const u32 a = (u32)reinterpret_cast<size_t>((__attribute__((address_space(3))) void*)p);
     __attribute__((address_space(3))) u32* w = (__attribute__((address_space(3))) u32*)(size_t)(a & ~3u);
     __hip_atomic_fetch_add(w, (a & 2) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // fire-and-forget ds_or_b32 on a dword of this wave's slot
+  __device__ __forceinline__ static void lds_or(u32* p, u32 bits) {
+    __attribute__((address_space(3))) u32* w = (__attribute__((address_space(3))) u32*)p;
+    __hip_atomic_fetch_or(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __device__ __forceinline__ int popc_lanes(u64 X) const {   // population of a lane-distributed bitboard
     int c = __popcll(X), t = 0;
@@ -371,24 +432,25 @@ struct Board {
   // verdict is known, so the Coord decode, the occupancy / simple-ko / suicide tests and the terminated() test are skipped;
   // the neighbour analysis that Play needs is not.
   template <class SK>
-  __device__ int forward_legal_action(int a, const SK& sk) { return forward_impl<true>(tr(a2i(a)), a, sk); }
+  __device__ int forward_legal_action(int a, const SK& sk) { return forward_impl<true>(0, a, sk); }
   template <bool TRUSTED, class SK>
   __device__ int forward_impl(int c, int a_trusted, const SK& sk) {
-    c = rfl(c);
+    if (!TRUSTED) c = rfl(c);
     if (!TRUSTED && terminated()) return 0;
     const int player = next_player, opp = S_BLACK + S_WHITE - player;
     const bool is_move = TRUSTED || !(c == M_PASS || c == M_RESIGN);
-    int i = 0, ka = 0;
+    const u64 mblack = player == S_BLACK ? ~0ull : 0ull;   // wave-uniform colour mask: X_black |= v & mblack, X_white |= v & ~mblack
+    int i = 0, ka = 0, a = 0;
     u64 abit = 0, zi = 0;
-    u32 nv = 0, nl = 0;   // lanes 0..3: label of the neighbour in delta4 order / liberties of its group
+    u32 nv = 0, nl = 0;   // lanes 0..3: label of the neighbour in delta4 order / liberties of its group; other lanes 0
     u32 emp4 = 0;         // bit j: neighbour j is empty
-    const int dl = dl4;
     if (is_move) {
       // ---- TryPlay, board.cc:788-827
-      int a;
       if (TRUSTED) {
         a = rfl(a_trusted);
-        i = a2i(a);
+        const int x = div_n(a), y = a - x * N;
+        i = a + S + 1 + 2 * x;
+        c = (y + 1) * S + (x + 1);
       } else {
         if (c >= G::P) return 0;
         int x = c % S - 1, y = c / S - 1;
@@ -402,11 +464,11 @@ struct Board {
         if (ko_pt == c && ko_age == 0 && ko_color == player) return 0;        // :234-240
       }
       zi = sload_u64(zob, i);                                                 // issued now (scalar cache), hashed in after Play
-      if (lane < 4) {                                                         // StoneLibertyAnalysis :161-199
-        nv = L->pt[i + dl];
-        nl = is_stone(nv) ? L->libs[nv & 0x7FFF] : 0;
-      }
-      emp4 = (u32)__ballot(lane < 4 && nv == 0);
+      // StoneLibertyAnalysis :161-199, branch-free: every lane reads (lanes >= 4 read libs[0] = 0 as their "label"), and the
+      // liberty lookup needs no stone test because libs[0] = 0 serves empty and border labels
+      nv = *(lane < 4 ? &L->pt[i + dl4] : &L->libs[0]);
+      nl = L->libs[nv & 0x7FFFu];
+      emp4 = (u32)bal_eq(nv, 0u) & 0xFu;
       if (!TRUSTED && emp4 == 0) {                                            // isSuicideMove :201-232
         const u32 pb = player == S_WHITE ? 0x8000u : 0u;
         const bool saves = lane < 4 && nv != PT_BORDER && (((nv & 0x8000u) == pb) ? nl > 1 : nl == 1);
@@ -417,14 +479,13 @@ struct Board {
     // ---- _add_board_hash (go_state.cc:113-121): record the PRE-move position, skipped for pass
     if (c != M_PASS) {
       sk.record(sk_len, hash, Bw, Ww, lane);
-      if (lane == 0) {
-        const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
-        atomicOr(&L->bloom[h1 >> 5], 1u << (h1 & 31));   // ds_or_b32, no return value to wait for
-        atomicOr(&L->bloom[h2 >> 5], 1u << (h2 & 31));
-      }
+      // Bloom insert: lane 0 sets the bit of the low hash word, lane 1 of the high word -- one ds_or_b32 for both (a
+      // lane-dependent address keeps the compiler from wrapping a uniform atomic in its single-lane election sequence)
+      const u32 hb = (lane == 0 ? (u32)hash : (u32)(hash >> 32)) & (G::BLOOM * 32 - 1);
+      if (lane < 2) lds_or(&L->bloom[hb >> 5], 1u << (hb & 31));
     }
     ELF_PHASE(*this, 3);   // superko record + bloom insert
-    int total_cap = 0, ko_c = 0;
+    int total_cap = 0, ko_c = 0, cap_a = 0;
     bool new_ko = false;
     if (is_move) {
       // ---- Play, board.cc:1297-1401
@@ -432,53 +493,60 @@ struct Board {
       // classify the <=4 distinct neighbour groups on lanes 0..3 (first occurrence wins, like GroupId4 slots)
       const u32 p1 = __builtin_amdgcn_update_dpp(0u, nv, 0x111, 0xf, 0xf, true), p2 = __builtin_amdgcn_update_dpp(0u, nv, 0x112, 0xf, 0xf, true),
                 p3 = __builtin_amdgcn_update_dpp(0u, nv, 0x113, 0xf, 0xf, true);   // lane j <- lanes j-1, j-2, j-3 (0 before lane 0)
-      const bool first = lane < 4 && is_stone(nv) && nv != p1 && nv != p2 && nv != p3;
-      const bool own = (nv & 0x8000u) == ownbit;
-      const u32 bo = (u32)__ballot(first && own);                 // own groups touched (merge candidates)
-      const u32 bc = (u32)__ballot(first && !own && nl == 1);     // enemy groups captured by this move
-      if (first && !own && nl != 1) L->libs[nv & 0x7FFF] = (u16)(nl - 1);   // surviving enemy groups lose the liberty at i (:1327)
+      const u64 firstm = bal_ne(nv & 0x7FFFu, 0u) & bal_ne(nv, p1) & bal_ne(nv, p2) & bal_ne(nv, p3);   // lanes >= 4 hold label 0
+      const u64 ownm = bal_eq(nv & 0x8000u, ownbit);
+      const u64 lib1 = bal_eq(nl, 1u);
+      const u32 bo = (u32)(firstm & ownm);                        // own groups touched (merge candidates)
+      const u64 enem = firstm & ~ownm;
+      const u32 bc = (u32)(enem & lib1);                          // enemy groups captured by this move
+      if (lane_bit(enem & ~lib1)) L->libs[nv & 0x7FFFu] = (u16)(nl - 1);   // surviving enemy groups lose the liberty at i (:1327)
       const int m = __popc(bo);
       const bool anycap = bc != 0;
       const u32 newv = m > 0 ? (u32)rl((int)nv, (int)__builtin_ctz(bo)) : (ownbit | (u32)i);
+      bool at_changed = false;
+      if (TRUSTED) at_changed = anycap || (enem & bal_eq(nl, 2u)) != 0;   // a capture, or an enemy neighbour group falls into atari
       ELF_PHASE(*this, 8);    // neighbour classification + enemy liberty decrement
       u64 capw = 0;   // lane-distributed bitboard of the stones captured by this move
       if (anycap) {
         // EmptyGroup / RemoveStoneAndAddLiberty (:526-572): wave-parallel removal
-        const int c0 = (bc & 1) ? rl((int)nv, 0) : -1, c1 = (bc & 2) ? rl((int)nv, 1) : -1, c2 = (bc & 4) ? rl((int)nv, 2) : -1,
-                  c3 = (bc & 8) ? rl((int)nv, 3) : -1;
+        const u32 c0 = (bc & 1) ? (u32)rl((int)nv, 0) : ~0u, c1 = (bc & 2) ? (u32)rl((int)nv, 1) : ~0u, c2 = (bc & 4) ? (u32)rl((int)nv, 2) : ~0u,
+                  c3 = (bc & 8) ? (u32)rl((int)nv, 3) : ~0u;
         u64 xh = 0;
         u32 v[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-          int vv = (int)v[k];
-          bool isc = vv == c0 || vv == c1 || vv == c2 || vv == c3;   // c* are stones: never matches pad/border
-          u64 bal = __ballot(isc) & rl64(mValid, k);
+          // c* are stone labels or ~0: never matches an empty / clamped point
+          const u64 bal = (bal_eq(v[k], c0) | bal_eq(v[k], c1) | bal_eq(v[k], c2) | bal_eq(v[k], c3)) & rl64(mValid, k);
           if (bal) {
             set_lane64(capw, k, bal);
+            if (total_cap == 0) cap_a = k * 64 + (int)__builtin_ctzll(bal);   // :1355 capture_c: the stone, when exactly one is captured
             total_cap += __popcll(bal);
             if (lane_bit(bal)) { L->pt[idx[k]] = 0; xh ^= zob_col(zob[idx[k]], opp); }
-            if (total_cap == 1 && ko_c == 0) ko_c = tr(a2i(k * 64 + (int)__builtin_ctzll(bal)));   // :1355 capture_c
           }
         }
+        ko_c = a2c_u(cap_a);
         hash ^= wave_xor64(xh);
-        if (player == S_BLACK) Ww &= ~capw; else Bw &= ~capw;
+        Ww &= ~(capw & mblack);
+        Bw &= ~(capw & ~mblack);
       }
       ELF_PHASE(*this, 9);    // capture removal
       // place the stone with its final label; fold further own groups into it (MergeGroups :712-752)
       if (lane == 0) L->pt[i] = (u16)newv;
-      if (lane == ka) { if (player == S_BLACK) Bw |= abit; else Ww |= abit; }
+      const u64 addw = lane == ka ? abit : 0ull;
+      Bw |= addw & mblack;
+      Ww |= addw & ~mblack;
       if (m >= 2) {
-        const int o0 = (bo & 1) ? rl((int)nv, 0) : -1, o1 = (bo & 2) ? rl((int)nv, 1) : -1, o2 = (bo & 4) ? rl((int)nv, 2) : -1,
-                  o3 = (bo & 8) ? rl((int)nv, 3) : -1;
+        const u32 o0 = (bo & 1) ? (u32)rl((int)nv, 0) : ~0u, o1 = (bo & 2) ? (u32)rl((int)nv, 1) : ~0u, o2 = (bo & 4) ? (u32)rl((int)nv, 2) : ~0u,
+                  o3 = (bo & 8) ? (u32)rl((int)nv, 3) : ~0u;
         u32 v[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-          int vv = (int)v[k];
-          if (vv != (int)newv && (vv == o0 || vv == o1 || vv == o2 || vv == o3)) L->pt[idx[k]] = (u16)newv;
+          const u64 mm = (bal_eq(v[k], o0) | bal_eq(v[k], o1) | bal_eq(v[k], o2) | bal_eq(v[k], o3)) & bal_ne(v[k], newv);
+          if (lane_bit(mm)) L->pt[idx[k]] = (u16)newv;
         }
       }
       wsync();
@@ -508,20 +576,23 @@ struct Board {
       if (m == 0) {
         // createNewGroup (:661-671): its liberties are the empty neighbours after captures
         if (anycap) {
-          u32 e = lane < 4 ? L->pt[i + dl] : 1u;
-          newlibs = __popcll(__ballot(e == 0));
+          const u32 e = *(lane < 4 ? &L->pt[i + dl4] : &L->pt[0]);   // pt[0] is a border point: not empty
+          newlibs = __popcll(bal_eq(e, 0u));
         } else {
           newlibs = __popc(emp4);
         }
       } else if (m == 1) {
         // MergeToGroup (:677-708) restated: the played point stops being a liberty; each previously
         // empty neighbour e counts only if no other stone of the group already touches it.
-        bool touch = false;                              // lanes 0..11: neighbour kk3, its jj-th side not facing i
-        if (lane < 12 && ((emp4 >> kk3) & 1u)) touch = L->pt[i + off12] == newv;
-        const u32 t = (u32)__ballot(touch);
+        // lanes 0..11: neighbour kk3, its jj-th side not facing i; the read is unconditional, the emp4 test below drops
+        // the triples of non-empty neighbours
+        const u32 side = *reinterpret_cast<const u16*>(reinterpret_cast<const char*>(&L->pt[i]) + t12_off);
+        const u32 t = (u32)bal_eq(side, newv) & 0xFFFu;
         const int add = ((emp4 & 1u) && ((t & 7u) == 0)) + ((emp4 & 2u) && (((t >> 3) & 7u) == 0)) +
                         ((emp4 & 4u) && (((t >> 6) & 7u) == 0)) + ((emp4 & 8u) && (((t >> 9) & 7u) == 0));
-        newlibs = (int)L->libs[root] - 1 + add;
+        const int old = (int)L->libs[root];
+        newlibs = old - 1 + add;
+        if (TRUSTED) at_changed |= (old == 1) != (newlibs == 1);
       } else {
         // RecomputeGroupLiberties (:754-782): |dilate(group) & empty| on bitboards
         u64 gw = 0;
@@ -529,17 +600,20 @@ struct Board {
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-          u64 bal = __ballot(v[k] == newv);
-          set_lane64(gw, k, bal);
-        }
+        for (int k = 0; k < R; ++k) set_lane64(gw, k, bal_eq(v[k], newv));
         gw &= mValid;
         newlibs = popc_lanes(dilate(gw) & ~(Bw | Ww));
+        if (TRUSTED) at_changed = true;
       }
       newlibs = rfl(newlibs);
       if (lane == 0) L->libs[root] = (u16)newlibs;
       hash ^= zob_col(sload_wait(zi), player);
       new_ko = (m == 0 && total_cap == 1 && newlibs == 1);                    // :1386
+      if (TRUSTED) {
+        // the played stone joins the atari set when its group ends with one liberty (exact when nothing else changed)
+        if (newlibs == 1) at_cache |= addw;
+        at_dirty |= at_changed;
+      }
     }
     ELF_PHASE(*this, 5);   // liberties of the mover's group
     // ---- history push (go_state.cc:90-92; BoardHistory(board) board_feature.h:45-56) as bitboards
@@ -549,8 +623,8 @@ struct Board {
     }
     // ---- header update: caps :1348-1351, ko :1384-1393, update_next_move :1225-1238
     if (is_move) {
-      if (player == S_BLACK) b_cap += total_cap; else w_cap += total_cap;
-      if (new_ko) { ko_pt = ko_c; ko_color = opp; ko_age = 0; }
+      if (total_cap) { if (player == S_BLACK) b_cap += total_cap; else w_cap += total_cap; }
+      if (new_ko) { ko_pt = ko_c; ko_a = cap_a; ko_color = opp; ko_age = 0; }
       else ko_age = (ko_age + 1) & 0xFFFF;
     }
     next_player = opp;
@@ -580,30 +654,46 @@ struct Board {
   //                                                         or an enemy neighbour group in atari  (isSuicideMove :201-232)
   //   eye   = E & ~dilate(E | Opp) & legal & ~fake          isEye :1850-1860, isFakeEye :1887-1906 via the four diagonal shifts
   // minus the simple-ko point (:234-240).  cand = legal minus the mover's own true eyes, for the config-2 policy.
-  template <bool WITH_EYES>
-  __device__ __forceinline__ void legal_moves(u64& legal, u64& cand) const {
-    const int player = next_player;
-    const u64 Own = player == S_BLACK ? Bw : Ww, Opp = player == S_BLACK ? Ww : Bw;
-    const u64 E = ~(Bw | Ww) & mValid;
+  // the atari set from the labels: libs[label & 0x7FFF] == 1 (empty points read libs[0] = 0)
+  __device__ __forceinline__ u64 atari_set() const {
     u32 v[R], lb[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
 #pragma unroll
-    for (int k = 0; k < R; ++k) lb[k] = L->libs[v[k] & 0x7FFFu];   // on-board points hold 0 or a stone label (never the border mark): index <= P
+    for (int k = 0; k < R; ++k) lb[k] = L->libs[v[k] & 0x7FFFu];   // on-board points hold 0 or a stone label (never the border mark)
     u64 At = 0;
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-      const u64 bal = __ballot((((v[k] + 1u) & 0xFFFFu) > 1u) & (lb[k] == 1u));   // is_stone & atari, branch-free
-      set_lane64(At, k, bal);
+    for (int k = 0; k < R; ++k) set_lane64(At, k, bal_eq(lb[k], 1u));
+    return At & (Bw | Ww);   // drops the clamped lanes of the last round (they re-read point 0)
+  }
+  // INCR (k_playout): reuse the atari set carried in at_cache unless the last move invalidated it
+  template <bool WITH_EYES, bool INCR = false>
+  __device__ __forceinline__ void legal_moves(u64& legal, u64& cand) {
+    const int player = next_player;
+    const u64 mblack = player == S_BLACK ? ~0ull : 0ull;
+    const u64 Own = (Bw & mblack) | (Ww & ~mblack), Opp = (Ww & mblack) | (Bw & ~mblack);
+    const u64 E = ~(Bw | Ww) & mValid;
+    u64 At;
+    if (INCR) {
+      if (at_dirty) { at_cache = atari_set(); at_dirty = 0; }
+      At = at_cache;
+    } else {
+      At = atari_set();
     }
-    At &= (Bw | Ww);   // drops the clamped lanes of the last round (they re-read point 0)
-    u64 okw = E & dilate(E | (Own & ~At) | (Opp & At));
+    u64 okw;
     u64 eyew = 0;
-    if (WITH_EYES) {
-      const u64 allown = okw & ~dilate(E | Opp);
-      if (__ballot(allown != 0)) {
-        const u64 om = sh_m1(Opp), op = sh_p1(Opp);
-        const u64 d1 = sh_mN(om), d2 = sh_mN(op), d3 = sh_pN(om), d4 = sh_pN(op);
+    if (!WITH_EYES) {
+      okw = E & dilate(E | (Own & ~At) | (Opp & At));
+    } else {
+      u64 d1w, d2w;
+      dilate2(E | (Own & ~At) | (Opp & At), E | Opp, d1w, d2w);
+      okw = E & d1w;
+      const u64 allown = okw & ~d2w;
+      if (bal_ne64(allown, 0ull)) {
+        // the four diagonal neighbours in Opp: (a-1 | a+1) first, the pair packed into one register, then -N / +N on both at once
+        const u64 pk = sh_m1(Opp) | dpp_u64<0x118>(sh_p1(Opp));
+        const u64 d1 = sh_mN(pk), d3 = sh_pN(pk);                   // lanes 0..R-1: from a-1; lanes 8..: from a+1
+        const u64 d2 = dpp_u64<0x108>(d1), d4 = dpp_u64<0x108>(d3);
         const u64 ge1 = d1 | d2 | d3 | d4;
         const u64 ge2 = (d1 & d2) | (d3 & d4) | ((d1 | d2) & (d3 | d4));
         const u64 fake = (mEdge & ge1) | (~mEdge & ge2);
@@ -611,8 +701,7 @@ struct Board {
       }
     }
     if (ko_age == 0 && ko_color == player && ko_pt != 0) {
-      const int a = i2a(tr(ko_pt));
-      if (lane == (a >> 6)) okw &= ~(1ull << (a & 63));
+      if (lane == (ko_a >> 6)) okw &= ~(1ull << (ko_a & 63));
     }
     legal = okw;
     cand = okw & ~eyew;
