@@ -139,20 +139,34 @@ __global__ __launch_bounds__(WAVE) void k_export(Pool<N> pool, const int32_t* id
 }
 
 // Whole games inside one launch: position stays in LDS from the first move to the last.
+// PLAYOUT_WAVES boards per workgroup, still one wave per board and no synchronisation after the prologue: the waves only
+// share a copy of the Zobrist constants in LDS (3.4 KiB at 19x19), so that the capture path reads them with ds_read instead
+// of a vector load from global memory (see Board::zob_v).
+#define PLAYOUT_WAVES 4
 template <int N>
-__global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* ids, const u64* seeds, int n,
-                                                   int max_steps, uint32_t* out) {
+__global__ __launch_bounds__(WAVE * PLAYOUT_WAVES) void k_playout(Pool<N> pool, const int32_t* ids, const u64* seeds, int n,
+                                                                   int max_steps, uint32_t* out) {
   using G = Geo<N>;
-  __shared__ Slot<N> lds;
-  int b = slot_of(ids, blockIdx.x);
+  __shared__ Slot<N> lds_all[PLAYOUT_WAVES];
+  __shared__ u64 zlds[G::P];
+  for (int j = threadIdx.x; j < G::P; j += WAVE * PLAYOUT_WAVES) zlds[j] = pool.zob[j];
+  __syncthreads();
+  const int wv = rfl((int)(threadIdx.x >> 6));   // wave-uniform by construction; say so, or the seed and the slot turn into vector values
+  const int game = blockIdx.x * PLAYOUT_WAVES + wv;
+  if (game >= n) return;
+  Slot<N>& lds = lds_all[wv];
+  int b = slot_of(ids, game);
   Board<N> bd;
   bd.init(&lds, pool.zob, pool.skr(b));
+  bd.zob_v = zlds;
   bd.load(&pool.slots[b]);
   const GameSK<N> sk{pool.skr(b)};
-  const u64 seed = seeds[blockIdx.x];
+  const u32 key = playout_key(seeds[game]);
+  bd.playout_begin(pool.skr(b));
   int steps = 0;
   ELF_PHASE(bd, 7);
   while (steps < max_steps && !bd.terminated()) {
+    const u32 x = playout_rng_k(key, (u32)bd.ply);   // depends on the ply only: issued ahead of the legal-move work
     u64 legal, cand;
     bd.template legal_moves<true, true>(legal, cand);
     ELF_PHASE(bd, 0);   // legal mask + true eyes
@@ -168,9 +182,8 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
     int pick_a = -1;   // action id of the chosen candidate, -1 = pass
     if (total > 0) {
       // rng % total without a runtime division: floor(2^32 / total) comes from a table behind the Zobrist constants through the
-      // scalar cache (issued now, it arrives while the counter RNG's multiplies run); the estimate is at most one too small
+      // scalar cache; the estimate is at most one too small
       const u64 magic = sload_u64(pool.zob + G::ZOBW + 4 * G::R, total);
-      const u32 x = playout_rng(seed, (u32)bd.ply);
       const u32 q = __umulhi(x, (u32)sload_wait(magic));
       u32 rr = x - q * (u32)total;
       if (rr >= (u32)total) rr -= (u32)total;
@@ -190,9 +203,9 @@ __global__ __launch_bounds__(WAVE) void k_playout(Pool<N> pool, const int32_t* i
   }
   ELF_PHASE_END(bd);
   bd.store(&pool.slots[b]);
-  if (threadIdx.x == 0) {
+  if (bd.lane == 0) {
     u64 h = bd.hash;
-    uint32_t* o = out + (size_t)blockIdx.x * 4;
+    uint32_t* o = out + (size_t)game * 4;
     o[0] = (u32)h; o[1] = (u32)(h >> 32); o[2] = (u32)bd.ply; o[3] = (u32)steps;
   }
 }
@@ -352,7 +365,7 @@ int elfgo_playout(ElfGoEngine* e, const int32_t* ids, const uint64_t* seeds, int
                   void* stream) {
   CHECK_N(e, ids, n);
   if (!seeds || !out) return ELFGO_E_BADARG;
-  DISPATCH(e, hipLaunchKernelGGL(k_playout<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids,
+  DISPATCH(e, hipLaunchKernelGGL(k_playout<N>, dim3((n + PLAYOUT_WAVES - 1) / PLAYOUT_WAVES), dim3(WAVE * PLAYOUT_WAVES), 0, (hipStream_t)stream, pool_of<N>(e), ids,
                                  (const u64*)seeds, n, max_steps, out));
   HIPCHK(hipGetLastError());
   return 0;

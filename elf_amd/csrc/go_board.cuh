@@ -163,26 +163,26 @@ __device__ __forceinline__ u64 zob_col(u64 h, int s) { return s == S_BLACK ? h :
 // Scalar (SMEM) load of a 64-bit table entry at a wave-uniform index.  The played point's Zobrist constant is read this way:
 // SMEM completion is tracked by lgkmcnt, so consuming it does not have to wait on vmcnt -- and on gfx9 vmcnt also counts the
 // fire-and-forget superko record STORES issued in between (an `s_waitcnt vmcnt(0)` for a vector load of this constant was found
-// to stall ~1 200 cycles per board step behind those stores).  The value must pass through sload_wait() before its first use:
-// inline asm is invisible to the compiler's own waitcnt insertion.
+// to stall ~1 200 cycles per board step behind those stores).  A constant-address-space load with a wave-uniform index: the
+// compiler emits s_load_dwordx2 and places the lgkmcnt wait itself (an inline-asm s_load + `s_waitcnt lgkmcnt(0)` also drained
+// every LDS operation in flight at the point of use).
 __device__ __forceinline__ u64 sload_u64(const u64* base, int uniform_index) {
-  u64 v;
-  asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(v) : "s"(base), "s"(uniform_index * 8) : "memory");
-  return v;
+  typedef const __attribute__((address_space(4))) u64 cu64;
+  return reinterpret_cast<cu64*>(reinterpret_cast<uintptr_t>(base))[uniform_index];
 }
-__device__ __forceinline__ u64 sload_wait(u64 v) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
-  return v;
-}
+__device__ __forceinline__ u64 sload_wait(u64 v) { return v; }
 
-// config-2 counter RNG; the CPU checkers under oracle/ restate the same function
-__device__ __forceinline__ u32 playout_rng(u64 seed, u32 t) {
-  u64 z = seed + (u64)(t + 1) * 0x9E3779B97F4A7C15ULL;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  z ^= z >> 31;
-  return (u32)(z >> 32);
+// config-2 counter RNG ("a counter-based RNG shared verbatim by CPU and GPU harness"); oracle/go_oracle.c and
+// oracle/ref_capi.cc restate the same two functions.  rand(seed, ply) = fmix32(key(seed) + ply * 0x9E3779B9) with the 32-bit
+// murmur3 finaliser: two 32-bit multiplies on the per-step chain (a splitmix64 round costs eleven on a 32-bit scalar ALU, and
+// the pick sits on the critical path of a board step); the per-board key is loop-invariant.
+__device__ __forceinline__ u32 fmix32(u32 h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
 }
+__device__ __forceinline__ u32 playout_key(u64 seed) { return fmix32((u32)seed) ^ fmix32((u32)(seed >> 32) + 0x7F4A7C15u); }
+__device__ __forceinline__ u32 playout_rng_k(u32 key, u32 t) { return fmix32(key + t * 0x9E3779B9u); }
+__device__ __forceinline__ u32 playout_rng(u64 seed, u32 t) { return playout_rng_k(playout_key(seed), t); }
 
 // Superko record store of a GAME board (GoState::_board_hashes, go_state.h:218): every pre-move position of the game so far,
 // one record per non-pass forward, in HBM: rec[MAXMOVE+2][SKW] u64 = {hash, black words [R], white words [R]} -- 104 B at
@@ -238,6 +238,9 @@ struct Board {
 
   Slot<N>* L;          // LDS image of this wave's board
   const u64* zob;      // Zobrist constants in INTERNAL index order (global memory) + geometry masks
+  const u64* zob_v;    // the same constants for per-lane (vector) reads: global memory by default; k_playout points it at a
+                       // copy in LDS, because on gfx9 a vector load's vmcnt wait also waits for every superko record store
+                       // issued before it (a capture stalled ~2 board steps' worth of time behind those stores)
   u64* sk_rec;         // this board's superko records  [MAXMOVE+2][SKW]   (HBM)
   int lane;
   int idx[R];          // LDS index of this lane's point in round k (clamped for invalid lanes)
@@ -260,6 +263,7 @@ struct Board {
   // and marks it dirty otherwise (a capture, a neighbour group falling to one liberty, the mover's group changing status)
   u64 at_cache;
   int at_dirty;
+  u64* sk_wp;          // k_playout only: where this lane's word of the next superko record goes (set by playout_begin)
   int nb_addr, t12_off;   // per-lane LDS byte offsets for the neighbour reads of forward (see init)
 #ifdef ELF_PROFILE
   unsigned long long ph_t, ph_acc[16];   // tools/playout_phases.hip
@@ -282,7 +286,7 @@ struct Board {
   __device__ __forceinline__ static void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
   __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skr) {
-    L = lds; zob = z; sk_rec = skr;
+    L = lds; zob = z; zob_v = z; sk_rec = skr;
     lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -332,6 +336,8 @@ struct Board {
   __device__ __forceinline__ u64 sh_mN(u64 X) const { const u64 p = dpp_prev(X); return (X << N) | (p >> (64 - N)); }
   __device__ __forceinline__ u64 sh_pN(u64 X) const { const u64 n = dpp_next(X); return ((X >> N) | (n << (64 - N))) & pValid; }
 
+  // k_playout, after load(): arm the running record pointer of forward_legal_action
+  __device__ __forceinline__ void playout_begin(u64* rec) { sk_wp = rec + (size_t)sk_len * G::SKW + lane; }
   __device__ __forceinline__ void load_hdr() {
     u32 w = lane < 16 ? reinterpret_cast<const u32*>(&L->h)[lane] : 0u;
     u32 w0 = rl(w, 0), w1 = rl(w, 1), w2 = rl(w, 2), w3 = rl(w, 3), w4 = rl(w, 4), w5 = rl(w, 5), w6 = rl(w, 6),
@@ -441,6 +447,7 @@ struct Board {
     const bool is_move = TRUSTED || !(c == M_PASS || c == M_RESIGN);
     const u64 mblack = player == S_BLACK ? ~0ull : 0ull;   // wave-uniform colour mask: X_black |= v & mblack, X_white |= v & ~mblack
     int i = 0, ka = 0, a = 0;
+    u32 iv = 0;           // i as a vector value (same in every lane)
     u64 abit = 0, zi = 0;
     u32 nv = 0, nl = 0;   // lanes 0..3: label of the neighbour in delta4 order / liberties of its group; other lanes 0
     u32 emp4 = 0;         // bit j: neighbour j is empty
@@ -448,15 +455,21 @@ struct Board {
       // ---- TryPlay, board.cc:788-827
       if (TRUSTED) {
         a = rfl(a_trusted);
-        const int x = div_n(a), y = a - x * N;
-        i = a + S + 1 + 2 * x;
-        c = (y + 1) * S + (x + 1);
+        // the ds_read address of the neighbours hangs on i: do the arithmetic on the vector ALU (24-bit multiplies issue at
+        // full rate; the scalar ALU's 32-bit multiply is several times slower) from a vector copy of the wave-uniform a
+        u32 av;
+        asm("v_mov_b32 %0, %1" : "=v"(av) : "s"(a));
+        const u32 xv = __umul24(av, (u32)G::DN_M) >> G::DN_S, yv = av - __umul24(xv, (u32)N);
+        iv = av + S + 1 + 2 * xv;
+        i = rfl((int)iv);
+        c = rfl((int)(__umul24(yv + 1, (u32)S) + xv + 1));
       } else {
         if (c >= G::P) return 0;
         int x = c % S - 1, y = c / S - 1;
         if (x < 0 || x >= N || y < 0 || y >= N) return 0;                     // :803
         i = (x + 1) * S + (y + 1);
         a = x * N + y;
+        iv = (u32)i;
       }
       ka = a >> 6; abit = 1ull << (a & 63);
       if (!TRUSTED) {
@@ -466,7 +479,7 @@ struct Board {
       zi = sload_u64(zob, i);                                                 // issued now (scalar cache), hashed in after Play
       // StoneLibertyAnalysis :161-199, branch-free: every lane reads (lanes >= 4 read libs[0] = 0 as their "label"), and the
       // liberty lookup needs no stone test because libs[0] = 0 serves empty and border labels
-      nv = *(lane < 4 ? &L->pt[i + dl4] : &L->libs[0]);
+      nv = *(lane < 4 ? &L->pt[iv + dl4] : &L->libs[0]);
       nl = L->libs[nv & 0x7FFFu];
       emp4 = (u32)bal_eq(nv, 0u) & 0xFu;
       if (!TRUSTED && emp4 == 0) {                                            // isSuicideMove :201-232
@@ -477,8 +490,16 @@ struct Board {
     }
     ELF_PHASE(*this, 2);   // TryPlay done
     // ---- _add_board_hash (go_state.cc:113-121): record the PRE-move position, skipped for pass
-    if (c != M_PASS) {
-      sk.record(sk_len, hash, Bw, Ww, lane);
+    const bool not_pass = TRUSTED || c != M_PASS;
+    if (not_pass) {
+      if (TRUSTED) {
+        // k_playout: running per-lane record pointer (two adds per step instead of a 64-bit multiply-add)
+        const u64 w = sk_record_word<N>(hash, Bw, Ww, lane);
+        if (lane < G::SKW) *sk_wp = w;
+        sk_wp += G::SKW;
+      } else {
+        sk.record(sk_len, hash, Bw, Ww, lane);
+      }
       // Bloom insert: lane 0 sets the bit of the low hash word, lane 1 of the high word -- one ds_or_b32 for both (a
       // lane-dependent address keeps the compiler from wrapping a uniform atomic in its single-lane election sequence)
       const u32 hb = (lane == 0 ? (u32)hash : (u32)(hash >> 32)) & (G::BLOOM * 32 - 1);
@@ -486,6 +507,7 @@ struct Board {
     }
     ELF_PHASE(*this, 3);   // superko record + bloom insert
     int total_cap = 0, ko_c = 0, cap_a = 0;
+    u32 bl1 = 0, bl2 = 0;   // Bloom words of the new position's hash, shifted to bit 0 (moves: probed early, see below)
     bool new_ko = false;
     if (is_move) {
       // ---- Play, board.cc:1297-1401
@@ -502,15 +524,17 @@ struct Board {
       if (lane_bit(enem & ~lib1)) L->libs[nv & 0x7FFFu] = (u16)(nl - 1);   // surviving enemy groups lose the liberty at i (:1327)
       const int m = __popc(bo);
       const bool anycap = bc != 0;
-      const u32 newv = m > 0 ? (u32)rl((int)nv, (int)__builtin_ctz(bo)) : (ownbit | (u32)i);
+      // label of the mover's group: the first own neighbour group's, else a new root at i (lane 31 holds label 0: the read is unconditional)
+      const u32 nv_first = (u32)rl((int)nv, (int)__builtin_ctz(bo | 0x80000000u));
+      const u32 newv = bo ? nv_first : (ownbit | (u32)i);
       bool at_changed = false;
       if (TRUSTED) at_changed = anycap || (enem & bal_eq(nl, 2u)) != 0;   // a capture, or an enemy neighbour group falls into atari
       ELF_PHASE(*this, 8);    // neighbour classification + enemy liberty decrement
       u64 capw = 0;   // lane-distributed bitboard of the stones captured by this move
       if (anycap) {
         // EmptyGroup / RemoveStoneAndAddLiberty (:526-572): wave-parallel removal
-        const u32 c0 = (bc & 1) ? (u32)rl((int)nv, 0) : ~0u, c1 = (bc & 2) ? (u32)rl((int)nv, 1) : ~0u, c2 = (bc & 4) ? (u32)rl((int)nv, 2) : ~0u,
-                  c3 = (bc & 8) ? (u32)rl((int)nv, 3) : ~0u;
+        const u32 cv = lane_bit((u64)bc) ? nv : ~0u;   // captured labels on their lanes, ~0 (no label) elsewhere
+        const u32 c0 = (u32)rl((int)cv, 0), c1 = (u32)rl((int)cv, 1), c2 = (u32)rl((int)cv, 2), c3 = (u32)rl((int)cv, 3);
         u64 xh = 0;
         u32 v[R];
 #pragma unroll
@@ -523,13 +547,20 @@ struct Board {
             set_lane64(capw, k, bal);
             if (total_cap == 0) cap_a = k * 64 + (int)__builtin_ctzll(bal);   // :1355 capture_c: the stone, when exactly one is captured
             total_cap += __popcll(bal);
-            if (lane_bit(bal)) { L->pt[idx[k]] = 0; xh ^= zob_col(zob[idx[k]], opp); }
+            if (lane_bit(bal)) { L->pt[idx[k]] = 0; xh ^= zob_col(zob_v[idx[k]], opp); }
           }
         }
         ko_c = a2c_u(cap_a);
         hash ^= wave_xor64(xh);
         Ww &= ~(capw & mblack);
         Bw &= ~(capw & ~mblack);
+      }
+      // the hash of the new position is final here: issue the Bloom probes of _check_superko now, consume them at the end
+      hash ^= zob_col(sload_wait(zi), player);
+      {
+        const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
+        bl1 = L->bloom[h1 >> 5] >> (h1 & 31);
+        bl2 = L->bloom[h2 >> 5] >> (h2 & 31);
       }
       ELF_PHASE(*this, 9);    // capture removal
       // place the stone with its final label; fold further own groups into it (MergeGroups :712-752)
@@ -538,8 +569,8 @@ struct Board {
       Bw |= addw & mblack;
       Ww |= addw & ~mblack;
       if (m >= 2) {
-        const u32 o0 = (bo & 1) ? (u32)rl((int)nv, 0) : ~0u, o1 = (bo & 2) ? (u32)rl((int)nv, 1) : ~0u, o2 = (bo & 4) ? (u32)rl((int)nv, 2) : ~0u,
-                  o3 = (bo & 8) ? (u32)rl((int)nv, 3) : ~0u;
+        const u32 ov = lane_bit((u64)bo) ? nv : ~0u;
+        const u32 o0 = (u32)rl((int)ov, 0), o1 = (u32)rl((int)ov, 1), o2 = (u32)rl((int)ov, 2), o3 = (u32)rl((int)ov, 3);
         u32 v[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = L->pt[idx[k]];
@@ -607,7 +638,6 @@ struct Board {
       }
       newlibs = rfl(newlibs);
       if (lane == 0) L->libs[root] = (u16)newlibs;
-      hash ^= zob_col(sload_wait(zi), player);
       new_ko = (m == 0 && total_cap == 1 && newlibs == 1);                    // :1386
       if (TRUSTED) {
         // the played stone joins the atari set when its group ends with one liberty (exact when nothing else changed)
@@ -631,15 +661,18 @@ struct Board {
     lm3 = lm2; lm2 = lm1; lm1 = lm0; lm0 = c;
     ply++;
     hist_cnt = (hist_cnt + 1) & 0xFFFF;
-    if (c != M_PASS) sk_len++;
+    if (not_pass) sk_len++;
     superko = 0;
     wsync();
     // ---- _check_superko (go_state.cc:96-111) for the new position, cached in the header.
     // Bloom filter in LDS first (two probes); the exact (hash, image) records in HBM only on a hit.
-    if (c != M_PASS) {
-      const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
-      const u32 b1 = L->bloom[h1 >> 5], b2 = L->bloom[h2 >> 5];
-      if (rfl((int)((b1 >> (h1 & 31)) & (b2 >> (h2 & 31)) & 1u))) {
+    if (not_pass) {
+      if (!is_move) {   // resign: the position (and its hash) is unchanged
+        const u32 h1 = (u32)hash & (G::BLOOM * 32 - 1), h2 = (u32)(hash >> 32) & (G::BLOOM * 32 - 1);
+        bl1 = L->bloom[h1 >> 5] >> (h1 & 31);
+        bl2 = L->bloom[h2 >> 5] >> (h2 & 31);
+      }
+      if (rfl((int)(bl1 & bl2 & 1u))) {
         if (sk.exact_hit(sk_len, hash, Bw, Ww, lane)) superko = 1;
       }
     }

@@ -106,12 +106,14 @@ int ref_sgf_moves(const char* path, int32_t* moves, int32_t* players, int cap) {
 
 // ---- config-2 protocol: random legal non-true-eye play to game end -------------
 // Counter-based RNG shared verbatim with the HIP kernel and oracle/go_oracle.c.
+static inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+/* rand(seed, ply) = fmix32(key(seed) + ply * 0x9E3779B9), key(seed) = fmix32(lo) ^ fmix32(hi + 0x7F4A7C15) */
 static inline uint32_t playout_rng(uint64_t seed, uint32_t t) {
-  uint64_t z = seed + (uint64_t)(t + 1) * 0x9E3779B97F4A7C15ULL;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  uint32_t key = fmix32((uint32_t)seed) ^ fmix32((uint32_t)(seed >> 32) + 0x7F4A7C15u);
+  return fmix32(key + t * 0x9E3779B9u);
 }
 
 // Plays one game on *s from its current position. Returns number of successful forwards.
