@@ -84,22 +84,31 @@ __global__ __launch_bounds__(WAVE) void k_legal_mask(Pool<N> pool, const int32_t
 
 // BoardFeature::extractAGZ (board_feature.cc:247-290) + Transform (board_feature.h:97-113): bit planes in output order
 // via ballots, then one flat vectorised store of the row (go_board.cuh: agz_bitplanes / agz_store).
+// AGZ_WAVES rows in flight per workgroup, each wave looping over rows (grid-stride): a 1-wave workgroup per row spends a large
+// share of its short life being launched.
+#define AGZ_WAVES 4
 template <int N>
-__global__ __launch_bounds__(WAVE) void k_extract_agz(Pool<N> pool, const int32_t* ids, const int32_t* d4s, int n,
-                                                       void* dst, int64_t stride, int fmt) {
+__global__ __launch_bounds__(WAVE * AGZ_WAVES) void k_extract_agz(Pool<N> pool, const int32_t* ids, const int32_t* d4s, int n,
+                                                                   void* dst, int64_t stride, int fmt) {
   using G = Geo<N>;
-  __shared__ u64 hist[HIST][2][G::R];
-  __shared__ u64 tpl[18][G::R];
-  const int lane = threadIdx.x;
-  int b = slot_of(ids, blockIdx.x);
-  const Slot<N>* sl = &pool.slots[b];
-  const u64* gh = &sl->hist[0][0][0];
-  for (int j = lane; j < HIST * 2 * G::R; j += WAVE) (&hist[0][0][0])[j] = gh[j];
-  const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
-  const int d4 = d4s ? d4s[blockIdx.x] : 0;
-  __syncthreads();
-  char* row = (char*)dst + (size_t)blockIdx.x * stride * (fmt == FEAT_F16_NHWC ? 2 : 4);
-  extract_agz_row<N>(hist, tpl, cnt, player, d4, row, fmt, lane);
+  __shared__ u64 hist_all[AGZ_WAVES][HIST][2][G::R];
+  __shared__ u64 tpl_all[AGZ_WAVES][18][G::R];
+  const int lane = threadIdx.x & 63, wv = rfl((int)(threadIdx.x >> 6));
+  u64 (*hist)[2][G::R] = hist_all[wv];
+  u64 (*tpl)[G::R] = tpl_all[wv];
+  const int nw = (int)gridDim.x * AGZ_WAVES;
+  for (int r = (int)blockIdx.x * AGZ_WAVES + wv; r < n; r += nw) {
+    int b = slot_of(ids, r);
+    const Slot<N>* sl = &pool.slots[b];
+    const u64* gh = &sl->hist[0][0][0];
+    for (int j = lane; j < HIST * 2 * G::R; j += WAVE) (&hist[0][0][0])[j] = gh[j];
+    const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
+    const int d4 = d4s ? d4s[r] : 0;
+    agz_wave_sync();
+    char* row = (char*)dst + (size_t)r * stride * (fmt == FEAT_F16_NHWC ? 2 : 4);
+    extract_agz_row<N>(hist, tpl, cnt, player, d4, row, fmt, lane);
+    agz_wave_sync();
+  }
 }
 
 template <int N>
@@ -326,7 +335,10 @@ int elfgo_extract_agz_fmt(ElfGoEngine* e, const int32_t* ids, const int32_t* d4,
   CHECK_N(e, ids, n);
   if (!dst || stride_elems < (int64_t)18 * e->n * e->n || (fmt != ELFGO_FEAT_F32_NCHW && fmt != ELFGO_FEAT_F16_NHWC)) return ELFGO_E_BADARG;
   if (((uintptr_t)dst & (fmt == ELFGO_FEAT_F16_NHWC ? 1 : 3)) != 0) return ELFGO_E_BADARG;
-  DISPATCH(e, hipLaunchKernelGGL(k_extract_agz<N>, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, pool_of<N>(e), ids, d4, n, dst,
+  // enough workgroups to fill 256 CUs x 8 waves per SIMD, then rows loop inside the waves
+  const int agz_wgs = 4096;
+  const int wgs = (n + AGZ_WAVES - 1) / AGZ_WAVES < agz_wgs ? (n + AGZ_WAVES - 1) / AGZ_WAVES : agz_wgs;
+  DISPATCH(e, hipLaunchKernelGGL(k_extract_agz<N>, dim3(wgs), dim3(WAVE * AGZ_WAVES), 0, (hipStream_t)stream, pool_of<N>(e), ids, d4, n, dst,
                                  stride_elems, fmt));
   HIPCHK(hipGetLastError());
   return 0;

@@ -801,6 +801,9 @@ struct Board {
 //     for an fp16 net); lanes own 16 consecutive BYTES of it, so every store instruction of the body is one
 //     contiguous 1-KiB segment (global_store_dwordx4) whatever the alignment of the row (head/tail peeled per element).
 enum { FEAT_F32_NCHW = 0, FEAT_F16_NHWC = 1 };
+// One wave extracts one row with its own LDS scratch; LDS operations of a wave execute in order, so the only synchronisation
+// between the phases is a compiler fence (several waves of a workgroup may be in different phases of different rows).
+__device__ __forceinline__ void agz_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 template <int N>
 __device__ __forceinline__ void agz_bitplanes(const u64 (*hist)[2][Geo<N>::R], int cnt, int player, int d4,
@@ -887,12 +890,171 @@ __device__ __forceinline__ void agz_store(const u64 (*tpl)[Geo<N>::R], void* __r
   }
 }
 
+// Fast paths (rows aligned to 4 bytes, i.e. every fp32 row and every fp16 row a tensor allocator hands out).  Per round of 64
+// output points the wave gathers, for each of the 16 history planes, the dword of the source bitboard that holds the
+// transformed point's bit (LDS, all 16 reads in flight together) and turns "bit set" into a wave mask with one v_and + v_cmp.
+//   fp16 NHWC (agz_direct): a lane owns its point's 18 halves = 36 contiguous bytes, written straight from the masks
+//     (v_cndmask on the SGPR pairs; dwordx4, dwordx4, dword) -- no staging at all.
+//   fp32 NCHW (agz_flat_f32): the masks are parked lane-wise (v_writelane) and then ORed, 64 words at a time, into ONE contiguous
+//     bit string in LDS whose bit f is element f of the flat [18][N][N] row; the store pass then is 16 bytes per lane, 1 KiB per
+//     instruction, 16-byte aligned: one ds_read2_b32 + v_alignbit gives a lane its 4 bits (a step of 64 lanes is exactly 8 dwords
+//     of the bit string, so the LDS address is an immediate and the shift a per-lane constant).
+//     (256-byte dword stores straight from the masks were measured at 0.7x of the old staged path: the memory pipe wants 16 B / lane.)
+// History entries that were never pushed read as empty boards: reset() zero-fills the ring and nothing else rewinds hist_cnt,
+// so "fewer than 8 positions so far" needs no test here (the staged path above keeps its explicit `hk < len`).
+struct __attribute__((packed, aligned(4))) AgzQuad { u32 x, y, z, w; };
+template <int N, int FMT, bool BLK>
+__device__ __forceinline__ void agz_direct(const u64 (*hist)[2][Geo<N>::R], int cnt, int d4, void* __restrict__ row, int lane) {
+  using G = Geo<N>;
+  constexpr int R = G::R, NP = G::NP;
+  const int rot = d4 & 3;
+  const bool flip = ((d4 >> 2) & 1) != 0;
+  // dwords of the ring: [slot][colour][2 R]; the mover's colour first (planes 2 hk), then the opponent's (planes 2 hk + 1)
+  const u32* h_own = reinterpret_cast<const u32*>(hist) + (BLK ? 0 : 2 * R);
+  const u32* h_opp = reinterpret_cast<const u32*>(hist) + (BLK ? 2 * R : 0);
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const u32 o = (u32)(k * 64 + lane);
+    const bool valid = (k + 1) * 64 <= NP || o < (u32)NP;
+    // Transform (board_feature.h:97-113): output point o = (xo, yo) shows source point (x, y)
+    u32 xo = __umul24(o, (u32)G::DN_M) >> G::DN_S, yo = o - __umul24(xo, (u32)N);
+    if (flip) { const u32 t = xo; xo = yo; yo = t; }
+    u32 x = xo, y = yo;
+    if (rot == 1) { x = N - 1 - yo; y = xo; }
+    else if (rot == 2) { x = N - 1 - xo; y = N - 1 - yo; }
+    else if (rot == 3) { x = yo; y = N - 1 - xo; }
+    const u32 a = valid ? __umul24(x, (u32)N) + y : 0u;
+    const u32 dw = a >> 5, bm = valid ? (1u << (a & 31)) : 0u;
+    u32 wo[HIST], wp[HIST];
+#pragma unroll
+    for (int hk = 0; hk < HIST; ++hk) {   // all 16 gathers in flight before the first is consumed
+      const int slot = (cnt - 1 - hk) & (HIST - 1);
+      wo[hk] = h_own[slot * (4 * R) + dw];
+      wp[hk] = h_opp[slot * (4 * R) + dw];
+    }
+    u64 m[18];
+#pragma unroll
+    for (int hk = 0; hk < HIST; ++hk) {
+      m[2 * hk] = bal_ne(wo[hk] & bm, 0u);
+      m[2 * hk + 1] = bal_ne(wp[hk] & bm, 0u);
+    }
+    const u64 full = bal_ne(bm, 0u);
+    m[16] = BLK ? full : 0ull;
+    m[17] = BLK ? 0ull : full;
+    if (valid) {
+      if (FMT == FEAT_F32_NCHW) {
+        float* out = (float*)row + o;
+#pragma unroll
+        for (int p = 0; p < 18; ++p) out[p * NP] = lane_bit(m[p]) ? 1.0f : 0.0f;
+      } else {
+        u32 d[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) d[j] = (lane_bit(m[2 * j]) ? 0x3C00u : 0u) | (lane_bit(m[2 * j + 1]) ? 0x3C000000u : 0u);
+        char* out = (char*)row + (size_t)o * 36;
+        *reinterpret_cast<AgzQuad*>(out) = AgzQuad{d[0], d[1], d[2], d[3]};
+        *reinterpret_cast<AgzQuad*>(out + 16) = AgzQuad{d[4], d[5], d[6], d[7]};
+        *reinterpret_cast<u32*>(out + 32) = d[8];
+      }
+    }
+  }
+}
+
+template <int N, bool BLK>
+__device__ __forceinline__ void agz_flat_f32(const u64 (*hist)[2][Geo<N>::R], u32* bs /* LDS, >= 18*NP/32 + 3 dwords */, int cnt, int d4,
+                                             float* __restrict__ out, int lane) {
+  using G = Geo<N>;
+  constexpr int R = G::R, NP = G::NP, TOTAL = 18 * NP, NDW = (TOTAL + 31) / 32 + 2, NW = 18 * R, NB = (NW + 63) / 64;
+  const int rot = d4 & 3;
+  const bool flip = ((d4 >> 2) & 1) != 0;
+  const u32* h_own = reinterpret_cast<const u32*>(hist) + (BLK ? 0 : 2 * R);
+  const u32* h_opp = reinterpret_cast<const u32*>(hist) + (BLK ? 2 * R : 0);
+  for (int j = lane; j < NDW; j += 64) bs[j] = 0;
+  u64 acc[NB];   // word w = p R + k of the plane-major mask array lives in lane w & 63 of acc[w >> 6]
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = 0;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const u32 o = (u32)(k * 64 + lane);
+    const bool valid = (k + 1) * 64 <= NP || o < (u32)NP;
+    u32 xo = __umul24(o, (u32)G::DN_M) >> G::DN_S, yo = o - __umul24(xo, (u32)N);
+    if (flip) { const u32 t = xo; xo = yo; yo = t; }
+    u32 x = xo, y = yo;
+    if (rot == 1) { x = N - 1 - yo; y = xo; }
+    else if (rot == 2) { x = N - 1 - xo; y = N - 1 - yo; }
+    else if (rot == 3) { x = yo; y = N - 1 - xo; }
+    const u32 a = valid ? __umul24(x, (u32)N) + y : 0u;
+    const u32 dw = a >> 5, bm = valid ? (1u << (a & 31)) : 0u;
+    u32 wo[HIST], wp[HIST];
+#pragma unroll
+    for (int hk = 0; hk < HIST; ++hk) {
+      const int slot = (cnt - 1 - hk) & (HIST - 1);
+      wo[hk] = h_own[slot * (4 * R) + dw];
+      wp[hk] = h_opp[slot * (4 * R) + dw];
+    }
+#pragma unroll
+    for (int hk = 0; hk < HIST; ++hk) {
+      const int w0 = (2 * hk) * R + k, w1 = (2 * hk + 1) * R + k;
+      set_lane64(acc[w0 >> 6], w0 & 63, bal_ne(wo[hk] & bm, 0u));
+      set_lane64(acc[w1 >> 6], w1 & 63, bal_ne(wp[hk] & bm, 0u));
+    }
+    const int wc = (BLK ? 16 : 17) * R + k;   // the "mover's colour" plane is all ones (plane 16 if Black is to move, else 17)
+    set_lane64(acc[wc >> 6], wc & 63, bal_ne(bm, 0u));
+  }
+  agz_wave_sync();   // the zero fill is ordered before the ORs: LDS operations of one wave execute in order
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const u32 w = (u32)(b * 64 + lane);
+    if (w < (u32)NW) {
+      const u32 p = R == 6 ? (__umul24(w, 43u) >> 8) : (w >> 1);   // w / R for R = 6 (w < 128) or 2
+      const u32 k = w - p * R;
+      const u32 B = p * NP + 64 * k, sft = B & 31;
+      const u64 v = acc[b], t = v << sft;
+      const u32 top = sft ? (u32)(v >> (64 - sft)) : 0u;
+      u32* d = bs + (B >> 5);
+      Board<N>::lds_or(d, (u32)t);
+      Board<N>::lds_or(d + 1, (u32)(t >> 32));
+      Board<N>::lds_or(d + 2, top);
+    }
+  }
+  agz_wave_sync();
+  // flat store pass: element f of the row is bit f of bs
+  const uintptr_t addr = (uintptr_t)out;
+  const int head = (int)(((16 - (addr & 15)) & 15) >> 2);     // floats up to the first 16-B boundary (aligning the 1-KiB store
+                                                              // instructions to 128 B instead, and nt stores, were measured: no gain)
+  if (lane < head) out[lane] = (float)((bs[0] >> lane) & 1u);
+  const int body = (TOTAL - head) >> 2;
+  float4* o4 = (float4*)(out + head);
+  const u32 f0 = (u32)(head + 4 * lane), sft = f0 & 31;
+  const u32* b0 = bs + (f0 >> 5);
+  constexpr int ITER = (TOTAL / 4 + 63) / 64;
+#pragma unroll
+  for (int t = 0; t < ITER; ++t) {
+    const int j = lane + 64 * t;
+    const u32 win = __builtin_amdgcn_alignbit(b0[8 * t + 1], b0[8 * t], sft);
+    if (j < body)
+      o4[j] = make_float4((float)(win & 1u), (float)((win >> 1) & 1u), (float)((win >> 2) & 1u), (float)((win >> 3) & 1u));
+  }
+  const int f = head + 4 * body + lane;
+  if (f < TOTAL) out[f] = (float)((bs[f >> 5] >> (f & 31)) & 1u);
+}
+
 // whole extraction of one position by one wave; `hist` and `tpl` are LDS
 template <int N>
 __device__ __forceinline__ void extract_agz_row(const u64 (*hist)[2][Geo<N>::R], u64 (*tpl)[Geo<N>::R], int cnt, int player, int d4,
                                                 void* __restrict__ row, int fmt, int lane) {
+  if (rfl((int)(((uintptr_t)row & 3) == 0))) {
+    const bool blk = player == S_BLACK;
+    if (fmt == FEAT_F16_NHWC) {
+      if (blk) agz_direct<N, FEAT_F16_NHWC, true>(hist, cnt, d4, row, lane); else agz_direct<N, FEAT_F16_NHWC, false>(hist, cnt, d4, row, lane);
+    } else {
+      u32* bs = reinterpret_cast<u32*>(tpl);
+      if (blk) agz_flat_f32<N, true>(hist, bs, cnt, d4, (float*)row, lane); else agz_flat_f32<N, false>(hist, bs, cnt, d4, (float*)row, lane);
+    }
+    return;
+  }
+  // rows at odd 2-byte offsets (fp16 only): staged path
   agz_bitplanes<N>(hist, cnt, player, d4, tpl, lane);
-  __syncthreads();
+  agz_wave_sync();
   if (fmt == FEAT_F16_NHWC) agz_store<N, FEAT_F16_NHWC>(tpl, row, lane);
   else agz_store<N, FEAT_F32_NCHW>(tpl, row, lane);
 }

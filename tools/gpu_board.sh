@@ -12,3 +12,4 @@ for b in 4096 16384; do
   python bench.py --workload board --boards $b --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_board_$b.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('board', d['config']['boards_per_gpu'], d['value'], d['roofline']['avg_kernel_ms'], d.get('parity_mismatches'))"
 done
 python bench.py --workload board --board-size 9 --boards 65536 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_board9.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('board9', d['config']['boards_per_gpu'], d['value'], d['roofline']['avg_kernel_ms'], d.get('parity_mismatches'))"
+python bench.py --workload feature --steps 20 --warmup 3 2>/dev/null | tee $OUT/bench_feature.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); f=d.get('feature_extract',d); print('feature f32', f['f32']['avg_kernel_ms'], f['f32']['roofline']['achieved'], 'f16', f['f16']['avg_kernel_ms'], f['f16']['roofline']['achieved'])"
