@@ -158,7 +158,9 @@ __global__ __launch_bounds__(WAVE * PLAYOUT_WAVES) void k_playout(Pool<N> pool, 
   using G = Geo<N>;
   __shared__ Slot<N> lds_all[PLAYOUT_WAVES];
   __shared__ u64 zlds[G::P];
+  __shared__ u32 mlds[G::NP + 2];   // floor(2^32 / d) for the pick's rng % candidates
   for (int j = threadIdx.x; j < G::P; j += WAVE * PLAYOUT_WAVES) zlds[j] = pool.zob[j];
+  for (int j = threadIdx.x; j < G::NP + 2; j += WAVE * PLAYOUT_WAVES) mlds[j] = (u32)pool.zob[G::ZOBW + 4 * G::R + j];
   __syncthreads();
   const int wv = rfl((int)(threadIdx.x >> 6));   // wave-uniform by construction; say so, or the seed and the slot turn into vector values
   const int game = blockIdx.x * PLAYOUT_WAVES + wv;
@@ -167,11 +169,10 @@ __global__ __launch_bounds__(WAVE * PLAYOUT_WAVES) void k_playout(Pool<N> pool, 
   int b = slot_of(ids, game);
   Board<N> bd;
   bd.init(&lds, pool.zob, pool.skr(b));
-  bd.zob_v = zlds;
   bd.load(&pool.slots[b]);
   const GameSK<N> sk{pool.skr(b)};
   const u32 key = playout_key(seeds[game]);
-  bd.playout_begin(pool.skr(b));
+  bd.playout_begin(pool.skr(b), zlds);
   int steps = 0;
   ELF_PHASE(bd, 7);
   while (steps < max_steps && !bd.terminated()) {
@@ -190,10 +191,9 @@ __global__ __launch_bounds__(WAVE * PLAYOUT_WAVES) void k_playout(Pool<N> pool, 
     const int total = rl(inc, G::R - 1);
     int pick_a = -1;   // action id of the chosen candidate, -1 = pass
     if (total > 0) {
-      // rng % total without a runtime division: floor(2^32 / total) comes from a table behind the Zobrist constants through the
-      // scalar cache; the estimate is at most one too small
-      const u64 magic = sload_u64(pool.zob + G::ZOBW + 4 * G::R, total);
-      const u32 q = __umulhi(x, (u32)sload_wait(magic));
+      // rng % total without a runtime division: floor(2^32 / total) from the workgroup's LDS copy of the table behind the Zobrist
+      // constants; the estimate is at most one too small
+      const u32 q = __umulhi(x, (u32)rfl((int)mlds[total]));
       u32 rr = x - q * (u32)total;
       if (rr >= (u32)total) rr -= (u32)total;
       // the word that holds the r-th candidate: the prefix sums are non-decreasing, so it is the number of words whose

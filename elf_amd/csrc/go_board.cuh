@@ -336,8 +336,12 @@ struct Board {
   __device__ __forceinline__ u64 sh_mN(u64 X) const { const u64 p = dpp_prev(X); return (X << N) | (p >> (64 - N)); }
   __device__ __forceinline__ u64 sh_pN(u64 X) const { const u64 n = dpp_next(X); return ((X >> N) | (n << (64 - N))) & pValid; }
 
-  // k_playout, after load(): arm the running record pointer of forward_legal_action
-  __device__ __forceinline__ void playout_begin(u64* rec) { sk_wp = rec + (size_t)sk_len * G::SKW + lane; }
+  // k_playout, after load(): arm the running record pointer of forward_legal_action and point the per-lane Zobrist reads at
+  // the workgroup's LDS copy of the constants
+  __device__ __forceinline__ void playout_begin(u64* rec, const u64* zob_lds) {
+    sk_wp = rec + (size_t)sk_len * G::SKW + lane;
+    zob_v = zob_lds;
+  }
   __device__ __forceinline__ void load_hdr() {
     u32 w = lane < 16 ? reinterpret_cast<const u32*>(&L->h)[lane] : 0u;
     u32 w0 = rl(w, 0), w1 = rl(w, 1), w2 = rl(w, 2), w3 = rl(w, 3), w4 = rl(w, 4), w5 = rl(w, 5), w6 = rl(w, 6),
@@ -476,7 +480,10 @@ struct Board {
         if (rl64(Bw | Ww, ka) & abit) return 0;                               // :808 occupied
         if (ko_pt == c && ko_age == 0 && ko_color == player) return 0;        // :234-240
       }
-      zi = sload_u64(zob, i);                                                 // issued now (scalar cache), hashed in after Play
+      // the played point's Zobrist constant, hashed in after Play.  k_playout: from the LDS copy (every lane reads the same
+      // address; with no scalar load left in the loop every LDS wait is an exact lgkmcnt(n)); elsewhere through the scalar cache
+      if (TRUSTED) zi = zob_v[iv];
+      else zi = sload_u64(zob, i);
       // StoneLibertyAnalysis :161-199, branch-free: every lane reads (lanes >= 4 read libs[0] = 0 as their "label"), and the
       // liberty lookup needs no stone test because libs[0] = 0 serves empty and border labels
       nv = *(lane < 4 ? &L->pt[iv + dl4] : &L->libs[0]);
