@@ -430,8 +430,10 @@ def run_feature(args, rank, local_rank, world, dist, steps, warmup):
     if rank != 0:
         return None
     return {"metric": "feature_rows_per_sec (extractAGZ 18 planes, random D4)", "rows": rows, "board_size": n, **res,
-            "note": "one wave per row; fp32 row = 25 992 B written + 736 B of history bit-planes read (SURVEY.md 8d); measured "
-                    "achievable HBM copy bandwidth on this part is ~6.3 TB/s (MI355X_MICROARCH.md)"}
+            "note": "one wave per row (4 rows in flight per workgroup, grid-stride); fp32 row = 25 992 B written + 736 B of history "
+                    "bit-planes read (SURVEY.md 8d).  The kernel is a pure streaming write: a fill of the same bytes (tools/fill_probe.py, "
+                    "torch fill_) runs at 6.6 TB/s on this part, a float4 copy at 6.3 TB/s (MI355X_MICROARCH.md); frac is against the "
+                    "8 TB/s spec peak"}
 
 
 # ------------------------------------------------------------------------------------------------------------------- MCTS

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Refresh profiles/pmc_issue.json (instructions per unit of work of the LDS-resident kernels) from the PMC summaries of one
+tools/gpu_round2.sh visit.  usage: python tools/update_issue.py gpurun_out/<tag> <tag>
+Units per launch come from the bench line that ran under the same rocprofv3 pass (stats_<workload>.log)."""
+import json, os, re, sys
+out, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(path, kernel):
+    acc = {}
+    for line in open(path):
+        m = re.match(r"(.{48}) (\S+)\s+n=(\d+) mean=(\S+)", line.rstrip("\n"))
+        if m and kernel in m.group(1):
+            acc[m.group(2)] = (float(m.group(4)), int(m.group(3)))
+    return acc
+
+
+def bench_line(path):
+    for line in open(path):
+        if line.startswith("{") and '"metric"' in line:
+            return json.loads(line)
+    return None
+
+
+p = os.path.join(root, "profiles", "pmc_issue.json")
+res = json.load(open(p)) if os.path.exists(p) else {}
+for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>", "board step", "board"),
+                                       ("board9", "k_playout<9>", "k_playout<9>", "board step", "board9"),
+                                       ("train", "k_replay_extract<19>", "k_replay_extract<19>", "replayed board step", "train")):
+    s = os.path.join(out, "summary_%s.txt" % wl)
+    log = os.path.join(out, "stats_%s.log" % wl)
+    if not (os.path.exists(s) and os.path.exists(log)):
+        continue
+    c = counters(s, kernel.split("<")[0])
+    d = bench_line(log)
+    if d is None or "SQ_INSTS_VALU" not in c:
+        continue
+    cfg = d["config"]
+    units = cfg["board_steps_per_pass"] if wl.startswith("board") else cfg["mean_replayed_plies"] * cfg["batch"]
+    res[key] = {"valu_per_unit": c["SQ_INSTS_VALU"][0] / units, "salu_per_unit": c["SQ_INSTS_SALU"][0] / units,
+                "lds_per_unit": c.get("SQ_INSTS_LDS", (0.0, 0))[0] / units, "unit": unit,
+                "profile": "profiles/%s_%s_rocprofv3.txt" % (tag, profile),
+                "note": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS, mean over %d launches of the bench.py --workload %s run "
+                        "of tools/gpu_round2.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
+json.dump(res, open(p, "w"), indent=1)
+print(json.dumps(res, indent=1))
