@@ -80,10 +80,14 @@ def issue_roof(kernel, units_per_launch, kernel_s):
     ach = units_per_launch * valu / kernel_s / 1e9
     return {"bound": "issue", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": ach / VALU_PEAK_GINST,
             "traffic": load_traffic(kernel), "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "valu_per_unit": valu,
-            "salu_per_unit": per.get("salu_per_unit"), "lds_per_unit": per.get("lds_per_unit"), "profile": per.get("profile"),
+            "salu_per_unit": per.get("salu_per_unit"), "lds_per_unit": per.get("lds_per_unit"),
+            "lds_bank_conflict_frac": per.get("lds_bank_conflict_frac"), "lds_active_cycles_per_unit": per.get("lds_active_cycles_per_unit"),
+            "wave_issue_frac": per.get("wave_issue_frac"), "wave_wait_frac": per.get("wave_wait_frac"), "profile": per.get("profile"),
             "note": "the position never leaves LDS, so HBM is not the roof: frac = VALU wave-instructions/s (SQ_INSTS_VALU per unit from "
                     "profiles/pmc_issue.json x units/s) / (1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 op), i.e. the VALU-pipe busy "
-                    "fraction at the maximum clock; traffic = PMC HBM bytes per launch"}
+                    "fraction at the maximum clock; traffic = PMC HBM bytes per launch; lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / "
+                    "SQ_LDS_IDX_ACTIVE (share of LDS-pipe cycles lost to bank conflicts), wave_issue_frac / wave_wait_frac = share of "
+                    "wave cycles in an issue state / parked on s_waitcnt, from the same committed PMC passes"}
 
 
 # ------------------------------------------------------------------------------------------------------------------- CPU baselines

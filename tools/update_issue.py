@@ -40,6 +40,13 @@ for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>
     units = cfg["board_steps_per_pass"] if wl.startswith("board") else cfg["mean_replayed_plies"] * cfg["batch"]
     res[key] = {"valu_per_unit": c["SQ_INSTS_VALU"][0] / units, "salu_per_unit": c["SQ_INSTS_SALU"][0] / units,
                 "lds_per_unit": c.get("SQ_INSTS_LDS", (0.0, 0))[0] / units, "unit": unit,
+                # north_star: LDS-bank utilisation of the board step.  SQ_LDS_IDX_ACTIVE = cycles the LDS index pipe is busy,
+                # SQ_LDS_BANK_CONFLICT = cycles it stalls on a bank conflict, SQ_BUSY_CYCLES = SQ-busy cycles of the launch
+                # (all summed over the chip's shader engines / CUs as rocprofv3 reports them)
+                "lds_bank_conflict_frac": (c["SQ_LDS_BANK_CONFLICT"][0] / c["SQ_LDS_IDX_ACTIVE"][0]) if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"][0] else None,
+                "lds_active_cycles_per_unit": (c["SQ_LDS_IDX_ACTIVE"][0] / units) if "SQ_LDS_IDX_ACTIVE" in c else None,
+                "wave_issue_frac": (c["SQ_ACTIVE_INST_ANY"][0] / c["SQ_WAVE_CYCLES"][0]) if "SQ_ACTIVE_INST_ANY" in c and "SQ_WAVE_CYCLES" in c else None,
+                "wave_wait_frac": (c["SQ_WAIT_ANY"][0] / c["SQ_WAVE_CYCLES"][0]) if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c else None,
                 "profile": "profiles/%s_%s_rocprofv3.txt" % (tag, profile),
                 "note": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS, mean over %d launches of the bench.py --workload %s run "
                         "of tools/gpu_round2.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
