@@ -489,7 +489,8 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     groups = max(1, args.groups)
     Gg = G // groups
     G = Gg * groups
-    sp = PipelinedSelfPlay(groups=groups, seed=1234, game_idx_base=rank * G, wait_rows=bool(args.wait_rows), board_size=n, num_games=Gg,
+    sp = PipelinedSelfPlay(groups=groups, seed=1234, game_idx_base=rank * G, wait_rows=bool(args.wait_rows), net_streams=args.net_streams,
+                           board_size=n, num_games=Gg,
                            device=local_rank, mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5,
                            mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5,
                            ply_pass_enabled=0, policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt,
@@ -928,6 +929,8 @@ def main():
     ap.add_argument("--feature-rows", type=int, default=16384)
     ap.add_argument("--games", type=int, default=256, help="games per GPU (split over --groups)")
     ap.add_argument("--groups", type=int, default=2, help="lock-step game groups pipelined against the net (1 = serial)")
+    ap.add_argument("--net-streams", type=int, default=1, help="net streams of the pipeline (1 = the groups' net calls queue on one stream; "
+                    "= --groups: every group's call on its own stream)")
     ap.add_argument("--rollouts", type=int, default=8192, help="TSOptions.num_rollouts_per_thread")
     ap.add_argument("--rollouts-per-batch", type=int, default=16)
     ap.add_argument("--mcts-threads", type=int, default=1, help="TSOptions.num_threads (search threads per game)")

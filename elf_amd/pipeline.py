@@ -20,14 +20,18 @@ from .selfplay import SelfPlay
 
 
 class PipelinedSelfPlay:
-    def __init__(self, groups=2, seed=0, game_idx_base=0, wait_rows=False, **kw):
+    def __init__(self, groups=2, seed=0, game_idx_base=0, wait_rows=False, net_streams=1, **kw):
         ng = int(kw["num_games"])
         self.groups = [SelfPlay(seed=seed, game_idx_base=game_idx_base + i * ng, **kw) for i in range(groups)]
         dev = self.groups[0].device
         self.device = dev
         self.wait_rows = bool(wait_rows)
         self.search_streams = [torch.cuda.Stream(device=dev) for _ in range(groups)]
-        self.net_stream = torch.cuda.Stream(device=dev)
+        # net_streams = 1: the groups' net calls queue on one stream, one after the other.  net_streams = groups: every group has its
+        # own net stream, so the memory-bound tails of one group's call (conv epilogues, heads) can run beside the other group's
+        # convolutions
+        self.net_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(net_streams)))]
+        self.net_stream = self.net_streams[0]
         self._ev_sel = [None] * groups
         self._rows = [0] * groups
         self._primed = False
@@ -68,17 +72,18 @@ class PipelinedSelfPlay:
         total = 0
         for i in range(n):
             g = self.groups[i]
-            with torch.cuda.stream(self.net_stream):
-                self.net_stream.wait_event(self._ev_sel[i])          # features of group i are in g.s
+            ns = self.net_streams[i % len(self.net_streams)]
+            with torch.cuda.stream(ns):
+                ns.wait_event(self._ev_sel[i])                       # features of group i are in g.s
                 if self.timing:
                     n0, n1 = self._pair()
-                    n0.record(self.net_stream)
+                    n0.record(ns)
                 pi, v = net_fn(g.s, self._rows[i])
                 if self.timing:
-                    n1.record(self.net_stream)
+                    n1.record(ns)
                     self.t_net.append((n0, n1))
                 ev_net = torch.cuda.Event()
-                ev_net.record(self.net_stream)
+                ev_net.record(ns)
             st = self.search_streams[i]
             with torch.cuda.stream(st):
                 st.wait_event(ev_net)
@@ -100,7 +105,8 @@ class PipelinedSelfPlay:
     def synchronize(self):
         for st in self.search_streams:
             st.synchronize()
-        self.net_stream.synchronize()
+        for ns in self.net_streams:
+            ns.synchronize()
 
     def stats(self):
         out = {}
