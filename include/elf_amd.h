@@ -82,7 +82,9 @@ int elfgo_info(ElfGoEngine* e, const int32_t* ids, int n, int32_t* out, void* st
 /* stone colour per point (uint8, 0/1/2) and liberties of the group on it (int16, 0 if empty), action order */
 int elfgo_export_board(ElfGoEngine* e, const int32_t* ids, int n, uint8_t* colour, int16_t* libs, void* stream);
 /* from each slot's current position play uniformly random legal, non-true-eye
- * moves (counter RNG on seeds[i] and ply) until GoState::terminated(); pass when none.
+ * moves until GoState::terminated(); pass when none.  The move is the (rand % count)-th candidate in x-major order with the
+ * counter RNG rand = fmix32(fmix32(lo32(seed)) ^ fmix32(hi32(seed) + 0x7F4A7C15) + ply * 0x9E3779B9), fmix32 = murmur3's
+ * 32-bit finaliser (oracle/go_oracle.c and oracle/ref_capi.cc state the same function for the CPU checkers).
  * out[i] = {hash_lo, hash_hi, ply, steps}.  Whole games run inside one launch, position in LDS. */
 int elfgo_playout(ElfGoEngine* e, const int32_t* ids, const uint64_t* seeds, int n, int max_steps,
                   uint32_t* out, void* stream);
