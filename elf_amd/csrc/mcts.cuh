@@ -554,32 +554,51 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   }
 }
 
-// rows of the net batch: game-major, leaf order within a game; row_base = exclusive prefix over games.
-// One wave per (game, unique leaf); the wave of (G-1, 0) also publishes the total row count.
+// rows of the net batch: game-major, leaf order within a game; row_base = exclusive prefix of n_nn over games.  One block scans
+// all games once per step (every feature wave used to recompute its own prefix over all G games); it also publishes the
+// total row count and the OR of the games' error bits.
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, void* __restrict__ s_out, int64_t stride, int fmt, RowRec* rowmap,
-                                                       int32_t* counts /* [0]=rows [1]=err-or [2..3]=u64 running total of rows */) {
+__global__ __launch_bounds__(1024) void k_mcts_rowbase(TreePool<N> tp, int32_t* counts /* [0]=rows [1]=err-or [2..3]=u64 running total of rows */) {
+  __shared__ int wsum[16], weor[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int base = 0, eor_all = 0;
+  for (int i0 = 0; i0 < tp.G; i0 += 1024) {
+    const int i = i0 + tid;
+    const int nn = i < tp.G ? tp.gs[i].n_nn : 0;
+    int eor = i < tp.G ? tp.gs[i].err : 0;
+    int inc = nn;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) eor |= __shfl_xor(eor, o, 64);
+    if (lane == 63) { wsum[wv] = inc; weor[wv] = eor; }
+    __syncthreads();
+    int before = 0, total = 0, e = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int t = wsum[w]; before += w < wv ? t : 0; total += t; e |= weor[w]; }
+    if (i < tp.G) tp.gs[i].row_base = base + before + inc - nn;
+    base += total; eor_all |= e;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counts[0] = base; counts[1] = eor_all;
+    *reinterpret_cast<unsigned long long*>(counts + 2) += (unsigned long long)base;   // running total (statistics)
+  }
+}
+
+// One wave per (game, unique leaf): the leaf's feature row at row_base + its index among the game's net leaves.
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, void* __restrict__ s_out, int64_t stride, int fmt, RowRec* rowmap) {
   using G = Geo<N>;
   __shared__ u64 hist[HIST][2][G::R];
   __shared__ u64 tpl[18][G::R];
   const int g = blockIdx.x / K, u = blockIdx.x % K, lane = threadIdx.x;
   const GameState& gs = tp.gs[g];
-  const bool last = (g == tp.G - 1 && u == 0);
-  if (u >= rfl(gs.n_unique) && !last) return;
-  int base = 0, eor = 0;
-  for (int i = lane; i < tp.G; i += 64) {
-    if (i < g) base += tp.gs[i].n_nn;
-    eor |= tp.gs[i].err;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { base += __shfl_xor(base, o, 64); eor |= __shfl_xor(eor, o, 64); }
-  if (last && lane == 0) {                      // single writer per launch
-    const int rows = base + gs.n_nn;
-    counts[0] = rows; counts[1] = eor;
-    *reinterpret_cast<unsigned long long*>(counts + 2) += (unsigned long long)rows;   // running total (statistics)
-  }
-  if (u == 0 && lane == 0) tp.gs[g].row_base = base;
   if (u >= rfl(gs.n_unique)) return;
+  const int base = rfl(gs.row_base);
   const LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + u];
   if (rfl(lr.kind) != LK_NN) return;
   const int row = base + rfl(lr.nn_index), node = rfl(lr.node), d4 = rfl(lr.d4);

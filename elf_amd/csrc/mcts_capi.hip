@@ -176,8 +176,9 @@ int elfmcts_select(ElfMcts* m, const int32_t* board_ids, void* s_dst, int64_t st
   DISPATCH(m->eng, {
     hipLaunchKernelGGL((k_mcts_select<N, Pool<N>>), dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
                        board_ids, m->cfg);
+    hipLaunchKernelGGL(k_mcts_rowbase<N>, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree_of<N>(m), counts);
     hipLaunchKernelGGL(k_mcts_features<N>, dim3(m->G * KT), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), KT, s_dst, stride_elems,
-                       m->feat_fmt, m->rowmap, counts);
+                       m->feat_fmt, m->rowmap);
   });
   HIPCHK(hipGetLastError());
   m->last_counts = counts;
