@@ -92,10 +92,10 @@ __global__ __launch_bounds__(WAVE * AGZ_WAVES) void k_extract_agz(Pool<N> pool, 
                                                                    void* dst, int64_t stride, int fmt) {
   using G = Geo<N>;
   __shared__ u64 hist_all[AGZ_WAVES][HIST][2][G::R];
-  __shared__ u64 tpl_all[AGZ_WAVES][18][G::R];
+  __shared__ u64 scratch_all[AGZ_WAVES][AGZ_SCRATCH_BYTES / 8];
   const int lane = threadIdx.x & 63, wv = rfl((int)(threadIdx.x >> 6));
   u64 (*hist)[2][G::R] = hist_all[wv];
-  u64 (*tpl)[G::R] = tpl_all[wv];
+  u64* tpl = scratch_all[wv];
   const int nw = (int)gridDim.x * AGZ_WAVES;
   for (int r = (int)blockIdx.x * AGZ_WAVES + wv; r < n; r += nw) {
     int b = slot_of(ids, r);

@@ -808,6 +808,9 @@ struct Board {
 //     for an fp16 net); lanes own 16 consecutive BYTES of it, so every store instruction of the body is one
 //     contiguous 1-KiB segment (global_store_dwordx4) whatever the alignment of the row (head/tail peeled per element).
 enum { FEAT_F32_NCHW = 0, FEAT_F16_NHWC = 1 };
+// LDS scratch one wave needs while it extracts a row: 64 points x 18 halves (fp16 path; the fp32 bit string and the staged
+// bit planes are smaller)
+constexpr int AGZ_SCRATCH_BYTES = 64 * 36;
 // One wave extracts one row with its own LDS scratch; LDS operations of a wave execute in order, so the only synchronisation
 // between the phases is a compiler fence (several waves of a workgroup may be in different phases of different rows).
 __device__ __forceinline__ void agz_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
@@ -900,18 +903,19 @@ __device__ __forceinline__ void agz_store(const u64 (*tpl)[Geo<N>::R], void* __r
 // Fast paths (rows aligned to 4 bytes, i.e. every fp32 row and every fp16 row a tensor allocator hands out).  Per round of 64
 // output points the wave gathers, for each of the 16 history planes, the dword of the source bitboard that holds the
 // transformed point's bit (LDS, all 16 reads in flight together) and turns "bit set" into a wave mask with one v_and + v_cmp.
-//   fp16 NHWC (agz_direct): a lane owns its point's 18 halves = 36 contiguous bytes, written straight from the masks
-//     (v_cndmask on the SGPR pairs; dwordx4, dwordx4, dword) -- no staging at all.
+//   fp16 NHWC (agz_nhwc_f16): a lane builds its point's 18 halves = 36 contiguous bytes straight from the masks (v_cndmask on
+//     the SGPR pairs), the 64 points of the round are transposed through LDS and leave as 1-KiB contiguous stores.
 //   fp32 NCHW (agz_flat_f32): the masks are parked lane-wise (v_writelane) and then ORed, 64 words at a time, into ONE contiguous
 //     bit string in LDS whose bit f is element f of the flat [18][N][N] row; the store pass then is 16 bytes per lane, 1 KiB per
 //     instruction, 16-byte aligned: one ds_read2_b32 + v_alignbit gives a lane its 4 bits (a step of 64 lanes is exactly 8 dwords
 //     of the bit string, so the LDS address is an immediate and the shift a per-lane constant).
-//     (256-byte dword stores straight from the masks were measured at 0.7x of the old staged path: the memory pipe wants 16 B / lane.)
+//     (256-byte dword stores straight from the masks were measured at 0.7x of the old staged path: the memory pipe wants 16 B / lane
+//     and long contiguous runs per instruction.)
 // History entries that were never pushed read as empty boards: reset() zero-fills the ring and nothing else rewinds hist_cnt,
 // so "fewer than 8 positions so far" needs no test here (the staged path above keeps its explicit `hk < len`).
 struct __attribute__((packed, aligned(4))) AgzQuad { u32 x, y, z, w; };
-template <int N, int FMT, bool BLK>
-__device__ __forceinline__ void agz_direct(const u64 (*hist)[2][Geo<N>::R], int cnt, int d4, void* __restrict__ row, int lane) {
+template <int N, bool BLK>
+__device__ __forceinline__ void agz_nhwc_f16(const u64 (*hist)[2][Geo<N>::R], u32* scratch, int cnt, int d4, void* __restrict__ row, int lane) {
   using G = Geo<N>;
   constexpr int R = G::R, NP = G::NP;
   const int rot = d4 & 3;
@@ -949,19 +953,29 @@ __device__ __forceinline__ void agz_direct(const u64 (*hist)[2][Geo<N>::R], int 
     m[16] = BLK ? full : 0ull;
     m[17] = BLK ? 0ull : full;
     if (valid) {
-      if (FMT == FEAT_F32_NCHW) {
-        float* out = (float*)row + o;
+      u32 d[9];
 #pragma unroll
-        for (int p = 0; p < 18; ++p) out[p * NP] = lane_bit(m[p]) ? 1.0f : 0.0f;
-      } else {
-        u32 d[9];
+      for (int j = 0; j < 9; ++j) d[j] = (lane_bit(m[2 * j]) ? 0x3C00u : 0u) | (lane_bit(m[2 * j + 1]) ? 0x3C000000u : 0u);
+      u32* t = scratch + lane * 9;   // 9-dword stride: conflict-free
 #pragma unroll
-        for (int j = 0; j < 9; ++j) d[j] = (lane_bit(m[2 * j]) ? 0x3C00u : 0u) | (lane_bit(m[2 * j + 1]) ? 0x3C000000u : 0u);
-        char* out = (char*)row + (size_t)o * 36;
-        *reinterpret_cast<AgzQuad*>(out) = AgzQuad{d[0], d[1], d[2], d[3]};
-        *reinterpret_cast<AgzQuad*>(out + 16) = AgzQuad{d[4], d[5], d[6], d[7]};
-        *reinterpret_cast<u32*>(out + 32) = d[8];
+      for (int j = 0; j < 9; ++j) t[j] = d[j];
+    }
+    {
+      // the round's 64 x 36 bytes leave as contiguous 16-byte pieces, 1 KiB per store instruction (a lane storing its own 36
+      // bytes -- 16, 16, 4 at a 36-byte lane stride -- ran at 0.65x of this)
+      agz_wave_sync();
+      const int npts = (k + 1) * 64 <= NP ? 64 : NP - k * 64;
+      const int nq = npts * 9 / 4;                          // whole 16-byte pieces of this round
+      char* outk = (char*)row + (size_t)k * 64 * 36;
+      const uint4* s4 = reinterpret_cast<const uint4*>(scratch);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int q = t * 64 + lane;
+        if (q < nq) { const uint4 v = s4[q]; *reinterpret_cast<AgzQuad*>(outk + 16 * q) = AgzQuad{v.x, v.y, v.z, v.w}; }
       }
+      const int rem = npts * 9 - nq * 4;                    // dwords after the last whole piece (0..3)
+      if (lane < rem) reinterpret_cast<u32*>(outk)[nq * 4 + lane] = scratch[nq * 4 + lane];
+      agz_wave_sync();
     }
   }
 }
@@ -1045,16 +1059,18 @@ __device__ __forceinline__ void agz_flat_f32(const u64 (*hist)[2][Geo<N>::R], u3
   if (f < TOTAL) out[f] = (float)((bs[f >> 5] >> (f & 31)) & 1u);
 }
 
-// whole extraction of one position by one wave; `hist` and `tpl` are LDS
+// whole extraction of one position by one wave; `hist` and `scratch` are LDS
 template <int N>
-__device__ __forceinline__ void extract_agz_row(const u64 (*hist)[2][Geo<N>::R], u64 (*tpl)[Geo<N>::R], int cnt, int player, int d4,
+__device__ __forceinline__ void extract_agz_row(const u64 (*hist)[2][Geo<N>::R], u64* scratch /* LDS, AGZ_SCRATCH_BYTES */, int cnt, int player, int d4,
                                                 void* __restrict__ row, int fmt, int lane) {
+  u64 (*tpl)[Geo<N>::R] = reinterpret_cast<u64 (*)[Geo<N>::R]>(scratch);
   if (rfl((int)(((uintptr_t)row & 3) == 0))) {
     const bool blk = player == S_BLACK;
     if (fmt == FEAT_F16_NHWC) {
-      if (blk) agz_direct<N, FEAT_F16_NHWC, true>(hist, cnt, d4, row, lane); else agz_direct<N, FEAT_F16_NHWC, false>(hist, cnt, d4, row, lane);
+      u32* sc = reinterpret_cast<u32*>(scratch);
+      if (blk) agz_nhwc_f16<N, true>(hist, sc, cnt, d4, row, lane); else agz_nhwc_f16<N, false>(hist, sc, cnt, d4, row, lane);
     } else {
-      u32* bs = reinterpret_cast<u32*>(tpl);
+      u32* bs = reinterpret_cast<u32*>(scratch);
       if (blk) agz_flat_f32<N, true>(hist, bs, cnt, d4, (float*)row, lane); else agz_flat_f32<N, false>(hist, bs, cnt, d4, (float*)row, lane);
     }
     return;

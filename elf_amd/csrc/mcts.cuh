@@ -594,7 +594,7 @@ template <int N>
 __global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, void* __restrict__ s_out, int64_t stride, int fmt, RowRec* rowmap) {
   using G = Geo<N>;
   __shared__ u64 hist[HIST][2][G::R];
-  __shared__ u64 tpl[18][G::R];
+  __shared__ u64 tpl[AGZ_SCRATCH_BYTES / 8];
   const int g = blockIdx.x / K, u = blockIdx.x % K, lane = threadIdx.x;
   const GameState& gs = tp.gs[g];
   if (u >= rfl(gs.n_unique)) return;

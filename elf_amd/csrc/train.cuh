@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void k_replay_extract(PoolT pool, ReplayStore s
                                                         const int32_t* d4s, int n, TrainBatch o) {
   using G = Geo<N>;
   __shared__ Slot<N> lds;
-  __shared__ u64 tpl[18][G::R];
+  __shared__ u64 tpl[AGZ_SCRATCH_BYTES / 8];
   const int i = blockIdx.x, lane = threadIdx.x;
   int r = rfl(rec[i]);
   r = r < 0 ? 0 : (r >= st.capacity ? st.capacity - 1 : r);   // an out-of-range record id must not read outside the store
