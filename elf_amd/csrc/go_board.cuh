@@ -468,8 +468,9 @@ struct Board {
         i = rfl((int)iv);
         c = rfl((int)(__umul24(yv + 1, (u32)S) + xv + 1));
       } else {
-        if (c >= G::P) return 0;
-        int x = c % S - 1, y = c / S - 1;
+        if (c < 0 || c >= G::P) return 0;
+        const int yq = div_s(c);                     // c / S by multiply + shift (0 <= c < P)
+        int x = c - yq * S - 1, y = yq - 1;
         if (x < 0 || x >= N || y < 0 || y >= N) return 0;                     // :803
         i = (x + 1) * S + (y + 1);
         a = x * N + y;

@@ -22,7 +22,7 @@ L.elfprof_expand_phases(out)
 names = ["row map + board load", "pass rule + legal mask", "reply read / coords / validity / keys", "bitonic sort (512 slots)",
          "sorted rows to LDS + tie test", "sequential fp32 normalisation", "unordered_map iteration order", "edge records to HBM"]
 tot = sum(out)
-rows = d["selfplay_stats"]["rows"]
+rows = d["selfplay_stats_window"]["rows"]
 print("  total %.0f ticks per row (%d rows)" % (tot / rows, rows))
 for n, v in zip(names, out):
     print("  %-40s %6.2f %%  %8.0f ticks/row" % (n, 100.0 * v / tot, v / rows))
