@@ -172,7 +172,7 @@ __global__ __launch_bounds__(WAVE * PLAYOUT_WAVES) void k_playout(Pool<N> pool, 
   bd.load(&pool.slots[b]);
   const GameSK<N> sk{pool.skr(b)};
   const u32 key = playout_key(seeds[game]);
-  bd.playout_begin(pool.skr(b), zlds);
+  bd.playout_begin(zlds);
   int steps = 0;
   ELF_PHASE(bd, 7);
   while (steps < max_steps && !bd.terminated()) {

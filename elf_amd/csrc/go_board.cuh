@@ -263,7 +263,8 @@ struct Board {
   // and marks it dirty otherwise (a capture, a neighbour group falling to one liberty, the mover's group changing status)
   u64 at_cache;
   int at_dirty;
-  u64* sk_wp;          // k_playout only: where this lane's word of the next superko record goes (set by playout_begin)
+  u64* sk_wp;          // where this lane's word of the next superko record goes when the record is written through the running
+                       // pointer (forward_legal_action); kept in step with sk_len by load() / reset() / the general forward
   int nb_addr, t12_off;   // per-lane LDS byte offsets for the neighbour reads of forward (see init)
 #ifdef ELF_PROFILE
   unsigned long long ph_t, ph_acc[16];   // tools/playout_phases.hip
@@ -336,12 +337,11 @@ struct Board {
   __device__ __forceinline__ u64 sh_mN(u64 X) const { const u64 p = dpp_prev(X); return (X << N) | (p >> (64 - N)); }
   __device__ __forceinline__ u64 sh_pN(u64 X) const { const u64 n = dpp_next(X); return ((X >> N) | (n << (64 - N))) & pValid; }
 
-  // k_playout, after load(): arm the running record pointer of forward_legal_action and point the per-lane Zobrist reads at
-  // the workgroup's LDS copy of the constants
-  __device__ __forceinline__ void playout_begin(u64* rec, const u64* zob_lds) {
-    sk_wp = rec + (size_t)sk_len * G::SKW + lane;
-    zob_v = zob_lds;
-  }
+  // k_playout, after load(): point the per-lane Zobrist reads at the workgroup's LDS copy of the constants (forward_legal_action
+  // reads the played stone's constant per lane; from global memory that read would queue behind the superko record stores).
+  // The running record pointer of forward_legal_action is armed by load() / reset() themselves.
+  __device__ __forceinline__ void playout_begin(const u64* zob_lds) { zob_v = zob_lds; }
+  __device__ __forceinline__ void arm_record_pointer() { sk_wp = sk_rec ? sk_rec + (size_t)sk_len * G::SKW + lane : nullptr; }
   __device__ __forceinline__ void load_hdr() {
     u32 w = lane < 16 ? reinterpret_cast<const u32*>(&L->h)[lane] : 0u;
     u32 w0 = rl(w, 0), w1 = rl(w, 1), w2 = rl(w, 2), w3 = rl(w, 3), w4 = rl(w, 4), w5 = rl(w, 5), w6 = rl(w, 6),
@@ -356,6 +356,7 @@ struct Board {
     superko = w8 & 0xFF;
     ko_a = ko_pt ? c2a_u(ko_pt) : 0;
     at_dirty = 1;
+    arm_record_pointer();
   }
   __device__ __forceinline__ void store_hdr() {
     if (lane == 0) {
@@ -402,6 +403,7 @@ struct Board {
     hash = 0; ply = 1; next_player = S_BLACK; ko_pt = 0; ko_age = 0; ko_color = 0;
     lm0 = lm1 = lm2 = lm3 = M_INVALID; b_cap = w_cap = 0; hist_cnt = 0; sk_len = 0; superko = 0;
     ko_a = 0; at_cache = 0; at_dirty = 1;
+    arm_record_pointer();
     Bw = Ww = 0;
     wsync();
   }
@@ -507,6 +509,7 @@ struct Board {
         sk_wp += G::SKW;
       } else {
         sk.record(sk_len, hash, Bw, Ww, lane);
+        sk_wp += G::SKW;   // stays where forward_legal_action expects it (k_playout mixes both: resignation never occurs there, but keep the invariant)
       }
       // Bloom insert: lane 0 sets the bit of the low hash word, lane 1 of the high word -- one ds_or_b32 for both (a
       // lane-dependent address keeps the compiler from wrapping a uniform atomic in its single-lane election sequence)
