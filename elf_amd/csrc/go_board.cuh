@@ -238,6 +238,7 @@ struct Board {
 
   Slot<N>* L;          // LDS image of this wave's board
   const u64* zob;      // Zobrist constants in INTERNAL index order (global memory) + geometry masks
+  bool zob_lds_on;     // zob_v points at an LDS copy (k_playout, k_replay_extract): every Zobrist read of forward goes there
   const u64* zob_v;    // the same constants for per-lane (vector) reads: global memory by default; k_playout points it at a
                        // copy in LDS, because on gfx9 a vector load's vmcnt wait also waits for every superko record store
                        // issued before it (a capture stalled ~2 board steps' worth of time behind those stores)
@@ -287,7 +288,7 @@ struct Board {
   __device__ __forceinline__ static void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
   __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skr) {
-    L = lds; zob = z; zob_v = z; sk_rec = skr;
+    L = lds; zob = z; zob_v = z; zob_lds_on = false; sk_rec = skr;
     lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -340,7 +341,7 @@ struct Board {
   // k_playout, after load(): point the per-lane Zobrist reads at the workgroup's LDS copy of the constants (forward_legal_action
   // reads the played stone's constant per lane; from global memory that read would queue behind the superko record stores).
   // The running record pointer of forward_legal_action is armed by load() / reset() themselves.
-  __device__ __forceinline__ void playout_begin(const u64* zob_lds) { zob_v = zob_lds; }
+  __device__ __forceinline__ void playout_begin(const u64* zob_lds) { zob_v = zob_lds; zob_lds_on = true; }
   __device__ __forceinline__ void arm_record_pointer() { sk_wp = sk_rec ? sk_rec + (size_t)sk_len * G::SKW + lane : nullptr; }
   __device__ __forceinline__ void load_hdr() {
     u32 w = lane < 16 ? reinterpret_cast<const u32*>(&L->h)[lane] : 0u;
@@ -485,7 +486,7 @@ struct Board {
       }
       // the played point's Zobrist constant, hashed in after Play.  k_playout: from the LDS copy (every lane reads the same
       // address; with no scalar load left in the loop every LDS wait is an exact lgkmcnt(n)); elsewhere through the scalar cache
-      if (TRUSTED) zi = zob_v[iv];
+      if (TRUSTED || zob_lds_on) zi = zob_v[iv];
       else zi = sload_u64(zob, i);
       // StoneLibertyAnalysis :161-199, branch-free: every lane reads (lanes >= 4 read libs[0] = 0 as their "label"), and the
       // liberty lookup needs no stone test because libs[0] = 0 serves empty and border labels

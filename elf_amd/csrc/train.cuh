@@ -56,7 +56,9 @@ __global__ __launch_bounds__(64) void k_replay_extract(PoolT pool, ReplayStore s
   using G = Geo<N>;
   __shared__ Slot<N> lds;
   __shared__ u64 tpl[AGZ_SCRATCH_BYTES / 8];
+  __shared__ u64 zlds[G::P];   // Zobrist constants: forward reads them from LDS, not behind its own superko record stores (Board::zob_v)
   const int i = blockIdx.x, lane = threadIdx.x;
+  for (int j = lane; j < G::P; j += 64) zlds[j] = pool.zob[j];
   int r = rfl(rec[i]);
   r = r < 0 ? 0 : (r >= st.capacity ? st.capacity - 1 : r);   // an out-of-range record id must not read outside the store
   const int d4 = rfl(d4s ? d4s[i] : 0) & 7;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(64) void k_replay_extract(PoolT pool, ReplayStore s
   Board<N> bd;
   bd.init(&lds, pool.zob, pool.skr(i));
   bd.reset();                                   // _state.reset()
+  bd.playout_begin(zlds);
   for (int t = 0; t < mt; ++t) {                // switchBeforeMove: for (i < move_to) _state.forward(moves[i])
     const int c = rfl((int)mv[t]);
     if (c == M_INVALID) continue;               // the reference throws here (go_state.cc:75-77); a refused move is skipped like any other
