@@ -316,13 +316,32 @@ struct Board {
     Bw = Ww = 0;
   }
 
+  // The word shifts of a lane-distributed bitboard on 32-bit halves.  Only two values cross lanes: the previous word's high half
+  // (it supplies the bits a left shift pulls in: shifts are < 32) and the next word's low half; every shifted half is then ONE
+  // v_alignbit_b32 (a funnel shift {a, b} >> s) instead of a 64-bit shift + 32-bit shift + or.
+  struct Halves { u32 lo, hi, phi, nlo; };
+  __device__ __forceinline__ static Halves halves(u64 X) {
+    Halves h;
+    h.lo = (u32)X; h.hi = (u32)(X >> 32);
+    h.phi = (u32)__builtin_amdgcn_update_dpp(0, (int)h.hi, 0x111, 0xf, 0xf, true);   // row_shr:1, 0 into lane 0 of a row
+    h.nlo = (u32)__builtin_amdgcn_update_dpp(0, (int)h.lo, 0x101, 0xf, 0xf, true);   // row_shl:1
+    return h;
+  }
+  __device__ __forceinline__ static u64 join(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+  // (X << s) | (prev >> (64 - s)) and (X >> s) | (next << (64 - s)), 0 < s < 32
+  template <int SH> __device__ __forceinline__ static u64 shl_w(const Halves& h) {
+    return join(__builtin_amdgcn_alignbit(h.lo, h.phi, 32 - SH), __builtin_amdgcn_alignbit(h.hi, h.lo, 32 - SH));
+  }
+  template <int SH> __device__ __forceinline__ static u64 shr_w(const Halves& h) {
+    return join(__builtin_amdgcn_alignbit(h.hi, h.lo, SH), __builtin_amdgcn_alignbit(h.nlo, h.hi, SH));
+  }
   // points adjacent to X (4-neighbourhood), X lane-distributed
   __device__ __forceinline__ u64 dilate(u64 X) const {
-    const u64 p = dpp_prev(X), n = dpp_next(X);
-    u64 d = ((X << 1) | (p >> 63)) & mTop;          // a-1 in X (same column run)
-    d |= ((X >> 1) | (n << 63)) & mBot;             // a+1 in X
-    d |= (X << N) | (p >> (64 - N));                // a-N in X
-    d |= (X >> N) | (n << (64 - N));                // a+N in X
+    const Halves h = halves(X);
+    u64 d = shl_w<1>(h) & mTop;                     // a-1 in X (same column run)
+    d |= shr_w<1>(h) & mBot;                        // a+1 in X
+    d |= shl_w<N>(h);                               // a-N in X
+    d |= shr_w<N>(h);                               // a+N in X
     return d & pValid;
   }
   // two dilations for the price of one: B rides in lanes 8..8+R-1.  dA is valid in lanes 0..R-1 (its lanes 8.. hold dilate(B):
@@ -333,10 +352,10 @@ struct Board {
   }
 
   // single-direction shifts of a lane-distributed bitboard: result bit a = X bit (a -/+ 1) within the column run, (a -/+ N)
-  __device__ __forceinline__ u64 sh_m1(u64 X) const { const u64 p = dpp_prev(X); return ((X << 1) | (p >> 63)) & mTop; }
-  __device__ __forceinline__ u64 sh_p1(u64 X) const { const u64 n = dpp_next(X); return ((X >> 1) | (n << 63)) & mBot; }
-  __device__ __forceinline__ u64 sh_mN(u64 X) const { const u64 p = dpp_prev(X); return (X << N) | (p >> (64 - N)); }
-  __device__ __forceinline__ u64 sh_pN(u64 X) const { const u64 n = dpp_next(X); return ((X >> N) | (n << (64 - N))) & pValid; }
+  __device__ __forceinline__ u64 sh_m1(u64 X) const { return shl_w<1>(halves(X)) & mTop; }
+  __device__ __forceinline__ u64 sh_p1(u64 X) const { return shr_w<1>(halves(X)) & mBot; }
+  __device__ __forceinline__ u64 sh_mN(u64 X) const { return shl_w<N>(halves(X)); }
+  __device__ __forceinline__ u64 sh_pN(u64 X) const { return shr_w<N>(halves(X)) & pValid; }
 
   // k_playout, after load(): point the per-lane Zobrist reads at the workgroup's LDS copy of the constants (forward_legal_action
   // reads the played stone's constant per lane; from global memory that read would queue behind the superko record stores).
