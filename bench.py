@@ -613,7 +613,10 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "per_rank_rollouts_per_sec": per_rank,
                    "parallelism": "independent games per GPU, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                     "traffic": (load_profile_json("pmc_traffic.json").get("k_mcts_search<%d>" % n, {}).get("hbm_bytes_per_rollout") or 0) * G * K * T or None,
+                     "traffic_note": "PMC HBM bytes per rollout of the four search kernels (profiles/pmc_traffic.json, search-only run at depth 6.3) x "
+                                     "rollouts per step",
                      "kernel": "k_mcts_select+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
                      "algorithmic_bytes_per_rollout": bytes_per_step / (G * K * T),
                      "select_kernel": {"achieved_GBps": (sel_bytes / (sel_ms / 1e3) / 1e9) if (sel_bytes and sel_ms > 0) else None,
