@@ -1,5 +1,5 @@
 // libelf_amd.so: HIP kernels (gfx950) + the C ABI declared in include/elf_amd.h.
-// One wave64 = one workgroup = one board; see go_board.cuh for the device engine.
+// One wave64 = one board (k_playout and k_extract_agz pack 4 independent waves per workgroup); see go_board.cuh for the device engine.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -8,8 +8,9 @@
 // internal to the reference and are not mirrored.
 //
 // Layout choices (all gfx950-specific):
-//  * wave64, one wave = one workgroup = one board: no cross-wave sync, __syncthreads() degenerates to a
-//    waitcnt, every control decision is wave-uniform (readlane -> SGPR) so branches are scalar.
+//  * wave64, one wave = one board: the engine never synchronises across waves (its only fence is a wavefront-scope compiler
+//    fence), every control decision is wave-uniform (readlane -> SGPR) so branches are scalar.  Kernels pack several such
+//    waves into a workgroup where they share read-only tables in LDS (k_playout: Zobrist constants, division table).
 //  * points live in LDS on a padded (N+2)^2 grid in x-major order so that NN action ids
 //    (a = x*N + y, board.h:189) map to consecutive LDS addresses: idx = (x+1)*(N+2) + (y+1).
 //    The reference Coord is the transpose, c = (y+1)*(N+2) + (x+1) (board.h:183); i<->c is an involution.
@@ -19,9 +20,10 @@
 //    Lane l owns points a = 64*k + l, k < R (R = 6 for 19x19, 2 for 9x9).
 //  * captures / merges / liberty recounts are wave-parallel scans over the R rounds with __ballot +
 //    __popcll; liberty give-back after a capture uses LDS atomics.
-//  * history = ring of 8 x {black,white} bitboards in action order (W u64 words each); superko keeps
-//    16-bit tags of every pre-move hash in LDS and the full (hash, bitboards) records in HBM, read only
-//    on a tag hit.
+//  * history = ring of 8 x {black,white} bitboards in action order (W u64 words each); superko keeps a Bloom
+//    filter of every pre-move hash in LDS and the full (hash, bitboards) records in HBM, read only on a filter hit.
+//  * the current position also lives in registers as two lane-distributed bitboards (lane k = actions [64k, 64k+64));
+//    the whole legality test is bitboard algebra on them (dilate / funnel shifts on 32-bit halves, DPP for the carries).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
