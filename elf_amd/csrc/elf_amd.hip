@@ -82,8 +82,9 @@ __global__ __launch_bounds__(WAVE) void k_legal_mask(Pool<N> pool, const int32_t
   if (bd.lane == 0) out[G::NP] = 1;  // pass is always accepted by TryPlay (board.cc:794-800)
 }
 
-// BoardFeature::extractAGZ (board_feature.cc:247-290) + Transform (board_feature.h:97-113): bit planes in output order
-// via ballots, then one flat vectorised store of the row (go_board.cuh: agz_bitplanes / agz_store).
+// BoardFeature::extractAGZ (board_feature.cc:247-290) + Transform (board_feature.h:97-113): wave masks of the 18 planes per
+// round of 64 output points, then 1-KiB contiguous stores of the row (go_board.cuh: agz_nhwc_f16 / agz_flat_f32; the staged
+// agz_bitplanes / agz_store pair remains for fp16 rows at odd 2-byte offsets).
 // AGZ_WAVES rows in flight per workgroup, each wave looping over rows (grid-stride): a 1-wave workgroup per row spends a large
 // share of its short life being launched.
 #define AGZ_WAVES 4
