@@ -1113,7 +1113,7 @@ template <int N>
 __device__ __forceinline__ void action_to_coord(int i, int d4, int& coord, int& a0) {
   constexpr int S = N + 2;
   if (i >= N * N) { coord = M_PASS; a0 = N * N; return; }
-  int xo = i / N, yo = i % N;
+  int xo = (int)(((u32)i * (u32)Geo<N>::DN_M) >> Geo<N>::DN_S), yo = i - xo * N;   // i / N, i % N for 0 <= i < N*N (Geo::DN_M)
   if ((d4 >> 2) & 1) { int t = xo; xo = yo; yo = t; }
   const int rot = d4 & 3;
   int x = xo, y = yo;
