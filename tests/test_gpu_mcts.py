@@ -338,3 +338,37 @@ def test_pipelined_graph_fp16_groups_equal_the_serial_fp32_loop(elf):
         assert len(rec) == Gg * m
         assert _per_game(rec, coord, visits, prior, reward, Gg) == serial[i], "group %d" % i
     pipe.close()
+
+
+# ---- SURVEY.md 8(d) config 3 as the survey defines it: the real net, the real reference, visit counts ------
+def test_config3_real_net_against_the_real_reference_stack(elf):
+    """Model_PolicyValue 20 x 256, torch.manual_seed(0), fp32, eval -- on this GPU -- drives BOTH the real reference stack
+    (oracle/_ref/libelfsp19.so: batcher + GoGameSelfPlay + MCTSGoAI + tree_search/*.h, through its batch interface) and the HIP
+    engine; num_games = 1, mcts_threads = 1, seed 1234, bs 16, puct 1.5, vloss 1, Dirichlet 0.25 / 0.03, persistent tree:
+    moves 1..8 at 512 rollouts and one 8192-rollout search.  Bar: root edge order, priors (after the noise), visit counts,
+    most-visited action, move played and root value bit for bit.  Accumulated rewards: bit-equal except where hazard H2 shows
+    (the reference backs the leaves of a batch up in heap-address order) -- then the sums may differ in
+    their last bits and nothing else; measured on 64 + 4 searches in profiles/r03a_config3_real_net_parity_*.json: 67 bit-equal,
+    one edge of one 8192-rollout search off by 1 ulp, no decision differs.
+    The net is made a pure function of the feature row (fixed evaluation batches, memoised by the row's digest:
+    tests/real_net_parity.py) so that both engines see identical (pi, V) for identical positions."""
+    import real_net_parity as rp
+    from pyoracle import RefSelfPlay
+    if not RefSelfPlay.available(19):
+        pytest.skip("oracle/_ref/libelfsp19.so (the reference compiled in place) is not present: make -C oracle ref")
+    memo = rp.make_memo_net(19, 20, 256)
+    for rollouts, moves, seed in ((512, 8, 1234), (8192, 1, 1234)):
+        cfg = rp.search_cfg(rollouts_per_thread=rollouts, seed=seed)
+        ref = rp.run_reference(memo, 19, cfg, 1, moves)
+        got, engine_only_rows = rp.run_engine(memo, 19, cfg, 1, moves)
+        res = rp.compare(ref, got, 1, moves)
+        assert res["searches_compared"] == moves
+        assert res["decision_diverged"] == 0, res
+        assert res["bit_equal"] + res["reward_ulps_only"] == moves, res
+        assert res["max_reward_ulps"] <= 64, res
+        assert engine_only_rows == 0          # the engine asked the net for positions the reference asked for, nothing else
+        for k in range(moves):
+            assert ref[0][k]["total_visits"] == got[0][k]["total_visits"]
+        # 8192 rollouts at bs 16: the all-at-root first batch adds no visit (SURVEY.md a16)
+        if rollouts == 8192:
+            assert ref[0][0]["total_visits"] == 8176
