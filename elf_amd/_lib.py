@@ -32,6 +32,10 @@ SIGNATURES = {
     "elfmcts_destroy": (_i, [_vp]),
     "elfmcts_set_options": (_i, [_vp, _vp]),
     "elfmcts_set_feature_format": (_i, [_vp, _i]),
+    "elfmcts_get_feature_format": (_i, [_vp, C.POINTER(_i)]),
+    "elfmcts_max_rollouts_per_step": (_i, []),
+    "elfmcts_set_game_mask": (_i, [_vp, _vp]),
+    "elfmcts_set_required_versions": (_i, [_vp, _vp]),
     "elfmcts_num_games": (_i, [_vp]),
     "elfmcts_edge_stride": (_i, [_vp]),
     "elfmcts_node_bytes": (_sz, [_vp]),
@@ -50,6 +54,14 @@ SIGNATURES = {
     "elfsp_engine": (_vp, [_vp]),
     "elfsp_mcts": (_vp, [_vp]),
     "elfsp_max_rows": (_i, [_vp]),
+    "elfsp_max_rows_actor": (_i, [_vp, _i]),
+    "elfsp_mcts_actor": (_vp, [_vp, _i]),
+    "elfsp_begin_step2": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "elfsp_end_step2": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "elfsp_last_rows2": (_i, [_vp, _vp]),
+    "elfsp_set_request2": (_i, [_vp, _vp]),
+    "elfsp_progress": (_i, [_vp, _vp]),
+    "elfsp_game_actor": (_i, [_vp, _i]),
     "elfsp_begin_step": (_i, [_vp, _vp, _i64, C.POINTER(_i), _vp]),
     "elfsp_end_step": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "elfsp_last_rows": (_i, [_vp, C.POINTER(_i)]),
@@ -78,6 +90,7 @@ SIGNATURES = {
     "elfrec_coords_to_sgfstr": (_i, [_i, _vp, _i, _vp, _sz]),
     "elfrec_sgfstr_to_coords": (_i, [_i, C.c_char_p, _vp, _i]),
     "elfrec_record_to_json": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _i, _i, C.c_uint64, C.c_uint64, _vp, _sz]),
+    "elfrec_record_to_json2": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _f, _i, _i, C.c_uint64, C.c_uint64, _vp, _sz]),
     "elfrec_quantise_policy": (_i, [_i, _vp, _vp, _i, _vp]),
     "elfnet_bias_act_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfnet_bias_act_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -39,7 +39,8 @@ namespace elfgo {
 enum { NS_NOT_VISITED = 0, NS_EVAL_REQUESTED = 1, NS_VISITED = 2 };   // NodeT::VisitType
 enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2 };
 enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8, MCTS_ERR_VERSION = 16 };
-constexpr int MCTS_KMAX = 64;   // max rollouts per step = num_threads x rollouts_per_batch (one lane per unique leaf)
+constexpr int MCTS_KMAX = 256;  // max rollouts per step = num_threads x rollouts_per_batch (leaf table of a step: LDS in select, 64-leaf chunks in backup)
+enum { GM_IDLE = 0, GM_SEARCH = 1, GM_POLICY_ONLY = 2 };   // per-game mask byte (elfmcts_set_game_mask)
 
 struct NodeHdr {          // 64 B
   int parent;             // node id, -1 for the root
@@ -121,8 +122,11 @@ struct TreePool {
   LeafRec* leaves;        // [G][MCTS_KMAX]
   unsigned char* d4buf;   // [G][W]  pre-drawn rng() % 8 of the actor's mt19937 (go/mcts/mcts.h:175-183)
   const double* sqrt_tab; // [sqrt_n] host libm sqrt((double)k): the reference's std::sqrt(int) (tree_search_base.h:153)
+  const unsigned char* mask;   // [G] or nullptr (every game GM_SEARCH): which games the per-game launches act on (GM_*)
+  const long long* req_ver;    // [G] or nullptr (TreeCfg.required_version for every game): MCTSActorParams.required_version per game
   int sqrt_n;
   int C, W, G;
+  __device__ __forceinline__ int game_mode(int g) const { return mask ? (int)mask[g] : (int)GM_SEARCH; }
   __device__ __forceinline__ NodeRec<N>* game_nodes(int g) const { return nodes + (size_t)g * C; }
 };
 
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(64) void k_mcts_clear(TreePool<N> tp, const int32_t
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool, const int32_t* board_ids) {
   const int g = blockIdx.x, lane = threadIdx.x;
+  if (rfl(tp.game_mode(g)) == GM_IDLE) return;
   NodeRec<N>* nodes = tp.game_nodes(g);
   GameState& s = tp.gs[g];
   const int root = rfl(s.root);
@@ -312,7 +317,15 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   using NR = NodeRec<N>;
   __shared__ Slot<N> lds;
   __shared__ __attribute__((aligned(16))) float uqs[64 + 8];   // unsigned child Qs of one round's visited edges, compacted
+  // the unique leaves of this step (unique per search thread), in first-occurrence order
+  __shared__ int lf_node[MCTS_KMAX], lf_count[MCTS_KMAX], lf_meta[MCTS_KMAX], lf_nn[MCTS_KMAX];
+  __shared__ float lf_value[MCTS_KMAX];
   const int g = blockIdx.x, lane = threadIdx.x;
+  const int mode = rfl(tp.game_mode(g));
+  if (mode == GM_IDLE) {                     // this game does not search in this step: no leaves, no rows
+    if (lane == 0) { tp.gs[g].n_unique = 0; tp.gs[g].n_nn = 0; }
+    return;
+  }
   const u64 lt_mask = (1ull << lane) - 1ull;
 #ifdef ELF_PROFILE_SELECT
   unsigned long long sel_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sel_t = __builtin_amdgcn_s_memtime();
@@ -327,13 +340,12 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   Board<N> bd;
   bd.init(&lds, pool.zob, nullptr);
 
-  // lane u holds the u-th unique leaf of this step (unique per search thread)
-  int my_leaf = -1, my_count = 0, my_kind = 0, my_d4 = 0, my_nn = 0, my_depth = 0;
-  float my_value = 0.0f;
   int n_unique = 0, n_nn = 0, thread_start = 0;
   const float vl_f = (float)cfg.virtual_loss;
   int visited_nodes = 0;
-  const int K = cfg.rollouts_per_batch, KT = K * cfg.num_threads;
+  // GM_POLICY_ONLY = TreeSearchT::runPolicyOnly (tree_search.h:385-407): the root is evaluated if it has not been yet, nothing else
+  const bool root_only = mode == GM_POLICY_ONLY;
+  const int K = root_only ? 1 : cfg.rollouts_per_batch, KT = root_only ? 1 : K * cfg.num_threads;
 
   for (int j = 0, jk = 0; j < KT; ++j, ++jk) {
     if (jk == K) jk = 0;
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     for (;;) {                   // single_rollout, tree_search.h:264-322
       h.set(hw);
       SEL_PHASE(0);   // header + scoring order arrive
-      if (h.status != NS_VISITED || h.n_edges == 0) break;
+      if (h.status != NS_VISITED || h.n_edges == 0 || root_only) break;
       NR& nd = nodes[node];
       // ---- findMove :205-231 + UCT :361-397 + EdgeInfo::getScore (tree_search_base.h:132-157)
       float umq = h.umq;
@@ -504,10 +516,16 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     }
     visited_nodes += depth;
     SEL_PHASE(5);   // slot store issue, loop exit
+    if (root_only && h.status == NS_VISITED) break;   // runPolicyOnly on an evaluated root: no evaluation, no leaf
     // ---- leaf bookkeeping: batch_rollouts :211-233 (requestEvaluation, duplicate leaves of THIS thread's batch)
-    const u64 dup = __ballot(lane >= thread_start && lane < n_unique && my_leaf == node);
-    if (dup) {
-      if (lane == (int)__builtin_ctzll(dup)) ++my_count;
+    int dup_idx = -1;
+    for (int b0 = thread_start & ~63; b0 < n_unique; b0 += 64) {
+      const int i = b0 + lane;
+      const u64 dup = __ballot(i >= thread_start && i < n_unique && lf_node[i] == node);
+      if (dup) { dup_idx = b0 + (int)__builtin_ctzll(dup); break; }
+    }
+    if (dup_idx >= 0) {
+      if (lane == 0) ++lf_count[dup_idx];
     } else {
       int kind = LK_REVISIT, d4 = 0;
       float value = 0.0f;
@@ -526,8 +544,9 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         }
         if (lane == 0) nodes[node].h.status = NS_EVAL_REQUESTED;
       }
-      if (lane == n_unique) {
-        my_leaf = node; my_count = 1; my_kind = kind; my_d4 = d4; my_value = value; my_nn = n_nn; my_depth = depth;
+      if (lane == 0) {
+        lf_node[n_unique] = node; lf_count[n_unique] = 1; lf_meta[n_unique] = kind | (d4 << 8) | (depth << 16);
+        lf_value[n_unique] = value; lf_nn[n_unique] = n_nn;
       }
       ++n_unique;
       if (kind == LK_NN) ++n_nn;
@@ -541,10 +560,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     g_select_phase[g][lane] += lane == 0 ? sel_acc[0] : lane == 1 ? sel_acc[1] : lane == 2 ? sel_acc[2] : lane == 3 ? sel_acc[3]
                              : lane == 4 ? sel_acc[4] : lane == 5 ? sel_acc[5] : lane == 6 ? sel_acc[6] : sel_acc[7];
 #endif
-  if (lane < n_unique) {
-    LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + lane];
-    lr.node = my_leaf; lr.count = my_count; lr.kind = my_kind; lr.d4 = my_d4; lr.value = my_value; lr.nn_index = my_nn;
-    lr.depth = my_depth;
+  for (int i = lane; i < n_unique; i += 64) {
+    LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + i];
+    const int meta = lf_meta[i];
+    lr.node = lf_node[i]; lr.count = lf_count[i]; lr.kind = meta & 0xFF; lr.d4 = (meta >> 8) & 0xFF; lr.value = lf_value[i];
+    lr.nn_index = lf_nn[i]; lr.depth = meta >> 16;
   }
   if (lane == 0) {
     gs.free_top = free_top; gs.rng_pos = rng_pos; gs.n_unique = n_unique; gs.n_nn = n_nn;
@@ -846,8 +866,8 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
   const int g = rowmap[row].game, node = rowmap[row].node, d4 = rowmap[row].d4;
   NR& nd = tp.game_nodes(g)[node];
   // MCTSActor::post_nn_result :210-217: the reply's model version must be the requested one (the reference throws)
-  if (rv != nullptr && cfg.required_version >= 0 && lane == 0 && rv[row] != cfg.required_version)
-    atomicOr(&tp.gs[g].err, MCTS_ERR_VERSION);
+  const long long need_ver = tp.req_ver ? tp.req_ver[g] : cfg.required_version;
+  if (rv != nullptr && need_ver >= 0 && lane == 0 && rv[row] != need_ver) atomicOr(&tp.gs[g].err, MCTS_ERR_VERSION);
 #ifdef ELF_PROFILE_EXPAND
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1015,7 +1035,7 @@ __global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* z
 }
 
 // ------------------------------------------------------------------------------------------------
-// backup: batch_rollouts :245-259, one wave per game, one LANE per unique leaf.
+// backup: batch_rollouts :245-259, one wave per game, one LANE per unique leaf (64 leaves at a time).
 // The trajectories are walked level by level from the deepest leaf's level up to the root's children, every lane at the
 // ancestor of its leaf on that level (the leaf's depth comes from select, so all lanes sit on the same tree level at the same
 // time).  Lanes whose trajectories have merged (same node) form a group; the edge above the group receives the group's rewards
@@ -1030,55 +1050,63 @@ __global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg)
   NR* nodes = tp.game_nodes(g);
   const int nu = rfl(tp.gs[g].n_unique);
   if (nu == 0) return;
-  const bool have = lane < nu;
-  int c = 0, d = 0, count = 0, kind = LK_REVISIT;
-  float lvalue = 0.0f;
-  if (have) {
-    const LeafRec lr = tp.leaves[(size_t)g * MCTS_KMAX + lane];
-    c = lr.node; d = lr.depth; count = lr.count; kind = lr.kind; lvalue = lr.value;
-  }
-  if (have && kind == LK_TERMINAL) {         // pre_evaluate result -> setEvaluation with an empty pi
-    NR& leaf = nodes[c];
-    leaf.h.V = lvalue;
-    leaf.h.flip = leaf.board.h.next_player == S_WHITE;
-    leaf.h.n_edges = 0;
-    leaf.h.status = NS_VISITED;
+  const LeafRec* leaves = tp.leaves + (size_t)g * MCTS_KMAX;
+  for (int i = lane; i < nu; i += 64) {      // pre_evaluate result -> setEvaluation with an empty pi
+    const LeafRec lr = leaves[i];
+    if (lr.kind == LK_TERMINAL) {
+      NR& leaf = nodes[lr.node];
+      leaf.h.V = lr.value;
+      leaf.h.flip = leaf.board.h.next_player == S_WHITE;
+      leaf.h.n_edges = 0;
+      leaf.h.status = NS_VISITED;
+    }
   }
   mem_sync();                                // a terminal leaf may be another search thread's revisited leaf in this step
-  const float reward = have ? nodes[c].h.V : 0.0f;   // MCTSActor::reward (go/mcts/mcts.h:163-165)
-  const float vsub = (float)(cfg.virtual_loss * count);
-  const int maxd = (int)wave_max_u32((u32)d);
-  for (int lvl = maxd; lvl >= 1; --lvl) {    // updateEdgeStats :253-278 along the trajectories
-    const bool act = have && d >= lvl;
-    const u64 am = __ballot(act);
-    int p = 0, e = 0;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) {
-      p = nodes[c].h.parent;
-      e = nodes[c].h.parent_edge;
-      s = nodes[p].stat[e];
+  // more than 64 unique leaves (num_threads x num_rollouts_per_batch up to MCTS_KMAX): chunks of 64 in leaf order, one after the
+  // other -- an edge then receives chunk 0's rewards in leaf order, then chunk 1's: the serial order
+  for (int c0 = 0; c0 < nu; c0 += 64) {
+    const bool have = c0 + lane < nu;
+    int c = 0, d = 0, count = 0;
+    if (have) {
+      const LeafRec lr = leaves[c0 + lane];
+      c = lr.node; d = lr.depth; count = lr.count;
     }
-    bool leader = true;
-    int zc = 0;
-    u64 m = am;
-    while (m) {
-      const int jl = (int)__builtin_ctzll(m);
-      m &= m - 1;
-      const int cj = rl(c, jl);
-      const float rj = rlf(reward, jl), vj = rlf(vsub, jl);
-      if (c == cj) {
-        if (jl < lane) leader = false;
-        s.y = __fadd_rn(s.y, rj);
-        s.w = __fsub_rn(s.w, vj);
-        ++zc;
+    const float reward = have ? nodes[c].h.V : 0.0f;   // MCTSActor::reward (go/mcts/mcts.h:163-165)
+    const float vsub = (float)(cfg.virtual_loss * count);
+    const int maxd = (int)wave_max_u32((u32)d);
+    for (int lvl = maxd; lvl >= 1; --lvl) {    // updateEdgeStats :253-278 along the trajectories
+      const bool act = have && d >= lvl;
+      const u64 am = __ballot(act);
+      int p = 0, e = 0;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (act) {
+        p = nodes[c].h.parent;
+        e = nodes[c].h.parent_edge;
+        s = nodes[p].stat[e];
       }
+      bool leader = true;
+      int zc = 0;
+      u64 m = am;
+      while (m) {
+        const int jl = (int)__builtin_ctzll(m);
+        m &= m - 1;
+        const int cj = rl(c, jl);
+        const float rj = rlf(reward, jl), vj = rlf(vsub, jl);
+        if (c == cj) {
+          if (jl < lane) leader = false;
+          s.y = __fadd_rn(s.y, rj);
+          s.w = __fsub_rn(s.w, vj);
+          ++zc;
+        }
+      }
+      if (act && leader) {
+        s.z = __int_as_float(__float_as_int(s.z) + zc);
+        nodes[p].stat[e] = s;
+        atomicAdd(&nodes[p].h.num_visits, zc);
+      }
+      if (act) c = p;
     }
-    if (act && leader) {
-      s.z = __int_as_float(__float_as_int(s.z) + zc);
-      nodes[p].stat[e] = s;
-      atomicAdd(&nodes[p].h.num_visits, zc);
-    }
-    if (act) c = p;
+    if (c0 + 64 < nu) mem_sync();            // the next chunk reads the edge sums this one stored
   }
 }
 
@@ -1089,6 +1117,7 @@ __global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg)
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const float* etas, const float* Z, float epsilon) {
   const int g = blockIdx.x, lane = threadIdx.x;
+  if (rfl(tp.game_mode(g)) == GM_IDLE) return;
   NodeRec<N>& r = tp.game_nodes(g)[rfl(tp.gs[g].root)];
   const int n = rfl(r.h.n_edges);
   if (rfl(r.h.status) != NS_VISITED) return;

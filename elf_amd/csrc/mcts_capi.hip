@@ -21,6 +21,8 @@ struct ElfMcts {
   int sqrt_n = 0;
   RowRec* rowmap = nullptr;
   int32_t* last_counts = nullptr;   // counts pointer of the last elfmcts_select (device), for elfmcts_expand(n_rows < 0)
+  const unsigned char* mask = nullptr;   // elfmcts_set_game_mask (device bytes, GM_*), nullptr = every game searches
+  const long long* req_ver = nullptr;    // elfmcts_set_required_versions (device int64 per game), nullptr = ElfMctsOptions.required_version
   TreeCfg cfg;
   size_t node_bytes = 0;
   int feat_fmt = ELFGO_FEAT_F32_NCHW;
@@ -38,12 +40,14 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   t.d4buf = m->d4buf;
   t.sqrt_tab = m->sqrt_tab;
   t.sqrt_n = m->sqrt_n;
+  t.mask = m->mask;
+  t.req_ver = m->req_ver;
   t.C = m->C; t.W = m->W; t.G = m->G;
   return t;
 }
 
 static int cfg_from(const ElfMctsOptions* o, TreeCfg* c) {
-  // one lane per unique leaf of a step: num_threads x num_rollouts_per_batch <= 64 (larger products are rejected, not truncated)
+  // leaf table of a step: num_threads x num_rollouts_per_batch <= MCTS_KMAX = 256 (larger products are rejected, not truncated)
   if (!o || o->num_rollouts_per_batch <= 0 || o->num_threads <= 0 ||
       (int64_t)o->num_rollouts_per_batch * o->num_threads > MCTS_KMAX)
     return ELFGO_E_BADARG;
@@ -129,6 +133,22 @@ int elfmcts_set_feature_format(ElfMcts* m, int fmt) {
   m->feat_fmt = fmt;
   return 0;
 }
+int elfmcts_get_feature_format(const ElfMcts* m, int* fmt) {
+  if (!m || !fmt) return ELFGO_E_BADARG;
+  *fmt = m->feat_fmt;
+  return 0;
+}
+int elfmcts_set_game_mask(ElfMcts* m, const uint8_t* mask) {
+  if (!m) return ELFGO_E_BADARG;
+  m->mask = mask;
+  return 0;
+}
+int elfmcts_set_required_versions(ElfMcts* m, const int64_t* versions) {
+  if (!m) return ELFGO_E_BADARG;
+  m->req_ver = reinterpret_cast<const long long*>(versions);
+  return 0;
+}
+int elfmcts_max_rollouts_per_step(void) { return MCTS_KMAX; }
 int elfmcts_num_games(const ElfMcts* m) { return m ? m->G : ELFGO_E_BADARG; }
 int elfmcts_edge_stride(const ElfMcts* m) { return m ? m->NE : ELFGO_E_BADARG; }
 size_t elfmcts_node_bytes(const ElfMcts* m) { return m ? m->node_bytes : 0; }

@@ -367,6 +367,25 @@ std::vector<uint16_t> sgf_main_line(const std::string& path, int n) {
 // ------------------------------------------------------------------------------------------------
 class Context;
 
+// the calling thread's current device is switched to the context's for a scope and restored afterwards
+struct DevScope {
+  int prev = -1;
+  explicit DevScope(int dev) {
+    int cur = -1;
+    if (elfgo_get_device(&cur) == 0 && cur != dev && elfgo_set_device(dev) == 0) prev = cur;
+  }
+  ~DevScope() { if (prev >= 0) elfgo_set_device(prev); }
+  DevScope(const DevScope&) = delete;
+  DevScope& operator=(const DevScope&) = delete;
+};
+
+static int pick_code(const std::string& m) {      // TreeSearchT::chooseAction, tree_search.h:506-519
+  if (m == "most_visited") return ELFSP_PICK_MOST_VISITED;
+  if (m == "strongest_prior") return ELFSP_PICK_STRONGEST_PRIOR;
+  if (m == "uniform_random") return ELFSP_PICK_UNIFORM_RANDOM;
+  return -1;
+}
+
 // GoGameSelfPlay accessors (common/game_selfplay.h:41-56)
 struct GameView {
   Context* ctx = nullptr;
@@ -388,12 +407,11 @@ class Context {
     if (online && co.num_games != 1)
       throw std::range_error("mode online: one game per context (the human_actor prompt is per game)");
     if (go.use_df_feature) throw std::range_error("use_df_feature: the DarkForest feature set is not on this path (AGZ planes only)");
-    if (go.black_use_policy_network_only || go.white_use_policy_network_only)
-      throw std::range_error("*_use_policy_network_only: policy-only play is not on this path (MCTS actors only)");
     const TSOptions& ts = co.mcts_options;
-    if (ts.pick_method != "most_visited") throw std::range_error("MCTS Pick method unknown! " + ts.pick_method);   // tree_search.h:521-524
-    if ((int64_t)ts.num_threads * ts.num_rollouts_per_batch > 64 || ts.num_threads < 1 || ts.num_rollouts_per_batch < 1)
-      throw std::range_error("num_threads x num_rollouts_per_batch must be in [1, 64] (one wave lane per leaf of a search step)");
+    if (pick_code(ts.pick_method) < 0) throw std::range_error("MCTS Pick method unknown! " + ts.pick_method);   // tree_search.h:521-524
+    if ((int64_t)ts.num_threads * ts.num_rollouts_per_batch > elfmcts_max_rollouts_per_step() || ts.num_threads < 1 || ts.num_rollouts_per_batch < 1)
+      throw std::range_error("num_threads x num_rollouts_per_batch must be in [1, " + std::to_string(elfmcts_max_rollouts_per_step()) +
+                             "] (the leaf table of one search step)");
     // GoFeature::registerExtractor (common/game_feature.h:159-206) with batchsize = ContextOptions.batchsize
     const int B = co.batchsize, NA = n * n + 1;
     add_field("s", "float", 4, B, {B, 18, n, n});
@@ -471,19 +489,25 @@ class Context {
     o.mcts.rotation_flip = 1;
     o.mcts.num_threads = ts.num_threads;
     o.mcts.required_version = -1;           // set by the first request
+    o.white_puct = go_.white_puct;
+    o.white_mcts_rollout_per_batch = go_.white_mcts_rollout_per_batch;
+    o.white_mcts_rollout_per_thread = go_.white_mcts_rollout_per_thread;
+    o.black_use_policy_network_only = go_.black_use_policy_network_only;
+    o.white_use_policy_network_only = go_.white_use_policy_network_only;
+    o.pick_method = pick_code(ts.pick_method);
+    o.cheat_eval_new_model_wins_half = go_.cheat_eval_new_model_wins_half;
+    o.cheat_selfplay_random_result = go_.cheat_selfplay_random_result;
+    o.following_pass = online_ && go_.following_pass;
     std::vector<uint64_t> zob = load_zobrist(n);
     int dev = go_.gpu;
     if (dev < 0) chk(elfgo_get_device(&dev), "hipGetDevice");
     device_ = dev;
     chk(elfsp_create(&o, dev, zob.data(), &sp_), "elfsp_create");
-    max_rows_ = elfsp_max_rows(sp_);
     NA_ = n * n + 1;
     row_floats_ = 18 * n * n;
-    // device staging: one step of leaf rows, and the replies of one step
-    dmalloc(&d_s_, (size_t)max_rows_ * row_floats_ * 4);
-    dmalloc(&d_pi_, (size_t)max_rows_ * NA_ * 4);
-    dmalloc(&d_v_, (size_t)max_rows_ * 4);
-    dmalloc(&d_rv_, (size_t)max_rows_ * 8);
+    // device staging: one step of leaf rows, and the replies of one step ("actor_white" staging is made by the first request
+    // that names a model for White)
+    alloc_staging(0);
     dmalloc(&d_one_, 4096);   // scratch: ids @0, info @64, board colours @256, liberties @1024, a float @3072
     if (!go_.preload_sgf.empty()) {
       const std::vector<uint16_t> mv = sgf_main_line(go_.preload_sgf, n);
@@ -502,7 +526,6 @@ class Context {
 
   // wait(): the next batch of some group, nullptr (None) when timeout_usec > 0 and nothing can be served
   SharedMem* wait(int timeout_usec) {
-    (void)timeout_usec;
     if (!started_) throw std::runtime_error("Context.wait() before start()");
     if (stopped_) return nullptr;
     if (current_) throw std::runtime_error("Context.wait(): the previous batch has not been released with step()");
@@ -525,7 +548,16 @@ class Context {
         if (sm) return serve(sm, 1, K_GAME_END);
         continue;
       }
-      if (rows_left_ > 0) return serve_actor_chunk();
+      if (rows_pending()) return serve_actor_chunk();
+      if (have_request_) {
+        // every game waits (a wait request / numThreads = 0): nothing will ever come out of a step
+        int64_t pr[6];
+        chk(elfsp_progress(sp_, pr), "elfsp_progress");
+        if (pr[4] == co_.num_games) {
+          if (timeout_usec > 0) return nullptr;
+          throw std::runtime_error("Context.wait(): every game is waiting for a request that gives it something to play");
+        }
+      }
       if (!have_request_)
         throw std::runtime_error(
             "Context.wait(): no request yet -- call getClient().setRequest(black_ver, -1, resign_thres, -1) (or GameContext.setRequest) "
@@ -553,19 +585,26 @@ class Context {
   }
 
   // ---- services for GameContext / Client
-  void setRequest(int64_t black_ver, int64_t white_ver, float thres, int num_threads) {
-    if (white_ver >= 0)
-      throw std::range_error("setRequest: white_ver >= 0 (a second AI for White, game_selfplay.cc:171-185) is not supported");
-    if (black_ver < 0) throw std::range_error("setRequest: black_ver < 0 is the reference's wait request; nothing to play");
-    if (num_threads >= 0 && num_threads < co_.num_games)
-      throw std::range_error("setRequest: numThreads < num_games (idle game threads) is not supported: size num_games instead");
+  void setRequest(int64_t black_ver, int64_t white_ver, float thres, int num_threads, bool player_swap = false) {
+    // GameContext::setRequest (inference/game_context.h:76-88) / Client::setRequest (train/distri_client.h:318-331).  player_swap
+    // (ClientCtrl.player_swap) is not an argument of the reference's method: there it only arrives in the server's MsgRequest
+    // (train/ctrl_eval.h); offered here as an optional fifth argument because the server is out of scope.
     if (!started_) throw std::runtime_error("setRequest before start()");
-    chk(elfsp_set_request(sp_, black_ver, white_ver, thres, 0.0f, go_.selfplay_async ? 1 : 0), "elfsp_set_request");
-    have_request_ = true;
-    black_ver_ = black_ver;
-    white_ver_ = white_ver;
-    // applied at once between two moves (the first request always is): its game_start batch comes before anything else
-    pending_game_start_ += elfsp_take_game_starts(sp_, nullptr, nullptr);
+    ElfSpRequest q;
+    memset(&q, 0, sizeof(q));
+    q.black_ver = black_ver;
+    q.white_ver = white_ver;
+    q.black_resign_thres = q.white_resign_thres = thres;
+    q.never_resign_prob = 0.0f;
+    q.num_game_thread_used = num_threads;
+    q.player_swap = player_swap ? 1 : 0;
+    q.async = go_.selfplay_async ? 1 : 0;
+    if (white_ver >= 0 && black_ver >= 0) alloc_staging(1);
+    chk(elfsp_set_request2(sp_, &q), "elfsp_set_request");
+    if (black_ver >= 0) have_request_ = true;
+    // applied at once by the games that are between two searches (the first request always is): its game_start batch comes
+    // before anything else
+    pending_game_start_ += elfsp_take_game_starts(sp_, &black_ver_, &white_ver_);
   }
 
   std::map<std::string, int> getParams() const {   // GoFeature::getParams, common/game_feature.h:208-221
@@ -647,8 +686,17 @@ class Context {
     return z;
   }
 
+  void alloc_staging(int a) {
+    if (d_s_[a]) return;
+    max_rows_[a] = elfsp_max_rows_actor(sp_, a);
+    dmalloc(&d_s_[a], (size_t)max_rows_[a] * row_floats_ * 4);
+    dmalloc(&d_pi_[a], (size_t)max_rows_[a] * NA_ * 4);
+    dmalloc(&d_v_[a], (size_t)max_rows_[a] * 4);
+    dmalloc(&d_rv_[a], (size_t)max_rows_[a] * 8);
+  }
+
   void dmalloc(void** p, size_t bytes) {
-    chk(elfgo_set_device(device_), "hipSetDevice");
+    DevScope _ds(device_);
     chk(elfgo_malloc(p, bytes), "hipMalloc");
     owned_.push_back(*p);
   }
@@ -656,7 +704,7 @@ class Context {
   void destroy() {
     if (sp_) { elfsp_destroy(sp_); sp_ = nullptr; }
     if (!owned_.empty()) {
-      elfgo_set_device(device_);
+      DevScope _ds(device_);
       for (void* p : owned_) elfgo_free(p);
       owned_.clear();
     }
@@ -693,65 +741,69 @@ class Context {
     chk(elfgo_stream_sync(stream_), "sync");
   }
 
-  // ---- MCTS leaves: one device step served in chunks of at most the group's batchsize
+  // ---- MCTS leaves: one device step served in chunks of at most the group's batchsize; rows of the "actor_black" AI first, then
+  // (evaluation games) the rows of the "actor_white" AI in their own group
   void begin_search_step() {
-    int rows = 0;
-    chk(elfsp_begin_step(sp_, d_s_, row_floats_, &rows, stream_), "elfsp_begin_step");
-    int64_t bv = 0, wv = -1;
-    pending_game_start_ += elfsp_take_game_starts(sp_, &bv, &wv);   // a request that restarted the games at this move boundary
+    int rows[2] = {0, 0};
+    void* dst[2] = {d_s_[0], d_s_[1]};
+    chk(elfsp_begin_step2(sp_, dst, row_floats_, rows, stream_), "elfsp_begin_step");
+    pending_game_start_ += elfsp_take_game_starts(sp_, &black_ver_, &white_ver_);   // a request that (re)started games at this boundary
     search_running_ = true;
-    step_rows_ = rows;
-    rows_left_ = rows;
-    rows_done_ = 0;
-    if (rows == 0) finish_search_step();   // nothing for the net in this step (every leaf terminal / revisited)
+    for (int a = 0; a < 2; ++a) { step_rows_[a] = rows[a]; rows_left_[a] = rows[a]; rows_done_[a] = 0; have_rv_[a] = false; }
+    if (rows[0] + rows[1] == 0) finish_search_step();   // nothing for the net in this step (every leaf terminal / revisited / games idle)
   }
 
+  bool rows_pending() const { return rows_left_[0] > 0 || rows_left_[1] > 0; }
+
   SharedMem* serve_actor_chunk() {
-    SharedMem* sm = pick("actor_black");   // one AI plays both colours in self-play (white_ver == -1, game_selfplay.cc:165-185)
-    if (!sm) throw std::runtime_error("no SharedMem allocated for group actor_black");
-    const int chunk = std::min(rows_left_, sm->opts.batchsize);
+    const int a = rows_left_[0] > 0 ? 0 : 1;
+    const char* group = a == 0 ? "actor_black" : "actor_white";   // MCTSActorParams.actor_name (game_selfplay.cc:166,172)
+    SharedMem* sm = pick(group);
+    if (!sm) throw std::runtime_error(std::string("no SharedMem allocated for group ") + group);
+    const int chunk = std::min(rows_left_[a], sm->opts.batchsize);
     AnyP* s = need(sm, "s", "float");
     const size_t rb = (size_t)row_floats_ * 4;
-    chk(elfgo_memcpy2d_async(reinterpret_cast<void*>(s->p), s->pitch(), (const char*)d_s_ + (size_t)rows_done_ * rb, rb, rb, (size_t)chunk,
-                             stream_), "copy of the feature rows");
+    chk(elfgo_memcpy2d_async(reinterpret_cast<void*>(s->p), s->pitch(), (const char*)d_s_[a] + (size_t)rows_done_[a] * rb, rb, rb,
+                             (size_t)chunk, stream_), "copy of the feature rows");
     chk(elfgo_stream_sync(stream_), "sync");   // rows [0, chunk) are in the caller's tensor before wait() returns
     chunk_rows_ = chunk;
+    chunk_actor_ = a;
     return serve(sm, (size_t)chunk, K_ACTOR);
   }
 
   void take_actor_reply(SharedMem* sm) {
+    const int a = chunk_actor_;
     AnyP* pi = need(sm, "pi", "float");
     AnyP* v = need(sm, "V", "float");
     const size_t pb = (size_t)NA_ * 4;
-    chk(elfgo_memcpy2d_async((char*)d_pi_ + (size_t)rows_done_ * pb, pb, reinterpret_cast<const void*>(pi->p), pi->pitch(), pb,
+    chk(elfgo_memcpy2d_async((char*)d_pi_[a] + (size_t)rows_done_[a] * pb, pb, reinterpret_cast<const void*>(pi->p), pi->pitch(), pb,
                              (size_t)chunk_rows_, stream_), "copy of pi");
-    chk(elfgo_memcpy2d_async((char*)d_v_ + (size_t)rows_done_ * 4, 4, reinterpret_cast<const void*>(v->p), v->pitch(), 4,
+    chk(elfgo_memcpy2d_async((char*)d_v_[a] + (size_t)rows_done_[a] * 4, 4, reinterpret_cast<const void*>(v->p), v->pitch(), 4,
                              (size_t)chunk_rows_, stream_), "copy of V");
     AnyP* rv = sm->get("rv");
-    have_rv_ = rv && rv->p != 0;
-    if (have_rv_)
-      chk(elfgo_memcpy2d_async((char*)d_rv_ + (size_t)rows_done_ * 8, 8, reinterpret_cast<const void*>(rv->p), rv->pitch(), 8,
+    have_rv_[a] = rv && rv->p != 0;
+    if (have_rv_[a])
+      chk(elfgo_memcpy2d_async((char*)d_rv_[a] + (size_t)rows_done_[a] * 8, 8, reinterpret_cast<const void*>(rv->p), rv->pitch(), 8,
                                (size_t)chunk_rows_, stream_), "copy of rv");
     // "a" (ReplyAction) is a reply key of the actor groups too; the MCTS actor never reads GoReply.c (go/mcts/mcts.h:209-230)
-    rows_done_ += chunk_rows_;
-    rows_left_ -= chunk_rows_;
-    if (rows_left_ == 0) finish_search_step();
+    rows_done_[a] += chunk_rows_;
+    rows_left_[a] -= chunk_rows_;
+    if (!rows_pending()) finish_search_step();
   }
 
   void finish_search_step() {
     const int64_t games_before = elfsp_games_finished(sp_);
-    int64_t st0[12];
-    chk(elfsp_stats(sp_, st0), "elfsp_stats");
-    const int rc = step_rows_ > 0
-        ? elfsp_end_step(sp_, (const float*)d_pi_, NA_, (const float*)d_v_, have_rv_ ? (const int64_t*)d_rv_ : nullptr, stream_)
-        : elfsp_end_step(sp_, nullptr, 0, nullptr, nullptr, stream_);
+    const float* pis[2] = {step_rows_[0] > 0 ? (const float*)d_pi_[0] : nullptr, step_rows_[1] > 0 ? (const float*)d_pi_[1] : nullptr};
+    const float* vs[2] = {step_rows_[0] > 0 ? (const float*)d_v_[0] : nullptr, step_rows_[1] > 0 ? (const float*)d_v_[1] : nullptr};
+    const int64_t* rvs[2] = {have_rv_[0] ? (const int64_t*)d_rv_[0] : nullptr, have_rv_[1] ? (const int64_t*)d_rv_[1] : nullptr};
+    const int rc = elfsp_end_step2(sp_, pis, NA_, vs, rvs, stream_);
     if (rc == ELFGO_E_MCTS_BASE - ELFMCTS_E_VERSION || (rc < ELFGO_E_MCTS_BASE && ((ELFGO_E_MCTS_BASE - rc) & ELFMCTS_E_VERSION)))
-      throw std::runtime_error("model version of a reply (rv) and required version " + std::to_string(black_ver_) +
-                               " are not consistent");                                   // go/mcts/mcts.h:210-217
+      throw std::runtime_error("model version of a reply (rv) and required version (black " + std::to_string(black_ver_) + ", white " +
+                               std::to_string(white_ver_) + ") are not consistent");      // go/mcts/mcts.h:210-217
     chk(rc, "elfsp_end_step");
-    int64_t st1[12];
-    chk(elfsp_stats(sp_, st1), "elfsp_stats");
-    if (st1[0] != st0[0]) search_running_ = false;   // a move was played: the search of this move is over
+    int64_t pr[6];
+    chk(elfsp_progress(sp_, pr), "elfsp_progress");     // host counters, no device synchronisation
+    if (pr[2] == 0) search_running_ = false;            // no search is open any more: the move boundary has been passed
     const int64_t done = elfsp_games_finished(sp_) - games_before;
     if (done > 0) note_finished((int)done);
   }
@@ -779,9 +831,9 @@ class Context {
     if (!sm) { search_running_ = true; begin_search_step(); return nullptr; }   // no human group: the AI plays every move
     AnyP* s = need(sm, "s", "float");
     // BoardFeature bf(s): D4 code 0 (no random symmetry for the human's view)
-    chk(elfgo_extract_agz(elfsp_engine(sp_), nullptr, nullptr, 1, (float*)d_s_, row_floats_, stream_), "extract_agz");
+    chk(elfgo_extract_agz(elfsp_engine(sp_), nullptr, nullptr, 1, (float*)d_s_[0], row_floats_, stream_), "extract_agz");
     const size_t rb = (size_t)row_floats_ * 4;
-    chk(elfgo_memcpy2d_async(reinterpret_cast<void*>(s->p), s->pitch(), d_s_, rb, rb, 1, stream_), "copy of the feature row");
+    chk(elfgo_memcpy2d_async(reinterpret_cast<void*>(s->p), s->pitch(), d_s_[0], rb, rb, 1, stream_), "copy of the feature row");
     chk(elfgo_stream_sync(stream_), "sync");
     return serve(sm, 1, K_HUMAN);
   }
@@ -823,20 +875,20 @@ class Context {
   void board_info(int game, int32_t* out) const {
     const int32_t g = game;
     char* d = (char*)d_one_;
-    chk(elfgo_set_device(device_), "hipSetDevice");
+    DevScope _ds(device_);
     chk(elfgo_memcpy_h2d(d, &g, 4), "memcpy");
-    chk(elfgo_info(elfsp_engine(sp_), (const int32_t*)d, 1, (int32_t*)(d + 64), nullptr), "elfgo_info");
-    chk(elfgo_stream_sync(nullptr), "sync");
+    chk(elfgo_info(elfsp_engine(sp_), (const int32_t*)d, 1, (int32_t*)(d + 64), stream_), "elfgo_info");
+    chk(elfgo_stream_sync(stream_), "sync");
     chk(elfgo_memcpy_d2h(out, d + 64, ELFGO_INFO_WORDS * 4), "memcpy");
   }
   void board_stones(int game, std::vector<uint8_t>* colour) const {
     const int32_t g = game;
     const int np = go_.board_size * go_.board_size;
     char* d = (char*)d_one_;
-    chk(elfgo_set_device(device_), "hipSetDevice");
+    DevScope _ds(device_);
     chk(elfgo_memcpy_h2d(d, &g, 4), "memcpy");
-    chk(elfgo_export_board(elfsp_engine(sp_), (const int32_t*)d, 1, (uint8_t*)(d + 256), (int16_t*)(d + 1024), nullptr), "elfgo_export_board");
-    chk(elfgo_stream_sync(nullptr), "sync");
+    chk(elfgo_export_board(elfsp_engine(sp_), (const int32_t*)d, 1, (uint8_t*)(d + 256), (int16_t*)(d + 1024), stream_), "elfgo_export_board");
+    chk(elfgo_stream_sync(stream_), "sync");
     colour->resize(np);
     chk(elfgo_memcpy_d2h(colour->data(), d + 256, np), "memcpy");
   }
@@ -844,10 +896,10 @@ class Context {
     const int32_t g = game;
     char* d = (char*)d_one_;
     float v = 0;
-    chk(elfgo_set_device(device_), "hipSetDevice");
+    DevScope _ds(device_);
     chk(elfgo_memcpy_h2d(d, &g, 4), "memcpy");
-    chk(elfgo_evaluate(elfsp_engine(sp_), (const int32_t*)d, 1, go_.komi, (float*)(d + 3072), nullptr), "elfgo_evaluate");
-    chk(elfgo_stream_sync(nullptr), "sync");
+    chk(elfgo_evaluate(elfsp_engine(sp_), (const int32_t*)d, 1, go_.komi, (float*)(d + 3072), stream_), "elfgo_evaluate");
+    chk(elfgo_stream_sync(stream_), "sync");
     chk(elfgo_memcpy_d2h(&v, d + 3072, 4), "memcpy");
     return v;
   }
@@ -865,13 +917,14 @@ class Context {
   GameStats stats_;
   ElfSelfPlay* sp_ = nullptr;
   void* stream_ = nullptr;
-  int device_ = 0, max_rows_ = 0, NA_ = 0, row_floats_ = 0;
-  void *d_s_ = nullptr, *d_pi_ = nullptr, *d_v_ = nullptr, *d_rv_ = nullptr, *d_one_ = nullptr;
+  int device_ = 0, max_rows_[2] = {0, 0}, NA_ = 0, row_floats_ = 0;
+  void *d_s_[2] = {nullptr, nullptr}, *d_pi_[2] = {nullptr, nullptr}, *d_v_[2] = {nullptr, nullptr}, *d_rv_[2] = {nullptr, nullptr};
+  void* d_one_ = nullptr;
   std::vector<void*> owned_;
-  bool started_ = false, stopped_ = false, have_request_ = false, search_running_ = false, have_rv_ = false;
+  bool started_ = false, stopped_ = false, have_request_ = false, search_running_ = false, have_rv_[2] = {false, false};
   int64_t black_ver_ = 0, white_ver_ = -1;
   int pending_game_start_ = 0, pending_game_end_ = 0;
-  int step_rows_ = 0, rows_left_ = 0, rows_done_ = 0, chunk_rows_ = 0;
+  int step_rows_[2] = {0, 0}, rows_left_[2] = {0, 0}, rows_done_[2] = {0, 0}, chunk_rows_ = 0, chunk_actor_ = 0;
   SharedMem* current_ = nullptr;
   int current_kind_ = 0;
 };
@@ -957,7 +1010,9 @@ float GameView::getLastScore() const {
 // ---- GameContext (inference/game_context.h:29-122, train/game_context.h:33-133), Client (train/distri_client.h:262-331) ----------
 struct Client {
   Context* ctx;
-  void setRequest(int64_t black_ver, int64_t white_ver, float thres, int numThreads) { ctx->setRequest(black_ver, white_ver, thres, numThreads); }
+  void setRequest(int64_t black_ver, int64_t white_ver, float thres, int numThreads, bool player_swap) {
+    ctx->setRequest(black_ver, white_ver, thres, numThreads, player_swap);
+  }
   GameStats& getGameStats() { return ctx->stats(); }
 };
 
@@ -1115,7 +1170,8 @@ PYBIND11_MODULE(_elf, m) {
       .def("getLastScore", &GameView::getLastScore);
 
   py::class_<Client>(go, "Client")
-      .def("setRequest", &Client::setRequest)
+      .def("setRequest", &Client::setRequest, py::arg("black_ver"), py::arg("white_ver"), py::arg("thres"), py::arg("numThreads") = -1,
+           py::arg("player_swap") = false)
       .def("getGameStats", &Client::getGameStats, ref);
 
   py::class_<Server>(go, "Server");

@@ -208,6 +208,7 @@ SpRecordMeta elfrec_meta_from_options(const ElfSpOptions& o) {
   m.c_puct = o.mcts.c_puct; m.root_epsilon = o.root_epsilon; m.root_alpha = o.root_alpha;
   m.black_resign_thres = o.resign_thres; m.white_resign_thres = o.resign_thres; m.never_resign_prob = o.never_resign_prob;
   m.num_game_thread_used = o.num_games;
+  m.pick_method = o.pick_method;
   return m;
 }
 
@@ -215,11 +216,14 @@ std::string elfrec_record_json(const SpRecordMeta& m, const SpRecord& r) {
   std::string o;
   o.reserve(4096 + r.policies.size() * 3);
   const int P = (m.board_size + 2) * (m.board_size + 2);
-  o += "{\"offline\":false,\"pri\":0.0,\"request\":{\"client_ctrl\":{\"async\":false,\"black_resign_thres\":";
+  o += "{\"offline\":false,\"pri\":0.0,\"request\":{\"client_ctrl\":{\"async\":";
+  put_bool(o, m.async);
+  o += ",\"black_resign_thres\":";
   put_float(o, m.black_resign_thres);
   o += ",\"client_type\":1,\"never_resign_prob\":"; put_float(o, m.never_resign_prob);
   o += ",\"num_game_thread_used\":" + std::to_string(m.num_game_thread_used);
-  o += ",\"player_swap\":false,\"white_resign_thres\":"; put_float(o, m.white_resign_thres);
+  o += ",\"player_swap\":"; put_bool(o, m.player_swap);
+  o += ",\"white_resign_thres\":"; put_float(o, m.white_resign_thres);
   o += "},\"vers\":{\"black_ver\":" + std::to_string(m.black_ver) + ",\"mcts_opt\":{\"alg_opt\":{\"c_puct\":"; put_float(o, m.c_puct);
   o += ",\"root_unexplored_q_zero\":"; put_bool(o, m.root_unexplored_q_zero);
   o += ",\"unexplored_q_zero\":"; put_bool(o, m.unexplored_q_zero);
@@ -227,7 +231,9 @@ std::string elfrec_record_json(const SpRecordMeta& m, const SpRecord& r) {
   o += "},\"log_prefix\":\"\",\"max_num_moves\":0,\"num_rollouts_per_batch\":" + std::to_string(m.num_rollouts_per_batch);
   o += ",\"num_rollouts_per_thread\":" + std::to_string(m.num_rollouts_per_thread);
   o += ",\"num_threads\":" + std::to_string(m.num_threads) + ",\"persistent_tree\":"; put_bool(o, m.persistent_tree);
-  o += ",\"pick_method\":\"most_visited\",\"root_alpha\":"; put_float(o, m.root_alpha);
+  o += std::string(",\"pick_method\":\"") + (m.pick_method == 1 ? "strongest_prior" : m.pick_method == 2 ? "uniform_random" : "most_visited") +
+       "\",\"root_alpha\":";
+  put_float(o, m.root_alpha);
   o += ",\"root_epsilon\":"; put_float(o, m.root_epsilon);
   o += ",\"seed\":0,\"verbose\":false,\"verbose_time\":false,\"virtual_loss\":" + std::to_string(m.virtual_loss);
   o += "},\"white_ver\":" + std::to_string(m.white_ver) + "}},\"result\":{\"black_never_resign\":"; put_bool(o, r.never_resign);
@@ -343,9 +349,9 @@ int elfrec_sgfstr_to_coords(int board_size, const char* sgf, uint16_t* out, int 
 }
 
 // Record JSON from plain arrays (what elfsp_pop_record returns for a finished game); usable without a GPU
-int elfrec_record_to_json(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const uint8_t* policies, int num_policies,
-                          const float* values, int num_values, float reward, int never_resign, int seq, uint64_t thread_id,
-                          uint64_t timestamp, char* out, size_t cap) {
+int elfrec_record_to_json2(const ElfSpOptions* opt, const ElfSpRequest* request, const uint16_t* moves, int num_moves,
+                           const uint8_t* policies, int num_policies, const float* values, int num_values, float reward, int never_resign,
+                           int seq, uint64_t thread_id, uint64_t timestamp, char* out, size_t cap) {
   if (!opt || num_moves < 0 || num_policies < 0 || num_values < 0 || (num_moves && !moves) || (num_policies && !policies) ||
       (num_values && !values)) return ELFGO_E_BADARG;
   SpRecord r;
@@ -354,10 +360,24 @@ int elfrec_record_to_json(const ElfSpOptions* opt, const uint16_t* moves, int nu
   r.policies.assign(policies, policies + (size_t)num_policies * P);
   r.values.assign(values, values + num_values);
   r.reward = reward; r.never_resign = never_resign != 0; r.num_move = num_moves; r.seq = seq; r.thread_id = thread_id; r.timestamp = timestamp;
-  const std::string t = elfrec_record_json(elfrec_meta_from_options(*opt), r);
+  SpRecordMeta m = elfrec_meta_from_options(*opt);
+  if (request) {
+    m.black_ver = request->black_ver; m.white_ver = request->white_ver;
+    m.black_resign_thres = request->black_resign_thres; m.white_resign_thres = request->white_resign_thres;
+    m.never_resign_prob = request->never_resign_prob; m.num_game_thread_used = request->num_game_thread_used;
+    m.player_swap = request->player_swap != 0; m.async = request->async != 0;
+  }
+  const std::string t = elfrec_record_json(m, r);
   if (out && cap > t.size()) { memcpy(out, t.data(), t.size()); out[t.size()] = 0; }
   else if (out) return ELFGO_E_BADSIZE;
   return (int)t.size();
+}
+
+int elfrec_record_to_json(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const uint8_t* policies, int num_policies,
+                          const float* values, int num_values, float reward, int never_resign, int seq, uint64_t thread_id,
+                          uint64_t timestamp, char* out, size_t cap) {
+  return elfrec_record_to_json2(opt, nullptr, moves, num_moves, policies, num_policies, values, num_values, reward, never_resign, seq,
+                                thread_id, timestamp, out, cap);
 }
 
 // GoStateExt::addMCTSPolicy (go_state_ext.h:158-181): out[(N+2)^2] <- 0; out[coord[k]] = (unsigned char)(prob[k] / max * 255)

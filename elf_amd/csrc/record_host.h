@@ -15,6 +15,8 @@ struct SpRecordMeta {          // the MsgRequest half of a Record (record.h:119-
   // ClientCtrl (record.h:32-55)
   float black_resign_thres, white_resign_thres, never_resign_prob;
   int num_game_thread_used;
+  bool player_swap = false, async = false;
+  int pick_method = 0;       // ELFSP_PICK_*
 };
 
 struct SpRecord {              // the MsgResult half (record.h:184-234) + Record's own fields (:236-262)

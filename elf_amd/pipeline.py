@@ -21,8 +21,10 @@ from .selfplay import SelfPlay
 
 class PipelinedSelfPlay:
     def __init__(self, groups=2, seed=0, game_idx_base=0, wait_rows=False, net_streams=1, **kw):
-        ng = int(kw["num_games"])
-        self.groups = [SelfPlay(seed=seed, game_idx_base=game_idx_base + i * ng, **kw) for i in range(groups)]
+        # the first group tells how many games a group holds (SelfPlay's own default when the caller does not say)
+        self.groups = [SelfPlay(seed=seed, game_idx_base=game_idx_base, **kw)]
+        ng = self.groups[0].num_games
+        self.groups += [SelfPlay(seed=seed, game_idx_base=game_idx_base + i * ng, **kw) for i in range(1, groups)]
         dev = self.groups[0].device
         self.device = dev
         self.wait_rows = bool(wait_rows)

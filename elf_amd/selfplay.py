@@ -32,7 +32,21 @@ class SpOptions(C.Structure):
                 ("root_alpha", C.c_float), ("seed", C.c_uint32), ("policy_distri_cutoff", C.c_int32),
                 ("move_cutoff", C.c_int32), ("resign_thres", C.c_float), ("never_resign_prob", C.c_float),
                 ("log_searches", C.c_int32), ("keep_records", C.c_int32), ("policy_distri_training_for_all", C.c_int32),
-                ("model_ver", C.c_int32), ("game_idx_base", C.c_int32), ("job_hash", C.c_uint64), ("mcts", MctsOptions)]
+                ("model_ver", C.c_int32), ("game_idx_base", C.c_int32), ("job_hash", C.c_uint64), ("mcts", MctsOptions),
+                ("white_puct", C.c_float), ("white_mcts_rollout_per_batch", C.c_int32), ("white_mcts_rollout_per_thread", C.c_int32),
+                ("black_use_policy_network_only", C.c_int32), ("white_use_policy_network_only", C.c_int32), ("pick_method", C.c_int32),
+                ("cheat_eval_new_model_wins_half", C.c_int32), ("cheat_selfplay_random_result", C.c_int32),
+                ("following_pass", C.c_int32), ("reserved1", C.c_int32)]
+
+
+class SpRequest(C.Structure):
+    """ElfSpRequest"""
+    _fields_ = [("black_ver", C.c_int64), ("white_ver", C.c_int64), ("black_resign_thres", C.c_float),
+                ("white_resign_thres", C.c_float), ("never_resign_prob", C.c_float), ("num_game_thread_used", C.c_int32),
+                ("player_swap", C.c_int32), ("async_", C.c_int32)]
+
+
+PICK_METHODS = {"most_visited": 0, "strongest_prior": 1, "uniform_random": 2}
 
 
 class SpSearch(C.Structure):
@@ -53,7 +67,11 @@ STAT_FIELDS = ("moves", "games", "rollouts", "rows", "steps", "logged", "steps_p
 
 
 class SelfPlay:
-    """G self-play games in lock-step on one GPU; trees, boards and leaf features live in HBM."""
+    """G self-play games stepped together on one GPU; trees, boards and leaf features live in HBM.
+
+    Seeds: game g of this context is the job-wide game game_idx_base + g and is seeded seed + game_idx_base + g (seed != 0).  Two
+    contexts created with the same seed AND the same game_idx_base therefore play identical games: give every context of a job
+    its own game_idx_base (PipelinedSelfPlay and bench.py do)."""
 
     def __init__(self, board_size=19, num_games=16, device=0, mcts_rollout_per_thread=8192, mcts_rollout_per_batch=16,
                  mcts_puct=1.5, mcts_virtual_loss=1, mcts_use_prior=True, mcts_persistent_tree=True, mcts_epsilon=0.0,
@@ -61,7 +79,10 @@ class SelfPlay:
                  ply_pass_enabled=0, policy_distri_cutoff=0, move_cutoff=-1, resign_thres=0.0, never_resign_prob=0.0,
                  seed=0, nodes_per_game=None, log_searches=0, rotation_flip=True, remove_pass_if_dangerous=True,
                  feature_format="f32_nchw", keep_records=0, policy_distri_training_for_all=False, model_ver=0,
-                 mcts_threads=1, game_idx_base=0, job_id="", required_version=-1):
+                 mcts_threads=1, game_idx_base=0, job_id="", required_version=-1, white_puct=-1.0, white_mcts_rollout_per_batch=-1,
+                 white_mcts_rollout_per_thread=-1, black_use_policy_network_only=False, white_use_policy_network_only=False,
+                 mcts_pick_method="most_visited", cheat_eval_new_model_wins_half=False, cheat_selfplay_random_result=False,
+                 following_pass=False):
         if not torch.cuda.is_available():
             raise RuntimeError("elf_amd.SelfPlay needs a ROCm GPU (no CPU fallback exists)")
         self.L = _lib.lib()
@@ -79,7 +100,9 @@ class SelfPlay:
         self.opt = SpOptions(self.n, self.num_games, nodes_per_game, mcts_rollout_per_thread, int(mcts_persistent_tree),
                              mcts_epsilon, mcts_alpha, seed, policy_distri_cutoff, move_cutoff, resign_thres, never_resign_prob,
                              log_searches, int(keep_records), int(policy_distri_training_for_all), int(model_ver), int(game_idx_base),
-                             job_hash(job_id), mo)
+                             job_hash(job_id), mo, white_puct, white_mcts_rollout_per_batch, white_mcts_rollout_per_thread,
+                             int(black_use_policy_network_only), int(white_use_policy_network_only), self._pick(mcts_pick_method),
+                             int(cheat_eval_new_model_wins_half), int(cheat_selfplay_random_result), int(following_pass), 0)
         z = np.fromfile(_lib.ZOBRIST_BIN, dtype="<u8")
         zz = np.ascontiguousarray(z[: (self.n + 2) ** 2])
         torch.cuda.set_device(self.device)
@@ -102,6 +125,12 @@ class SelfPlay:
         self._rows = C.c_int(0)
         self._waited = True
         self._cb = {}
+
+    @staticmethod
+    def _pick(name):
+        if name not in PICK_METHODS:
+            raise ValueError("MCTS Pick method unknown! " + str(name))   # tree_search.h:521-524
+        return PICK_METHODS[name]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -150,9 +179,58 @@ class SelfPlay:
         else:
             check(self.L.elfsp_end_step(self._h, None, 0, None, None, self._stream()))
 
-    def set_request(self, black_ver, white_ver=-1, resign_thres=0.0, never_resign_prob=0.0, async_=False):
-        """Client::setRequest (train/distri_client.h:318-331); takes effect at the next move boundary"""
-        check(self.L.elfsp_set_request(self._h, int(black_ver), int(white_ver), float(resign_thres), float(never_resign_prob), int(async_)))
+    def set_request(self, black_ver, white_ver=-1, resign_thres=0.0, never_resign_prob=0.0, async_=False, num_game_thread_used=-1,
+                    player_swap=False, white_resign_thres=None):
+        """Client::setRequest (train/distri_client.h:318-331): every game receives it at the top of its next fifth act (at once
+        while it waits); white_ver >= 0 starts evaluation games with a second AI for White (step them with begin_step2 / end_step2)"""
+        q = SpRequest(int(black_ver), int(white_ver), float(resign_thres), float(resign_thres if white_resign_thres is None else white_resign_thres),
+                      float(never_resign_prob), int(num_game_thread_used), int(player_swap), int(async_))
+        check(self.L.elfsp_set_request2(self._h, C.byref(q)))
+
+    # ---- games with two AIs: rows of the "actor_black" AI in self.s, rows of the "actor_white" AI in self.s_white
+    def _white_rows(self):
+        if getattr(self, "s_white", None) is None:
+            rows = self.L.elfsp_max_rows_actor(self._h, 1)
+            if self.feature_format == "f16_nhwc":
+                self.s_white = torch.zeros((rows, self.n, self.n, 18), dtype=torch.float16, device=self.device).permute(0, 3, 1, 2)
+            else:
+                self.s_white = torch.zeros((rows, 18, self.n, self.n), dtype=torch.float32, device=self.device)
+            self.max_rows_white = rows
+        return self.s_white
+
+    def begin_step2(self):
+        """-> (rows of actor_black, rows of actor_white)"""
+        sw = self._white_rows()
+        dst = (C.c_void_p * 2)(self.s.data_ptr(), sw.data_ptr())
+        rows = (C.c_int * 2)(0, 0)
+        check(self.L.elfsp_begin_step2(self._h, dst, 18 * self.n * self.n, rows, self._stream()))
+        self._rows2 = (rows[0], rows[1])
+        return self._rows2
+
+    def end_step2(self, replies):
+        """replies = [(pi, V, rv or None) or None for the two actors]"""
+        pis, vs, rvs, keep = (C.c_void_p * 2)(), (C.c_void_p * 2)(), (C.c_void_p * 2)(), []
+        stride = self.num_action
+        for a in range(2):
+            if not self._rows2[a]:
+                continue
+            pi, v, rv = replies[a]
+            pi = pi.float().contiguous()
+            v = v.float().contiguous().reshape(-1)
+            if pi.shape[0] < self._rows2[a] or pi.shape[1] != self.num_action or v.shape[0] < self._rows2[a]:
+                raise ValueError("reply shapes do not match the batch")
+            keep += [pi, v]
+            pis[a], vs[a] = pi.data_ptr(), v.data_ptr()
+            if rv is not None:
+                rv = rv.to(device=self.device, dtype=torch.int64).reshape(-1).contiguous()
+                keep.append(rv)
+                rvs[a] = rv.data_ptr()
+        check(self.L.elfsp_end_step2(self._h, pis, stride, vs, rvs, self._stream()))
+
+    def progress(self):
+        out = (C.c_int64 * 6)()
+        check(self.L.elfsp_progress(self._h, out))
+        return dict(zip(("searches", "games", "open", "steps", "waiting", "barrier"), [int(x) for x in out]))
 
     def reg_callback(self, key, cb):
         """GCWrapper.reg_callback (utils_elf.py:340-359): cb(batch) -> dict(pi=..., V=...)"""

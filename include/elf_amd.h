@@ -83,8 +83,9 @@ int elfgo_info(ElfGoEngine* e, const int32_t* ids, int n, int32_t* out, void* st
 int elfgo_export_board(ElfGoEngine* e, const int32_t* ids, int n, uint8_t* colour, int16_t* libs, void* stream);
 /* from each slot's current position play uniformly random legal, non-true-eye
  * moves until GoState::terminated(); pass when none.  The move is the (rand % count)-th candidate in x-major order with the
- * counter RNG rand = fmix32(fmix32(lo32(seed)) ^ fmix32(hi32(seed) + 0x7F4A7C15) + ply * 0x9E3779B9), fmix32 = murmur3's
- * 32-bit finaliser (oracle/go_oracle.c and oracle/ref_capi.cc state the same function for the CPU checkers).
+ * counter RNG   key = fmix32(lo32(seed)) ^ fmix32(hi32(seed) + 0x7F4A7C15);   rand = fmix32(key + ply * 0x9E3779B9)
+ * (32-bit wrapping arithmetic; fmix32 = murmur3's 32-bit finaliser; oracle/go_oracle.c and oracle/ref_capi.cc state the same
+ * function for the CPU checkers).
  * out[i] = {hash_lo, hash_hi, ply, steps}.  Whole games run inside one launch, position in LDS. */
 int elfgo_playout(ElfGoEngine* e, const int32_t* ids, const uint64_t* seeds, int n, int max_steps,
                   uint32_t* out, void* stream);
@@ -102,7 +103,7 @@ typedef struct ElfMcts ElfMcts;
 
 /* TSOptions + SearchAlgoOptions (elf/ai/tree_search/tree_search_options.h:23-229), MCTSActorParams (go/mcts/mcts.h:17-37) */
 typedef struct ElfMctsOptions {
-  int32_t num_rollouts_per_batch;   /* TSOptions.num_rollouts_per_batch, <= 64 */
+  int32_t num_rollouts_per_batch;   /* TSOptions.num_rollouts_per_batch */
   int32_t virtual_loss;             /* TSOptions.virtual_loss */
   int32_t use_prior;                /* alg_opt.use_prior */
   int32_t unexplored_q_zero;        /* alg_opt.unexplored_q_zero */
@@ -115,7 +116,8 @@ typedef struct ElfMctsOptions {
   int32_t num_threads;              /* TSOptions.num_threads: search threads per game (tree_search.h:345-368), >= 1; one step runs
                                      * their batch_rollouts in sequence on the shared tree, so a move costs
                                      * num_threads x num_rollouts_per_thread rollouts (tree_search.h:472-476).
-                                     * num_threads x num_rollouts_per_batch must be <= 64 (ELFGO_E_BADARG otherwise) */
+                                     * num_threads x num_rollouts_per_batch must be <= elfmcts_max_rollouts_per_step() = 256
+                                     * (the leaf table of one step; ELFGO_E_BADARG otherwise) */
   int32_t reserved0;
   int64_t required_version;         /* MCTSActorParams.required_version: < 0 = replies of any model version are accepted */
 } ElfMctsOptions;
@@ -138,6 +140,17 @@ int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt);
 /* row format elfmcts_select / elfsp_begin_step write into s_dst (ELFGO_FEAT_*; default fp32 NCHW). With
  * ELFGO_FEAT_F16_NHWC s_dst points to halfs and the stride argument counts halfs. */
 int elfmcts_set_feature_format(ElfMcts* m, int fmt);
+int elfmcts_get_feature_format(const ElfMcts* m, int* fmt);
+/* largest num_threads x num_rollouts_per_batch a search step can hold (256) */
+int elfmcts_max_rollouts_per_step(void);
+/* Which games the per-game launches that follow act on: mask = device bytes [num_games], 0 = the game is left alone (no root
+ * check, no noise, no descents, no rows), 1 = it searches, 2 = TreeSearchT::runPolicyOnly (tree_search.h:385-407: the root is
+ * evaluated if it has not been, nothing else).  NULL (the default) = every game searches.  Applies to elfmcts_set_root,
+ * elfmcts_dirichlet, elfmcts_select (and through it to expand / backup).  The pointer is kept, not copied. */
+int elfmcts_set_game_mask(ElfMcts* m, const uint8_t* mask);
+/* MCTSActorParams.required_version per game (device int64 [num_games], < 0 = any version); NULL (the default) = the value of
+ * ElfMctsOptions.required_version for every game.  The pointer is kept, not copied. */
+int elfmcts_set_required_versions(ElfMcts* m, const int64_t* versions);
 int elfmcts_num_games(const ElfMcts* m);
 int elfmcts_edge_stride(const ElfMcts* m);   /* row length of the per-edge arrays (368 at 19x19, 96 at 9x9) */
 size_t elfmcts_node_bytes(const ElfMcts* m);
@@ -202,14 +215,34 @@ typedef struct ElfSpOptions {
   int32_t game_idx_base;            /* global index of this context's game 0 in the whole job (rank x games + group offset) */
   uint64_t job_hash;                /* std::hash of ContextOptions.job_id, only used by the seed == 0 rule below */
   ElfMctsOptions mcts;
+  /* the second AI of evaluation games (a request with white_ver >= 0): init_ai's overrides, game_selfplay.cc:171-181 */
+  float white_puct;                         /* GameOptions.white_puct: > 0 replaces c_puct for the "actor_white" AI */
+  int32_t white_mcts_rollout_per_batch;     /* GameOptions.white_mcts_rollout_per_batch: > 0 replaces num_rollouts_per_batch */
+  int32_t white_mcts_rollout_per_thread;    /* GameOptions.white_mcts_rollout_per_thread: > 0 replaces num_rollouts_per_thread */
+  int32_t black_use_policy_network_only;    /* GameOptions.*_use_policy_network_only: that colour's moves are MCTSAI_T::actPolicyOnly */
+  int32_t white_use_policy_network_only;    /*   (elf/ai/tree_search/mcts.h:83-90, game_selfplay.cc:357-372) */
+  int32_t pick_method;                      /* TSOptions.pick_method, ELFSP_PICK_* (tree_search.h:495-528) */
+  int32_t cheat_eval_new_model_wins_half;   /* GameOptions.cheat_* (finish_game, game_selfplay.cc:122-129) */
+  int32_t cheat_selfplay_random_result;
+  int32_t following_pass;                   /* GameOptions.following_pass with a human opponent (mcts_update_info :104-111) */
+  int32_t reserved1;
 } ElfSpOptions;
+#define ELFSP_PICK_MOST_VISITED 0
+#define ELFSP_PICK_STRONGEST_PRIOR 1
+#define ELFSP_PICK_UNIFORM_RANDOM 2   /* the reference draws from a process-wide mt19937 seeded with time(NULL) (tree_search_base.h:238);
+                                         here one generator per context, seeded seed ^ 0x5EED, or time(NULL) for seed == 0 */
+#define ELFSP_ACTOR_BLACK 0           /* the AI created as "actor_black" with the request's black_ver */
+#define ELFSP_ACTOR_WHITE 1           /* the AI created as "actor_white" with the request's white_ver (evaluation games only) */
 /* Per-game RNG seeds.  The reference seeds every GoGameBase with GameOptions.seed itself (common/game_base.h:32-38), so with a
  * non-zero seed and a deterministic net all its games are identical; its time-seeded default (seed == 0) is what production
  * runs use.  Here game g (global index i = game_idx_base + g) is seeded
  *   seed != 0:  seed + i            (the rule of this repository's reference harness, oracle/ref_selfplay.cc: distinct,
  *                                    reproducible games; i is unique over groups and ranks, so no two games of a job collide)
- *   seed == 0:  (unix_seconds*1000 + unix_milliseconds + (i ^ job_hash) * 2341479) % 100000000
- *                                   (elf_utils::get_seed, elf/utils/utils.h:50-57, as GoGameBase calls it)
+ *   seed == 0:  (unix_seconds*1000 + unix_milliseconds + int32(int32(i ^ job_hash) * 2341479)) % 100000000
+ *                                   (elf_utils::get_seed(int), elf/utils/utils.h:50-57, as GoGameBase calls it: the game term is a
+ *                                    32-bit int product that wraps; job_hash is any 64-bit hash of the job id -- the reference's
+ *                                    std::hash<std::string> through the pybind boundary -- so the seeds are of the same form, and
+ *                                    time-based like the reference's, never reproducible)
  * and the MCTS actor seed is the first draw of that generator (game_selfplay.cc:45-47). */
 
 /* what GameNotifierBase::OnMCTSResult (common/notifier.h:13) sees after one search */
@@ -223,6 +256,10 @@ int elfsp_destroy(ElfSelfPlay* sp);
 ElfGoEngine* elfsp_engine(ElfSelfPlay* sp);
 ElfMcts* elfsp_mcts(ElfSelfPlay* sp);
 int elfsp_max_rows(const ElfSelfPlay* sp);   /* num_games * num_threads * num_rollouts_per_batch */
+/* the same bound for one of the two AIs (the "actor_white" AI may have its own batch override) */
+int elfsp_max_rows_actor(const ElfSelfPlay* sp, int actor);
+/* the tree pool of one AI; NULL until a request has created it (actor 1) */
+ElfMcts* elfsp_mcts_actor(ElfSelfPlay* sp, int actor);
 /* s_dst: device rows in the context's feature format (elfmcts_set_feature_format: fp32 [18][N][N] or fp16 [N][N][18]), rows
  * stride_elems elements apart.  n_rows != NULL: the call waits for the device and stores the number of rows that need the net.
  * n_rows == NULL: nothing is waited for inside a move -- the row count stays on the device, the net evaluates elfsp_max_rows()
@@ -235,12 +272,43 @@ int elfsp_begin_step(ElfSelfPlay* sp, void* s_dst, int64_t stride_elems, int* n_
 int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, const float* value, const int64_t* rv, void* stream);
 /* rows of the last begin_step (synchronises the stream of that call) */
 int elfsp_last_rows(ElfSelfPlay* sp, int* n_rows);
-/* Client::setRequest / GameContext::setRequest (train/distri_client.h:318-331, inference/game_context.h:76-88): model versions
- * and resign threshold for the games from the next move boundary on.  A new black_ver restarts every game from the empty board
- * without a record (GoGameSelfPlay::OnReceive -> restart, game_selfplay.cc:222-270) and becomes the version replies must carry
- * ("rv"; async != 0 switches the check off, setAsync :150-156) and records report.  white_ver >= 0 (a second AI for White,
- * game_selfplay.cc:171-185) is not supported: ELFGO_E_BADARG. */
+/* The same pair for games with two AIs (a request with white_ver >= 0): index ELFSP_ACTOR_BLACK / ELFSP_ACTOR_WHITE = the batch
+ * group the rows belong to ("actor_black" / "actor_white", game_selfplay.cc:165-181), each evaluated by its own model.  s_dst[a]
+ * may be NULL while AI a has no game searching (always true for actor 1 under a self-play request); n_rows (may be NULL) <- the
+ * two row counts.  A game searches with the AI of the colour to move (player_swap exchanges the two); the AIs may need different
+ * numbers of steps per move, so searches of different games are not in step.  elfsp_begin_step / elfsp_end_step are the
+ * one-AI forms of these calls and refuse (ELFGO_E_BADARG) a step in which the second AI has rows. */
+int elfsp_begin_step2(ElfSelfPlay* sp, void* const* s_dst, int64_t stride_elems, int* n_rows, void* stream);
+int elfsp_end_step2(ElfSelfPlay* sp, const float* const* pi, int64_t pi_stride_floats, const float* const* value,
+                    const int64_t* const* rv, void* stream);
+int elfsp_last_rows2(ElfSelfPlay* sp, int* n_rows);
+/* Client::setRequest / GameContext::setRequest (train/distri_client.h:318-331, inference/game_context.h:76-88): a MsgRequest
+ * (common/record.h:119-149) for the games.  As in the reference a game looks at its mailbox at the top of every fifth act
+ * (game_selfplay.cc:273-289) -- or at once while it is waiting -- and then (GoGameSelfPlay::OnReceive :222-270):
+ *   black_ver < 0                      the game waits (ModelPair::wait) until a request gives it something to play;
+ *   num_game_thread_used = k >= 0      games k, k+1, ... receive the request as a wait request (DispatcherCallback::OnFirstSend);
+ *   new versions / new player_swap / the game was waiting:  restart from the empty board without a record, new AIs seeded with
+ *                                      the next draws of the game's generator; white_ver >= 0 creates the second AI for White
+ *                                      (own tree pool, ElfSpOptions.white_* overrides); player_swap exchanges the two;
+ *   same versions or async             only thresholds (and with async: no version check on replies) change.
+ * Restarted games stay idle until every game has received the request; then one "game_start" is due
+ * (elfsp_take_game_starts) and they play.  Replies must carry the AI's version in "rv" unless async.
+ * Requests queue: each is delivered to all games before the next one goes out (elf/base/dispatcher.h:104-152). */
+typedef struct ElfSpRequest {
+  int64_t black_ver, white_ver;       /* ModelPair */
+  float black_resign_thres, white_resign_thres, never_resign_prob;   /* ClientCtrl; the resign check uses the mean of the two */
+  int32_t num_game_thread_used;       /* ClientCtrl.num_game_thread_used, -1 = all games */
+  int32_t player_swap;                /* ClientCtrl.player_swap */
+  int32_t async;                      /* ClientCtrl.async */
+} ElfSpRequest;
+int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* request);
+/* the same with both thresholds equal, every game used, no swap */
 int elfsp_set_request(ElfSelfPlay* sp, int64_t black_ver, int64_t white_ver, float resign_thres, float never_resign_prob, int async);
+/* host-only progress counters, no device synchronisation: out6 = {searches finished, games finished, searches open, steps,
+ * games waiting for a request, games waiting at a request barrier} */
+int elfsp_progress(const ElfSelfPlay* sp, int64_t* out6);
+/* which AI of `game` is searching now (ELFSP_ACTOR_*), -1 = between two searches; host-only */
+int elfsp_game_actor(const ElfSelfPlay* sp, int game);
 /* number of times the games were (re)started by a request since the last call (each is one "game_start" batch of the reference,
  * common/dispatcher_callback.h:86-88); *black_ver / *white_ver <- the versions of the current request */
 int elfsp_take_game_starts(ElfSelfPlay* sp, int64_t* black_ver, int64_t* white_ver);
@@ -351,6 +419,11 @@ int elfrec_sgfstr_to_coords(int board_size, const char* sgf, uint16_t* out, int 
 int elfrec_record_to_json(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const uint8_t* policies, int num_policies,
                           const float* values, int num_values, float reward, int never_resign, int seq, uint64_t thread_id,
                           uint64_t timestamp, char* out, size_t cap);
+/* the same under an explicit MsgRequest (evaluation games: white_ver, player_swap, the request's thresholds and thread count);
+ * request == NULL: the self-play request of the options, as above */
+int elfrec_record_to_json2(const ElfSpOptions* opt, const ElfSpRequest* request, const uint16_t* moves, int num_moves,
+                           const uint8_t* policies, int num_policies, const float* values, int num_values, float reward, int never_resign,
+                           int seq, uint64_t thread_id, uint64_t timestamp, char* out, size_t cap);
 /* GoStateExt::addMCTSPolicy (go_state_ext.h:158-181): out[(N+2)^2] = (unsigned char)(prob / max(prob) * 255) at each coord */
 int elfrec_quantise_policy(int board_size, const int32_t* coord, const float* prob, int n, uint8_t* out);
 

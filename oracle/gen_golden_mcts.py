@@ -37,6 +37,24 @@ CASES = {
     "mcts_9_r128_bs64": (9, dict(rollouts_per_thread=128, rollouts_per_batch=64, batchsize=64, max_searches=30, net_salt=35,
                                  ply_pass_enabled=4, komi=5.5)),
     "mcts_9_r64_ties": (9, dict(rollouts_per_thread=64, max_searches=60, net_tie_levels=3, root_epsilon=0.1, root_alpha=0.5)),
+    # evaluation games: a second MCTSGoAI for White (game_selfplay.cc:165-185) with its own model ("actor_white" rows get another
+    # stub net), puct / batch / rollout overrides (init_ai :51-70); games run to the cutoff and restart
+    "mcts_9_eval_two_ai": (9, dict(rollouts_per_thread=64, rollouts_per_batch=8, batchsize=8, max_searches=60, black_ver=5, white_ver=6,
+                                   net_salt=51, white_net_salt=52, white_puct=0.9, white_rollouts_per_batch=4,
+                                   white_rollouts_per_thread=48, policy_distri_cutoff=6, move_cutoff=40)),
+    "mcts_19_eval_swap": (19, dict(rollouts_per_thread=128, max_searches=10, black_ver=2, white_ver=3, player_swap=1, net_salt=53,
+                                   white_net_salt=54, policy_distri_cutoff=4)),
+    # TSOptions.pick_method = strongest_prior (tree_search.h:506-509; the MCTS policy is then the normalised priors)
+    "mcts_9_pick_prior": (9, dict(rollouts_per_thread=64, max_searches=30, pick_method=1, net_salt=55, policy_distri_cutoff=5)),
+    # GameOptions.white_use_policy_network_only: White's moves are MCTSAI_T::actPolicyOnly (mcts.h:83-90), one AI
+    "mcts_9_policy_only_white": (9, dict(rollouts_per_thread=64, max_searches=40, white_policy_only=1, net_salt=56,
+                                         policy_distri_cutoff=4, move_cutoff=30)),
+    "mcts_9_policy_only_eval": (9, dict(rollouts_per_thread=64, max_searches=40, black_policy_only=1, black_ver=1, white_ver=2,
+                                        net_salt=57, white_net_salt=58, move_cutoff=30)),
+    # TSOptions without a bound on the batch: 128 rollouts per batch in one search thread (tree_search_options.h:81)
+    "mcts_9_r256_bs128": (9, dict(rollouts_per_thread=256, rollouts_per_batch=128, batchsize=128, max_searches=20, net_salt=59,
+                                  policy_distri_cutoff=4)),
+    "mcts_19_r512_bs256": (19, dict(rollouts_per_thread=512, rollouts_per_batch=256, batchsize=256, max_searches=4, net_salt=60)),
 }
 
 
@@ -61,7 +79,8 @@ def main():
             total_visits=np.array([s.total_visits for s in S], np.int32),
             n_edges=np.array([s.n_edges for s in S], np.int32),
             root_value=np.array([s.root_value for s in S], np.float32),
-            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"])
+            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"],
+            rows=np.int64(r["rows"]), white_rows=np.int64(r["white_rows"]))
         print(name, "searches", len(S), "moves", [s.move_played for s in S][:12], "rows", r["rows"], "ref search s", r["usec"] / 1e6)
 
 

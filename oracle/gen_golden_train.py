@@ -41,6 +41,16 @@ RECORD_CASES = {
 }
 
 
+# round 3: records of evaluation games (Record.request carries white_ver / player_swap, using_models both versions); written as
+# records_*.npz only -- the train_*.npz rows above stay as they were generated
+RECORD_CASES_R3 = {
+    "records_9_eval": (9, dict(rollouts_per_thread=48, max_searches=70, policy_distri_cutoff=6, net_salt=71, white_net_salt=72,
+                               black_ver=11, white_ver=12, white_rollouts_per_thread=32, white_puct=1.2, move_cutoff=24)),
+    "records_9_eval_swap_resign": (9, dict(rollouts_per_thread=32, max_searches=160, policy_distri_cutoff=4, net_salt=73, white_net_salt=74,
+                                           black_ver=21, white_ver=20, player_swap=1, resign_thres=0.9, move_cutoff=70)),
+}
+
+
 def split_records(txt):
     return [json.dumps(j, separators=(",", ":")) for j in json.loads(txt)]
 
@@ -76,44 +86,52 @@ def synth_record(n, seed, rng, with_policies):
             "seq": int(rng.integers(2, 50)), "thread_id": 0, "timestamp": 0}
 
 
+def dump_case(name, n, kw):
+    R = RefSelfPlay(n)
+    cfg = dict(MCTS_DEFAULTS)
+    kw = dict(kw)
+    pre = kw.pop("preload", None)
+    extra = {}
+    if pre is not None:
+        port = Port(n)
+        st = port.new()
+        mv = port.playout_moves(st, int(playout_seeds(1, base=pre[0])[0]))[: pre[1]]
+        port.free(st)
+        path = "/tmp/elf_preload_%s.sgf" % name
+        with open(path, "w") as fh:
+            fh.write("(;GM[1]FF[4]SZ[%d]KM[7.5]" % n + R.coords2sgfstr(mv)[1:])
+        R.set_preload(path, pre[2])
+        extra = dict(preload_moves=np.array(mv, np.uint16), preload_move_to=np.int32(pre[2]))
+    cfg.update(kw)
+    r = R.run(**cfg)
+    R.set_preload("", -1)
+    recs = json.loads(r["records"])
+    exact = [R.record_roundtrip(t) for t in split_records(r["records"])]
+    assert len(recs) >= 1, name
+    # the round trip through Record::createFromJson must reproduce the text the game thread dumped
+    assert "[" + ",".join(exact) + "]" == r["records"], name
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), board_size=np.int32(n),
+                        cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], np.float64),
+                        records=np.array(exact), searches=np.int32(len(r["search"])),
+                        move_played=np.array([s.move_played for s in r["search"]], np.int32),
+                        best_action=np.array([s.best_action for s in r["search"]], np.int32),
+                        n_edges=np.array([s.n_edges for s in r["search"]], np.int32),
+                        root_value=np.array([s.root_value for s in r["search"]], np.float32),
+                        coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"], **extra)
+    print(name, "records", len(exact), [(j["seq"], j["result"]["num_move"], j["result"]["reward"], len(j["result"].get("policies", [])))
+                                        for j in recs])
+    return exact
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    for name, (n, kw) in RECORD_CASES_R3.items():
+        dump_case(name, n, kw)
+    if "--only-r3" in sys.argv:
+        return
     by_size = {9: [], 19: []}
     for name, (n, kw) in RECORD_CASES.items():
-        R = RefSelfPlay(n)
-        cfg = dict(MCTS_DEFAULTS)
-        kw = dict(kw)
-        pre = kw.pop("preload", None)
-        extra = {}
-        if pre is not None:
-            port = Port(n)
-            st = port.new()
-            mv = port.playout_moves(st, int(playout_seeds(1, base=pre[0])[0]))[: pre[1]]
-            port.free(st)
-            path = "/tmp/elf_preload_%s.sgf" % name
-            with open(path, "w") as fh:
-                fh.write("(;GM[1]FF[4]SZ[%d]KM[7.5]" % n + R.coords2sgfstr(mv)[1:])
-            R.set_preload(path, pre[2])
-            extra = dict(preload_moves=np.array(mv, np.uint16), preload_move_to=np.int32(pre[2]))
-        cfg.update(kw)
-        r = R.run(**cfg)
-        R.set_preload("", -1)
-        recs = json.loads(r["records"])
-        exact = [R.record_roundtrip(t) for t in split_records(r["records"])]
-        assert len(recs) >= 1, name
-        # the round trip through Record::createFromJson must reproduce the text the game thread dumped
-        assert "[" + ",".join(exact) + "]" == r["records"], name
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), board_size=np.int32(n),
-                            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], np.float64),
-                            records=np.array(exact), searches=np.int32(len(r["search"])),
-                            move_played=np.array([s.move_played for s in r["search"]], np.int32),
-                            best_action=np.array([s.best_action for s in r["search"]], np.int32),
-                            n_edges=np.array([s.n_edges for s in r["search"]], np.int32),
-                            root_value=np.array([s.root_value for s in r["search"]], np.float32),
-                            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"], **extra)
-        print(name, "records", len(exact), [(j["seq"], j["result"]["num_move"], j["result"]["reward"], len(j["result"].get("policies", [])))
-                                            for j in recs])
-        by_size[n] += exact
+        by_size[n] += dump_case(name, n, kw)
     for n in (9, 19):
         R = RefSelfPlay(n)
         rng = np.random.default_rng(100 + n)

@@ -204,7 +204,11 @@ class RefSpConfig(C.Structure):
         [("c_puct", C.c_float), ("root_epsilon", C.c_float), ("root_alpha", C.c_float), ("seed", C.c_uint32), ("komi", C.c_float),
          ("ply_pass_enabled", C.c_int32), ("policy_distri_cutoff", C.c_int32), ("move_cutoff", C.c_int32),
          ("resign_thres", C.c_float), ("never_resign_prob", C.c_float), ("net_salt", C.c_uint32), ("net_tie_levels", C.c_int32),
-         ("max_searches", C.c_int32), ("timeout_usec", C.c_int32)]
+         ("max_searches", C.c_int32), ("timeout_usec", C.c_int32),
+         # round 3 (read by oracle/ref_selfplay.cc only; the CPU restatement plays one AI per game)
+         ("black_ver", C.c_int32), ("white_ver", C.c_int32), ("player_swap", C.c_int32), ("white_puct", C.c_float),
+         ("white_rollouts_per_batch", C.c_int32), ("white_rollouts_per_thread", C.c_int32), ("white_net_salt", C.c_uint32),
+         ("pick_method", C.c_int32), ("black_policy_only", C.c_int32), ("white_policy_only", C.c_int32), ("thread_used", C.c_int32)]
 
 
 class RefSpSearch(C.Structure):
@@ -215,7 +219,10 @@ class RefSpSearch(C.Structure):
 MCTS_DEFAULTS = dict(num_games=1, batchsize=16, mcts_threads=1, rollouts_per_thread=8192, rollouts_per_batch=16, virtual_loss=1,
                      persistent_tree=1, use_prior=1, unexplored_q_zero=0, root_unexplored_q_zero=0, c_puct=1.5, root_epsilon=0.25,
                      root_alpha=0.03, seed=1234, komi=7.5, ply_pass_enabled=0, policy_distri_cutoff=0, move_cutoff=-1,
-                     resign_thres=0.0, never_resign_prob=0.0, net_salt=7, net_tie_levels=0, max_searches=4, timeout_usec=10)
+                     resign_thres=0.0, never_resign_prob=0.0, net_salt=7, net_tie_levels=0, max_searches=4, timeout_usec=10,
+                     black_ver=0, white_ver=-1, player_swap=0, white_puct=-1.0, white_rollouts_per_batch=-1,
+                     white_rollouts_per_thread=-1, white_net_salt=8, pick_method=0, black_policy_only=0, white_policy_only=0,
+                     thread_used=0)
 
 
 class RefSelfPlay:
@@ -260,8 +267,10 @@ class RefSelfPlay:
                              prior.ctypes.data_as(C.c_void_p), reward.ctypes.data_as(C.c_void_p), stats)
         if k < 0:
             raise RuntimeError("refsp_run failed")
+        self.L.refsp_white_rows.restype = C.c_int64
         return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
-                    batches=int(stats[0]), rows=int(stats[1]), usec=int(stats[2]), records=self.last_records())
+                    batches=int(stats[0]), rows=int(stats[1]), usec=int(stats[2]), records=self.last_records(),
+                    white_rows=int(self.L.refsp_white_rows()))
 
     # ---- records (GoStateExt::dumpRecord) and the trainer's extractors (GoStateExtOffline + GoFeature)
     def _text(self, fn, *args):

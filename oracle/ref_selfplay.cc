@@ -62,6 +62,16 @@ struct RefSpConfig {
   // stop after this many searches (summed over games) have been recorded
   int32_t max_searches;
   int32_t timeout_usec;         // batch collector timeout (game.py:365-402 --gpu path uses 10)
+  // ---- round 3: evaluation games (two AIs), pick methods, policy-only play, idle game threads
+  int32_t black_ver;            // MsgRequest.vers.black_ver (replies carry it in "rv")
+  int32_t white_ver;            // MsgRequest.vers.white_ver: -1 = self-play, >= 0 = a second AI for White
+  int32_t player_swap;          // ClientCtrl.player_swap
+  float white_puct;             // GameOptions.white_puct / white_mcts_rollout_per_batch / white_mcts_rollout_per_thread (<= 0: no override)
+  int32_t white_rollouts_per_batch, white_rollouts_per_thread;
+  uint32_t white_net_salt;      // stub net of the "actor_white" group
+  int32_t pick_method;          // 0 most_visited, 1 strongest_prior, 2 uniform_random
+  int32_t black_policy_only, white_policy_only;   // GameOptions.*_use_policy_network_only
+  int32_t thread_used;          // ClientCtrl.num_game_thread_used (0 = num_games, the harness' historical value; -1 = all)
 };
 
 // One record per finished search (MCTSAI_T::act), in completion order.
@@ -145,6 +155,7 @@ struct GameCapture : public GameNotifierBase {
 std::string g_preload_sgf;     // GameOptions.preload_sgf for the next refsp_run ("" = none)
 int g_preload_move_to = -1;
 std::string g_last_records;   // JSON array text of the records of the last refsp_run
+int64_t g_white_rows = 0;     // rows served to the "actor_white" group by the last refsp_run
 
 struct Buffers {
   std::vector<float> s, pi, V;
@@ -178,7 +189,7 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     ts.alg_opt.c_puct = cfg->c_puct;
     ts.alg_opt.unexplored_q_zero = cfg->unexplored_q_zero != 0;
     ts.alg_opt.root_unexplored_q_zero = cfg->root_unexplored_q_zero != 0;
-    ts.pick_method = "most_visited";
+    ts.pick_method = cfg->pick_method == 1 ? "strongest_prior" : cfg->pick_method == 2 ? "uniform_random" : "most_visited";
 
     GameOptions opt;
     opt.mode = "selfplay";
@@ -191,6 +202,11 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     opt.port = 0;
     opt.preload_sgf = g_preload_sgf;
     opt.preload_sgf_move_to = g_preload_move_to;
+    opt.white_puct = cfg->white_puct > 0.0f ? cfg->white_puct : -1.0f;
+    opt.white_mcts_rollout_per_batch = cfg->white_rollouts_per_batch > 0 ? cfg->white_rollouts_per_batch : -1;
+    opt.white_mcts_rollout_per_thread = cfg->white_rollouts_per_thread > 0 ? cfg->white_rollouts_per_thread : -1;
+    opt.black_use_policy_network_only = cfg->black_policy_only != 0;
+    opt.white_use_policy_network_only = cfg->white_policy_only != 0;
 
     const int n = cfg->num_games, B = cfg->batchsize;
     elf::Context ctx;
@@ -259,17 +275,19 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     {
       // Client::setRequest (train/distri_client.h:318-331) / GameContext::setRequest (inference/game_context.h:76-88)
       MsgRequest req;
-      req.vers.black_ver = 0;
-      req.vers.white_ver = -1;   // self-play: one AI plays both colours
+      req.vers.black_ver = cfg->black_ver;
+      req.vers.white_ver = cfg->white_ver;   // -1 = self-play: one AI plays both colours
+      req.client_ctrl.player_swap = cfg->player_swap != 0;
       req.vers.mcts_opt = co.mcts_options;
       req.client_ctrl.black_resign_thres = cfg->resign_thres;
       req.client_ctrl.white_resign_thres = cfg->resign_thres;
       req.client_ctrl.never_resign_prob = cfg->never_resign_prob;
-      req.client_ctrl.num_game_thread_used = n;
+      req.client_ctrl.num_game_thread_used = cfg->thread_used == 0 ? n : cfg->thread_used;
       disp.sendToThread(req);
     }
 
     int64_t batches = 0, rows = 0;
+    g_white_rows = 0;
     const auto t0 = std::chrono::steady_clock::now();
     const int NA = BOARD_NUM_ACTION;
     while (cap.count.load() < cfg->max_searches) {
@@ -280,9 +298,11 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
       Buffers& b = bufs[idx2buf[smo.getIdx()]];
       const std::string& label = smo.getLabel();
       if (label == "actor_black" || label == "actor_white") {
+        const bool white_group = label == "actor_white";
         if (net) net(b.s.data(), eb, b.pi.data(), b.V.data(), net_user);
-        else stubnet_eval(b.s.data(), eb, BOARD_SIZE, cfg->net_salt, cfg->net_tie_levels, b.pi.data(), b.V.data());
-        for (int i = 0; i < eb; ++i) { b.rv[i] = 0; b.a[i] = 0; }
+        else stubnet_eval(b.s.data(), eb, BOARD_SIZE, white_group ? cfg->white_net_salt : cfg->net_salt, cfg->net_tie_levels, b.pi.data(), b.V.data());
+        for (int i = 0; i < eb; ++i) { b.rv[i] = white_group ? cfg->white_ver : cfg->black_ver; b.a[i] = 0; }
+        if (white_group) g_white_rows += eb;
         (void)NA;
         batches++; rows += eb;
       }
@@ -312,6 +332,8 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     return -1;
   }
 }
+
+int64_t refsp_white_rows() { return g_white_rows; }
 
 // GameOptions.preload_sgf / preload_sgf_move_to for the following refsp_run calls (path "" switches it off)
 void refsp_set_preload(const char* path, int move_to) {

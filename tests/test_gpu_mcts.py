@@ -9,38 +9,23 @@ import pytest
 
 from conftest import GOLDEN
 from pyoracle import stub_net
+from sp_drive import drive_stub, sp_from_fixture_cfg
 
 pytestmark = pytest.mark.gpu
 
 
 def run_case(elf_amd, name, max_searches=None):
-    import torch
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
     n = int(g["board_size"])
     m = len(g["move_played"]) if max_searches is None else min(max_searches, len(g["move_played"]))
-    sp = elf_amd.SelfPlay(
-        board_size=n, num_games=1, device=0, mcts_rollout_per_thread=int(cfg["rollouts_per_thread"]),
-        mcts_rollout_per_batch=int(cfg["rollouts_per_batch"]), mcts_puct=float(np.float32(cfg["c_puct"])),
-        mcts_virtual_loss=int(cfg["virtual_loss"]), mcts_use_prior=bool(cfg["use_prior"]),
-        mcts_persistent_tree=bool(cfg["persistent_tree"]), mcts_epsilon=float(np.float32(cfg["root_epsilon"])),
-        mcts_alpha=float(np.float32(cfg["root_alpha"])), mcts_unexplored_q_zero=bool(cfg["unexplored_q_zero"]),
-        mcts_root_unexplored_q_zero=bool(cfg["root_unexplored_q_zero"]), komi=float(np.float32(cfg["komi"])),
-        ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
-        move_cutoff=int(cfg["move_cutoff"]), resign_thres=float(np.float32(cfg["resign_thres"])),
-        never_resign_prob=float(np.float32(cfg["never_resign_prob"])), seed=int(cfg["seed"]), log_searches=m)
-    salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
-    rows_total = 0
-    while sp.stats()["logged"] < m:
-        rows = sp.begin_step()
-        rows_total += rows
-        if rows:
-            pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), salt, ties)
-            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
-        else:
-            sp.end_step(None, None)
-        if rows_total < 4096:   # the node records' own invariants (scoring order, child back links, visit sums) after every step
+    sp = sp_from_fixture_cfg(elf_amd, n, cfg, log_searches=m)
+
+    def check_trees(sp, rows_total):
+        if sum(rows_total) < 4096:   # the node records' own invariants (scoring order, child back links, visit sums) after every step
             assert sp.validate_trees()[0] == 0, "%s: node record invariants %s" % (name, sp.validate_trees())
+
+    rows_total = drive_stub(sp, n, cfg, lambda sp: sp.stats()["logged"] >= m, check_trees)
     rec, coord, visits, prior, reward = sp.search_log()
     na = n * n + 1
     for i in range(m):
@@ -56,8 +41,10 @@ def run_case(elf_amd, name, max_searches=None):
         assert np.float32(rec[i].root_value) == g["root_value"][i], ctx
         assert rec[i].move_played == int(g["move_played"][i]), ctx + ": move played"
     assert na <= coord.shape[1]
+    if max_searches is None and "white_rows" in g.files and int(cfg["white_ver"]) >= 0:
+        assert rows_total[1] > 0          # the second AI's rows went to their own batch group
     sp.close()
-    return rows_total
+    return sum(rows_total)
 
 
 @pytest.fixture(scope="module")
@@ -70,6 +57,27 @@ def elf(built):
                                   "mcts_9_r512", "mcts_9_r64_ties", "mcts_19_r128_vl0", "mcts_19_r128_noprior", "mcts_9_r128_rootq0",
                                   "mcts_9_r96_bs4", "mcts_9_r128_bs64"])
 def test_search_matches_reference(elf, name):
+    run_case(elf, name)
+
+
+@pytest.mark.parametrize("name", ["mcts_9_eval_two_ai", "mcts_19_eval_swap", "mcts_9_policy_only_eval"])
+def test_two_ai_games_match_reference(elf, name):
+    """A request with white_ver >= 0: a second MCTSGoAI plays White (game_selfplay.cc:165-185, 364-366) with its own tree,
+    model ("actor_white" rows, own version in rv), rng stream and the white_* overrides; player_swap exchanges the two; both
+    trees follow every move.  Fixtures from the real reference stack with two different stub nets."""
+    run_case(elf, name)
+
+
+@pytest.mark.parametrize("name", ["mcts_9_pick_prior", "mcts_9_policy_only_white"])
+def test_pick_method_and_policy_only_match_reference(elf, name):
+    """TSOptions.pick_method = strongest_prior (tree_search.h:506-509) and GameOptions.white_use_policy_network_only
+    (MCTSAI_T::actPolicyOnly, mcts.h:83-90 / runPolicyOnly tree_search.h:385-407)."""
+    run_case(elf, name)
+
+
+@pytest.mark.parametrize("name", ["mcts_9_r256_bs128", "mcts_19_r512_bs256"])
+def test_more_than_64_rollouts_per_batch(elf, name):
+    """num_rollouts_per_batch 128 / 256 (tree_search_options.h:81 has no bound): the leaf table of a step holds up to 256 leaves."""
     run_case(elf, name)
 
 
@@ -235,7 +243,7 @@ def test_step_without_host_wait_equals_step_with_it(elf):
     assert logs[0] == logs[1]
 
 
-@pytest.mark.parametrize("n,T,K,roll", [(9, 2, 8, 64), (19, 2, 16, 96), (9, 4, 4, 32)])
+@pytest.mark.parametrize("n,T,K,roll", [(9, 2, 8, 64), (19, 2, 16, 96), (9, 4, 4, 32), (9, 2, 64, 256), (19, 4, 32, 128)])
 def test_search_threads_equal_their_restatement(elf, n, T, K, roll):
     """TSOptions.num_threads = T > 1: T x num_rollouts_per_thread rollouts per move (tree_search.h:472-476), the T batch_rollouts
     of a round run back to back on the shared tree.  The reference's racing threads are not deterministic; the
@@ -261,8 +269,8 @@ def test_search_threads_equal_their_restatement(elf, n, T, K, roll):
     assert 0.5 * T * roll < rec[0].total_visits <= T * roll - T * K
     assert sp.stats()["rollouts"] == m * T * ((roll + K - 1) // K) * K
     sp.close()
-    with pytest.raises(Exception):     # one lane per unique leaf of a step: T x K <= 64, rejected loudly beyond
-        elf.SelfPlay(board_size=9, num_games=1, mcts_rollout_per_batch=16, mcts_threads=8)
+    with pytest.raises(Exception):     # the leaf table of a step holds T x K <= 256 leaves, rejected loudly beyond
+        elf.SelfPlay(board_size=9, num_games=1, mcts_rollout_per_batch=32, mcts_threads=16)
 
 
 def test_backup_order_is_first_occurrence_with_unquantised_values(elf):
@@ -372,3 +380,111 @@ def test_config3_real_net_against_the_real_reference_stack(elf):
         # 8192 rollouts at bs 16: the all-at-root first batch adds no visit
         if rollouts == 8192:
             assert ref[0][0]["total_visits"] == 8176
+
+
+# ---- round 3: requests, idle games, evaluation games out of step, uniform_random ------------------------------------------------
+def _live_per_game(n, cfg, G, per_game):
+    """the reference stack running G game threads (game g seeded seed + g) -> {g: [search tuples]}"""
+    from pyoracle import RefSelfPlay
+    r = RefSelfPlay(n).run(**dict(cfg, max_searches=G * per_game * 3))
+    return _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G), r
+
+
+def test_evaluation_games_out_of_step_equal_the_reference_game_by_game(elf):
+    """Four evaluation games in one context, the two AIs with different rollout budgets and batch sizes (Black 48 rollouts at
+    bs 16 = 3 steps per move, White 40 rollouts at bs 8 = 5 steps), games ended by resignation at different plies (52..58) or by
+    the cutoff: from the first game end on the games' searches are out of step -- different AIs searching in the same step,
+    moves and restarts at different steps -- and every game must still reproduce the reference's game thread (live, oracle/_ref)."""
+    from pyoracle import MCTS_DEFAULTS, RefSelfPlay
+    n, G, per_game = 9, 4, 72
+    if not RefSelfPlay.available(n):
+        pytest.skip("oracle/_ref/libelfsp9.so is not present")
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=G, rollouts_per_thread=48, seed=7001, net_salt=61, white_net_salt=62, black_ver=3, white_ver=4,
+               white_rollouts_per_thread=40, white_rollouts_per_batch=8, white_puct=1.1, policy_distri_cutoff=5, move_cutoff=64,
+               resign_thres=0.9)
+    r = RefSelfPlay(n).run(**dict(cfg, max_searches=G * per_game * 2))
+    want = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)
+    assert all(len(want[g]) >= per_game for g in range(G)), [len(want[g]) for g in range(G)]
+    sp = sp_from_fixture_cfg(elf, n, cfg, log_searches=G * per_game * 2, nodes_per_game=2048)
+    seen = {}
+    L = elf.lib()
+
+    def out_of_step(sp, rows_total):
+        a = tuple(L.elfsp_game_actor(sp._h, g) for g in range(G))
+        seen[a] = seen.get(a, 0) + 1
+
+    def enough(sp):
+        if sp.progress()["searches"] < G * per_game:
+            return False
+        rec = sp.search_log()[0]
+        return all(sum(1 for x in rec if x.game == g) >= per_game for g in range(G))
+
+    drive_stub(sp, n, cfg, enough, out_of_step)
+    rec, coord, visits, prior, reward = sp.search_log()
+    na = n * n + 1
+    got = _per_game(rec, coord[:, :na], visits[:, :na], prior[:, :na], reward[:, :na], G)
+    for g in range(G):
+        for k in range(per_game):
+            assert got[g][k] == want[g][k], "game %d search %d" % (g, k)
+    assert any(len(set(a)) > 1 for a in seen), seen      # at some step the games were searching with different AIs
+    assert sp.games_finished() >= G                      # every game ended at least once (both trees reset, next game started)
+    sp.close()
+
+
+def test_idle_game_threads_equal_the_reference(elf):
+    """num_game_thread_used = 2 of 3 games (DispatcherCallback::OnFirstSend): game 2 waits, games 0 and 1 equal the reference's."""
+    from pyoracle import MCTS_DEFAULTS, RefSelfPlay
+    n, G, per_game = 9, 3, 6
+    if not RefSelfPlay.available(n):
+        pytest.skip("oracle/_ref/libelfsp9.so is not present")
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=G, rollouts_per_thread=48, seed=8100, net_salt=63, thread_used=2, policy_distri_cutoff=3)
+    # games 0 and 1 of the reference do not depend on the idle thread: they are the reference's two-game context with the same
+    # seeds.  (The reference itself cannot be run to completion with an idle game thread: that thread blocks in waitMail for
+    # ever and Context::stop never joins it.)
+    r = RefSelfPlay(n).run(**dict(cfg, num_games=2, thread_used=0, max_searches=2 * per_game * 2))
+    want = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)
+    assert len(want[2]) == 0 and min(len(want[0]), len(want[1])) >= per_game
+    sp = sp_from_fixture_cfg(elf, n, cfg, log_searches=64, nodes_per_game=2048)
+    drive_stub(sp, n, cfg, lambda sp: sp.stats()["logged"] >= 2 * per_game)
+    rec, coord, visits, prior, reward = sp.search_log()
+    na = n * n + 1
+    got = _per_game(rec, coord[:, :na], visits[:, :na], prior[:, :na], reward[:, :na], G)
+    assert len(got[2]) == 0 and sp.progress()["waiting"] == 1
+    for g in range(2):
+        for k in range(per_game):
+            assert got[g][k] == want[g][k], "game %d search %d" % (g, k)
+    # a request that uses all three threads starts the waiting game from the empty board (is_prev_waiting -> restart)
+    sp.set_request(0, -1, num_game_thread_used=3)
+    drive_stub(sp, n, cfg, lambda sp: sum(1 for x in sp.search_log()[0] if x.game == 2) >= 2)
+    assert sp.progress()["waiting"] == 0
+    first = [x for x in sp.search_log()[0] if x.game == 2][0]
+    assert first.total_visits == 48 - 16           # a first search of a fresh game: the all-at-root first batch adds no visit
+    sp.close()
+
+
+def test_pick_method_uniform_random(elf):
+    """TSOptions.pick_method = uniform_random (tree_search.h:514-517, addActions :243-279): the move is the random_idx-th root edge
+    in iteration order, random_idx = rng() % edges, every edge scores 1 -- so max_score is 1 and, with the opening temperature on,
+    the sampled move comes from the uniform policy.  The reference draws from a process-wide time-seeded generator, so there is no
+    fixture to equal; pinned here: the structure, and determinism under a fixed GameOptions.seed."""
+    import torch
+    runs = []
+    for _ in range(2):
+        sp = elf.SelfPlay(board_size=9, num_games=4, mcts_rollout_per_thread=32, mcts_rollout_per_batch=16, seed=99, log_searches=40,
+                          mcts_pick_method="uniform_random", policy_distri_cutoff=0, nodes_per_game=1024, move_cutoff=20)
+        while sp.stats()["logged"] < 40:
+            rows = sp.begin_step()
+            pi, v = stub_net(9, sp.s[:rows].cpu().numpy(), 5, 0)
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        rec, coord, visits, prior, reward = sp.search_log()
+        for i, r in enumerate(rec):
+            assert r.max_score == 1.0 and r.best_action in coord[i, :r.n_edges] and r.move_played == r.best_action
+        # not the most visited edge every time (that would be most_visited in disguise)
+        assert sum(1 for i, r in enumerate(rec) if r.best_action != coord[i, int(np.argmax(visits[i, :r.n_edges]))]) > 10
+        runs.append([(r.game, r.move_played) for r in rec])
+        sp.close()
+    assert runs[0] == runs[1]
+    with pytest.raises(ValueError):
+        elf.SelfPlay(board_size=9, num_games=1, mcts_pick_method="softmax")

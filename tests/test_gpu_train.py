@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
+from sp_drive import drive_stub, sp_from_fixture_cfg
 from pyoracle import Port, port_train_sample, sgfstr2coords, stub_net
 
 pytestmark = pytest.mark.gpu
@@ -114,7 +115,8 @@ def test_loader_argument_errors(elf):
     ld.close()
 
 
-@pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff"])
+@pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff",
+                                  "records_9_eval", "records_9_eval_swap_resign"])
 def test_selfplay_records_equal_reference_dump(elf, name):
     """GPU self-play under the fixture's configuration leaves the same Record JSON text as the reference's
     GoStateExt::dumpRecord for every finished game (content, quantised policies, predicted values, reward, seq), timestamp aside."""
@@ -123,30 +125,15 @@ def test_selfplay_records_equal_reference_dump(elf, name):
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
     n = int(g["board_size"])
     want = [json.loads(str(t)) for t in g["records"]]
-    sp = elf.SelfPlay(
-        board_size=n, num_games=1, device=0, mcts_rollout_per_thread=int(cfg["rollouts_per_thread"]),
-        mcts_rollout_per_batch=int(cfg["rollouts_per_batch"]), mcts_puct=float(np.float32(cfg["c_puct"])),
-        mcts_virtual_loss=int(cfg["virtual_loss"]), mcts_use_prior=bool(cfg["use_prior"]),
-        mcts_persistent_tree=bool(cfg["persistent_tree"]), mcts_epsilon=float(np.float32(cfg["root_epsilon"])),
-        mcts_alpha=float(np.float32(cfg["root_alpha"])), komi=float(np.float32(cfg["komi"])),
-        ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
-        move_cutoff=int(cfg["move_cutoff"]), resign_thres=float(np.float32(cfg["resign_thres"])),
-        never_resign_prob=float(np.float32(cfg["never_resign_prob"])), seed=int(cfg["seed"]), keep_records=8, nodes_per_game=4096,
-        log_searches=int(g["searches"]))
+    sp = sp_from_fixture_cfg(elf, n, cfg, keep_records=8, nodes_per_game=4096, log_searches=int(g["searches"]))
     if "preload_moves" in g.files:
         sp.preload(g["preload_moves"], int(g["preload_move_to"]))
-    salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
     got = []
-    for _ in range(200000):
-        rows = sp.begin_step()
-        if rows:
-            pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), salt, ties)
-            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
-        else:
-            sp.end_step(None, None)
-        got += sp.pop_records()
-        if len(got) >= len(want):
-            break
+
+    def collect(sp, rows_total):
+        got.extend(sp.pop_records())
+
+    drive_stub(sp, n, cfg, lambda sp: len(got) >= len(want), collect)
     assert len(got) >= len(want)
     # every search of the run, across game ends and restarts: root edges in iteration order, visits, priors, rewards, move played
     rec, coord, visits, prior, reward = sp.search_log()

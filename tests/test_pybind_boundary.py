@@ -60,6 +60,11 @@ def options_from_cfg(go, cfg, n=19, **over):
     opt.mode, opt.seed, opt.komi = "selfplay", int(cfg["seed"]), float(np.float32(cfg["komi"]))
     opt.policy_distri_cutoff, opt.ply_pass_enabled, opt.move_cutoff = int(cfg["policy_distri_cutoff"]), int(cfg["ply_pass_enabled"]), int(cfg["move_cutoff"])
     opt.use_mcts, opt.board_size = True, n
+    if "white_ver" in cfg:          # round-3 fixtures: evaluation games, pick methods, policy-only play
+        opt.white_puct = float(np.float32(cfg["white_puct"]))
+        opt.white_mcts_rollout_per_batch, opt.white_mcts_rollout_per_thread = int(cfg["white_rollouts_per_batch"]), int(cfg["white_rollouts_per_thread"])
+        opt.black_use_policy_network_only, opt.white_use_policy_network_only = bool(cfg["black_policy_only"]), bool(cfg["white_policy_only"])
+        ts.pick_method = {0: "most_visited", 1: "strongest_prior", 2: "uniform_random"}[int(cfg["pick_method"])]
     for k, v in over.items():
         setattr(opt, k, v)
     return co, opt
@@ -119,14 +124,21 @@ def test_error_conventions(mods):
     with pytest.raises(ValueError):            # training server: out of scope, said loudly
         go.GameContext(co, opt)
     opt.mode = "selfplay"
+    co.mcts_options.num_threads, co.mcts_options.num_rollouts_per_batch = 16, 32
+    with pytest.raises(ValueError):            # 16 x 32 leaves per step exceed the leaf table (256): rejected, never truncated
+        go.GameContext(co, opt)
     co.mcts_options.num_threads, co.mcts_options.num_rollouts_per_batch = 16, 8
-    with pytest.raises(ValueError):            # 16 x 8 leaves per step exceed one wave: rejected, never truncated
-        go.GameContext(co, opt)
+    go.GameContext(co, opt)                    # 128 leaves per step are fine
     co.mcts_options.num_threads = 2
-    co.mcts_options.pick_method = "strongest_prior"
-    with pytest.raises(ValueError):            # tree_search.h:521-524
+    co.mcts_options.pick_method = "softmax"
+    with pytest.raises(ValueError):            # "MCTS Pick method unknown!" tree_search.h:521-524
         go.GameContext(co, opt)
-    co.mcts_options.pick_method = "most_visited"
+    for m in ("strongest_prior", "uniform_random", "most_visited"):   # the three the reference knows (tree_search.h:506-519)
+        co.mcts_options.pick_method = m
+        go.GameContext(co, opt)
+    opt.black_use_policy_network_only = True   # MCTSAI_T::actPolicyOnly is on this path
+    go.GameContext(co, opt)
+    opt.black_use_policy_network_only = False
     GC = go.GameContext(co, opt)
     assert GC.getParams() == {"num_action": 362, "board_size": 19, "num_future_actions": 3, "num_planes": 18, "our_stone_plane": 0,
                               "opponent_stone_plane": 1, "ACTION_SKIP": -100, "ACTION_PASS": -99, "ACTION_RESIGN": -98, "ACTION_CLEAR": -97}
@@ -272,7 +284,7 @@ def _wrapper_module():
     return gcwrapper_restated, False
 
 
-def _session(mods, cfg, m, n=19, device_resident=False, force_restated=False, batchsize=None, rv_value=0, games=None, **over):
+def _session(mods, cfg, m, n=19, device_resident=False, force_restated=False, batchsize=None, rv_value=None, games=None, **over):
     """One GCWrapper session shaped like scripts/elfgames/go/selfplay.py:115-199; returns (search log, events)."""
     import contextlib
     import io
@@ -284,7 +296,7 @@ def _session(mods, cfg, m, n=19, device_resident=False, force_restated=False, ba
         cfg["num_games"] = games
     if batchsize:
         cfg["batchsize"] = batchsize
-    co, opt = options_from_cfg(go, cfg, n=n, log_searches=m, **over)
+    co, opt = options_from_cfg(go, cfg, n=n, log_searches=over.pop("log_searches", m), **over)
     GC = go.GameContext(co, opt)
     mod, is_ref = _wrapper_module()
     if device_resident or force_restated:
@@ -297,17 +309,21 @@ def _session(mods, cfg, m, n=19, device_resident=False, force_restated=False, ba
         kw["use_numpy"] = False
     with contextlib.redirect_stdout(io.StringIO()):
         gcw = mod.GCWrapper(GC, co.batchsize, game_py_desc(co.batchsize), **kw)
-    ev = dict(rows=[], starts=[], ends=0, kinds=set(), is_ref=is_ref)
-    salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
+    ev = dict(rows=[], starts=[], ends=0, kinds=set(), is_ref=is_ref, white_rows=0)
+    ties = int(cfg["net_tie_levels"])
+    bv, wv = int(cfg.get("black_ver", 0)), int(cfg.get("white_ver", -1))
 
-    def actor(batch):                                  # Evaluator.actor-shaped: reply keys = the group's reply list
-        s = batch["s"]
-        ev["rows"].append(batch.batchsize)
-        ev["kinds"].add(s.device.type)
-        pi, v = stub_net(n, s.cpu().numpy(), salt, ties)
-        k = s.shape[0]
-        return dict(pi=torch.from_numpy(pi).cuda(), V=torch.from_numpy(v).cuda(), a=torch.zeros(k, dtype=torch.int64).cuda(),
-                    rv=torch.full((k,), rv_value, dtype=torch.int64).cuda())
+    def make_actor(salt, ver, white):
+        def actor(batch):                              # Evaluator.actor-shaped: reply keys = the group's reply list
+            s = batch["s"]
+            ev["rows"].append(batch.batchsize)
+            ev["white_rows"] += batch.batchsize if white else 0
+            ev["kinds"].add(s.device.type)
+            pi, v = stub_net(n, s.cpu().numpy(), salt, ties)
+            k = s.shape[0]
+            return dict(pi=torch.from_numpy(pi).cuda(), V=torch.from_numpy(v).cuda(), a=torch.zeros(k, dtype=torch.int64).cuda(),
+                        rv=torch.full((k,), ver if rv_value is None else rv_value, dtype=torch.int64).cuda())
+        return actor
 
     def game_start(batch):
         ev["starts"].append((int(batch["black_ver"][0]), int(batch["white_ver"][0])))
@@ -315,12 +331,16 @@ def _session(mods, cfg, m, n=19, device_resident=False, force_restated=False, ba
     def game_end(batch):
         ev["ends"] += 1
 
-    gcw.reg_callback("actor_black", actor)
-    gcw.reg_callback("actor_white", actor)
+    gcw.reg_callback("actor_black", make_actor(int(cfg["net_salt"]), bv, False))
+    gcw.reg_callback("actor_white", make_actor(int(cfg.get("white_net_salt", cfg["net_salt"])), wv, True))
     gcw.reg_callback_if_exists("game_start", game_start)
     gcw.reg_callback_if_exists("game_end", game_end)
     gcw.start()
-    GC.getClient().setRequest(0, -1, float(np.float32(cfg["resign_thres"])), -1)
+    # Client::setRequest(black_ver, white_ver, thres, numThreads); the fixtures' harness sent num_game_thread_used = num_games
+    if int(cfg.get("player_swap", 0)):   # ClientCtrl.player_swap: the optional fifth argument (the reference's server sends it in its MsgRequest)
+        GC.getClient().setRequest(bv, wv, float(np.float32(cfg["resign_thres"])), int(cfg.get("thread_used", 0)) or -1, True)
+    else:
+        GC.getClient().setRequest(bv, wv, float(np.float32(cfg["resign_thres"])), int(cfg.get("thread_used", 0)) or -1)
     guard = 0
     while len(GC.ctx().searchLog()) < m:
         gcw.run()
@@ -497,10 +517,12 @@ def test_online_mode_human_actor(mods):
 
 
 @pytest.mark.gpu
-def test_new_request_restarts_the_games_at_the_next_move_boundary(mods):
-    """Client::setRequest with a new model version while a search is running (GoGameSelfPlay::OnReceive, game_selfplay.cc:222-270):
-    the search in progress finishes with the old version; at the move boundary every game restarts from the empty board, one
-    game_start batch carries the new versions, and from then on replies must carry the new version in rv."""
+def test_new_request_is_looked_at_every_fifth_act(mods):
+    """Client::setRequest with a new model version while the games play (GoGameSelfPlay::OnReceive, game_selfplay.cc:222-270): a
+    game looks at its mailbox at the top of every fifth act (`_online_counter % 5 == 0`, :273-289), so the request sent during the
+    4th search is received before the 6th; until then searches run -- and replies are checked -- under the old version.  Then
+    every game restarts from the empty board, one game_start batch carries the new versions, and from then on replies must carry
+    the new version in rv."""
     import contextlib
     import io
     import torch
@@ -536,19 +558,59 @@ def test_new_request_restarts_the_games_at_the_next_move_boundary(mods):
     assert state["starts"] == [(0, -1)] and GC.getGame(0).getNextPlayer() == "W"
     gcw.run()                                          # a batch of the 4th search: that search is now open
     client.setRequest(7, -1, 0.0, -1)                  # new model while the search runs
-    moves_before = len(GC.ctx().searchLog())
-    while len(GC.ctx().searchLog()) == moves_before:   # the running search completes under version 0 (rv = 0 still accepted)
+    while len(GC.ctx().searchLog()) < 2 * 5:           # acts 4 and 5 of both games still run under version 0 (rv = 0 accepted)
         gcw.run()
-    state["rv"] = 7
-    for _ in range(6):
-        gcw.run()
+    assert state["starts"] == [(0, -1)] and GC.getGame(0).getNextPlayer() == "W"
+    state["rv"] = 7                                    # the 6th act begins with the mailbox: restart under version 7
+    gcw.run()                                          # the game_start batch comes before any row of the restarted games
     assert state["starts"] == [(0, -1), (7, -1)]
-    g = GC.getGame(0)
-    assert g.getNextPlayer() == "B" or len(GC.ctx().searchLog()) > moves_before + 2    # restarted from the empty board
+    assert GC.getGame(0).getNextPlayer() == "B" and GC.getGame(1).getNextPlayer() == "B"    # both restarted from the empty board
+    for _ in range(3):
+        gcw.run()
     state["rv"] = 0                                    # the old model's replies are now refused
     with pytest.raises(RuntimeError):
         for _ in range(8):
             gcw.run()
-    with pytest.raises(ValueError):
-        client.setRequest(1, 2, 0.0, -1)               # a second AI for White is not supported: said loudly
+    gcw.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mcts_9_eval_two_ai", "mcts_19_eval_swap"])
+def test_gcwrapper_session_plays_evaluation_games_with_two_ais(mods, name):
+    """Client.setRequest(black_ver, white_ver >= 0, ...): the second MCTSGoAI's leaves arrive in the "actor_white" group and are
+    answered by another model (its own version in rv); the session reproduces the reference's fixture bit for bit through the
+    pybind boundary with the restated GCWrapper (game.py-shaped desc, num_recv = 2)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    n = int(g["board_size"])
+    m = min(24, len(g["move_played"]))
+    log, ev = _session(mods, cfg, m, n=n, force_restated=True)
+    _check_fixture(log, g, m)
+    assert ev["starts"] == [(int(cfg["black_ver"]), int(cfg["white_ver"]))]
+    assert ev["white_rows"] > 0 and ev["white_rows"] < sum(ev["rows"])
+    ev["gcw"].stop()
+
+
+@pytest.mark.gpu
+def test_idle_game_threads_and_wait_requests(mods):
+    """setRequest(..., numThreads = k): games k.. receive the request as a wait request (DispatcherCallback::OnFirstSend,
+    common/dispatcher_callback.h:28-44) and stay idle; a later request with more threads starts them from the empty board; a
+    wait request (black_ver < 0) idles every game at its next mailbox look."""
+    from pyoracle import MCTS_DEFAULTS
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(num_games=3, rollouts_per_thread=32, seed=11, net_salt=4, thread_used=2)
+    log, ev = _session(mods, cfg, 8, n=9, force_restated=True, log_searches=256)
+    assert sorted(set(r[0] for r in log)) == [0, 1]                     # game 2 never searched
+    GC, gcw = ev["GC"], ev["gcw"]
+    assert ev["starts"] == [(0, -1)]
+    GC.getClient().setRequest(0, -1, 0.0, 3)                            # all three threads: game 2 starts now (it was waiting)
+    while len([r for r in GC.ctx().searchLog() if r[0] == 2]) < 2:
+        gcw.run()
+    assert ev["starts"] == [(0, -1), (0, -1)]                           # the waiting game's start is a game_start batch
+    GC.getClient().setRequest(-1, -1, 0.0, -1)                          # [wait]
+    with pytest.raises(RuntimeError) as e:                              # every game idles within five acts: nothing left to serve
+        for _ in range(400):
+            gcw.run()
+    assert "waiting" in str(e.value)
+    assert GC.ctx().wait(10) is None                                    # with a timeout: None, as the reference's wait(timeout) does
     gcw.stop()
