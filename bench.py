@@ -57,6 +57,17 @@ def seeds_for(rank, boards, rep):
     return b * np.uint64(0x9E3779B9) + np.uint64(1)
 
 
+PARITY_NOTE = ("bit-exactness of this configuration rests on: mcts_threads = 1; reference fixtures with a stub net whose value head is on the "
+               "1/256 grid (tests/golden/mcts_*.npz); the real 20x256 fp32 net against the real reference stack on this GPU "
+               "(tests/test_gpu_mcts.py::test_config3_real_net_against_the_real_reference_stack; profiles/r03a_config3_real_net_parity_*.json: "
+               "68 searches, 67 bit-equal, 1 edge off by 1 ulp of its reward sum, no visit count / move differs); hazard H2 (backup order "
+               "of a batch: heap-address order in the reference, first occurrence here) measured reference-vs-restatement with an "
+               "un-quantised value head on 454 searches: reward sums differ in their last bits, no decision differs "
+               "(profiles/r03_h2_divergence_stub_cpu.json); serial-loop equality of the pipelined / graph-replayed / fp16 path "
+               "(test_pipelined_graph_fp16_groups_equal_the_serial_fp32_loop); mcts_threads > 1 and two-group pipelining are pinned on "
+               "the CPU restatement / the engine itself (the reference races there)")
+
+
 def load_profile_json(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -64,22 +75,43 @@ def load_profile_json(name):
         return {}
 
 
+def pmc_source_match(name):
+    """True when profiles/<name> was measured on the kernel sources that are in the tree now (elf_amd._lib.kernel_source_hash)."""
+    try:
+        from elf_amd._lib import kernel_source_hash
+        return load_profile_json(name).get("_source", {}).get("kernel_source_hash") == kernel_source_hash()
+    except Exception:
+        return False
+
+
 def load_traffic(kernel):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/gpu_round.sh), committed under profiles/."""
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/gpu_round.sh), committed under profiles/; None when the
+    kernels have changed since the passes were run."""
+    if not pmc_source_match("pmc_traffic.json"):
+        return None
     return load_profile_json("pmc_traffic.json").get(kernel, {}).get("hbm_bytes_per_launch")
 
 
 def issue_roof(kernel, units_per_launch, kernel_s):
     """Instruction-issue roof of a kernel that lives in LDS/registers (board engine): VALU wave-instructions per second against
     what 1024 SIMD-32 can issue (one wave64 VALU op per 2 cycles at 2.4 GHz).  The per-unit VALU count comes from the committed
-    PMC pass (profiles/pmc_issue.json: SQ_INSTS_VALU / units); HBM bytes per launch are reported as `traffic`."""
+    PMC pass (profiles/pmc_issue.json: SQ_INSTS_VALU / units); HBM bytes per launch are reported as `traffic`.  The counts belong
+    to one version of the kernels: pmc_source_match says whether that is the version in the tree, and no fraction is printed
+    when it is not."""
     per = load_profile_json("pmc_issue.json").get(kernel, {})
     valu = per.get("valu_per_unit")
     if not valu:
         return None
+    match = pmc_source_match("pmc_issue.json")
+    if not match:
+        return {"bound": "issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
+                "traffic": None, "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "pmc_source_match": False,
+                "note": "profiles/pmc_issue.json was measured on other kernel sources than the tree holds (kernel_source_hash differs): "
+                        "no issue-roof fraction is derived from stale instruction counts; re-run tools/gpu_r3_pmc.sh + tools/update_issue.py"}
     ach = units_per_launch * valu / kernel_s / 1e9
     return {"bound": "issue", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": ach / VALU_PEAK_GINST,
-            "traffic": load_traffic(kernel), "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "valu_per_unit": valu,
+            "traffic": load_traffic(kernel), "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "valu_per_unit": valu, "pmc_source_match": True,
+            "pmc_source_hash": load_profile_json("pmc_issue.json").get("_source", {}).get("kernel_source_hash"),
             "salu_per_unit": per.get("salu_per_unit"), "lds_per_unit": per.get("lds_per_unit"),
             "lds_bank_conflict_frac": per.get("lds_bank_conflict_frac"), "lds_active_cycles_per_unit": per.get("lds_active_cycles_per_unit"),
             "wave_issue_frac": per.get("wave_issue_frac"), "wave_wait_frac": per.get("wave_wait_frac"), "profile": per.get("profile"),
@@ -280,6 +312,18 @@ def gather_per_rank(dist, dev, value, world):
     return [float(x) for x in t.tolist()]
 
 
+def scaling_report(world, value, per_rank, key):
+    """What one `bench.py --gpus N` line says about scaling (BASELINE configs[3]: independent games per GPU): the per-rank values,
+    their sum, and the per-GPU fraction of the N = 1 value on record (profiles/headline_n1.json, written from a 1-GPU run of the same
+    configuration).  The driver computes efficiency itself from its N = 1, 2, 4, 8 runs; this is the same quantity from inside one run."""
+    ref = load_profile_json("headline_n1.json").get(key)
+    return {"n_gpus": world, "per_rank": per_rank, "sum_over_ranks": float(sum(per_rank)) if per_rank else None,
+            "n1_reference": ref, "n1_reference_source": load_profile_json("headline_n1.json").get("source"),
+            "per_gpu_fraction_of_n1": (value / world / ref) if (ref and world) else None,
+            "measured_curve": "none: no multi-GPU node was available to the builder; N > 1 is covered by the gloo tests and, on a node, by "
+                              "running this command with --gpus 2/4/8"}
+
+
 def make_barrier(dist):
     def barrier():
         if dist is not None:
@@ -306,7 +350,8 @@ def run_stub(args, rank, local_rank, world, dist, steps, warmup):
         return None
     return {"metric": "stub_units_per_sec", "value": total / dt_max, "unit": "units/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
-            "data": "synthetic", "config": {"workload": "CPU stub (plumbing test of the N-rank path)", "per_rank_units": per_rank, "units": total}}
+            "data": "synthetic", "config": {"workload": "CPU stub (plumbing test of the N-rank path)", "per_rank_units": per_rank, "units": total,
+                                            "scaling_report": scaling_report(world, total / dt_max, [u / dt_max for u in per_rank], "stub_units_per_sec")}}
 
 
 # ------------------------------------------------------------------------------------------------------------------- board step
@@ -611,12 +656,18 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "games_per_sec_note": "ESTIMATED, not measured: rollouts/s / (rollouts per move x 250 moves per game) -- a 19x19 game at "
                                          "8192 rollouts/move takes hours; measured games/s on a shortened configuration: selfplay_games",
                    "per_rank_rollouts_per_sec": per_rank,
+                   "scaling_report": scaling_report(world, roll_all / dt_max, per_rank, "mcts_rollouts_per_sec"),
+                   "parity_note": PARITY_NOTE,
+                   "pregrow_note": "the untimed tree-growing steps answer the leaves with random priors (not the net): the window's mean depth "
+                                   "is that of trees shaped by noise priors plus the timed net steps; the search kernels are ~2 %% of the step either way",
                    "parallelism": "independent games per GPU, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                     "traffic": (load_profile_json("pmc_traffic.json").get("k_mcts_search<%d>" % n, {}).get("hbm_bytes_per_rollout") or 0) * G * K * T or None,
+                     "traffic": ((load_profile_json("pmc_traffic.json").get("k_mcts_search<%d>" % n, {}).get("hbm_bytes_per_rollout") or 0) * G * K * T or None)
+                                if pmc_source_match("pmc_traffic.json") else None,
+                     "pmc_source_match": pmc_source_match("pmc_traffic.json"),
                      "traffic_note": "PMC HBM bytes per rollout of the four search kernels (profiles/pmc_traffic.json, search-only run at depth 6.3) x "
-                                     "rollouts per step",
+                                     "rollouts per step; withheld (null) when the kernel sources have changed since the PMC passes",
                      "kernel": "k_mcts_select+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
                      "algorithmic_bytes_per_rollout": bytes_per_step / (G * K * T),
                      "select_kernel": {"achieved_GBps": (sel_bytes / (sel_ms / 1e3) / 1e9) if (sel_bytes and sel_ms > 0) else None,
@@ -732,11 +783,13 @@ def run_games(args, rank, local_rank, world, dist):
     st = sp.stats()
     recs = sum(len(g.pop_records()) for g in sp.groups)
     dt_max, games_all = reduce_max_sum(dist, dev, dt, st["games"])
+    per_rank = gather_per_rank(dist, dev, st["games"] / dt, world)
     sp.close()
     if rank != 0:
         return None
     return {"metric": "selfplay_games_per_sec (MEASURED, shortened configuration)", "value": games_all / dt_max, "unit": "games/s",
-            "games_finished": games_all, "seconds": dt_max, "moves": st["moves"], "records_kept": recs,
+            "n_gpus": world, "games_finished": games_all, "seconds": dt_max, "moves": st["moves"], "records_kept": recs,
+            "per_rank_games_per_sec": per_rank, "scaling_report": scaling_report(world, games_all / dt_max, per_rank, "selfplay_games_per_sec"),
             "config": {"workload": "the headline's self-play loop with %d rollouts/move (bs %d) and move_cutoff %d: %d games per GPU, "
                                    "%d generations of games played to the cutoff, scored, recorded and restarted" % (roll, K, cutoff, G, args.games_generations),
                        "rollouts_per_move": roll, "move_cutoff": cutoff, "games_per_gpu": G, "net": "resnet" if net is not None else args.net}}
@@ -865,8 +918,8 @@ def cpu_baseline_train(n, records_json, nfa):
 
 
 def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
-    """the trainer's input pipeline.  One step = one "train" batch of --train-batch samples: draw (record, ply,
-    D4) like GoGameTrain::act, replay each record to its ply and extract every field, in ONE k_replay_extract launch."""
+    """the trainer's input pipeline.  One step = --train-prefetch "train" batches of --train-batch samples: draw
+    (record, ply, D4) like GoGameTrain::act, replay each record to its ply and extract every field, in ONE k_replay_extract launch."""
     import ctypes as C
     import elf_amd
     from elf_amd.selfplay import MctsOptions, SpOptions
@@ -876,8 +929,9 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     moves = synth_games(n, R, plies, dev, local_rank, 4242 + rank).cpu().numpy().astype(np.uint16)
     rng = np.random.default_rng(7 + rank)
     P = (n + 2) ** 2
+    KB = max(1, args.train_prefetch)    # train batches drawn + extracted per launch (the trainer prefetches; start_server.sh:11-12 runs 2048 loader threads)
     ld = elf_amd.ReplayLoader(board_size=n, capacity=R, batchsize=B, device=local_rank, num_future_actions=nfa, seed=1234 + 1000 * rank,
-                              feature_format="f16_nhwc" if args.features in ("auto", "f16") else "f32_nchw")
+                              feature_format="f16_nhwc" if args.features in ("auto", "f16") else "f32_nchw", batches_per_launch=KB)
     recs_json = []
     L = elf_amd.lib()
     opt = SpOptions(n, 1, 1024, 1600, 1, 0.25, 0.03, 0, 30, -1, 0.0, 0.0, 0, 1, 1, 0, 0, 0, MctsOptions(16, 1, 1, 0, 0, 1.5, 7.5, 0, 1, 1, 1, 0, -1))
@@ -895,6 +949,7 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
             buf = C.create_string_buffer(k + 1)
             L.elfrec_record_to_json(*args_, buf, k + 1)
             recs_json.append(buf.raw[:k].decode())
+    B1, B = B, B * KB                   # below, B = samples per launch
     out = ld._alloc(B)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     mt_sum = torch.zeros((), dtype=torch.int64, device=dev)
@@ -926,9 +981,11 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "value": samples_all / dt_max, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
         "data": "synthetic",
-        "config": {"workload": "SURVEY.md 8f-1 trainer input pipeline: batch %d, %d records of %d plies (random legal play on the device "
-                               "engine), one MCTS policy per ply, num_future_actions %d, s rows %s" % (B, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
-                   "batch": B, "records": R, "board_size": n, "mean_replayed_plies": replayed / (B * steps),
+        "config": {"workload": "SURVEY.md 8f-1 trainer input pipeline: train batches of %d samples, %d batches drawn + extracted per launch (one "
+                               "step = one launch: the trainer prefetches), %d records of %d plies (random legal play on the device engine), one "
+                               "MCTS policy per ply, num_future_actions %d, s rows %s" % (B1, KB, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
+                   "batch": B1, "batches_per_launch": KB, "samples_per_launch": B, "records": R, "board_size": n,
+                   "mean_replayed_plies": replayed / (B * steps),
                    "replayed_board_steps_per_sec": replayed / dt,
                    "algorithmic_GBps": B * per_sample / (kern_ms / 1e3) / 1e9,
                    "algorithmic_note": "SURVEY.md 8d bytes per sample (replayed plies x 8730 B + features + policy row + scores): the data "
@@ -953,6 +1010,7 @@ def main():
     ap.add_argument("--workload", choices=["mcts", "board", "train", "feature", "boundary", "games", "both", "stub"], default="both",
                     help="both (default) = mcts headline + every sub-result at N = 1")
     ap.add_argument("--train-batch", type=int, default=2048)
+    ap.add_argument("--train-prefetch", type=int, default=8, help="train batches drawn + extracted per launch (1 = one batch per launch)")
     ap.add_argument("--train-records", type=int, default=256)
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--boards9", type=int, default=65536)
@@ -1032,7 +1090,9 @@ def main():
             res = bd
         elif rank == 0:
             res["boundary"] = bd
-    if args.workload == "games" or sub:
+    if args.workload == "games" or sub or (args.workload == "both" and world > 1 and not args.no_sub):
+        # N > 1: the measured games/s of the shortened configuration rides with the headline, so that one `bench.py --gpus N` line
+        # per N yields the games/sec scaling curve BASELINE.json names (measured, not the 250-moves-per-game estimate)
         gm = run_games(args, rank, local_rank, world, dist)
         if args.workload == "games":
             res = gm

@@ -9,6 +9,20 @@ ZOBRIST_BIN = os.path.join(HERE, "data", "zobrist21.bin")
 
 _lib = None
 
+# the sources every device kernel of libelf_amd.so is compiled from: measurements that are tied to the kernels' instruction
+# streams (profiles/pmc_issue.json, pmc_traffic.json) record this hash, and bench.py only prices against them while it matches
+KERNEL_SOURCES = ("go_board.cuh", "mcts.cuh", "train.cuh", "stl_emul.h", "engine_host.h", "elf_amd.hip", "mcts_capi.hip", "train_capi.hip",
+                  "net_epilogue.hip", "Makefile")
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
 # name -> (restype, argtypes); mirrors include/elf_amd.h one to one
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -96,6 +110,7 @@ SIGNATURES = {
     "elfnet_bias_act_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "elfgo_set_device": (_i, [_i]),
     "elfgo_get_device": (_i, [C.POINTER(_i)]),
+    "elfgo_mem_info": (_i, [_i, C.POINTER(_sz), C.POINTER(_sz)]),
     "elfgo_pointer_kind": (_i, [_vp, C.POINTER(_i)]),
     "elfgo_memcpy2d_async": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
     "elfgo_stream_sync": (_i, [_vp]),

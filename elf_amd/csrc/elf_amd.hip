@@ -386,6 +386,12 @@ int elfgo_playout(ElfGoEngine* e, const int32_t* ids, const uint64_t* seeds, int
 
 int elfgo_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
 int elfgo_get_device(int* device) { if (!device) return ELFGO_E_BADARG; HIPCHK(hipGetDevice(device)); return 0; }
+int elfgo_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return ELFGO_E_BADARG;
+  DevGuard _dg(device);
+  HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
 int elfgo_pointer_kind(const void* p, int* device) {
   if (device) *device = -1;
   if (!p) return 0;

@@ -614,6 +614,27 @@ class Context {
             {"ACTION_RESIGN", -98}, {"ACTION_CLEAR", -97}};
   }
 
+  // Limits of this engine that the reference does not have, so that a caller can size a job instead of discovering them by error
+  // code (not part of the reference's interface; getParams() stays exactly the reference's dictionary)
+  std::map<std::string, int64_t> getLimits() const {
+    const TSOptions& ts = co_.mcts_options;
+    const int64_t per_move = (int64_t)ts.num_rollouts_per_thread * ts.num_threads;
+    const int64_t npg = go_.nodes_per_game > 0 ? (go_.nodes_per_game + 63) / 64 * 64 : (4 * per_move + 1024 + 63) / 64 * 64;
+    const int n = go_.board_size;
+    const int64_t node_bytes = n == 19 ? 12800 : (sp_ ? (int64_t)elfmcts_node_bytes(elfsp_mcts(sp_)) : 0);
+    std::map<std::string, int64_t> out = {{"max_rollouts_per_step", elfmcts_max_rollouts_per_step()}, {"nodes_per_game", npg},
+                                          {"node_bytes", node_bytes}, {"tree_bytes_per_game_per_ai", npg * node_bytes}};
+    size_t fr = 0, tot = 0;
+    int dev = go_.gpu;
+    if (dev < 0 && elfgo_get_device(&dev) != 0) dev = 0;
+    if (elfgo_mem_info(dev, &fr, &tot) == 0) {
+      out["hbm_free_bytes"] = (int64_t)fr;
+      out["hbm_total_bytes"] = (int64_t)tot;
+      if (node_bytes > 0) out["max_games_by_free_hbm"] = (int64_t)(fr * 9 / 10) / (npg * node_bytes);
+    }
+    return out;
+  }
+
   const GameView* getGame(int i) const {
     if (i < 0 || i >= (int)views_.size()) {
       std::cerr << "Invalid game_idx [" << i << "]" << std::endl;   // game_context.h:66-70
@@ -1023,6 +1044,7 @@ class GameContextBase {
   GameContextBase(const ContextOptions& co, const GameOptions& opt, bool online) : ctx_(new Context(co, opt, online)), client_{ctx_.get()} {}
   Context* ctx() { return ctx_.get(); }
   std::map<std::string, int> getParams() const { return ctx_->getParams(); }
+  std::map<std::string, int64_t> getLimits() const { return ctx_->getLimits(); }
   const GameView* getGame(int i) const { return ctx_->getGame(i); }
   std::vector<std::string> popRecords() { return ctx_->popRecords(); }
  protected:
@@ -1185,6 +1207,7 @@ PYBIND11_MODULE(_elf, m) {
       .def("getGame", &GameContextInference::getGame, ref)
       .def("setRequest", &GameContextInference::setRequest, py::arg("black_ver"), py::arg("white_ver"), py::arg("thres"),
            py::arg("numThreads") = -1)
+      .def("getLimits", &GameContextInference::getLimits)
       .def("popRecords", &GameContextInference::popRecords);
 
   py::class_<GameContextTrain>(go, "GameContextTrain")
@@ -1194,6 +1217,7 @@ PYBIND11_MODULE(_elf, m) {
       .def("getGame", &GameContextTrain::getGame, ref)
       .def("getClient", &GameContextTrain::getClient, ref)
       .def("getServer", &GameContextTrain::getServer, ref)
+      .def("getLimits", &GameContextTrain::getLimits)
       .def("popRecords", &GameContextTrain::popRecords);
 
   // _elf._logging / _elf._options (elf/logging/Pybind.cc, elf/options/Pybind.cc: spdlog factories, OptionSpec/OptionMap) are the

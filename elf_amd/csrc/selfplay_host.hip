@@ -33,6 +33,7 @@
 #include <deque>
 #include <functional>
 #include <string>
+#include <thread>
 
 #include "engine_host.h"
 #include "record_host.h"
@@ -145,6 +146,22 @@ struct ElfSelfPlay {
     int _rc = (x);                \
     if (_rc != 0) return _rc;     \
   } while (0)
+
+// Per-game host work of a move boundary (gamma draws for the Dirichlet noise, the D4 draws of the coming search) touches only
+// that game's generators: spread over a few host threads when many games are at the boundary together.
+template <class F>
+static void sp_for_games(const std::vector<int32_t>& ids, F fn) {
+  const size_t n = ids.size();
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 16) nt = 16;
+  if (n < 16 || nt < 2) { for (int g : ids) fn(g); return; }
+  if (nt > n / 4) nt = (unsigned)(n / 4);
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t]() { for (size_t i = t; i < n; i += nt) fn(ids[i]); });
+  for (auto& x : th) x.join();
+}
 
 static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {
   // Record.request = curr_request_ (go_state_ext.h:134): the game's own request, mcts_opt = the context's TSOptions
@@ -397,10 +414,11 @@ static int sp_begin_searches(ElfSelfPlay* sp) {
       HIPCHK(hipMemcpyAsync(sp->h_info.data(), sp->d_info, sizeof(int32_t) * G * ELFMCTS_ROOT_WORDS, hipMemcpyDeviceToHost, sp->stream));
       HIPCHK(hipStreamSynchronize(sp->stream));
       // NodeT::enhanceExploration (tree_search_node.h:132-155), draws from actors_[0]->rng(); not part of runPolicyOnly
-      for (int g : starting[a]) {
+      for (int g : starting[a])
         if (sp->h_info[g * ELFMCTS_ROOT_WORDS + 6]) return ELFGO_E_MCTS_BASE - sp->h_info[g * ELFMCTS_ROOT_WORDS + 6];
+      sp_for_games(starting[a], [&](int g) {
         float* et = &sp->h_etas[(size_t)g * sp->NE];
-        if (sp->games[g].policy_only) { sp->h_Z[g] = 1.0f; continue; }
+        if (sp->games[g].policy_only) { sp->h_Z[g] = 1.0f; return; }
         const int n = sp->h_info[g * ELFMCTS_ROOT_WORDS + 0];
         std::gamma_distribution<> dis(sp->opt.root_alpha);
         float Z = 1e-10;
@@ -409,7 +427,7 @@ static int sp_begin_searches(ElfSelfPlay* sp) {
           Z += et[i];
         }
         sp->h_Z[g] = Z;
-      }
+      });
       // policy-only games of this batch must not receive noise: they are masked out for the noise launch
       bool mixed = false;
       for (int g : starting[a]) mixed = mixed || sp->games[g].policy_only;
@@ -425,12 +443,12 @@ static int sp_begin_searches(ElfSelfPlay* sp) {
       if (mixed) HIPCHK(hipStreamSynchronize(sp->stream));   // m2 is a temporary
     }
     // BoardFeature::RandomShuffle draws of this move (go/mcts/mcts.h:175-183), from a copy of the actor stream
-    for (int g : starting[a]) {
+    sp_for_games(starting[a], [&](int g) {
       std::mt19937 c = sp->games[g].actor_rng[a];
       uint8_t* d = &p.h_d4[(size_t)g * p.W];
       const int w = sp->games[g].policy_only ? 1 : p.W;
       for (int i = 0; i < w; ++i) d[i] = (uint8_t)(c() % 8);
-    }
+    });
     SPCHK(elfmcts_set_d4(p.mcts, p.h_d4.data(), sp->stream));
   }
   return 0;

@@ -50,15 +50,25 @@ __device__ __forceinline__ int coord_to_action(int c, int d4) {
   return ox * N + oy;
 }
 
+// REPLAY_WAVES samples per workgroup, one wave each and no synchronisation after the prologue: the waves share the LDS copy of
+// the Zobrist constants (3.4 KiB at 19x19), which lifts the LDS-bound occupancy from 16 to 20 resident waves per CU.  The kernel
+// is a dependent latency chain per wave (a replay of ~160 plies), so what it needs is resident waves: elftrain_extract takes
+// any number of samples per launch (several train batches at once: the trainer prefetches).
+#define REPLAY_WAVES 4
 template <int N, class PoolT>
-__global__ __launch_bounds__(64) void k_replay_extract(PoolT pool, ReplayStore st, const int32_t* rec, const int32_t* move_to,
-                                                        const int32_t* d4s, int n, TrainBatch o) {
+__global__ __launch_bounds__(64 * REPLAY_WAVES) void k_replay_extract(PoolT pool, ReplayStore st, const int32_t* rec, const int32_t* move_to,
+                                                                       const int32_t* d4s, int n, TrainBatch o) {
   using G = Geo<N>;
-  __shared__ Slot<N> lds;
-  __shared__ u64 tpl[AGZ_SCRATCH_BYTES / 8];
+  __shared__ Slot<N> lds_all[REPLAY_WAVES];
+  __shared__ u64 tpl_all[REPLAY_WAVES][AGZ_SCRATCH_BYTES / 8];
   __shared__ u64 zlds[G::P];   // Zobrist constants: forward reads them from LDS, not behind its own superko record stores (Board::zob_v)
-  const int i = blockIdx.x, lane = threadIdx.x;
-  for (int j = lane; j < G::P; j += 64) zlds[j] = pool.zob[j];
+  for (int j = threadIdx.x; j < G::P; j += 64 * REPLAY_WAVES) zlds[j] = pool.zob[j];
+  __syncthreads();
+  const int wv = rfl((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int i = blockIdx.x * REPLAY_WAVES + wv;
+  if (i >= n) return;
+  Slot<N>& lds = lds_all[wv];
+  u64* tpl = tpl_all[wv];
   int r = rfl(rec[i]);
   r = r < 0 ? 0 : (r >= st.capacity ? st.capacity - 1 : r);   // an out-of-range record id must not read outside the store
   const int d4 = rfl(d4s ? d4s[i] : 0) & 7;

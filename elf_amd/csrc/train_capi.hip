@@ -122,7 +122,7 @@ int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, c
   o.offline_a = b->offline_a; o.nfa = b->num_future_actions;
   o.winner = b->winner; o.mcts_scores = b->mcts_scores; o.predicted_value = b->predicted_value;
   o.move_idx = b->move_idx; o.num_move = b->num_move; o.aug_code = b->aug_code; o.selfplay_ver = b->selfplay_ver;
-  DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_extract<N, Pool<N>>), dim3(n), dim3(64), 0, (hipStream_t)stream, pool_of<N>(r->eng), r->st,
+  DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_extract<N, Pool<N>>), dim3((n + REPLAY_WAVES - 1) / REPLAY_WAVES), dim3(64 * REPLAY_WAVES), 0, (hipStream_t)stream, pool_of<N>(r->eng), r->st,
                                       rec, move_to, d4, n, o));
   HIPCHK(hipGetLastError());
   return 0;

@@ -68,7 +68,7 @@ class ReplayLoader:
     """HBM-resident replay store + one-launch batch extraction (k_replay_extract)."""
 
     def __init__(self, board_size=19, capacity=1024, batchsize=2048, device=0, max_moves=None, with_policies=True,
-                 num_future_actions=1, seed=0, feature_format="f32_nchw"):
+                 num_future_actions=1, seed=0, feature_format="f32_nchw", batches_per_launch=1):
         if not torch.cuda.is_available():
             raise RuntimeError("elf_amd.ReplayLoader needs a ROCm GPU (no CPU fallback exists)")
         self.L = _lib.lib()
@@ -80,12 +80,15 @@ class ReplayLoader:
         self.f16 = feature_format == "f16_nhwc"
         if not self.f16 and feature_format != "f32_nchw":
             raise ValueError("feature_format must be 'f32_nchw' or 'f16_nhwc'")
-        self.engine = GoEngine(self.n, self.batchsize, device)   # replay scratch: sample i replays in board slot i
+        # the trainer prefetches: `batches_per_launch` train batches are drawn and extracted by ONE launch (sample_batches); the
+        # replay of a sample is a dependent chain of ~160 board steps, so the kernel wants many samples in flight
+        self.batches_per_launch = max(1, int(batches_per_launch))
+        self.engine = GoEngine(self.n, self.batchsize * self.batches_per_launch, device)   # replay scratch: sample i replays in board slot i
         self.device = self.engine.device
         h = C.c_void_p()
         check(self.L.elftrain_create(self.engine._h, int(capacity), self.max_moves, int(with_policies), int(seed) & 0xFFFFFFFF, C.byref(h)))
         self._h = h
-        B, dev = self.batchsize, self.device
+        B, dev = self.batchsize * self.batches_per_launch, self.device
         self._draw = torch.zeros((3, B), dtype=torch.int32, device=dev)
 
     def close(self):
@@ -135,8 +138,8 @@ class ReplayLoader:
         t = [x.to(device=dev, dtype=torch.int32).contiguous() if isinstance(x, torch.Tensor)
              else torch.tensor(np.asarray(x, np.int32), device=dev) for x in (rec, move_to, d4)]
         n = t[0].numel()
-        if n > self.batchsize:
-            raise ValueError("batch larger than the loader's batchsize")
+        if n > self.batchsize * self.batches_per_launch:
+            raise ValueError("more samples than the loader's batchsize x batches_per_launch")
         b = out if out is not None else self._alloc(n)
         tb = TrainBatch(b["s"].data_ptr(), 18 * self.n * self.n, 1 if self.f16 else 0, self.nfa, b["offline_a"].data_ptr(),
                         b["winner"].data_ptr(), b["mcts_scores"].data_ptr(), b["predicted_value"].data_ptr(), b["move_idx"].data_ptr(),
@@ -153,3 +156,12 @@ class ReplayLoader:
         check(self.L.elftrain_draw(self._h, n, self.nfa, C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()),
                                    C.c_void_p(d[2].data_ptr()), self._stream()))
         return self.extract(d[0, :n], d[1, :n], d[2, :n], out=out)
+
+    def sample_batches(self, k=None, out=None):
+        """k train batches (default batches_per_launch) of `batchsize` samples drawn and extracted by one launch: the same
+        samples, in the same order, as k consecutive sample() calls (the draws come from the same mt19937 stream).
+        -> list of k batch dicts (views of one allocation)."""
+        k = int(k or self.batches_per_launch)
+        B = self.batchsize
+        big = self.sample(k * B, out=out)
+        return [{key: t[i * B:(i + 1) * B] for key, t in big.items()} for i in range(k)]

@@ -443,6 +443,9 @@ int elfnet_bias_act_bf16(void* x, const void* bias, const void* res, int64_t row
  * thread's current device unless a device is named */
 int elfgo_set_device(int device);
 int elfgo_get_device(int* device);
+/* free / total HBM of a device in bytes (hipMemGetInfo): what a caller sizes num_games x nodes_per_game against -- a tree node
+ * record is elfmcts_node_bytes() (12 800 B at 19x19) and a game keeps nodes_per_game of them per AI */
+int elfgo_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 /* what kind of memory a caller-provided address is: 0 = pageable host (or unknown), 1 = page-locked (pinned) host, 2 = device;
  * *device (may be NULL) <- the owning device for kind 2 */
 int elfgo_pointer_kind(const void* p, int* device);

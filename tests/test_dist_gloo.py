@@ -48,3 +48,8 @@ def test_bench_spawns_its_own_ranks():
     assert rep["n_gpus"] == 2 and rep["steps"] == 5 and rep["scaling"] == "weak"
     assert rep["config"]["units"] == 5 * (1000 + 1001) and rep["config"]["per_rank_units"] == [5000.0, 5005.0]
     assert rep["ms_per_step"] >= 4.0        # rank 1 sleeps 4 ms per step: the report carries the slowest rank
+    # what a multi-GPU line says about scaling (the headline and the measured games/s carry the same block)
+    sr = rep["config"]["scaling_report"]
+    assert sr["n_gpus"] == 2 and len(sr["per_rank"]) == 2 and abs(sr["sum_over_ranks"] - sum(sr["per_rank"])) < 1e-6
+    assert set(sr) >= {"per_rank", "sum_over_ranks", "n1_reference", "per_gpu_fraction_of_n1", "measured_curve"}
+    assert "no multi-GPU node" in sr["measured_curve"]

@@ -219,3 +219,31 @@ def test_selfplay_soak_records_replay_on_the_oracle(elf):
     free = info[:, 7].cpu().numpy()
     assert (free >= 1024 - 32 * 4 - 64).all(), free.min()
     sp.close()
+
+
+def test_prefetched_batches_equal_single_batch_launches(elf):
+    """ReplayLoader(batches_per_launch = k): one k_replay_extract launch draws and extracts k train batches (the trainer
+    prefetches; the replay kernel is a latency chain per sample and wants many samples in flight).  Same samples, in the same order,
+    bit for bit, as k single-batch launches of a loader with the same seed."""
+    import torch
+    n, B, k = 9, 64, 3
+    g, recs = load_rows(n)
+    outs = []
+    for kk in (1, k):
+        ld = elf.ReplayLoader(board_size=n, capacity=len(recs), batchsize=B, device=0, num_future_actions=1, seed=77, batches_per_launch=kk)
+        for i, t in enumerate(recs):
+            ld.put(i, t)
+        if kk == 1:
+            got = [{key: v.clone() for key, v in ld.sample().items()} for _ in range(k)]
+        else:
+            got = [{key: v.clone() for key, v in b.items()} for b in ld.sample_batches()]
+        torch.cuda.synchronize()
+        outs.append(got)
+        ld.close()
+    for a, b in zip(*outs):
+        assert set(a) == set(b)
+        for key in a:
+            # bit patterns: a record whose recorded policy sums to zero yields NaN rows (0 / 0, as in the reference), and NaN != NaN
+            va = a[key].contiguous().view(torch.int32 if a[key].element_size() == 4 else torch.int64 if a[key].element_size() == 8 else torch.int16)
+            vb = b[key].contiguous().view(va.dtype)
+            assert a[key].shape[0] == B and torch.equal(va, vb), key

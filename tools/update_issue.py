@@ -50,5 +50,10 @@ for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>
                 "profile": "profiles/%s_%s_rocprofv3.txt" % (tag, profile),
                 "note": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS, mean over %d launches of the bench.py --workload %s run "
                         "of tools/gpu_round2.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
+sys.path.insert(0, root)
+from elf_amd._lib import KERNEL_SOURCES, kernel_source_hash   # noqa: E402
+res["_source"] = {"kernel_source_hash": kernel_source_hash(), "files": ["elf_amd/csrc/" + f for f in KERNEL_SOURCES], "visit": tag,
+                  "note": "sha256[:16] over the kernel sources the PMC passes were run on; bench.py prints pmc_source_match and withholds "
+                          "the issue-roof fraction / PMC traffic when the sources have changed since"}
 json.dump(res, open(p, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -46,5 +46,10 @@ if os.path.exists(t):
             res["k_extract_agz<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
                                         "note": "tools/feat_bench.py: 16384 rows per launch, fp32 NCHW and fp16 NHWC launches averaged together (%d launches); "
                                                 "algorithmic bytes 26728 / 13732 per row; source profiles/%s_feat_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
+sys.path.insert(0, root)
+from elf_amd._lib import KERNEL_SOURCES, kernel_source_hash   # noqa: E402
+res["_source"] = {"kernel_source_hash": kernel_source_hash(), "files": ["elf_amd/csrc/" + f for f in KERNEL_SOURCES], "visit": tag,
+                  "note": "sha256[:16] over the kernel sources the PMC passes were run on; bench.py prints pmc_source_match and withholds "
+                          "the issue-roof fraction / PMC traffic when the sources have changed since"}
 json.dump(res, open(p, "w"), indent=1)
 print(json.dumps(res, indent=1))
