@@ -458,6 +458,8 @@ def run_feature(args, rank, local_rank, world, dist, steps, warmup):
     d4 = torch.randint(0, 8, (rows,), device=dev, dtype=torch.int32)
     res = {}
     for fmt, key in (("f32_nchw", "f32"), ("f16_nhwc", "f16")):
+        if key not in args.feature_formats.split(","):
+            continue
         dst = None
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         for _ in range(warmup):
@@ -1016,6 +1018,7 @@ def main():
     ap.add_argument("--boards9", type=int, default=65536)
     ap.add_argument("--board-size", type=int, default=19)
     ap.add_argument("--feature-rows", type=int, default=16384)
+    ap.add_argument("--feature-formats", default="f32,f16", help="row formats the feature workload times (one per PMC pass: both use the same kernel)")
     ap.add_argument("--games", type=int, default=256, help="games per GPU (split over --groups)")
     ap.add_argument("--groups", type=int, default=2, help="lock-step game groups pipelined against the net (1 = serial)")
     ap.add_argument("--net-streams", type=int, default=1, help="net streams of the pipeline (1 = the groups' net calls queue on one stream; "

@@ -312,6 +312,8 @@ __device__ unsigned long long g_select_phase[4096][8];   // per block id: no ato
 #define SEL_PHASE(k)
 #endif
 
+__device__ __attribute__((noinline)) double sqrt_beyond_table(int v) { return sqrt((double)v); }
+
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
   using NR = NodeRec<N>;
@@ -384,20 +386,19 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       typedef const __attribute__((address_space(4))) u64 cu64;
       const u64 sq_bits = reinterpret_cast<cu64*>(reinterpret_cast<uintptr_t>(tp.sqrt_tab))[rfl(sq_tab ? all_visits : 0)];
       const int ne = h.n_edges, nt = h.n_touched;
-      const double sq = sq_tab ? __longlong_as_double((long long)sq_bits) : sqrt((double)all_visits);
+      // beyond the table (a node with >= 2^17 visits: not reached by any configured search) the square root is computed in double
+      // precision by a call that is kept out of line, so that the common path does not carry its ~12 FP64 instructions
+      double sq = __longlong_as_double((long long)sq_bits);
+      if (__builtin_expect(!sq_tab, 0)) sq = sqrt_beyond_table(all_visits);
       u32 best_key = 0, unt_key0 = 0;
       int best_e = 0x7FFFFFFF, best_pos = 0, best_child = -1, best_mv = 0;
       float best_vl = 0.0f, best_prior_v = 0.0f, tq = 0.0f;
       int tv = 0;
-      for (int base = 0; base < ne; base += 64) {
-        const int pos = base + lane;
-        const bool in = pos < ne;
-        const int pc = in ? pos : 0;
-        // further rounds (nodes with more than ~60 followed edges, or a long run of equal priors) are read on demand
-        const float4 st = base == 0 ? st0 : nd.stat[pc];
-        const int ch = base == 0 ? ch0 : nd.child[pc];
-        const u32 cd = base == 0 ? cd0 : (u32)nd.coord[pc];
-        const int e = (int)(base == 0 ? og0 : (u32)nd.orig[pc]);
+      // one round of 64 entries of the scoring order; returns whether the next round has to be looked at.  The first round works
+      // on the entries that arrived with the header (one instantiation without loads or waits); further rounds (nodes with more
+      // than ~60 followed edges, or a long run of equal priors) are read on demand by a second instantiation.
+      auto score_round = [&](const int base, const float4 st, const int ch, const u32 cd, const int e) -> bool {
+        const bool in = base + lane < ne;
         const float prior = st.x, reward = st.y, vl = st.w;
         const int nv = __float_as_int(st.z);
         // one formula for both kinds of edge: with N = 0, vl = 0, reward = 0 it yields nvl = 0, Q = first-play urgency,
@@ -448,10 +449,15 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
             best_child = rl(ch, bl); best_mv = rl((int)cd, bl); best_vl = rlf(vl, bl); best_prior_v = rlf(prior, bl);
           }
         }
-        if (base + 64 >= ne) break;                          // every edge has been scored
-        if (base + 64 <= nt) continue;                       // followed edges (or the first never-followed one) are still ahead
+        if (base + 64 >= ne) return false;                   // every edge has been scored
+        if (base + 64 <= nt) return true;                    // followed edges (or the first never-followed one) are still ahead
         if (nt >= base) unt_key0 = (u32)rl((int)key, nt - base);   // this round holds the head of the prior-sorted run
-        if ((u32)rl((int)key, 63) != unt_key0) break;        // the run of maximal never-followed scores ends inside this round
+        return (u32)rl((int)key, 63) == unt_key0;            // false: the run of maximal never-followed scores ends inside this round
+      };
+      bool more = score_round(0, st0, ch0, cd0, (int)og0);
+      for (int base = 64; more; base += 64) {
+        const int pc = base + lane < ne ? base + lane : 0;
+        more = score_round(base, nd.stat[pc], nd.child[pc], (u32)nd.coord[pc], (int)(u32)nd.orig[pc]);
       }
       SEL_PHASE(1);   // statistics gather, scores, reductions, FPU sum
       if (best_e == 0x7FFFFFFF) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors

@@ -39,13 +39,16 @@ if os.path.exists(t):
             res["k_replay_extract<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
                                            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d launches of bench.py --workload train "
                                                    "(2048 samples per launch, ~159 replayed plies each); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_train_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
-t = os.path.join(out, "summary_feat.txt")
-if os.path.exists(t):
+for key, algo in (("f32", 26728), ("f16", 13732)):
+    t = os.path.join(out, "summary_feat%s.txt" % ("32" if key == "f32" else "16"))
+    if not os.path.exists(t):
+        continue
     for k, c in counters(t).items():
         if "k_extract_agz" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            res["k_extract_agz<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
-                                        "note": "tools/feat_bench.py: 16384 rows per launch, fp32 NCHW and fp16 NHWC launches averaged together (%d launches); "
-                                                "algorithmic bytes 26728 / 13732 per row; source profiles/%s_feat_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
+            res["k_extract_agz<19>:%s" % key] = {
+                "hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
+                "note": "bench.py --workload feature --feature-formats %s: 16384 rows per launch (%d launches); algorithmic bytes %d per row; "
+                        "source profiles/%s_feat%s_rocprofv3.txt" % (key, c["FETCH_SIZE"][1], algo, tag, "32" if key == "f32" else "16")}
 sys.path.insert(0, root)
 from elf_amd._lib import KERNEL_SOURCES, kernel_source_hash   # noqa: E402
 res["_source"] = {"kernel_source_hash": kernel_source_hash(), "files": ["elf_amd/csrc/" + f for f in KERNEL_SOURCES], "visit": tag,
