@@ -38,7 +38,7 @@ if os.path.exists(t):
         if "k_replay_extract" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             res["k_replay_extract<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
                                            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d launches of bench.py --workload train "
-                                                   "(2048 samples per launch, ~159 replayed plies each); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_train_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
+                                                   "(16384 samples = 8 train batches per launch, ~159 replayed plies each); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_train_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
 for key, algo in (("f32", 26728), ("f16", 13732)):
     t = os.path.join(out, "summary_feat%s.txt" % ("32" if key == "f32" else "16"))
     if not os.path.exists(t):
@@ -54,5 +54,6 @@ from elf_amd._lib import KERNEL_SOURCES, kernel_source_hash   # noqa: E402
 res["_source"] = {"kernel_source_hash": kernel_source_hash(), "files": ["elf_amd/csrc/" + f for f in KERNEL_SOURCES], "visit": tag,
                   "note": "sha256[:16] over the kernel sources the PMC passes were run on; bench.py prints pmc_source_match and withholds "
                           "the issue-roof fraction / PMC traffic when the sources have changed since"}
+res.pop("k_extract_agz<19>", None)   # the round-2 entry that averaged both row formats
 json.dump(res, open(p, "w"), indent=1)
 print(json.dumps(res, indent=1))
