@@ -264,10 +264,14 @@ std::string elfrec_record_json(const SpRecordMeta& m, const SpRecord& r) {
   o += ",\"using_models\":[";
   {
     bool first = true;   // std::set<int64_t>: ascending, without negatives (addCurrentModel, go_state_ext.h:69-74)
-    int64_t a = m.black_ver, b = m.white_ver;
-    if (a > b) { int64_t t = a; a = b; b = t; }
-    if (a >= 0) { o += std::to_string(a); first = false; }
-    if (b >= 0 && b != a) { if (!first) o += ','; o += std::to_string(b); }
+    if (!r.using_models.empty()) {
+      for (int64_t v : r.using_models) { if (!first) o += ','; o += std::to_string(v); first = false; }
+    } else {
+      int64_t a = m.black_ver, b = m.white_ver;
+      if (a > b) { int64_t t = a; a = b; b = t; }
+      if (a >= 0) { o += std::to_string(a); first = false; }
+      if (b >= 0 && b != a) { if (!first) o += ','; o += std::to_string(b); }
+    }
   }
   o += "],\"values\":[";
   for (size_t i = 0; i < r.values.size(); ++i) { if (i) o += ','; put_float(o, r.values[i]); }

@@ -28,6 +28,7 @@ struct SpRecord {              // the MsgResult half (record.h:184-234) + Record
   int num_move = 0;
   uint64_t timestamp = 0, thread_id = 0;
   int seq = 0;
+  std::vector<int64_t> using_models;      // GoStateExt::using_models_ (a std::set: ascending, unique); empty = the request's versions
 };
 
 struct ElfSpOptions;

@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <new>
 #include <random>
+#include <set>
 #include <utility>
 #include <vector>
 
@@ -79,6 +80,11 @@ struct SpGame {
   int step = 0, steps = 0;     // batches done / batches of this search
   bool policy_only = false;    // MCTSAI_T::actPolicyOnly instead of act
   SpRecord rec;                // GoStateExt::_mcts_policies / _predicted_values / the game's moves (go_state_ext.h:131-148)
+  std::set<int64_t> using_models;   // GoStateExt::using_models_: every model version this game has been played with
+  void add_current_model() {   // GoStateExt::addCurrentModel (go_state_ext.h:68-73)
+    if (req.black_ver >= 0) using_models.insert(req.black_ver);
+    if (req.white_ver >= 0) using_models.insert(req.white_ver);
+  }
 };
 
 struct SpPool {              // one MCTSGoAI role: its tree pool and options
@@ -185,6 +191,7 @@ static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int fina
     r.num_move = final_ply - 1;                  // _state.getPly() - 1
     r.thread_id = (uint64_t)g;
     r.seq = gm.seq;                              // _seq: ctor restart() -> 1, first request restart() -> 2, then +1 per game
+    r.using_models.assign(gm.using_models.begin(), gm.using_models.end());
     r.timestamp = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
     if ((int)sp->records.size() >= sp->opt.keep_records) sp->records.pop_front();
     sp->records.push_back(elfrec_record_json(sp_meta(sp, gm), r));
@@ -197,6 +204,8 @@ static void sp_state_restart(SpGame& gm) {
   gm.ply = 1; gm.never_resign = false; gm.has_calculated_never_resign = false; gm.last_predicted = 0.0f;
   gm.seq++;
   gm.rec = SpRecord();
+  gm.using_models.clear();
+  gm.add_current_model();
 }
 
 // GoGameSelfPlay::restart :202-219: forward the first preload_sgf_move_to moves of the preloaded SGF on the listed (fresh) game boards
@@ -315,6 +324,7 @@ static bool sp_on_receive(ElfSelfPlay* sp, int g, const SpRequest& r, bool* mode
   gm.phase = PH_PLAY;
   if (r.async) {                                 // setAsync :150-156
     gm.actor_ver[0] = gm.actor_ver[1] = -1;
+    gm.add_current_model();
     if (!same_vers) *model_changed = true;       // UPDATE_MODEL_ASYNC
   }
   return false;

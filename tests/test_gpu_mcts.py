@@ -488,3 +488,42 @@ def test_pick_method_uniform_random(elf):
     assert runs[0] == runs[1]
     with pytest.raises(ValueError):
         elf.SelfPlay(board_size=9, num_games=1, mcts_pick_method="softmax")
+
+
+def test_async_request_changes_the_model_without_restarting_the_games(elf):
+    """ClientCtrl.async (GoGameSelfPlay::OnReceive :251-262 -> setAsync :150-156): a request with new versions does NOT restart the
+    games; the AIs stop checking reply versions, the game's Record lists every model it was played with (GoStateExt::using_models_),
+    and a game_start is due (UPDATE_MODEL_ASYNC).  Engine-side semantics (the reference harness sends one request per run)."""
+    import json
+    import torch
+    n = 9
+    sp = elf.SelfPlay(board_size=n, num_games=2, mcts_rollout_per_thread=32, mcts_rollout_per_batch=16, seed=5, move_cutoff=14,
+                      keep_records=4, nodes_per_game=1024, model_ver=3)
+
+    def step(ver):
+        rows = sp.begin_step()
+        pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), 9, 0)
+        sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device),
+                    torch.full((rows,), ver, dtype=torch.int64, device=sp.device))
+
+    L = elf.lib()
+    import ctypes as C
+    bv, wv = C.c_int64(-5), C.c_int64(-5)
+    while sp.progress()["searches"] < 2 * 3:
+        step(3)
+    assert L.elfsp_take_game_starts(sp._h, C.byref(bv), C.byref(wv)) == 1 and (bv.value, wv.value) == (3, -1)
+    sp.set_request(8, -1, async_=True)
+    plies_before = sp.board_engine().info_host()["ply"].copy()
+    while sp.progress()["searches"] < 2 * 6:      # received at the sixth act of each game; until then version 3 is still required
+        step(3)
+    step(12345)                                    # now any version is accepted ...
+    assert L.elfsp_take_game_starts(sp._h, C.byref(bv), C.byref(wv)) == 1 and (bv.value, wv.value) == (8, -1)
+    assert (sp.board_engine().info_host()["ply"] >= plies_before).all()    # ... and the games went on, not back to the empty board
+    recs = []
+    while len(recs) < 2:
+        step(777)
+        recs += sp.pop_records()
+    j = json.loads(recs[0])
+    assert j["result"]["using_models"] == [3, 8] and j["request"]["vers"]["black_ver"] == 8 and j["request"]["client_ctrl"]["async"] is True
+    assert j["result"]["num_move"] == 13           # one uninterrupted game to the cutoff
+    sp.close()
