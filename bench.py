@@ -1012,7 +1012,7 @@ def main():
     ap.add_argument("--workload", choices=["mcts", "board", "train", "feature", "boundary", "games", "both", "stub"], default="both",
                     help="both (default) = mcts headline + every sub-result at N = 1")
     ap.add_argument("--train-batch", type=int, default=2048)
-    ap.add_argument("--train-prefetch", type=int, default=8, help="train batches drawn + extracted per launch (1 = one batch per launch)")
+    ap.add_argument("--train-prefetch", type=int, default=16, help="train batches drawn + extracted per launch (1 = one batch per launch)")
     ap.add_argument("--train-records", type=int, default=256)
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--boards9", type=int, default=65536)

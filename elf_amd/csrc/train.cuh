@@ -9,6 +9,7 @@
 //                                                    extractStateExtAGZ :103-106, extractMCTSPi :107-127,
 //                                                    extractOfflineAction :129-139, extractStateSelfplayVersion :141-145
 #pragma once
+#include <cstddef>
 #include "go_board.cuh"
 
 namespace elfgo {
@@ -59,8 +60,10 @@ template <int N, class PoolT>
 __global__ __launch_bounds__(64 * REPLAY_WAVES) void k_replay_extract(PoolT pool, ReplayStore st, const int32_t* rec, const int32_t* move_to,
                                                                        const int32_t* d4s, int n, TrainBatch o) {
   using G = Geo<N>;
+  // 19x19: the extraction's scratch reuses the front of the wave's own slot (see below); the 9x9 slot is smaller than the scratch
+  constexpr bool ALIAS = offsetof(Slot<N>, bloom) >= (size_t)AGZ_SCRATCH_BYTES && sizeof(Slot<N>) - offsetof(Slot<N>, bloom) >= sizeof(u64) * HIST * 2 * G::R;
   __shared__ Slot<N> lds_all[REPLAY_WAVES];
-  __shared__ u64 tpl_all[REPLAY_WAVES][AGZ_SCRATCH_BYTES / 8];
+  __shared__ u64 tpl_all[ALIAS ? 1 : REPLAY_WAVES][ALIAS ? 1 : AGZ_SCRATCH_BYTES / 8];
   __shared__ u64 zlds[G::P];   // Zobrist constants: forward reads them from LDS, not behind its own superko record stores (Board::zob_v)
   for (int j = threadIdx.x; j < G::P; j += 64 * REPLAY_WAVES) zlds[j] = pool.zob[j];
   __syncthreads();
@@ -68,7 +71,6 @@ __global__ __launch_bounds__(64 * REPLAY_WAVES) void k_replay_extract(PoolT pool
   const int i = blockIdx.x * REPLAY_WAVES + wv;
   if (i >= n) return;
   Slot<N>& lds = lds_all[wv];
-  u64* tpl = tpl_all[wv];
   int r = rfl(rec[i]);
   r = r < 0 ? 0 : (r >= st.capacity ? st.capacity - 1 : r);   // an out-of-range record id must not read outside the store
   const int d4 = rfl(d4s ? d4s[i] : 0) & 7;
@@ -86,9 +88,28 @@ __global__ __launch_bounds__(64 * REPLAY_WAVES) void k_replay_extract(PoolT pool
     bd.forward(c);
   }
   bd.store(&pool.slots[i]);                     // the replayed GoState stays inspectable through elfgo_* (slot i)
-  // "s": extractStateExtAGZ -> BoardFeature::extractAGZ under the sample's D4 code
+  // "s": extractStateExtAGZ -> BoardFeature::extractAGZ under the sample's D4 code.  After the store only the history ring of the
+  // LDS image is still needed: it moves into the (dead) Bloom words, and the extraction's scratch takes the front of the slot
+  // (header + labels + liberties + old ring = 2624 B >= AGZ_SCRATCH_BYTES at 19x19) -- no scratch of its own, so 8 instead of 5
+  // waves per SIMD fit the LDS.
+  const u64 (*ring)[2][G::R] = lds.hist;
+  u64* tpl = tpl_all[ALIAS ? 0 : wv];
+  if (ALIAS) {
+    Board<N>::wsync();                          // the slot's LDS reads of the store are issued before the ring is overwritten
+    u64* ring_src = &lds.hist[0][0][0];
+    u64* ring_dst = reinterpret_cast<u64*>(&lds.bloom[0]);
+    constexpr int NW = HIST * 2 * G::R, NQ = (NW + 63) / 64;
+    u64 ring_v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int j = q * 64 + lane; ring_v[q] = j < NW ? ring_src[j] : 0ull; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int j = q * 64 + lane; if (j < NW) ring_dst[j] = ring_v[q]; }
+    Board<N>::wsync();
+    ring = reinterpret_cast<const u64 (*)[2][G::R]>(ring_dst);
+    tpl = reinterpret_cast<u64*>(&lds);
+  }
   char* row = (char*)o.s + (size_t)i * o.s_stride * (o.fmt == FEAT_F16_NHWC ? 2 : 4);
-  extract_agz_row<N>(lds.hist, tpl, bd.hist_cnt, bd.next_player, d4, row, o.fmt, lane);
+  extract_agz_row<N>(ring, tpl, bd.hist_cnt, bd.next_player, d4, row, o.fmt, lane);
   const int idx = bd.ply - 1;                   // every extractor's move_to = _state.getPly() - 1
   if (lane == 0) {
     if (o.move_idx) o.move_idx[i] = idx;
