@@ -247,3 +247,71 @@ def test_prefetched_batches_equal_single_batch_launches(elf):
             va = a[key].contiguous().view(torch.int32 if a[key].element_size() == 4 else torch.int64 if a[key].element_size() == 8 else torch.int16)
             vb = b[key].contiguous().view(va.dtype)
             assert a[key].shape[0] == B and torch.equal(va, vb), key
+
+
+def test_evaluation_games_soak_with_requests(elf):
+    """Evaluation games under churn: 48 games with two AIs (different step counts, so the games drift out of step), Black's AI
+    playing policy-only, resignations and cutoffs, a player_swap request and a thread-count request arriving mid-run.  Every
+    record must replay on the CPU oracle, carry the request it was played under, the tree records must keep their invariants in
+    both pools, and no node may leak."""
+    import ctypes as C
+    import torch
+    n, G = 9, 48
+    sp = elf.SelfPlay(board_size=n, num_games=G, mcts_rollout_per_thread=48, mcts_rollout_per_batch=16, mcts_puct=1.5, mcts_virtual_loss=1,
+                      mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=20, policy_distri_cutoff=8,
+                      seed=77, nodes_per_game=1024, keep_records=100000, white_mcts_rollout_per_thread=32, white_mcts_rollout_per_batch=8,
+                      white_puct=1.0, black_use_policy_network_only=True, move_cutoff=60)
+    sp.set_request(4, 5, resign_thres=0.35, never_resign_prob=0.2)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    L = elf.lib()
+    recs, mixed = [], 0
+    for step in range(20000):
+        rb, rw = sp.begin_step2()
+        rep = [None, None]
+        for a, rows in enumerate((rb, rw)):
+            if rows:
+                pi = torch.softmax(3.0 * torch.randn((rows, n * n + 1), device="cuda", generator=gen), dim=1)
+                v = torch.tanh(0.8 * torch.randn((rows,), device="cuda", generator=gen))
+                rep[a] = (pi, v, None)
+        sp.end_step2(rep)
+        mixed += rb > 0 and rw > 0          # both AIs had leaves in this step: games are out of step with each other
+        if step == 300:
+            sp.set_request(4, 5, resign_thres=0.35, never_resign_prob=0.2, player_swap=True)     # every game restarts, AIs swap colours
+        if step == 900:
+            sp.set_request(4, 5, resign_thres=0.35, never_resign_prob=0.2, player_swap=True, num_game_thread_used=G - 8)   # 8 games go idle
+        if step % 97 == 0:
+            for a in range(2):
+                out = np.zeros(5, np.int32)
+                assert L.elfmcts_validate(L.elfsp_mcts_actor(sp._h, a), out.ctypes.data) == 0 and out[0] == 0, (step, a, out)
+            recs += sp.pop_records()
+            if len(recs) >= 150 and step > 1200:
+                break
+    recs += sp.pop_records()
+    assert len(recs) >= 150 and mixed > 0
+    assert sp.progress()["waiting"] == 8
+    port = Port(n)
+    swapped = 0
+    for t in recs:
+        j = json.loads(t)
+        res, ctrl = j["result"], j["request"]["client_ctrl"]
+        assert j["request"]["vers"]["black_ver"] == 4 and j["request"]["vers"]["white_ver"] == 5 and res["using_models"] == [4, 5]
+        swapped += bool(ctrl["player_swap"])
+        mv = sgfstr2coords(n, res["content"])
+        assert len(mv) == res["num_move"]
+        s = port.new()
+        for c in mv:
+            assert port.forward(s, int(c)) == 1
+        if len(res["values"]) == len(mv) + 1:
+            assert res["reward"] == (1.0 if len(mv) % 2 == 1 else -1.0) and len(mv) + 1 >= 50
+        else:
+            assert res["reward"] == port.evaluate(s, 7.5)
+        port.free(s)
+    assert 0 < swapped < len(recs)
+    # node pools of both AIs: nothing leaked over the restarts
+    for a in range(2):
+        info = torch.zeros((G, 8), dtype=torch.int32, device="cuda")
+        assert L.elfmcts_root(L.elfsp_mcts_actor(sp._h, a), C.c_void_p(info.data_ptr()), None, None, None, None, None, None) == 0
+        torch.cuda.synchronize()
+        free = info[:, 7].cpu().numpy()
+        assert (free >= 1024 - 48 * 4 - 64).all(), (a, free.min())
+    sp.close()
