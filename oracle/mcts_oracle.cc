@@ -17,6 +17,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <ctime>
 #include <random>
 #include <unordered_map>
 #include <utility>
@@ -57,6 +58,12 @@ struct SpConfig {
   float resign_thres, never_resign_prob;
   uint32_t net_salt;
   int32_t net_tie_levels, max_searches, timeout_usec;
+  // round 3: evaluation games, pick methods, policy-only play (same layout as RefSpConfig's tail)
+  int32_t black_ver, white_ver, player_swap;
+  float white_puct;
+  int32_t white_rollouts_per_batch, white_rollouts_per_thread;
+  uint32_t white_net_salt;
+  int32_t pick_method, black_policy_only, white_policy_only, thread_used;
 };
 struct SpSearch {
   int32_t game, move_played, best_action, total_visits, n_edges;
@@ -131,6 +138,7 @@ struct Actor {   // elfgames/go/mcts/mcts.h:40-333 MCTSActor
   const SpConfig* cfg;
   net_fn net;
   void* user;
+  uint32_t salt = 0;          // stub net of this actor's batch group ("actor_black" / "actor_white")
   int64_t rows = 0, batches = 0;
 
   // BoardFeature::action2Coord (base/board_feature.h:139-144) with InvTransform (:115-130)
@@ -188,7 +196,7 @@ struct Actor {   // elfgames/go/mcts/mcts.h:40-333 MCTSActor
     std::vector<float> feat((size_t)b * fs), pi((size_t)b * na), v(b);
     for (int j = 0; j < b; ++j) orc_extract_agz(states[sel[j]], d4s[j], &feat[(size_t)j * fs]);
     if (net) net(feat.data(), b, pi.data(), v.data(), user);
-    else orc_stub_net(feat.data(), b, cfg->net_salt, cfg->net_tie_levels, pi.data(), v.data());
+    else orc_stub_net(feat.data(), b, salt, cfg->net_tie_levels, pi.data(), v.data());
     rows += b; batches++;
     for (int j = 0; j < b; ++j) {
       Response& r = (*resps)[sel[j]];
@@ -208,6 +216,10 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
   Tree tree;
   const SpConfig* cfg;
   Actor* actor;
+  // TSOptions of this AI after init_ai's overrides (game_selfplay.cc:51-70)
+  float c_puct = 0;
+  int rollouts_per_batch = 0, rollouts_per_thread = 0;
+  size_t next_move_number = 0;   // MCTSAI_T::nextMoveNumber_
 
   // EdgeInfo::getScore (tree_search_base.h:132-157) + NodeT::UCT :361-397 + BestAction :321-358 + findMove :205-231
   bool find_move(Node* nd, int depth, Coord* action) {
@@ -228,7 +240,7 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
       const float unsigned_q = e.num_visits > 0 ? e.reward / e.num_visits : nd->unsigned_mean_q;
       const float prior = e.prior / (1 + e.num_visits) * std::sqrt(all_visits);   // float * double sqrt(int) -> float
       const bool first_visit = nvl == 0;
-      const float score = cfg->use_prior ? (prior * cfg->c_puct + q) : q;
+      const float score = cfg->use_prior ? (prior * c_puct + q) : q;
       if (score > max_score) { max_score = score; best = ap.first; }
       if (!first_visit) { total_unsigned_q += unsigned_q; total_visits++; }
     }
@@ -282,8 +294,8 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
     std::vector<std::pair<Node*, std::pair<Traj*, int>>> counts;
   };
   void descend(Batch& b) {
-    b.trajs.reserve(cfg->rollouts_per_batch);
-    for (int j = 0; j < cfg->rollouts_per_batch; ++j) b.trajs.push_back(single_rollout());
+    b.trajs.reserve(rollouts_per_batch);
+    for (int j = 0; j < rollouts_per_batch; ++j) b.trajs.push_back(single_rollout());
     for (Traj& t : b.trajs) {
       if (t.leaf->status == NOT_VISITED) {   // requestEvaluation :142-153
         t.leaf->status = EVAL_REQUESTED;
@@ -342,9 +354,37 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
         i++;
       }
     }
-    for (int idx = 0; idx < cfg->rollouts_per_thread; idx += cfg->rollouts_per_batch) batch_rollouts();   // tree_search.h:112-117
+    for (int idx = 0; idx < rollouts_per_thread; idx += rollouts_per_batch) batch_rollouts();   // tree_search.h:112-117
     return true;
   }
+
+  // TreeSearchT::runPolicyOnly :385-407: the root is evaluated if it has not been yet; no noise, no rollouts
+  bool run_policy_only(const OrcState* root_state) {
+    Node* root = tree.at(tree.root);
+    if (root->state == nullptr) root->state = orc_clone(root_state);
+    if (orc_hash(root_state) != orc_hash(root->state)) return false;
+    if (root->status != VISITED) {
+      std::vector<const OrcState*> one(1, root->state);
+      std::vector<Response> resps;
+      actor->evaluate(one, &resps);
+      for (const auto& ap : resps[0].pi) root->sa.insert(std::make_pair(ap.first, Edge(ap.second)));
+      root->V = resps[0].value;
+      root->flip = resps[0].q_flip;
+      root->status = VISITED;
+    }
+    return true;
+  }
+
+  // MCTSAI_T::align_state (elf/ai/tree_search/mcts.h:141-167)
+  void align_state(const std::vector<Coord>& moves) {
+    if (!cfg->persistent_tree) { tree.clear(); next_move_number = 0; }
+    else if (next_move_number > moves.size()) { tree.clear(); next_move_number = 0; }   // moves_since fails -> resetTree
+    else {
+      for (size_t i = next_move_number; i < moves.size(); ++i) tree.advance(moves[i]);
+      next_move_number = moves.size();
+    }
+  }
+  void end_game() { tree.clear(); next_move_number = 0; }   // MCTSAI_T::endGame -> resetTree
 };
 
 std::vector<Coord> g_preload;   // GameOptions.preload_sgf as Coords for the following orcsp_run calls
@@ -369,15 +409,32 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
   const int n = orc_board_size(), na = n * n + 1, max_move = 2 * n * n;
   std::mt19937 game_rng;
   game_rng.seed(cfg->seed);                      // GoGameBase, common/game_base.h:32-38
-  Actor actor;
-  actor.n = n; actor.na = na; actor.komi = cfg->komi; actor.ply_pass_enabled = cfg->ply_pass_enabled;
-  actor.cfg = cfg; actor.net = net; actor.user = user;
-  actor.rng.seed(game_rng());                    // params.seed = _rng() :47, MCTSActor::rng_(params.seed) mcts.h:52
-  Search search;
-  search.cfg = cfg; search.actor = &actor;
+  // GoGameSelfPlay::restart :158-200: "actor_black" first, then (white_ver >= 0) "actor_white" with the white_* overrides, each
+  // seeded with the next draw of the game's generator (init_ai :45-47); player_swap exchanges the two
+  const bool two = cfg->white_ver >= 0;
+  Actor actors[2];
+  Search searches[2];
+  for (int a = 0; a < (two ? 2 : 1); ++a) {
+    Actor& actor = actors[a];
+    actor.n = n; actor.na = na; actor.komi = cfg->komi; actor.ply_pass_enabled = cfg->ply_pass_enabled;
+    actor.cfg = cfg; actor.net = net; actor.user = user;
+    actor.salt = a == 0 ? cfg->net_salt : cfg->white_net_salt;
+    actor.rng.seed(game_rng());                  // params.seed = _rng() :47, MCTSActor::rng_(params.seed) mcts.h:52
+    Search& se = searches[a];
+    se.cfg = cfg; se.actor = &actor;
+    se.c_puct = cfg->c_puct; se.rollouts_per_batch = cfg->rollouts_per_batch; se.rollouts_per_thread = cfg->rollouts_per_thread;
+    if (a == 1) {
+      if (cfg->white_puct > 0.0f) se.c_puct = cfg->white_puct;
+      if (cfg->white_rollouts_per_batch > 0) se.rollouts_per_batch = cfg->white_rollouts_per_batch;
+      if (cfg->white_rollouts_per_thread > 0) se.rollouts_per_thread = cfg->white_rollouts_per_thread;
+    }
+  }
+  Search* ai = &searches[0];
+  Search* ai2 = two ? &searches[1] : nullptr;
+  if (two && cfg->player_swap) std::swap(ai, ai2);
+  std::mt19937 pick_rng((unsigned)time(nullptr));   // MCTSResultT::addActions' static generator (tree_search_base.h:238), uniform_random only
   OrcState* st = orc_new();
   std::vector<Coord> moves;                      // GoState::_moves
-  size_t next_move_number = 0;                   // MCTSAI_T::nextMoveNumber_
   bool never_resign = false, has_never = false;  // ResignCheck
   size_t sgf_iter = 0;                           // GoGameSelfPlay::restart :202-219: forward the first preload_sgf_move_to moves
   for (int i = 0; sgf_iter < g_preload.size() && i < g_preload_move_to; ++i, ++sgf_iter) {
@@ -386,15 +443,15 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
   }
   int k = 0;
   while (k < cfg->max_searches) {
-    // MCTSAI_T::act: align_state
-    if (!cfg->persistent_tree) { search.tree.clear(); next_move_number = 0; }
-    else if (next_move_number > moves.size()) { search.tree.clear(); next_move_number = 0; }   // moves_since fails -> resetTree
-    else {
-      for (size_t i = next_move_number; i < moves.size(); ++i) search.tree.advance(moves[i]);
-      next_move_number = moves.size();
-    }
-    if (!search.run(st)) { orc_free(st); return -2; }
-    // chooseAction / MCTSResultT::addActions (tree_search_base.h:237-294), MOST_VISITED
+    // GoGameSelfPlay::act :354-372: the AI of the colour to move; MCTSAI_T::act or actPolicyOnly (align_state first)
+    const bool white_to_move = orc_next_player(st) == S_WHITE;
+    Search& search = (ai2 != nullptr && white_to_move) ? *ai2 : *ai;
+    const bool policy_only = white_to_move ? cfg->white_policy_only != 0 : cfg->black_policy_only != 0;
+    search.align_state(moves);
+    if (policy_only) { if (!search.run_policy_only(st)) { orc_free(st); return -2; } }
+    else if (!search.run(st)) { orc_free(st); return -2; }
+    // chooseAction :495-528 / runPolicyOnly :401-405 with MCTSResultT::addActions (tree_search_base.h:237-294)
+    const int method = policy_only ? 1 : cfg->pick_method;   // 0 most_visited, 1 strongest_prior, 2 uniform_random
     Node* root = search.tree.at(search.tree.root);
     SpSearch& S = out_search[k];
     memset(&S, 0, sizeof(S));
@@ -403,11 +460,13 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
     const Edge* best_edge = nullptr;
     int i = 0;
     for (int j = 0; j < na; ++j) { out_coord[(size_t)k * na + j] = -1; out_visits[(size_t)k * na + j] = 0; out_prior[(size_t)k * na + j] = 0; out_reward[(size_t)k * na + j] = 0; }
+    const int random_idx = (method == 2 && !root->sa.empty()) ? (int)(pick_rng() % root->sa.size()) : 0;
     for (const auto& ap : root->sa) {
-      const float score = (float)ap.second.num_visits;
+      const float score = method == 0 ? (float)ap.second.num_visits : method == 1 ? ap.second.prior : 1.0f;
       policy.push_back(std::make_pair(ap.first, score));
       S.total_visits += ap.second.num_visits;
-      if (score > S.max_score) { S.max_score = score; S.best_action = ap.first; best_edge = &ap.second; }
+      if (method == 2) { if (i == random_idx) { S.max_score = score; S.best_action = ap.first; best_edge = &ap.second; } }
+      else if (score > S.max_score) { S.max_score = score; S.best_action = ap.first; best_edge = &ap.second; }
       out_coord[(size_t)k * na + i] = ap.first; out_visits[(size_t)k * na + i] = ap.second.num_visits;
       out_prior[(size_t)k * na + i] = ap.second.prior; out_reward[(size_t)k * na + i] = ap.second.reward;
       ++i;
@@ -415,7 +474,7 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
     S.n_edges = i;
     Coord c = (Coord)S.best_action;
     // mcts_make_diverse_move: MCTSPolicy::normalize (t = 1) + sample_multinomial (elf/utils/utils.h:159-182)
-    if (orc_ply(st) <= cfg->policy_distri_cutoff) {
+    if (!policy_only && orc_ply(st) <= cfg->policy_distri_cutoff) {
       float exp_sum = 0;
       for (auto& e : policy) { const float v = std::pow(e.second, 1.0 / 1.0f); e.second = v; exp_sum += v; }
       for (auto& e : policy) e.second /= exp_sum;
@@ -456,13 +515,14 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
       if (cfg->move_cutoff > 0 && orc_ply(st) >= cfg->move_cutoff) finished = true;    // :427-429
       (void)max_move;
     }
-    if (finished) {   // finish_game :121-149: _ai->endGame (resetTree), _state_ext.restart()
-      search.tree.clear(); next_move_number = 0;
+    if (finished) {   // finish_game :121-149: _ai->endGame / _ai2->endGame (resetTree), _state_ext.restart()
+      ai->end_game();
+      if (ai2 != nullptr) ai2->end_game();
       orc_reset(st); moves.clear();
       never_resign = false; has_never = false;
     }
   }
-  if (stats) { stats[0] = actor.batches; stats[1] = actor.rows; stats[2] = 0; }
+  if (stats) { stats[0] = actors[0].batches + actors[1].batches; stats[1] = actors[0].rows + actors[1].rows; stats[2] = 0; }
   orc_free(st);
   return k;
 }

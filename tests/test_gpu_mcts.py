@@ -395,16 +395,22 @@ def test_evaluation_games_out_of_step_equal_the_reference_game_by_game(elf):
     bs 16 = 3 steps per move, White 40 rollouts at bs 8 = 5 steps), games ended by resignation at different plies (52..58) or by
     the cutoff: from the first game end on the games' searches are out of step -- different AIs searching in the same step,
     moves and restarts at different steps -- and every game must still reproduce the reference's game thread (live, oracle/_ref)."""
-    from pyoracle import MCTS_DEFAULTS, RefSelfPlay
+    from pyoracle import MCTS_DEFAULTS, PortSelfPlay, RefSelfPlay
     n, G, per_game = 9, 4, 72
-    if not RefSelfPlay.available(n):
-        pytest.skip("oracle/_ref/libelfsp9.so is not present")
     cfg = dict(MCTS_DEFAULTS)
     cfg.update(num_games=G, rollouts_per_thread=48, seed=7001, net_salt=61, white_net_salt=62, black_ver=3, white_ver=4,
                white_rollouts_per_thread=40, white_rollouts_per_batch=8, white_puct=1.1, policy_distri_cutoff=5, move_cutoff=64,
                resign_thres=0.9)
-    r = RefSelfPlay(n).run(**dict(cfg, max_searches=G * per_game * 2))
-    want = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)
+    if RefSelfPlay.available(n):
+        r = RefSelfPlay(n).run(**dict(cfg, max_searches=G * per_game * 2))
+        want = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)
+    else:       # a fresh clone: the CPU restatement (pinned on the reference's evaluation-game fixtures) plays the games one by one
+        want = {}
+        for g in range(G):
+            r = PortSelfPlay(n).run(**dict(cfg, num_games=1, seed=cfg["seed"] + g, max_searches=per_game))
+            for x in r["search"]:
+                x.game = g
+            want[g] = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)[g]
     assert all(len(want[g]) >= per_game for g in range(G)), [len(want[g]) for g in range(G)]
     sp = sp_from_fixture_cfg(elf, n, cfg, log_searches=G * per_game * 2, nodes_per_game=2048)
     seen = {}
@@ -434,17 +440,23 @@ def test_evaluation_games_out_of_step_equal_the_reference_game_by_game(elf):
 
 def test_idle_game_threads_equal_the_reference(elf):
     """num_game_thread_used = 2 of 3 games (DispatcherCallback::OnFirstSend): game 2 waits, games 0 and 1 equal the reference's."""
-    from pyoracle import MCTS_DEFAULTS, RefSelfPlay
+    from pyoracle import MCTS_DEFAULTS, PortSelfPlay, RefSelfPlay
     n, G, per_game = 9, 3, 6
-    if not RefSelfPlay.available(n):
-        pytest.skip("oracle/_ref/libelfsp9.so is not present")
     cfg = dict(MCTS_DEFAULTS)
     cfg.update(num_games=G, rollouts_per_thread=48, seed=8100, net_salt=63, thread_used=2, policy_distri_cutoff=3)
     # games 0 and 1 of the reference do not depend on the idle thread: they are the reference's two-game context with the same
     # seeds.  (The reference itself cannot be run to completion with an idle game thread: that thread blocks in waitMail for
     # ever and Context::stop never joins it.)
-    r = RefSelfPlay(n).run(**dict(cfg, num_games=2, thread_used=0, max_searches=2 * per_game * 2))
-    want = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)
+    if RefSelfPlay.available(n):
+        r = RefSelfPlay(n).run(**dict(cfg, num_games=2, thread_used=0, max_searches=2 * per_game * 2))
+        want = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)
+    else:
+        want = {2: []}
+        for g in range(2):
+            r = PortSelfPlay(n).run(**dict(cfg, num_games=1, thread_used=0, seed=cfg["seed"] + g, max_searches=per_game))
+            for x in r["search"]:
+                x.game = g
+            want[g] = _per_game(r["search"], r["coord"], r["visits"], r["prior"], r["reward"], G)[g]
     assert len(want[2]) == 0 and min(len(want[0]), len(want[1])) >= per_game
     sp = sp_from_fixture_cfg(elf, n, cfg, log_searches=64, nodes_per_game=2048)
     drive_stub(sp, n, cfg, lambda sp: sp.stats()["logged"] >= 2 * per_game)

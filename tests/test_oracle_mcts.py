@@ -12,6 +12,9 @@ from pyoracle import MCTS_DEFAULTS, PortSelfPlay, RefSelfPlay, stub_net
 
 CASES = ["mcts_19_r8192", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512_client", "mcts_19_r128_fresh", "mcts_9_r512",
          "mcts_9_r64_ties", "mcts_19_r128_vl0", "mcts_19_r128_noprior", "mcts_9_r128_rootq0", "mcts_9_r96_bs4", "mcts_9_r128_bs64"]
+# round 3: evaluation games (two AIs), strongest_prior, policy-only play, more than 64 rollouts per batch
+CASES_R3 = ["mcts_9_eval_two_ai", "mcts_19_eval_swap", "mcts_9_pick_prior", "mcts_9_policy_only_white", "mcts_9_policy_only_eval",
+            "mcts_9_r256_bs128", "mcts_19_r512_bs256"]
 
 
 @pytest.mark.parametrize("n", [19, 9])
@@ -46,7 +49,7 @@ def test_fixture_invariants(name):
         assert ne <= n * n + 1
 
 
-@pytest.mark.parametrize("name", ["mcts_19_r128_fresh", "mcts_9_r64_ties"])
+@pytest.mark.parametrize("name", ["mcts_19_r128_fresh", "mcts_9_r64_ties", "mcts_9_eval_two_ai", "mcts_9_policy_only_white"])
 def test_reference_reproduces_fixture(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     n = int(g["board_size"])
@@ -63,10 +66,10 @@ def test_reference_reproduces_fixture(name):
 
 
 RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
-               "records_19_cutoff"]
+               "records_19_cutoff", "records_9_eval", "records_9_eval_swap_resign"]
 
 
-@pytest.mark.parametrize("name", CASES + RECORD_RUNS)
+@pytest.mark.parametrize("name", CASES + CASES_R3 + RECORD_RUNS)
 def test_restatement_matches_reference_fixture(built, name):
     """oracle/mcts_oracle.cc (the CPU restatement of MCTSActor, the tree search and the self-play loop over go_oracle.c) replays
     the fixture's configuration and must give what the REAL reference gave: every search's root edges in iteration order,
@@ -75,7 +78,7 @@ def test_restatement_matches_reference_fixture(built, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
     n = int(g["board_size"])
-    fl = ("c_puct", "root_epsilon", "root_alpha", "komi", "resign_thres", "never_resign_prob")
+    fl = ("c_puct", "root_epsilon", "root_alpha", "komi", "resign_thres", "never_resign_prob", "white_puct")
     kw = {k: (float(np.float32(v)) if k in fl else int(v)) for k, v in cfg.items()}
     m = len(g["move_played"])
     if name == "mcts_19_r8192":
