@@ -797,6 +797,79 @@ def run_games(args, rank, local_rank, world, dist):
                        "rollouts_per_move": roll, "move_cutoff": cutoff, "games_per_gpu": G, "net": "resnet" if net is not None else args.net}}
 
 
+def run_client(args, rank, local_rank, world, dist):
+    """The reference's canonical self-play CLIENT configuration (scripts/elfgames/go/start_client.sh:11-30): puct 0.85, virtual loss 5,
+    Dirichlet 0.25 / 0.03, 8 search threads x 200 rollouts with 1 rollout per batch (the option's default), persistent tree,
+    ply_pass_enabled 160, policy_distri_cutoff 30, fp16 net -- here with 256 games per GPU (the script runs 32 per client process) in
+    two pipelined groups.  A move is 200 steps of 8 rollouts per game; the window crosses a move boundary.  The 8 search threads are
+    the deterministic interleaving of DESIGN.md (the reference races there)."""
+    from elf_amd.pipeline import PipelinedSelfPlay
+    n = args.board_size
+    dev = torch.device("cuda", local_rank)
+    net, dtype = build_net(args, n, dev)
+    G, groups, T, K, roll = args.games, max(1, args.groups), 8, 1, 200
+    Gg = G // groups
+    feat_fmt = "f16_nhwc" if (net is not None and dtype == torch.float16) else "f32_nchw"
+    sp = PipelinedSelfPlay(groups=groups, seed=2468, game_idx_base=rank * G, wait_rows=False, board_size=n, num_games=Gg, device=local_rank,
+                           mcts_rollout_per_thread=roll, mcts_rollout_per_batch=K, mcts_threads=T, mcts_puct=0.85, mcts_virtual_loss=5,
+                           mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=160,
+                           policy_distri_cutoff=30, policy_distri_training_for_all=True, keep_records=4, nodes_per_game=8192,
+                           feature_format=feat_fmt)
+    rnd = RandomReplies(sp.groups[0].max_rows, n * n + 1, dev, 17 + rank)
+    graphs = {}
+    if net is not None:
+        with torch.no_grad():
+            net({"s": sp.groups[0].s})
+        from elf_amd.net import GraphedNet
+        try:
+            for g in sp.groups:
+                graphs[g.s.data_ptr()] = GraphedNet(net, g.s)
+        except Exception:
+            graphs = {}
+
+    def net_fn(s, rows):
+        if net is None:
+            return rnd()
+        gn = graphs.get(s.data_ptr())
+        if gn is not None:
+            o = gn()
+        else:
+            with torch.no_grad():
+                o = net({"s": s})
+        return o["pi"], o["V"]
+
+    barrier = make_barrier(dist)
+    spm = sp.groups[0].stats()["steps_per_move"]
+    steps, warm = 40, 4
+    for _ in range(spm - warm - steps // 2):          # untimed: grow the trees with cheap replies up to shortly before the move ends
+        sp.step(lambda s, rows: rnd())
+    for _ in range(warm):
+        sp.step(net_fn)
+    sp.synchronize()
+    s0 = sp.stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sp.step(net_fn)
+    sp.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    s1 = sp.stats()
+    d = {k: s1[k] - s0[k] for k in ("moves", "rollouts", "rows", "boundaries", "boundary_ns", "node_visits")}
+    dt_max, roll_all = reduce_max_sum(dist, dev, dt, d["rollouts"])
+    sp.close()
+    if rank != 0:
+        return None
+    return {"metric": "mcts_rollouts_per_sec (start_client.sh configuration)", "value": roll_all / dt_max, "unit": "rollouts/s", "n_gpus": world,
+            "ms_per_step": dt_max / steps * 1e3, "steps": steps, "moves_in_window": d["moves"], "moves_per_sec": roll_all / dt_max / (roll * T),
+            "net_rows_per_step": d["rows"] / steps, "mean_depth": d["node_visits"] / max(d["rollouts"], 1),
+            "move_boundary_ms": (d["boundary_ns"] / 1e6 / d["boundaries"]) if d["boundaries"] else None,
+            "config": {"workload": "scripts/elfgames/go/start_client.sh: puct 0.85, vloss 5, Dirichlet 0.25/0.03, mcts_threads 8 x 200 rollouts, "
+                                   "1 rollout per batch, persistent tree, ply_pass_enabled 160, policy_distri_cutoff 30, %d games per GPU in %d "
+                                   "pipelined groups, %s" % (G, groups, "20x256 fp16 net" if net is not None else "no conv net"),
+                       "rollouts_per_move": roll * T, "steps_per_move": spm, "games_per_gpu": G}}
+
+
 def run_boundary(args, rank, local_rank, world, dist, steps, warmup):
     """The pybind11 drop-in boundary (_elf / _elfgames_go) in a serial wait()/step() loop, as src_py/elf/utils_elf.py drives it:
     once with the batch tensors in pinned host memory (what the reference's Allocator makes: s rows D2H, replies H2D, every step),
@@ -1009,7 +1082,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["mcts", "board", "train", "feature", "boundary", "games", "both", "stub"], default="both",
+    ap.add_argument("--workload", choices=["mcts", "board", "train", "feature", "boundary", "games", "client", "both", "stub"], default="both",
                     help="both (default) = mcts headline + every sub-result at N = 1")
     ap.add_argument("--train-batch", type=int, default=2048)
     ap.add_argument("--train-prefetch", type=int, default=16, help="train batches drawn + extracted per launch (1 = one batch per launch)")
@@ -1101,6 +1174,12 @@ def main():
             res = gm
         elif rank == 0:
             res["selfplay_games"] = gm
+    if args.workload == "client" or sub:
+        cl = run_client(args, rank, local_rank, world, dist)
+        if args.workload == "client":
+            res = cl
+        elif rank == 0:
+            res["client_config"] = cl
     if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
