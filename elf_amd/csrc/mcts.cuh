@@ -856,8 +856,9 @@ __device__ unsigned long long g_expand_rowmax[65536];     // per block id: longe
 #define EXP_PHASE(k)
 #endif
 
+// 6 waves per SIMD: 80 VGPRs instead of 81 (the allocation granule is 8, so 81 meant 5 waves); the LDS region allows 26 per CU
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_expand(TreePool<N> tp, const u64* zob, const RowRec* rowmap, const float* __restrict__ pi,
+__global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64* zob, const RowRec* rowmap, const float* __restrict__ pi,
                                                      int64_t pi_stride, const float* __restrict__ value, const int64_t* __restrict__ rv,
                                                      int n_rows_host, const int32_t* __restrict__ counts, TreeCfg cfg) {
   using G = Geo<N>;
