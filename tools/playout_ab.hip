@@ -1,7 +1,7 @@
 // GPU-box tool (not part of the library): times k_playout of the library's own translation unit, without phase markers.
 // A/B method: an experiment adds an `#ifdef ELF_AB_<name>` switch to the kernel source for its duration (never committed), one
 // binary per switch is cross-compiled here and all of them run in one short GPU visit:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DELF_AB_x] tools/playout_ab.hip -o build/ab_x
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -ffp-contract=off [-DELF_AB_x] tools/playout_ab.hip -o build/ab_x
 #include <hip/hip_runtime.h>
 #include "../elf_amd/csrc/elf_amd.hip"
 #include <chrono>

@@ -1,5 +1,5 @@
 // GPU-box tool (not part of the library): cycle attribution of k_playout<19> by phase.  Compiles the library's own
-// translation unit with phase markers switched on:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
+// translation unit with phase markers switched on:  hipcc --offload-arch=gfx950 -O2 -std=c++17 -ffp-contract=off
 //   tools/playout_phases.hip -o /tmp/playout_phases && /tmp/playout_phases [boards]
 #include <hip/hip_runtime.h>
 #define ELF_PROFILE 1
