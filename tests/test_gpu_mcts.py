@@ -356,8 +356,8 @@ def test_config3_real_net_against_the_real_reference_stack(elf):
     moves 1..8 at 512 rollouts and one 8192-rollout search.  Bar: root edge order, priors (after the noise), visit counts,
     most-visited action, move played and root value bit for bit.  Accumulated rewards: bit-equal except where hazard H2 shows
     (the reference backs the leaves of a batch up in heap-address order) -- then the sums may differ in
-    their last bits and nothing else; measured on 64 + 4 searches in profiles/r03a_config3_real_net_parity_*.json: 67 bit-equal,
-    one edge of one 8192-rollout search off by 1 ulp, no decision differs.
+    their last bits and nothing else; measured on 138 searches in profiles/r03a_ and r03m_config3_real_net_parity_*.json: 135
+    bit-equal, three with one edge off by 1 ulp, no decision differs.
     The net is made a pure function of the feature row (fixed evaluation batches, memoised by the row's digest:
     tests/real_net_parity.py) so that both engines see identical (pi, V) for identical positions."""
     import real_net_parity as rp
