@@ -48,6 +48,13 @@ RECORD_CASES_R3 = {
                                black_ver=11, white_ver=12, white_rollouts_per_thread=32, white_puct=1.2, move_cutoff=24)),
     "records_9_eval_swap_resign": (9, dict(rollouts_per_thread=32, max_searches=160, policy_distri_cutoff=4, net_salt=73, white_net_salt=74,
                                            black_ver=21, white_ver=20, player_swap=1, resign_thres=0.9, move_cutoff=70)),
+    # a second request while the (single) game plays, put into its mailbox during search 7 and read at the game's next fifth act
+    # (game_selfplay.cc:272-290): other version, not async -> the running game is dropped and restarted under the new request
+    # (restart() :159-220, seq advances, nothing recorded); async -> the game goes on, its record names both models
+    "records_9_req2_restart": (9, dict(rollouts_per_thread=48, max_searches=44, policy_distri_cutoff=4, net_salt=75, num_games=1,
+                                       black_ver=3, move_cutoff=14, req2_after_searches=7, req2_black_ver=4)),
+    "records_9_req2_async": (9, dict(rollouts_per_thread=48, max_searches=44, policy_distri_cutoff=4, net_salt=75, num_games=1,
+                                     black_ver=3, move_cutoff=14, req2_after_searches=7, req2_black_ver=4, req2_async=1)),
 }
 
 
@@ -87,6 +94,8 @@ def synth_record(n, seed, rng, with_policies):
 
 
 def dump_case(name, n, kw):
+    if "--missing" in sys.argv and os.path.exists(os.path.join(OUT, name + ".npz")):
+        return []
     R = RefSelfPlay(n)
     cfg = dict(MCTS_DEFAULTS)
     kw = dict(kw)
@@ -117,7 +126,8 @@ def dump_case(name, n, kw):
                         best_action=np.array([s.best_action for s in r["search"]], np.int32),
                         n_edges=np.array([s.n_edges for s in r["search"]], np.int32),
                         root_value=np.array([s.root_value for s in r["search"]], np.float32),
-                        coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"], **extra)
+                        coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"],
+                        game_starts=np.int32(r["game_starts"]), start_versions=np.array(r["start_versions"], np.int64), **extra)
     print(name, "records", len(exact), [(j["seq"], j["result"]["num_move"], j["result"]["reward"], len(j["result"].get("policies", [])))
                                         for j in recs])
     return exact

@@ -64,6 +64,7 @@ struct SpConfig {
   int32_t white_rollouts_per_batch, white_rollouts_per_thread;
   uint32_t white_net_salt;
   int32_t pick_method, black_policy_only, white_policy_only, thread_used;
+  int32_t req2_after_searches, req2_black_ver, req2_async;   // a second request mid-run: read by oracle/ref_selfplay.cc only
 };
 struct SpSearch {
   int32_t game, move_played, best_action, total_visits, n_edges;
@@ -414,7 +415,12 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
   const bool two = cfg->white_ver >= 0;
   Actor actors[2];
   Search searches[2];
+  int64_t batches_before = 0, rows_before = 0;
+  auto init_ais = [&]() {
   for (int a = 0; a < (two ? 2 : 1); ++a) {
+    batches_before += actors[a].batches; rows_before += actors[a].rows;
+    actors[a] = Actor{};
+    searches[a] = Search{};
     Actor& actor = actors[a];
     actor.n = n; actor.na = na; actor.komi = cfg->komi; actor.ply_pass_enabled = cfg->ply_pass_enabled;
     actor.cfg = cfg; actor.net = net; actor.user = user;
@@ -429,9 +435,12 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
       if (cfg->white_rollouts_per_thread > 0) se.rollouts_per_thread = cfg->white_rollouts_per_thread;
     }
   }
+  };
+  init_ais();
   Search* ai = &searches[0];
   Search* ai2 = two ? &searches[1] : nullptr;
   if (two && cfg->player_swap) std::swap(ai, ai2);
+  bool req2_pending = cfg->req2_after_searches > 0;
   std::mt19937 pick_rng((unsigned)time(nullptr));   // MCTSResultT::addActions' static generator (tree_search_base.h:238), uniform_random only
   OrcState* st = orc_new();
   std::vector<Coord> moves;                      // GoState::_moves
@@ -443,6 +452,24 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
   }
   int k = 0;
   while (k < cfg->max_searches) {
+    // GoGameSelfPlay::act :272-290: the mailbox is read at every fifth act (_online_counter % 5; here one act = one search).  The
+    // second request of oracle/ref_selfplay.cc reaches the mailbox during search number req2_after_searches (0-based), so the
+    // first look that finds it is the next multiple of five after that.  OnReceive :222-270: other versions and not async ->
+    // restart() :159-220 (both AIs rebuilt with fresh seeds from the game's generator, the state reset, nothing recorded);
+    // async -> the game goes on (the versions only show in the record)
+    if (req2_pending && k > cfg->req2_after_searches && k % 5 == 0) {
+      req2_pending = false;
+      if (!cfg->req2_async && cfg->req2_black_ver != cfg->black_ver) {
+        init_ais();
+        orc_reset(st); moves.clear();
+        never_resign = false; has_never = false;
+        sgf_iter = 0;
+        for (int i = 0; sgf_iter < g_preload.size() && i < g_preload_move_to; ++i, ++sgf_iter) {
+          if (!orc_forward(st, g_preload[sgf_iter])) { orc_free(st); return -4; }
+          moves.push_back(g_preload[sgf_iter]);
+        }
+      }
+    }
     // GoGameSelfPlay::act :354-372: the AI of the colour to move; MCTSAI_T::act or actPolicyOnly (align_state first)
     const bool white_to_move = orc_next_player(st) == S_WHITE;
     Search& search = (ai2 != nullptr && white_to_move) ? *ai2 : *ai;
@@ -522,7 +549,7 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
       never_resign = false; has_never = false;
     }
   }
-  if (stats) { stats[0] = actors[0].batches + actors[1].batches; stats[1] = actors[0].rows + actors[1].rows; stats[2] = 0; }
+  if (stats) { stats[0] = batches_before + actors[0].batches + actors[1].batches; stats[1] = rows_before + actors[0].rows + actors[1].rows; stats[2] = 0; }
   orc_free(st);
   return k;
 }

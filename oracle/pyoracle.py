@@ -208,7 +208,8 @@ class RefSpConfig(C.Structure):
          # round 3 (read by oracle/ref_selfplay.cc only; the CPU restatement plays one AI per game)
          ("black_ver", C.c_int32), ("white_ver", C.c_int32), ("player_swap", C.c_int32), ("white_puct", C.c_float),
          ("white_rollouts_per_batch", C.c_int32), ("white_rollouts_per_thread", C.c_int32), ("white_net_salt", C.c_uint32),
-         ("pick_method", C.c_int32), ("black_policy_only", C.c_int32), ("white_policy_only", C.c_int32), ("thread_used", C.c_int32)]
+         ("pick_method", C.c_int32), ("black_policy_only", C.c_int32), ("white_policy_only", C.c_int32), ("thread_used", C.c_int32),
+         ("req2_after_searches", C.c_int32), ("req2_black_ver", C.c_int32), ("req2_async", C.c_int32)]
 
 
 class RefSpSearch(C.Structure):
@@ -222,7 +223,7 @@ MCTS_DEFAULTS = dict(num_games=1, batchsize=16, mcts_threads=1, rollouts_per_thr
                      resign_thres=0.0, never_resign_prob=0.0, net_salt=7, net_tie_levels=0, max_searches=4, timeout_usec=10,
                      black_ver=0, white_ver=-1, player_swap=0, white_puct=-1.0, white_rollouts_per_batch=-1,
                      white_rollouts_per_thread=-1, white_net_salt=8, pick_method=0, black_policy_only=0, white_policy_only=0,
-                     thread_used=0)
+                     thread_used=0, req2_after_searches=0, req2_black_ver=0, req2_async=0)
 
 
 class RefSelfPlay:
@@ -268,9 +269,12 @@ class RefSelfPlay:
         if k < 0:
             raise RuntimeError("refsp_run failed")
         self.L.refsp_white_rows.restype = C.c_int64
+        self.L.refsp_game_starts.restype = C.c_int64
+        vers8 = (C.c_int64 * 8)()
+        starts = int(self.L.refsp_game_starts(vers8))
         return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
                     batches=int(stats[0]), rows=int(stats[1]), usec=int(stats[2]), records=self.last_records(),
-                    white_rows=int(self.L.refsp_white_rows()))
+                    white_rows=int(self.L.refsp_white_rows()), game_starts=starts, start_versions=[int(v) for v in vers8][:min(starts, 8)])
 
     # ---- records (GoStateExt::dumpRecord) and the trainer's extractors (GoStateExtOffline + GoFeature)
     def _text(self, fn, *args):

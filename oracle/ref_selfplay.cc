@@ -72,6 +72,13 @@ struct RefSpConfig {
   int32_t pick_method;          // 0 most_visited, 1 strongest_prior, 2 uniform_random
   int32_t black_policy_only, white_policy_only;   // GameOptions.*_use_policy_network_only
   int32_t thread_used;          // ClientCtrl.num_game_thread_used (0 = num_games, the harness' historical value; -1 = all)
+  // a second request while the games play (num_games = 1 for a reproducible arrival): sent when `req2_after_searches` searches
+  // have been captured and the next search has its first batch waiting for a reply -- the harness then sleeps 1.5 s before it
+  // replies, so that the dispatcher thread (500 ms poll, elf/base/dispatcher.h:22) has put the request into the game's mailbox
+  // before the search can finish: the game receives it at its next mailbox look, i.e. at the top of its next fifth act
+  int32_t req2_after_searches;  // 0 = no second request
+  int32_t req2_black_ver;
+  int32_t req2_async;           // ClientCtrl.async of the second request
 };
 
 // One record per finished search (MCTSAI_T::act), in completion order.
@@ -156,6 +163,8 @@ std::string g_preload_sgf;     // GameOptions.preload_sgf for the next refsp_run
 int g_preload_move_to = -1;
 std::string g_last_records;   // JSON array text of the records of the last refsp_run
 int64_t g_white_rows = 0;     // rows served to the "actor_white" group by the last refsp_run
+int64_t g_game_starts = 0;    // "game_start" batches of the last refsp_run
+int64_t g_start_vers[8] = {0};   // black_ver of the first 8 of them
 
 struct Buffers {
   std::vector<float> s, pi, V;
@@ -288,6 +297,9 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
 
     int64_t batches = 0, rows = 0;
     g_white_rows = 0;
+    g_game_starts = 0;
+    int64_t cur_black_rv = cfg->black_ver;   // the version the "actor_black" model answers with: follows the game_start batches
+    bool req2_sent = false;
     const auto t0 = std::chrono::steady_clock::now();
     const int NA = BOARD_NUM_ACTION;
     while (cap.count.load() < cfg->max_searches) {
@@ -297,11 +309,30 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
       const auto& smo = sm->getSharedMemOptions();
       Buffers& b = bufs[idx2buf[smo.getIdx()]];
       const std::string& label = smo.getLabel();
+      if (label == "game_start") {           // Python loads the models the batch names (selfplay.py game_start callback)
+        if (g_game_starts < 8) g_start_vers[g_game_starts] = b.black_ver[0];
+        g_game_starts++;
+        cur_black_rv = b.black_ver[0];
+      }
       if (label == "actor_black" || label == "actor_white") {
         const bool white_group = label == "actor_white";
+        if (cfg->req2_after_searches > 0 && !req2_sent && cap.count.load() >= cfg->req2_after_searches) {
+          MsgRequest req2;
+          req2.vers.black_ver = cfg->req2_black_ver;
+          req2.vers.white_ver = -1;
+          req2.vers.mcts_opt = co.mcts_options;
+          req2.client_ctrl.black_resign_thres = cfg->resign_thres;
+          req2.client_ctrl.white_resign_thres = cfg->resign_thres;
+          req2.client_ctrl.never_resign_prob = cfg->never_resign_prob;
+          req2.client_ctrl.num_game_thread_used = cfg->thread_used == 0 ? n : cfg->thread_used;
+          req2.client_ctrl.async = cfg->req2_async != 0;
+          disp.sendToThread(req2);
+          std::this_thread::sleep_for(std::chrono::milliseconds(1500));
+          req2_sent = true;
+        }
         if (net) net(b.s.data(), eb, b.pi.data(), b.V.data(), net_user);
         else stubnet_eval(b.s.data(), eb, BOARD_SIZE, white_group ? cfg->white_net_salt : cfg->net_salt, cfg->net_tie_levels, b.pi.data(), b.V.data());
-        for (int i = 0; i < eb; ++i) { b.rv[i] = white_group ? cfg->white_ver : cfg->black_ver; b.a[i] = 0; }
+        for (int i = 0; i < eb; ++i) { b.rv[i] = white_group ? cfg->white_ver : cur_black_rv; b.a[i] = 0; }
         if (white_group) g_white_rows += eb;
         (void)NA;
         batches++; rows += eb;
@@ -334,6 +365,10 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
 }
 
 int64_t refsp_white_rows() { return g_white_rows; }
+int64_t refsp_game_starts(int64_t* vers8) {
+  if (vers8) memcpy(vers8, g_start_vers, sizeof(g_start_vers));
+  return g_game_starts;
+}
 
 // GameOptions.preload_sgf / preload_sgf_move_to for the following refsp_run calls (path "" switches it off)
 void refsp_set_preload(const char* path, int move_to) {

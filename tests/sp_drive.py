@@ -34,9 +34,10 @@ def sp_from_fixture_cfg(elf_amd, n, cfg, **over):
     return sp
 
 
-def drive_stub(sp, n, cfg, done, on_step=None):
+def drive_stub(sp, n, cfg, done, on_step=None, black_ver=None):
     """serve batches with the stub nets of the fixture until done(sp); two-AI games through begin_step2 / end_step2 with the
-    "actor_white" rows evaluated by the second stub net and every reply carrying its model's version in rv"""
+    "actor_white" rows evaluated by the second stub net and every reply carrying its model's version in rv (black_ver: a callable
+    giving the version the "actor_black" model has now, for runs in which a later request changes it)"""
     import torch
     salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
     two = int(cfg.get("white_ver", -1)) >= 0
@@ -59,7 +60,7 @@ def drive_stub(sp, n, cfg, done, on_step=None):
             if rows:
                 pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), salt, ties)
                 sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device),
-                            torch.full((rows,), bv, dtype=torch.int64, device=sp.device))
+                            torch.full((rows,), bv if black_ver is None else black_ver(), dtype=torch.int64, device=sp.device))
             else:
                 sp.end_step(None, None)
         if on_step:

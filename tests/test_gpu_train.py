@@ -134,6 +134,11 @@ def test_selfplay_records_equal_reference_dump(elf, name):
         got.extend(sp.pop_records())
 
     drive_stub(sp, n, cfg, lambda sp: len(got) >= len(want), collect)
+    _check_run_against_fixture(sp, g, got, want, name)
+    sp.close()
+
+
+def _check_run_against_fixture(sp, g, got, want, name):
     assert len(got) >= len(want)
     # every search of the run, across game ends and restarts: root edges in iteration order, visits, priors, rewards, move played
     rec, coord, visits, prior, reward = sp.search_log()
@@ -163,6 +168,44 @@ def test_selfplay_records_equal_reference_dump(elf, name):
         assert json.dumps(j, separators=(",", ":"), sort_keys=True) == json.dumps(w, separators=(",", ":"), sort_keys=True)
         t2 = t.replace('"timestamp":%d' % json.loads(t)["timestamp"], '"timestamp":%d' % w["timestamp"])
         assert t2 == str(g["records"][got.index(t)])   # text-identical to the reference's json::dump()
+
+
+@pytest.mark.parametrize("name", ["records_9_req2_restart", "records_9_req2_async"])
+def test_second_request_while_a_game_plays_equals_reference(elf, name):
+    """The reference run of the fixture got a second request (black_ver 3 -> 4) into the game's mailbox during its eighth search
+    (oracle/ref_selfplay.cc req2_*).  GoGameSelfPlay::act reads the mailbox at every fifth act only (game_selfplay.cc:273-289), so
+    searches 8 and 9 still run under the old request; at the eleventh act OnReceive (:222-270) either restarts the game from the
+    empty board with new AIs, nothing recorded, seq advanced (other versions) or lets it go on (async; the record then names both
+    models).  Same search log, same record texts, same "game_start" batches as the reference."""
+    import ctypes as C
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    n = int(g["board_size"])
+    want = [json.loads(str(t)) for t in g["records"]]
+    sp = sp_from_fixture_cfg(elf, n, cfg, keep_records=8, nodes_per_game=4096, log_searches=int(g["searches"]))
+    L = elf.lib()
+    got, starts, state = [], [], dict(sent=False, ver=int(cfg["black_ver"]))
+
+    def model_version():
+        # a request restarts the games at the top of an act, i.e. inside begin_step: the "game_start" it makes due comes before the
+        # rows of the new games are answered (its callback loads the model the batch names, selfplay.py)
+        bv, wv = C.c_int64(-9), C.c_int64(-9)
+        for _ in range(L.elfsp_take_game_starts(sp._h, C.byref(bv), C.byref(wv))):
+            starts.append(bv.value)
+            state["ver"] = bv.value
+        return state["ver"]
+
+    def on_step(sp, rows_total):
+        got.extend(sp.pop_records())
+        if not state["sent"] and sp.progress()["searches"] >= int(cfg["req2_after_searches"]):
+            sp.set_request(int(cfg["req2_black_ver"]), -1, float(np.float32(cfg["resign_thres"])), float(np.float32(cfg["never_resign_prob"])),
+                           async_=bool(cfg["req2_async"]), num_game_thread_used=1)
+            state["sent"] = True
+
+    drive_stub(sp, n, cfg, lambda sp: len(got) >= len(want) and sp.progress()["searches"] >= int(g["searches"]), on_step,
+               black_ver=model_version)
+    assert starts == g["start_versions"].tolist() and len(starts) == int(g["game_starts"])
+    _check_run_against_fixture(sp, g, got, want, name)
     sp.close()
 
 

@@ -12,7 +12,7 @@ from conftest import GOLDEN
 from pyoracle import RefSelfPlay, sgfstr2coords
 
 CASES = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff",
-         "records_9_eval", "records_9_eval_swap_resign"]
+         "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart"]
 
 
 def sp_options(elf_amd, n, cfg, num_games=1):
@@ -31,8 +31,8 @@ def to_json(elf_amd, opt, p, j):
     args = (mv.ctypes.data, mv.size, pol.ctypes.data if pol.size else None, pol.shape[0], val.ctypes.data, val.size,
             C.c_float(p["reward"]), int(j["result"]["black_never_resign"]), j["seq"], j["thread_id"], j["timestamp"])
     vers, ctrl = j["request"]["vers"], j["request"]["client_ctrl"]
-    if vers["white_ver"] >= 0 or ctrl["player_swap"]:
-        # evaluation games: the record carries the request it was played under (elfrec_record_to_json2)
+    if vers["white_ver"] >= 0 or ctrl["player_swap"] or vers["black_ver"] != 0:
+        # evaluation games, a later request: the record carries the request it was played under (elfrec_record_to_json2)
         q = SpRequest(vers["black_ver"], vers["white_ver"], ctrl["black_resign_thres"], ctrl["white_resign_thres"], ctrl["never_resign_prob"],
                       ctrl["num_game_thread_used"], int(ctrl["player_swap"]), int(ctrl["async"]))
         fn, head = L.elfrec_record_to_json2, (C.byref(opt), C.byref(q))
