@@ -75,6 +75,7 @@ SIGNATURES = {
     "elfsp_last_rows2": (_i, [_vp, _vp]),
     "elfsp_set_request2": (_i, [_vp, _vp]),
     "elfsp_progress": (_i, [_vp, _vp]),
+    "elfsp_set_pick_seed": (_i, [_vp, C.c_uint32]),
     "elfsp_game_actor": (_i, [_vp, _i]),
     "elfsp_begin_step": (_i, [_vp, _vp, _i64, C.POINTER(_i), _vp]),
     "elfsp_end_step": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),

@@ -979,6 +979,12 @@ int elfsp_take_game_starts(ElfSelfPlay* sp, int64_t* black_ver, int64_t* white_v
   return n;
 }
 
+int elfsp_set_pick_seed(ElfSelfPlay* sp, uint32_t seed) {
+  if (!sp) return ELFGO_E_BADARG;
+  sp->pick_rng.seed((std::mt19937::result_type)seed);
+  return 0;
+}
+
 // host-only progress counters (no device synchronisation): 0 searches finished (moves played or games resigned), 1 games finished,
 // 2 searches open, 3 steps, 4 games waiting for a request, 5 games waiting at a request barrier
 int elfsp_progress(const ElfSelfPlay* sp, int64_t* out6) {

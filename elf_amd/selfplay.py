@@ -227,6 +227,10 @@ class SelfPlay:
                 rvs[a] = rv.data_ptr()
         check(self.L.elfsp_end_step2(self._h, pis, stride, vs, rvs, self._stream()))
 
+    def set_pick_seed(self, seed):
+        """seed of the uniform_random pick generator (the reference: time(NULL) at the first search of the process)"""
+        check(self.L.elfsp_set_pick_seed(self._h, int(seed) & 0xFFFFFFFF))
+
     def progress(self):
         out = (C.c_int64 * 6)()
         check(self.L.elfsp_progress(self._h, out))

@@ -230,7 +230,8 @@ typedef struct ElfSpOptions {
 #define ELFSP_PICK_MOST_VISITED 0
 #define ELFSP_PICK_STRONGEST_PRIOR 1
 #define ELFSP_PICK_UNIFORM_RANDOM 2   /* the reference draws from a process-wide mt19937 seeded with time(NULL) (tree_search_base.h:238);
-                                         here one generator per context, seeded seed ^ 0x5EED, or time(NULL) for seed == 0 */
+                                         here one generator per context, seeded seed ^ 0x5EED, or time(NULL) for seed == 0;
+                                         elfsp_set_pick_seed re-seeds it */
 #define ELFSP_ACTOR_BLACK 0           /* the AI created as "actor_black" with the request's black_ver */
 #define ELFSP_ACTOR_WHITE 1           /* the AI created as "actor_white" with the request's white_ver (evaluation games only) */
 /* Per-game RNG seeds.  The reference seeds every GoGameBase with GameOptions.seed itself (common/game_base.h:32-38), so with a
@@ -304,6 +305,11 @@ typedef struct ElfSpRequest {
 int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* request);
 /* the same with both thresholds equal, every game used, no swap */
 int elfsp_set_request(ElfSelfPlay* sp, int64_t black_ver, int64_t white_ver, float resign_thres, float never_resign_prob, int async);
+/* Seed of the uniform_random pick generator: MCTSResultT::addActions' `static std::mt19937 rng(time(NULL))`
+ * (tree_search_base.h:238) draws random_idx = rng() % edges once per search of that method.  A context that is given the value
+ * time(NULL) had in a reference process picks the edges that process picked (one game per context: the reference's game threads
+ * race for the generator). */
+int elfsp_set_pick_seed(ElfSelfPlay* sp, uint32_t seed);
 /* host-only progress counters, no device synchronisation: out6 = {searches finished, games finished, searches open, steps,
  * games waiting for a request, games waiting at a request barrier} */
 int elfsp_progress(const ElfSelfPlay* sp, int64_t* out6);

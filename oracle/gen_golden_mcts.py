@@ -55,33 +55,65 @@ CASES = {
     "mcts_9_r256_bs128": (9, dict(rollouts_per_thread=256, rollouts_per_batch=128, batchsize=128, max_searches=20, net_salt=59,
                                   policy_distri_cutoff=4)),
     "mcts_19_r512_bs256": (19, dict(rollouts_per_thread=512, rollouts_per_batch=256, batchsize=256, max_searches=4, net_salt=60)),
+    # TSOptions.pick_method = uniform_random (tree_search.h:514-517): random_idx = rng() % edges from MCTSResultT::addActions'
+    # process-wide `static std::mt19937 rng(time(NULL))` (tree_search_base.h:238).  fixed_time = what time() returns to the
+    # reference in the generating process (oracle/ref_selfplay.cc refsp_set_time); one game, so the draws have one order; the
+    # case runs in a process of its own because the generator is seeded once per process
+    "mcts_9_pick_uniform": (9, dict(rollouts_per_thread=48, max_searches=40, net_salt=63, policy_distri_cutoff=6, num_games=1,
+                                    pick_method=2, move_cutoff=25, fixed_time=1234567)),
 }
+
+
+def run_case(name, path):
+    n, kw = CASES[name]
+    R = RefSelfPlay(n)
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(kw)
+    fixed_time = cfg.pop("fixed_time", None)
+    if fixed_time is None:
+        r = R.run(**cfg)
+        r2 = R.run(**cfg)
+        assert all(np.array_equal(r[k], r2[k]) for k in ("coord", "visits", "prior", "reward")), "reference not deterministic"
+        extra = {}
+    else:
+        R.set_time(fixed_time)
+        r = R.run(**cfg)
+        extra = dict(fixed_time=np.int64(fixed_time))
+    S = r["search"]
+    np.savez_compressed(
+        path,
+        board_size=np.int32(n),
+        cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], np.float64),
+        move_played=np.array([s.move_played for s in S], np.int32),
+        best_action=np.array([s.best_action for s in S], np.int32),
+        total_visits=np.array([s.total_visits for s in S], np.int32),
+        n_edges=np.array([s.n_edges for s in S], np.int32),
+        root_value=np.array([s.root_value for s in S], np.float32),
+        coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"],
+        rows=np.int64(r["rows"]), white_rows=np.int64(r["white_rows"]), **extra)
+    print(name, "searches", len(S), "moves", [s.move_played for s in S][:12], "rows", r["rows"], "ref search s", r["usec"] / 1e6)
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--one" in sys.argv:
+        i = sys.argv.index("--one")
+        run_case(sys.argv[i + 1], sys.argv[i + 2])
+        return
     for name, (n, kw) in CASES.items():
-        if "--all" not in sys.argv and os.path.exists(os.path.join(OUT, name + ".npz")):
+        path = os.path.join(OUT, name + ".npz")
+        if "--all" not in sys.argv and os.path.exists(path):
             continue
-        R = RefSelfPlay(n)
-        cfg = dict(MCTS_DEFAULTS)
-        cfg.update(kw)
-        r = R.run(**cfg)
-        r2 = R.run(**cfg)
-        assert all(np.array_equal(r[k], r2[k]) for k in ("coord", "visits", "prior", "reward")), "reference not deterministic"
-        S = r["search"]
-        np.savez_compressed(
-            os.path.join(OUT, name + ".npz"),
-            board_size=np.int32(n),
-            cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], np.float64),
-            move_played=np.array([s.move_played for s in S], np.int32),
-            best_action=np.array([s.best_action for s in S], np.int32),
-            total_visits=np.array([s.total_visits for s in S], np.int32),
-            n_edges=np.array([s.n_edges for s in S], np.int32),
-            root_value=np.array([s.root_value for s in S], np.float32),
-            coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"],
-            rows=np.int64(r["rows"]), white_rows=np.int64(r["white_rows"]))
-        print(name, "searches", len(S), "moves", [s.move_played for s in S][:12], "rows", r["rows"], "ref search s", r["usec"] / 1e6)
+        if "fixed_time" not in kw:
+            run_case(name, path)
+            continue
+        import subprocess
+        tmp = ["/tmp/%s_%d.npz" % (name, i) for i in range(2)]
+        for t in tmp:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name, t], check=True)
+        a, b = np.load(tmp[0]), np.load(tmp[1])
+        assert all(np.array_equal(a[k], b[k]) for k in a.files), "reference not deterministic under a fixed clock"
+        os.replace(tmp[0], path)
 
 
 if __name__ == "__main__":

@@ -405,6 +405,10 @@ void orcsp_set_preload(const uint16_t* moves, int n, int move_to) {
 // init_ai :30-78, mcts_make_diverse_move :80-95, mcts_update_info :97-119, finish_game :121-149, ResignCheck
 // (common/game_utils.h:14-54), MCTSAI_T::act / align_state / advanceMoves (elf/ai/tree_search/mcts.h:59-81,141-167).
 // Outputs as refsp_run of oracle/ref_selfplay.cc: one SpSearch per search + the root edges in iteration order.
+static int64_t g_fixed_time = 0;
+static bool g_reseed = true;
+void orcsp_set_time(int64_t t) { g_fixed_time = t; g_reseed = true; }
+
 int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search, int32_t* out_coord, int32_t* out_visits,
               float* out_prior, float* out_reward, int64_t* stats) {
   const int n = orc_board_size(), na = n * n + 1, max_move = 2 * n * n;
@@ -441,7 +445,11 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
   Search* ai2 = two ? &searches[1] : nullptr;
   if (two && cfg->player_swap) std::swap(ai, ai2);
   bool req2_pending = cfg->req2_after_searches > 0;
-  std::mt19937 pick_rng((unsigned)time(nullptr));   // MCTSResultT::addActions' static generator (tree_search_base.h:238), uniform_random only
+  // MCTSResultT::addActions' static generator (tree_search_base.h:238), uniform_random only: one per process, seeded with
+  // time(NULL) at the first search; orcsp_set_time fixes that value (before the first run of the process, as for the reference)
+  // (the restatement, unlike the reference, can be re-seeded within a process: orcsp_set_time starts the sequence again)
+  static std::mt19937 pick_rng;
+  if (g_reseed) { pick_rng.seed((unsigned)(g_fixed_time != 0 ? g_fixed_time : (int64_t)time(nullptr))); g_reseed = false; }
   OrcState* st = orc_new();
   std::vector<Coord> moves;                      // GoState::_moves
   bool never_resign = false, has_never = false;  // ResignCheck

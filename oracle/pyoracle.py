@@ -286,6 +286,11 @@ class RefSelfPlay:
         fn(*args, buf, C.c_int64(n))
         return buf.raw[:n].decode()
 
+    def set_time(self, t):
+        """the value the reference's time(NULL) returns (seed of MCTSResultT::addActions' static uniform_random generator): set it
+        before the first search of the process"""
+        self.L.refsp_set_time(C.c_int64(int(t)))
+
     def set_preload(self, path, move_to=-1):
         """GameOptions.preload_sgf / preload_sgf_move_to for the following run() calls ("" = off)"""
         self.L.refsp_set_preload(C.c_char_p((path or "").encode()), C.c_int(move_to))
@@ -341,6 +346,9 @@ class PortSelfPlay:
         Port(n)   # loads the library's Zobrist table
         self.L = C.CDLL(os.path.join(HERE, "libgo_oracle%d.so" % n))
         self.L.orcsp_run.restype = C.c_int
+
+    def set_time(self, t):
+        self.L.orcsp_set_time(C.c_int64(int(t)))
 
     def set_preload(self, moves, move_to=-1):
         """GameOptions.preload_sgf as Coords for the following run() calls (empty = off)"""

@@ -365,6 +365,23 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
 }
 
 int64_t refsp_white_rows() { return g_white_rows; }
+
+// MCTSResultT::addActions owns `static std::mt19937 rng(time(NULL))` (tree_search_base.h:238): the generator of the uniform_random
+// pick method, seeded at the first search of the process.  This library is linked with -Bsymbolic-functions, so that the
+// reference's call of time() binds to the definition below: a fixture generator sets the value BEFORE the first search of its
+// process and the draws become reproducible.  0 (the default) = the real clock.
+static std::atomic<int64_t> g_fixed_time{0};
+void refsp_set_time(int64_t t) { g_fixed_time = t; }
+time_t time(time_t* out) noexcept {
+  time_t t = (time_t)g_fixed_time.load();
+  if (t == 0) {
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    t = ts.tv_sec;
+  }
+  if (out) *out = t;
+  return t;
+}
 int64_t refsp_game_starts(int64_t* vers8) {
   if (vers8) memcpy(vers8, g_start_vers, sizeof(g_start_vers));
   return g_game_starts;

@@ -20,6 +20,8 @@ def run_case(elf_amd, name, max_searches=None):
     n = int(g["board_size"])
     m = len(g["move_played"]) if max_searches is None else min(max_searches, len(g["move_played"]))
     sp = sp_from_fixture_cfg(elf_amd, n, cfg, log_searches=m)
+    if "fixed_time" in g.files:       # uniform_random: the value time(NULL) gave the reference's pick generator
+        sp.set_pick_seed(int(g["fixed_time"]))
 
     def check_trees(sp, rows_total):
         if sum(rows_total) < 4096:   # the node records' own invariants (scoring order, child back links, visit sums) after every step
@@ -73,6 +75,14 @@ def test_pick_method_and_policy_only_match_reference(elf, name):
     """TSOptions.pick_method = strongest_prior (tree_search.h:506-509) and GameOptions.white_use_policy_network_only
     (MCTSAI_T::actPolicyOnly, mcts.h:83-90 / runPolicyOnly tree_search.h:385-407)."""
     run_case(elf, name)
+
+
+def test_pick_method_uniform_random_matches_reference(elf):
+    """TSOptions.pick_method = uniform_random (tree_search.h:514-517): random_idx = rng() % edges from MCTSResultT::addActions'
+    process-wide generator seeded with time(NULL) (tree_search_base.h:238).  The fixture is a reference process whose time() was
+    held at a known value (oracle/ref_selfplay.cc refsp_set_time); the context seeded with it picks the same edges: 40 searches,
+    best action, uniform policy, sampled opening moves, game restarts."""
+    run_case(elf, "mcts_9_pick_uniform")
 
 
 @pytest.mark.parametrize("name", ["mcts_9_r256_bs128", "mcts_19_r512_bs256"])
@@ -479,8 +489,9 @@ def test_idle_game_threads_equal_the_reference(elf):
 def test_pick_method_uniform_random(elf):
     """TSOptions.pick_method = uniform_random (tree_search.h:514-517, addActions :243-279): the move is the random_idx-th root edge
     in iteration order, random_idx = rng() % edges, every edge scores 1 -- so max_score is 1 and, with the opening temperature on,
-    the sampled move comes from the uniform policy.  The reference draws from a process-wide time-seeded generator, so there is no
-    fixture to equal; pinned here: the structure, and determinism under a fixed GameOptions.seed."""
+    the sampled move comes from the uniform policy.  Several games here (in the reference its game threads race for the one
+    process-wide generator, so only the one-game fixture above can be equalled): the structure, and determinism under a fixed
+    GameOptions.seed."""
     import torch
     runs = []
     for _ in range(2):

@@ -14,7 +14,7 @@ CASES = ["mcts_19_r8192", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512
          "mcts_9_r64_ties", "mcts_19_r128_vl0", "mcts_19_r128_noprior", "mcts_9_r128_rootq0", "mcts_9_r96_bs4", "mcts_9_r128_bs64"]
 # round 3: evaluation games (two AIs), strongest_prior, policy-only play, more than 64 rollouts per batch
 CASES_R3 = ["mcts_9_eval_two_ai", "mcts_19_eval_swap", "mcts_9_pick_prior", "mcts_9_policy_only_white", "mcts_9_policy_only_eval",
-            "mcts_9_r256_bs128", "mcts_19_r512_bs256"]
+            "mcts_9_r256_bs128", "mcts_19_r512_bs256", "mcts_9_pick_uniform"]
 
 
 @pytest.mark.parametrize("n", [19, 9])
@@ -85,6 +85,8 @@ def test_restatement_matches_reference_fixture(built, name):
         m = 1                       # 8192 rollouts per search: one search keeps the CPU suite short
     kw["max_searches"] = m
     P = PortSelfPlay(n)
+    if "fixed_time" in g.files:     # uniform_random: the value time(NULL) gave the reference's pick generator in the generating process
+        P.set_time(int(g["fixed_time"]))
     if "preload_moves" in g.files:
         P.set_preload(g["preload_moves"], int(g["preload_move_to"]))
     try:
