@@ -55,6 +55,16 @@ RECORD_CASES_R3 = {
                                        black_ver=3, move_cutoff=14, req2_after_searches=7, req2_black_ver=4)),
     "records_9_req2_async": (9, dict(rollouts_per_thread=48, max_searches=44, policy_distri_cutoff=4, net_salt=75, num_games=1,
                                      black_ver=3, move_cutoff=14, req2_after_searches=7, req2_black_ver=4, req2_async=1)),
+    # GameOptions.cheat_* (finish_game, game_selfplay.cc:122-129 -> GoStateExt::setFinalValue go_state_ext.h:86-99): the result of
+    # a self-play game is a draw of the game's generator (also for a resigned game; the draw shifts the stream the next game
+    # samples its moves from); the result of an evaluation game is the parity of a hash of the two version strings, negated
+    # under player_swap
+    "records_9_cheat_selfplay": (9, dict(rollouts_per_thread=32, max_searches=150, policy_distri_cutoff=6, net_salt=76, num_games=1,
+                                         resign_thres=0.9, move_cutoff=64, cheat_selfplay_random_result=1)),
+    "records_9_cheat_eval": (9, dict(rollouts_per_thread=32, max_searches=60, policy_distri_cutoff=4, net_salt=77, white_net_salt=78,
+                                     black_ver=11, white_ver=12, move_cutoff=18, cheat_eval_new_model_wins_half=1)),
+    "records_9_cheat_eval_swap": (9, dict(rollouts_per_thread=32, max_searches=60, policy_distri_cutoff=4, net_salt=77, white_net_salt=78,
+                                          black_ver=14, white_ver=12, player_swap=1, move_cutoff=18, cheat_eval_new_model_wins_half=1)),
 }
 
 

@@ -64,7 +64,8 @@ struct SpConfig {
   int32_t white_rollouts_per_batch, white_rollouts_per_thread;
   uint32_t white_net_salt;
   int32_t pick_method, black_policy_only, white_policy_only, thread_used;
-  int32_t req2_after_searches, req2_black_ver, req2_async;   // a second request mid-run: read by oracle/ref_selfplay.cc only
+  int32_t req2_after_searches, req2_black_ver, req2_async;   // a second request mid-run: see orcsp_run
+  int32_t cheat_eval_new_model_wins_half, cheat_selfplay_random_result;
 };
 struct SpSearch {
   int32_t game, move_played, best_action, total_visits, n_edges;
@@ -551,6 +552,9 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
       (void)max_move;
     }
     if (finished) {   // finish_game :121-149: _ai->endGame / _ai2->endGame (resetTree), _state_ext.restart()
+      // FR_CHEAT_SELFPLAY_RANDOM_RESULT (:126-129, GoStateExt::setFinalValue go_state_ext.h:96-99): the result of a self-play game
+      // is a draw of the game's generator -- one more draw in the stream the next game's move sampling reads
+      if (!two && cfg->cheat_selfplay_random_result) (void)game_rng();
       ai->end_game();
       if (ai2 != nullptr) ai2->end_game();
       orc_reset(st); moves.clear();

@@ -209,7 +209,8 @@ class RefSpConfig(C.Structure):
          ("black_ver", C.c_int32), ("white_ver", C.c_int32), ("player_swap", C.c_int32), ("white_puct", C.c_float),
          ("white_rollouts_per_batch", C.c_int32), ("white_rollouts_per_thread", C.c_int32), ("white_net_salt", C.c_uint32),
          ("pick_method", C.c_int32), ("black_policy_only", C.c_int32), ("white_policy_only", C.c_int32), ("thread_used", C.c_int32),
-         ("req2_after_searches", C.c_int32), ("req2_black_ver", C.c_int32), ("req2_async", C.c_int32)]
+         ("req2_after_searches", C.c_int32), ("req2_black_ver", C.c_int32), ("req2_async", C.c_int32),
+         ("cheat_eval_new_model_wins_half", C.c_int32), ("cheat_selfplay_random_result", C.c_int32)]
 
 
 class RefSpSearch(C.Structure):
@@ -223,7 +224,8 @@ MCTS_DEFAULTS = dict(num_games=1, batchsize=16, mcts_threads=1, rollouts_per_thr
                      resign_thres=0.0, never_resign_prob=0.0, net_salt=7, net_tie_levels=0, max_searches=4, timeout_usec=10,
                      black_ver=0, white_ver=-1, player_swap=0, white_puct=-1.0, white_rollouts_per_batch=-1,
                      white_rollouts_per_thread=-1, white_net_salt=8, pick_method=0, black_policy_only=0, white_policy_only=0,
-                     thread_used=0, req2_after_searches=0, req2_black_ver=0, req2_async=0)
+                     thread_used=0, req2_after_searches=0, req2_black_ver=0, req2_async=0,
+                     cheat_eval_new_model_wins_half=0, cheat_selfplay_random_result=0)
 
 
 class RefSelfPlay:

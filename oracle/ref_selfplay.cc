@@ -79,6 +79,7 @@ struct RefSpConfig {
   int32_t req2_after_searches;  // 0 = no second request
   int32_t req2_black_ver;
   int32_t req2_async;           // ClientCtrl.async of the second request
+  int32_t cheat_eval_new_model_wins_half, cheat_selfplay_random_result;   // GameOptions.cheat_* (finish_game, game_selfplay.cc:122-129)
 };
 
 // One record per finished search (MCTSAI_T::act), in completion order.
@@ -212,6 +213,8 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     opt.preload_sgf = g_preload_sgf;
     opt.preload_sgf_move_to = g_preload_move_to;
     opt.white_puct = cfg->white_puct > 0.0f ? cfg->white_puct : -1.0f;
+    opt.cheat_eval_new_model_wins_half = cfg->cheat_eval_new_model_wins_half != 0;
+    opt.cheat_selfplay_random_result = cfg->cheat_selfplay_random_result != 0;
     opt.white_mcts_rollout_per_batch = cfg->white_rollouts_per_batch > 0 ? cfg->white_rollouts_per_batch : -1;
     opt.white_mcts_rollout_per_thread = cfg->white_rollouts_per_thread > 0 ? cfg->white_rollouts_per_thread : -1;
     opt.black_use_policy_network_only = cfg->black_policy_only != 0;

@@ -25,6 +25,9 @@ def sp_from_fixture_cfg(elf_amd, n, cfg, **over):
                   white_mcts_rollout_per_thread=int(cfg["white_rollouts_per_thread"]),
                   black_use_policy_network_only=bool(cfg["black_policy_only"]), white_use_policy_network_only=bool(cfg["white_policy_only"]),
                   mcts_pick_method=PICK[int(cfg["pick_method"])], model_ver=int(cfg["black_ver"]))
+    if "cheat_selfplay_random_result" in cfg:
+        kw.update(cheat_eval_new_model_wins_half=bool(cfg["cheat_eval_new_model_wins_half"]),
+                  cheat_selfplay_random_result=bool(cfg["cheat_selfplay_random_result"]))
     kw.update(over)
     sp = elf_amd.SelfPlay(**kw)
     if "white_ver" in cfg and (int(cfg["white_ver"]) >= 0 or int(cfg["black_ver"]) != 0 or int(cfg["thread_used"]) != 0):
