@@ -43,6 +43,7 @@ RECORD_CASES = {
 
 # round 3: records of evaluation games (Record.request carries white_ver / player_swap, using_models both versions); written as
 # records_*.npz only -- the train_*.npz rows above stay as they were generated
+SKIP, PASS, RESIGN, CLEAR = -100, -99, -98, -97   # SpecialActionType (common/game_feature.h:17) = GameContext.getParams()["ACTION_*"]
 RECORD_CASES_R3 = {
     "records_9_eval": (9, dict(rollouts_per_thread=48, max_searches=70, policy_distri_cutoff=6, net_salt=71, white_net_salt=72,
                                black_ver=11, white_ver=12, white_rollouts_per_thread=32, white_puct=1.2, move_cutoff=24)),
@@ -65,6 +66,17 @@ RECORD_CASES_R3 = {
                                      black_ver=11, white_ver=12, move_cutoff=18, cheat_eval_new_model_wins_half=1)),
     "records_9_cheat_eval_swap": (9, dict(rollouts_per_thread=32, max_searches=60, policy_distri_cutoff=4, net_salt=77, white_net_salt=78,
                                           black_ver=14, white_ver=12, player_swap=1, move_cutoff=18, cheat_eval_new_model_wins_half=1)),
+    # GameOptions.mode = "online": the human_actor prompts of GoGameSelfPlay::act :290-330 answered from a script (a move, the same
+    # move again = illegal and prompted again, SKIP = the AI searches and moves, PASS, CLEAR, RESIGN), every prompt's feature planes
+    # kept; following_pass (mcts_update_info :104-111) with a stub net that is sure White wins / sure Black wins
+    "online_9_script": (9, dict(rollouts_per_thread=32, rollouts_per_batch=8, batchsize=8, max_searches=100, net_salt=81, num_games=1, online=1,
+                                human_script=[30, 30, SKIP, 50, SKIP, 22, SKIP, PASS, SKIP, CLEAR, 40, SKIP, RESIGN, 11, SKIP, 12])),
+    "online_9_following_pass": (9, dict(rollouts_per_thread=32, rollouts_per_batch=8, batchsize=8, max_searches=100, net_salt=81, num_games=1,
+                                        online=1, following_pass=1, net_value_on=1, net_value=-1.0,
+                                        human_script=[PASS, SKIP, 33, SKIP, PASS, SKIP, 20])),
+    "online_9_not_following": (9, dict(rollouts_per_thread=32, rollouts_per_batch=8, batchsize=8, max_searches=100, net_salt=81, num_games=1,
+                                       online=1, following_pass=1, net_value_on=1, net_value=1.0,
+                                       human_script=[PASS, SKIP, 33, SKIP, PASS, SKIP, 20, CLEAR, 5])),
 }
 
 
@@ -121,9 +133,15 @@ def dump_case(name, n, kw):
             fh.write("(;GM[1]FF[4]SZ[%d]KM[7.5]" % n + R.coords2sgfstr(mv)[1:])
         R.set_preload(path, pre[2])
         extra = dict(preload_moves=np.array(mv, np.uint16), preload_move_to=np.int32(pre[2]))
+    script = kw.pop("human_script", None)
     cfg.update(kw)
-    r = R.run(**cfg)
+    r = R.run(human_script=script, **cfg)
     R.set_preload("", -1)
+    if script is not None:
+        r2 = R.run(human_script=script, **cfg)
+        strip = lambda t: [dict(j, timestamp=0) for j in json.loads(t)]
+        assert np.array_equal(r["prompts"], r2["prompts"]) and strip(r["records"]) == strip(r2["records"]) and np.array_equal(r["visits"], r2["visits"]), name
+        extra.update(human_script=np.array(script, np.int64), prompts=np.packbits(r["prompts"].reshape(len(r["prompts"]), -1), axis=1))
     recs = json.loads(r["records"])
     exact = [R.record_roundtrip(t) for t in split_records(r["records"])]
     assert len(recs) >= 1, name

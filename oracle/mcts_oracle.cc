@@ -66,6 +66,8 @@ struct SpConfig {
   int32_t pick_method, black_policy_only, white_policy_only, thread_used;
   int32_t req2_after_searches, req2_black_ver, req2_async;   // a second request mid-run: see orcsp_run
   int32_t cheat_eval_new_model_wins_half, cheat_selfplay_random_result;
+  int32_t online, following_pass, net_value_on;   // online mode: oracle/ref_selfplay.cc only
+  float net_value;
 };
 struct SpSearch {
   int32_t game, move_played, best_action, total_visits, n_edges;

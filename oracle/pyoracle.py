@@ -210,7 +210,8 @@ class RefSpConfig(C.Structure):
          ("white_rollouts_per_batch", C.c_int32), ("white_rollouts_per_thread", C.c_int32), ("white_net_salt", C.c_uint32),
          ("pick_method", C.c_int32), ("black_policy_only", C.c_int32), ("white_policy_only", C.c_int32), ("thread_used", C.c_int32),
          ("req2_after_searches", C.c_int32), ("req2_black_ver", C.c_int32), ("req2_async", C.c_int32),
-         ("cheat_eval_new_model_wins_half", C.c_int32), ("cheat_selfplay_random_result", C.c_int32)]
+         ("cheat_eval_new_model_wins_half", C.c_int32), ("cheat_selfplay_random_result", C.c_int32),
+         ("online", C.c_int32), ("following_pass", C.c_int32), ("net_value_on", C.c_int32), ("net_value", C.c_float)]
 
 
 class RefSpSearch(C.Structure):
@@ -225,7 +226,8 @@ MCTS_DEFAULTS = dict(num_games=1, batchsize=16, mcts_threads=1, rollouts_per_thr
                      black_ver=0, white_ver=-1, player_swap=0, white_puct=-1.0, white_rollouts_per_batch=-1,
                      white_rollouts_per_thread=-1, white_net_salt=8, pick_method=0, black_policy_only=0, white_policy_only=0,
                      thread_used=0, req2_after_searches=0, req2_black_ver=0, req2_async=0,
-                     cheat_eval_new_model_wins_half=0, cheat_selfplay_random_result=0)
+                     cheat_eval_new_model_wins_half=0, cheat_selfplay_random_result=0, online=0, following_pass=0, net_value_on=0,
+                     net_value=0.0)
 
 
 class RefSelfPlay:
@@ -245,11 +247,14 @@ class RefSelfPlay:
         self.L = C.CDLL(self.path(n))
         self.L.refsp_run.restype = C.c_int
 
-    def run(self, net=None, **kw):
-        """-> dict(search=list[RefSpSearch], coord, visits, prior, reward [k, NA], stats)"""
+    def run(self, net=None, human_script=None, **kw):
+        """-> dict(search=list[RefSpSearch], coord, visits, prior, reward [k, NA], stats); online=1 with human_script = the answers
+        ("a") to the human_actor prompts additionally gives prompts [p, 18, n, n] uint8"""
         cfg = dict(MCTS_DEFAULTS)
         cfg.update(kw)
         c = RefSpConfig(**cfg)
+        hs = np.ascontiguousarray(human_script if human_script is not None else [], np.int64)
+        self.L.refsp_set_human_script(hs.ctypes.data_as(C.c_void_p), C.c_int(hs.size))
         m, na = c.max_searches, self.na
         S = (RefSpSearch * m)()
         coord = np.full((m, na), -1, np.int32); visits = np.zeros((m, na), np.int32)
@@ -274,7 +279,12 @@ class RefSelfPlay:
         self.L.refsp_game_starts.restype = C.c_int64
         vers8 = (C.c_int64 * 8)()
         starts = int(self.L.refsp_game_starts(vers8))
-        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
+        self.L.refsp_last_prompts.restype = C.c_int64
+        npr = int(self.L.refsp_last_prompts(None, C.c_int64(0)))
+        prompts = np.zeros((npr, 18, self.n, self.n), np.uint8)
+        if npr:
+            self.L.refsp_last_prompts(prompts.ctypes.data_as(C.c_void_p), C.c_int64(prompts.size))
+        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k], prompts=prompts,
                     batches=int(stats[0]), rows=int(stats[1]), usec=int(stats[2]), records=self.last_records(),
                     white_rows=int(self.L.refsp_white_rows()), game_starts=starts, start_versions=[int(v) for v in vers8][:min(starts, 8)])
 
@@ -370,7 +380,12 @@ class PortSelfPlay:
                              prior.ctypes.data_as(C.c_void_p), reward.ctypes.data_as(C.c_void_p), stats)
         if k < 0:
             raise RuntimeError("orcsp_run failed: %d" % k)
-        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
+        self.L.refsp_last_prompts.restype = C.c_int64
+        npr = int(self.L.refsp_last_prompts(None, C.c_int64(0)))
+        prompts = np.zeros((npr, 18, self.n, self.n), np.uint8)
+        if npr:
+            self.L.refsp_last_prompts(prompts.ctypes.data_as(C.c_void_p), C.c_int64(prompts.size))
+        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k], prompts=prompts,
                     batches=int(stats[0]), rows=int(stats[1]))
 
 

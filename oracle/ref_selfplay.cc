@@ -80,6 +80,13 @@ struct RefSpConfig {
   int32_t req2_black_ver;
   int32_t req2_async;           // ClientCtrl.async of the second request
   int32_t cheat_eval_new_model_wins_half, cheat_selfplay_random_result;   // GameOptions.cheat_* (finish_game, game_selfplay.cc:122-129)
+  // GameOptions.mode = "online" (one game): the "human_actor" prompts of GoGameSelfPlay::act :290-330 are answered from the script
+  // of refsp_set_human_script ("a" = an action index or ACTION_SKIP / PASS / RESIGN / CLEAR); the run ends at the prompt after the
+  // last scripted answer; every prompt's "s" rows are kept (refsp_last_prompts)
+  int32_t online;
+  int32_t following_pass;       // GameOptions.following_pass (mcts_update_info :104-111)
+  int32_t net_value_on;         // stub net: V = net_value for every row (a position the AI is sure about)
+  float net_value;
 };
 
 // One record per finished search (MCTSAI_T::act), in completion order.
@@ -164,6 +171,9 @@ std::string g_preload_sgf;     // GameOptions.preload_sgf for the next refsp_run
 int g_preload_move_to = -1;
 std::string g_last_records;   // JSON array text of the records of the last refsp_run
 int64_t g_white_rows = 0;     // rows served to the "actor_white" group by the last refsp_run
+std::vector<int64_t> g_human_script;   // answers to the "human_actor" prompts of an online run
+std::vector<uint8_t> g_prompts;         // "s" of every prompt of the last online run, one byte per plane point
+int64_t g_n_prompts = 0;
 int64_t g_game_starts = 0;    // "game_start" batches of the last refsp_run
 int64_t g_start_vers[8] = {0};   // black_ver of the first 8 of them
 
@@ -202,7 +212,8 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     ts.pick_method = cfg->pick_method == 1 ? "strongest_prior" : cfg->pick_method == 2 ? "uniform_random" : "most_visited";
 
     GameOptions opt;
-    opt.mode = "selfplay";
+    opt.mode = cfg->online ? "online" : "selfplay";
+    opt.following_pass = cfg->following_pass != 0;
     opt.seed = cfg->seed;
     opt.komi = cfg->komi;
     opt.ply_pass_enabled = cfg->ply_pass_enabled;
@@ -253,6 +264,10 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
         {"game_start", {"black_ver", "white_ver"}, 1, 0},
         {"game_end", {}, 1, 0},
     };
+    // game.py:366-378.  A finite collector timeout, unlike game.py's: a collector that waits for game messages without one never sees
+    // Context::stop's PREPARE_TO_STOP (self-play wakes every collector with dummy messages, game_selfplay.cc:334-357; online mode
+    // has no such path for "human_actor"), and this harness has to stop
+    if (cfg->online) groups = {{"human_actor", {"s", "pi", "V", "a"}, 1, 10}, {"actor_black", {"s", "pi", "V", "a", "rv"}, B, cfg->timeout_usec}};
     std::vector<Buffers> bufs;
     bufs.reserve(groups.size() * 2 + 1);
     std::vector<int> idx2buf;
@@ -305,6 +320,8 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     bool req2_sent = false;
     const auto t0 = std::chrono::steady_clock::now();
     const int NA = BOARD_NUM_ACTION;
+    g_prompts.clear();
+    g_n_prompts = 0;
     while (cap.count.load() < cfg->max_searches) {
       const elf::SharedMem* sm = ctx.wait(100000);
       if (sm == nullptr) { continue; }
@@ -316,6 +333,18 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
         if (g_game_starts < 8) g_start_vers[g_game_starts] = b.black_ver[0];
         g_game_starts++;
         cur_black_rv = b.black_ver[0];
+      }
+      if (label == "human_actor") {
+        for (size_t i = 0; i < (size_t)18 * BOARD_SIZE * BOARD_SIZE; ++i) g_prompts.push_back(b.s[i] != 0.f ? 1 : 0);
+        if (g_n_prompts >= (int64_t)g_human_script.size()) {   // the prompt after the last answer: the run is over (answered SKIP,
+          g_n_prompts++;                                        // so that the game blocks in a search batch as at any other stop)
+          { std::lock_guard<std::mutex> l(cap.m); cap.max_searches = (int)cap.searches.size(); }   // what runs during the shutdown is not part of the run
+          b.a[0] = SA_SKIP;
+          ctx.step();
+          break;
+        }
+        b.a[0] = g_human_script[g_n_prompts++];
+        b.V[0] = 0.f;
       }
       if (label == "actor_black" || label == "actor_white") {
         const bool white_group = label == "actor_white";
@@ -335,6 +364,7 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
         }
         if (net) net(b.s.data(), eb, b.pi.data(), b.V.data(), net_user);
         else stubnet_eval(b.s.data(), eb, BOARD_SIZE, white_group ? cfg->white_net_salt : cfg->net_salt, cfg->net_tie_levels, b.pi.data(), b.V.data());
+        if (cfg->net_value_on) for (int i = 0; i < eb; ++i) b.V[i] = cfg->net_value;
         for (int i = 0; i < eb; ++i) { b.rv[i] = white_group ? cfg->white_ver : cur_black_rv; b.a[i] = 0; }
         if (white_group) g_white_rows += eb;
         (void)NA;
@@ -384,6 +414,13 @@ time_t time(time_t* out) noexcept {
   }
   if (out) *out = t;
   return t;
+}
+void refsp_set_human_script(const int64_t* actions, int n) { g_human_script.assign(actions, actions + (n > 0 ? n : 0)); }
+// prompts of the last online run: returns their number, copies min(number * 18 * N * N, cap) bytes
+int64_t refsp_last_prompts(uint8_t* buf, int64_t cap) {
+  const int64_t len = (int64_t)g_prompts.size();
+  if (buf && cap > 0) memcpy(buf, g_prompts.data(), (size_t)std::min(len, cap));
+  return g_n_prompts;
 }
 int64_t refsp_game_starts(int64_t* vers8) {
   if (vers8) memcpy(vers8, g_start_vers, sizeof(g_start_vers));

@@ -360,7 +360,8 @@ def _check_fixture(log, g, m):
         assert coord == [int(c) for c in g["coord"][i, :ne]], "search %d: edge order" % i
         assert visits == [int(c) for c in g["visits"][i, :ne]], "search %d: visit counts" % i
         assert np.array_equal(np.array(reward, np.float32).view(np.uint32), g["reward"][i, :ne].view(np.uint32)), "search %d: rewards" % i
-        assert (move, best, total) == (int(g["move_played"][i]), int(g["best_action"][i]), int(g["total_visits"][i])), i
+        want_total = int(g["total_visits"][i]) if "total_visits" in g.files else int(g["visits"][i, :ne].sum())
+        assert (move, best, total) == (int(g["move_played"][i]), int(g["best_action"][i]), want_total), i
 
 
 @pytest.mark.gpu
@@ -451,6 +452,77 @@ def test_game_end_batches_and_game_stats(mods):
     assert j["result"]["num_move"] == 4 and j["request"]["vers"]["black_ver"] == 0 and j["request"]["vers"]["mcts_opt"]["num_rollouts_per_thread"] == 16
     assert GC.getClient().getGameStats().getPlayedGames() == []
     ev["gcw"].stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["online_9_script", "online_9_following_pass", "online_9_not_following"])
+def test_online_mode_equals_reference(mods, name):
+    """mode online against the REAL reference (oracle/ref_selfplay.cc online = 1: the reference's GoGameSelfPlay with a scripted
+    "human_actor"): the same answers -- moves, an illegal move, SKIP (the AI searches and moves), PASS, CLEAR, RESIGN -- give the
+    same prompts (all 18 feature planes of every prompt), the same searches (root edges, visits, rewards, moves) and the same
+    Record texts; GameOptions.following_pass with a net that is sure of the result: the AI answers the human's pass with a pass
+    exactly where the reference does (mcts_update_info, game_selfplay.cc:104-111)."""
+    import contextlib
+    import io
+    import json
+    import torch
+    import gcwrapper_restated as mod
+    from pyoracle import stub_net
+    _elf, _, goi = mods
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    n = int(g["board_size"])
+    script = [int(a) for a in g["human_script"]]
+    want_prompts = np.unpackbits(g["prompts"], axis=1)[:, :18 * n * n].reshape(-1, 18, n, n)
+    want_records = [json.loads(str(t)) for t in g["records"]]
+    m = int(g["searches"])
+    co, opt = options_from_cfg(goi, cfg, n=n, log_searches=m + 4, keep_records=8, following_pass=bool(cfg["following_pass"]))
+    opt.mode = "online"
+    GC = goi.GameContext(co, opt)
+    params = GC.getParams()
+    assert (params["ACTION_SKIP"], params["ACTION_PASS"], params["ACTION_RESIGN"], params["ACTION_CLEAR"]) == (-100, -99, -98, -97)
+    desc = {"human_actor": dict(input=["s"], reply=["pi", "a", "V"], batchsize=1),
+            "actor_black": dict(input=["s"], reply=["pi", "V", "a", "rv"], timeout_usec=10, batchsize=co.batchsize)}
+    with contextlib.redirect_stdout(io.StringIO()):
+        gcw = mod.GCWrapper(GC, co.batchsize, desc, num_recv=2, gpu=0, params=params)
+    prompts, records = [], []
+
+    def human(batch):
+        prompts.append(batch["s"].cpu().numpy()[0].copy())
+        a = script[len(prompts) - 1] if len(prompts) <= len(script) else params["ACTION_SKIP"]
+        return dict(pi=torch.zeros(1, n * n + 1).cuda(), V=torch.zeros(1).cuda(), a=torch.tensor([a], dtype=torch.int64).cuda())
+
+    def actor(batch):
+        s = batch["s"]
+        pi, v = stub_net(n, s.cpu().numpy(), int(cfg["net_salt"]), int(cfg["net_tie_levels"]))
+        if int(cfg["net_value_on"]):
+            v[:] = np.float32(cfg["net_value"])
+        k = s.shape[0]
+        return dict(pi=torch.from_numpy(pi).cuda(), V=torch.from_numpy(v).cuda(), a=torch.zeros(k, dtype=torch.int64).cuda(),
+                    rv=torch.zeros(k, dtype=torch.int64).cuda())
+
+    gcw.reg_callback("human_actor", human)
+    gcw.reg_callback("actor_black", actor)
+    gcw.start()
+    GC.setRequest(0, -1, 0.0, 1)             # numThreads as the harness sent it (it shows in Record.request)
+    guard = 0
+    while len(prompts) < len(script) + 1:
+        gcw.run()
+        records += GC.popRecords()
+        guard += 1
+        assert guard < 20000
+    assert len(prompts) == len(want_prompts)
+    for i, (p, w) in enumerate(zip(prompts, want_prompts)):
+        assert np.array_equal(p != 0, w != 0), "%s: prompt %d" % (name, i)
+    _check_fixture(GC.ctx().searchLog(), g, m)
+    assert len(records) == len(want_records)
+    for t, w in zip(records, want_records):
+        j = json.loads(t)
+        j["timestamp"] = w["timestamp"]
+        for part in ("client_ctrl", "vers"):
+            assert j["request"][part] == w["request"][part], (name, w["seq"], part, j["request"][part], w["request"][part])
+        assert j == w, (name, w["seq"])
+    gcw.stop()
 
 
 @pytest.mark.gpu
