@@ -1005,8 +1005,18 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     rng = np.random.default_rng(7 + rank)
     P = (n + 2) ** 2
     KB = max(1, args.train_prefetch)    # train batches drawn + extracted per launch (the trainer prefetches; start_server.sh:11-12 runs 2048 loader threads)
-    ld = elf_amd.ReplayLoader(board_size=n, capacity=R, batchsize=B, device=local_rank, num_future_actions=nfa, seed=1234 + 1000 * rank,
-                              feature_format="f16_nhwc" if args.features in ("auto", "f16") else "f32_nchw", batches_per_launch=KB)
+    fmt = "f16_nhwc" if args.features in ("auto", "f16") else "f32_nchw"
+    queues = args.train_sampler == "queues"
+    if queues:
+        # the reference's replay buffer and draws: ReaderQueues filled with InsertWithParity, GoGameTrain::act's draws by B / 64 game
+        # threads per train batch (elf_amd.ReplayBuffer; bit-exact against the real GoGameTrain path, tests/test_gpu_train.py)
+        rb = elf_amd.ReplayBuffer(board_size=n, num_reader=args.train_readers, queue_min_size=10, queue_max_size=1000, batchsize=B,
+                                  batches_per_launch=KB, insert_seed=77 + rank, seed=1234 + 1000 * rank, device=local_rank,
+                                  num_future_actions=nfa, feature_format=fmt)
+        ld = rb.loader
+    else:
+        ld = elf_amd.ReplayLoader(board_size=n, capacity=R, batchsize=B, device=local_rank, num_future_actions=nfa, seed=1234 + 1000 * rank,
+                                  feature_format=fmt, batches_per_launch=KB)
     recs_json = []
     L = elf_amd.lib()
     opt = SpOptions(n, 1, 1024, 1600, 1, 0.25, 0.03, 0, 30, -1, 0.0, 0.0, 0, 1, 1, 0, 0, 0, MctsOptions(16, 1, 1, 0, 0, 1.5, 7.5, 0, 1, 1, 1, 0, -1))
@@ -1017,7 +1027,10 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         pol[np.arange(plies), moves[r]] = 255
         val = np.tanh(rng.standard_normal(plies)).astype(np.float32)
         rec = dict(moves=moves[r], reward=float(rng.choice([-1.0, 1.0])), black_ver=0, policies=pol, values=val)
-        ld.put(r, rec)
+        if queues:
+            rb.insert(rec)
+        else:
+            ld.put(r, rec)
         if with_cpu and r < 32:                                    # the CPU baseline reads the same records as Record JSON
             args_ = (C.byref(opt), moves[r].ctypes.data, plies, pol.ctypes.data, plies, val.ctypes.data, plies, C.c_float(rec["reward"]), 0, 2, 0, 0)
             k = L.elfrec_record_to_json(*args_, None, 0)
@@ -1031,22 +1044,25 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     barrier = make_barrier(dist)
     d = ld._draw
     for i in range(warmup):
-        ld.sample(B, out=out)
+        (rb.sample(B // 64, out=out) if queues else ld.sample(B, out=out))
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        check_rc = ld.L.elftrain_draw(ld._h, B, nfa, C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()), C.c_void_p(d[2].data_ptr()), ld._stream())
-        assert check_rc == 0
-        ev[i][0].record()
-        ld.extract(d[0, :B], d[1, :B], d[2, :B], out=out)          # the dominant kernel, on torch's current stream
-        ev[i][1].record()
+        if queues:
+            rb.sample(B // 64, out=out, events=ev[i])               # the events bracket the kernel, not the index copies
+        else:
+            check_rc = ld.L.elftrain_draw(ld._h, B, nfa, C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()), C.c_void_p(d[2].data_ptr()), ld._stream())
+            assert check_rc == 0
+            ev[i][0].record()
+            ld.extract(d[0, :B], d[1, :B], d[2, :B], out=out)          # the dominant kernel, on torch's current stream
+            ev[i][1].record()
         mt_sum += out["move_idx"].sum()
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     replayed = int(mt_sum.item())
     dt_max, samples_all = reduce_max_sum(dist, dev, dt, B * steps)
-    ld.close()
+    (rb.close() if queues else ld.close())
     if rank != 0:
         return None
     per_sample = replayed / (B * steps) * STEP_BYTES[n] + (26728 if n == 19 else 6008) + P + 4 * (n * n + 1) + 40
@@ -1060,6 +1076,9 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                "step = one launch: the trainer prefetches), %d records of %d plies (random legal play on the device engine), one "
                                "MCTS policy per ply, num_future_actions %d, s rows %s" % (B1, KB, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
                    "batch": B1, "batches_per_launch": KB, "samples_per_launch": B, "records": R, "board_size": n,
+                   "sampler": ("reference replay buffer: %d ReaderQueues (q_min 10, q_max 1000) filled with InsertWithParity, draws of "
+                               "GoGameTrain::act by %d game threads taking turns (64 states per act)" % (args.train_readers, B1 // 64)) if queues
+                   else "uniform over the records (elftrain_draw)",
                    "mean_replayed_plies": replayed / (B * steps),
                    "replayed_board_steps_per_sec": replayed / dt,
                    "algorithmic_GBps": B * per_sample / (kern_ms / 1e3) / 1e9,
@@ -1087,6 +1106,9 @@ def main():
     ap.add_argument("--train-batch", type=int, default=2048)
     ap.add_argument("--train-prefetch", type=int, default=16, help="train batches drawn + extracted per launch (1 = one batch per launch)")
     ap.add_argument("--train-records", type=int, default=256)
+    ap.add_argument("--train-sampler", choices=["queues", "uniform"], default="queues",
+                    help="queues = the reference's ReaderQueues + GoGameTrain::act draws (elf_amd.ReplayBuffer); uniform = elftrain_draw")
+    ap.add_argument("--train-readers", type=int, default=4, help="ReaderQueues.num_reader for --train-sampler queues (reference default 50)")
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--boards9", type=int, default=65536)
     ap.add_argument("--board-size", type=int, default=19)

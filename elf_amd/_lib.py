@@ -74,6 +74,12 @@ SIGNATURES = {
     "elfsp_end_step2": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "elfsp_last_rows2": (_i, [_vp, _vp]),
     "elfsp_set_request2": (_i, [_vp, _vp]),
+    "elfrq_create": (_i, [_i, _i, _i, C.c_uint32, C.POINTER(_vp)]),
+    "elfrq_destroy": (_i, [_vp]),
+    "elfrq_insert": (_i, [_vp, C.c_int32, C.c_int32, _i, C.POINTER(C.c_int32)]),
+    "elfrq_sizes": (_i, [_vp, _vp]),
+    "elfrq_set_threads": (_i, [_vp, _i, _i64, C.c_uint64]),
+    "elfrq_draw": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "elfsp_progress": (_i, [_vp, _vp]),
     "elfsp_set_pick_seed": (_i, [_vp, C.c_uint32]),
     "elfsp_game_actor": (_i, [_vp, _i]),

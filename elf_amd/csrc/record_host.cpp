@@ -9,6 +9,11 @@
 #include <math.h>
 #include <string.h>
 
+#include <time.h>
+
+#include <algorithm>
+#include <deque>
+#include <random>
 #include <vector>
 
 #include "../../include/elf_amd.h"
@@ -394,6 +399,135 @@ int elfrec_quantise_policy(int board_size, const int32_t* coord, const float* pr
   for (int k = 0; k < n; ++k) {
     if (coord[k] < 0 || coord[k] >= P) return ELFGO_E_BADARG;
     out[coord[k]] = static_cast<unsigned char>(prob[k] / max_val * 255);
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The trainer's replay buffer and GoGameTrain::act's draws (host only).  elf::shared::ReaderQueuesT<Record>
+// (elf/distributed/shared_reader.h:165-340): num_reader queues, each a deque bounded by queue_max_size (ReaderQueueT::Insert :88-100),
+// filled by TrainCtrl::OnReceive with InsertWithParity(record, rng, reward > 0) (train/game_ctrl.h:306-311; shared_reader.h:212-219):
+// games Black won go to the odd queues, the others to the even ones.  A record here is a handle (a slot of an ElfReplay store).
+struct ElfReaderQueues {
+  struct Rec { int32_t slot, num_moves; };
+  std::vector<std::deque<Rec>> qs;
+  size_t queue_min_size = 1, queue_max_size = 1000;
+  int parity_sizes[2] = {0, 0};
+  bool min_size_satisfied = false;
+  std::mt19937 insert_rng;                 // TrainCtrl::rng_ (game_ctrl.h:244,367)
+  std::vector<std::mt19937> thread_rng;    // GoGameBase::_rng of every GoGameTrain game thread (common/game_base.h:32-38)
+  int64_t next_act = 0;                    // acts go round the threads
+};
+
+int elfrq_create(int num_reader, int queue_min_size, int queue_max_size, uint32_t insert_seed, ElfReaderQueues** out) {
+  if (!out || num_reader < 2 || (num_reader & 1) || queue_min_size < 1 || queue_max_size < queue_min_size) return ELFGO_E_BADARG;
+  ElfReaderQueues* q = new ElfReaderQueues();
+  q->qs.resize((size_t)num_reader);
+  q->queue_min_size = (size_t)queue_min_size;
+  q->queue_max_size = (size_t)queue_max_size;
+  q->insert_rng.seed(insert_seed != 0 ? insert_seed : (uint32_t)time(NULL));   // the reference: rng_(time(NULL))
+  q->thread_rng.resize(1);
+  q->thread_rng[0].seed(1);
+  *out = q;
+  return 0;
+}
+
+int elfrq_destroy(ElfReaderQueues* q) {
+  delete q;
+  return 0;
+}
+
+int elfrq_insert(ElfReaderQueues* q, int32_t slot, int32_t num_moves, int black_win, int32_t* evicted) {
+  if (!q || slot < 0 || num_moves < 0) return ELFGO_E_BADARG;
+  const int ii = (int)(q->insert_rng() % (q->qs.size() / 2));
+  const int idx = 2 * ii + (black_win ? 1 : 0);
+  std::deque<ElfReaderQueues::Rec>& buf = q->qs[(size_t)idx];
+  buf.push_back({slot, num_moves});
+  int delta = 1;
+  int32_t out = -1;
+  while (buf.size() > q->queue_max_size) {       // at most one: every insert adds one
+    out = buf.front().slot;
+    buf.pop_front();
+    delta--;
+  }
+  q->parity_sizes[idx % 2] += delta;
+  if (evicted) *evicted = out;
+  return idx;
+}
+
+int elfrq_sizes(const ElfReaderQueues* q, int32_t* per_queue) {
+  if (!q || !per_queue) return ELFGO_E_BADARG;
+  for (size_t i = 0; i < q->qs.size(); ++i) per_queue[i] = (int32_t)q->qs[i].size();
+  return (int)q->qs.size();
+}
+
+// One generator per GoGameTrain game thread.  seed != 0: thread t is seeded seed + t (this repository's rule for games, see
+// ElfSpOptions: the reference proper gives every thread `seed` itself, i.e. identical streams); seed == 0: elf_utils::get_seed
+// (elf/utils/utils.h:50-57) of t ^ job_hash, the reference's time-based default.
+int elfrq_set_threads(ElfReaderQueues* q, int num_threads, int64_t seed, uint64_t job_hash) {
+  if (!q || num_threads < 1) return ELFGO_E_BADARG;
+  q->thread_rng.resize((size_t)num_threads);
+  struct timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  const int64_t now_ms = (int64_t)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+  for (int t = 0; t < num_threads; ++t) {
+    uint64_t sd;
+    if (seed != 0) sd = (uint64_t)(seed + t);
+    else {
+      const int32_t idx = (int32_t)(uint32_t)((uint64_t)t ^ job_hash);
+      const int32_t term = (int32_t)((uint32_t)idx * 2341479u);
+      sd = (uint64_t)(((now_ms / 1000) * 1000 + now_ms + (int64_t)term) % 100000000ll);
+    }
+    q->thread_rng[(size_t)t].seed((std::mt19937::result_type)sd);
+  }
+  q->next_act = 0;
+  return 0;
+}
+
+// GoGameTrain::act (train/game_train.cc:23-58) num_acts times, the game threads taking turns; kNumState = 64 states per act, each:
+//   getSamplerWithParity (shared_reader.h:251-274): queue pair rng() % (nq / 2); the odd one if uniform_real(0, 1) > even_ratio,
+//     even_ratio = even / (even + odd + 1e-6) clamped to [0.45, 0.55] -- Black's and White's wins are sampled about equally often
+//     whatever their share of the buffer;
+//   Sampler::sample (:47-61): record rng() % queue size (a queue below queue_min_size gives none: the state is drawn again);
+//   switchRandomMove (go_state_ext.h:282-296): a record with fewer than num_future_actions moves is dropped and the state drawn
+//     again, else move_to = rng() % (num_moves - num_future_actions + 1);
+//   generateD4Code (:298-300): rng() % 8.
+// Host arrays of num_acts * 64.  Before the first draw every queue must hold queue_min_size records (the reference waits there,
+// wait_for_sufficient_data :327-336): ELFGO_E_BADARG otherwise, and when no record is long enough.
+int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t* slot, int32_t* move_to, int32_t* d4) {
+  if (!q || num_acts < 0 || num_future_actions < 1 || !slot || !move_to || !d4) return ELFGO_E_BADARG;
+  if (!q->min_size_satisfied) {
+    for (const auto& b : q->qs) if (b.size() < q->queue_min_size) return ELFGO_E_BADARG;
+    q->min_size_satisfied = true;
+  }
+  bool any = false;
+  for (const auto& b : q->qs) for (const auto& r : b) any = any || r.num_moves > num_future_actions - 1;
+  if (!any) return ELFGO_E_BADARG;
+  const float kSafeMargin = 0.45;
+  const int kNumState = 64;
+  for (int a = 0; a < num_acts; ++a) {
+    std::mt19937& rng = q->thread_rng[(size_t)(q->next_act++ % (int64_t)q->thread_rng.size())];
+    for (int i = 0; i < kNumState; ++i) {
+      const size_t o = (size_t)a * kNumState + i;
+      while (true) {
+        const int even = q->parity_sizes[0], odd = q->parity_sizes[1];
+        float even_ratio = static_cast<float>(even) / (even + odd + 1e-6);
+        even_ratio = std::max(even_ratio, kSafeMargin);
+        even_ratio = std::min(even_ratio, 1.0f - kSafeMargin);
+        std::uniform_real_distribution<> dis(0.0, 1.0);
+        int idx = (int)(rng() % (q->qs.size() / 2));
+        idx *= 2;
+        if (dis(rng) > even_ratio) idx++;
+        const std::deque<ElfReaderQueues::Rec>& buf = q->qs[(size_t)idx];
+        if (buf.size() < q->queue_min_size) continue;
+        const ElfReaderQueues::Rec& r = buf[rng() % buf.size()];
+        if (r.num_moves <= num_future_actions - 1) continue;
+        slot[o] = r.slot;
+        move_to[o] = (int32_t)(rng() % (size_t)(r.num_moves - num_future_actions + 1));
+        break;
+      }
+      d4[o] = (int32_t)(rng() % 8);
+    }
   }
   return 0;
 }

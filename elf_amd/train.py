@@ -165,3 +165,120 @@ class ReplayLoader:
         B = self.batchsize
         big = self.sample(k * B, out=out)
         return [{key: t[i * B:(i + 1) * B] for key, t in big.items()} for i in range(k)]
+
+
+class ReaderQueues:
+    """elf::shared::ReaderQueuesT<Record> + the draws of GoGameTrain::act over it (elfrq_*, host only): see include/elf_amd.h.
+    Records are handles (slots of a ReplayLoader)."""
+
+    def __init__(self, num_reader=50, queue_min_size=10, queue_max_size=1000, insert_seed=0, num_threads=1, seed=0, job_id=""):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        check(self.L.elfrq_create(int(num_reader), int(queue_min_size), int(queue_max_size), int(insert_seed) & 0xFFFFFFFF, C.byref(h)))
+        self._h = h
+        self.num_reader = int(num_reader)
+        from .selfplay import job_hash
+        check(self.L.elfrq_set_threads(self._h, int(num_threads), int(seed), job_hash(job_id)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.elfrq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def insert(self, slot, num_moves, black_win):
+        """InsertWithParity -> (queue index, evicted handle or -1)"""
+        ev = C.c_int32(-1)
+        q = self.L.elfrq_insert(self._h, int(slot), int(num_moves), int(bool(black_win)), C.byref(ev))
+        if q < 0:
+            check(q)
+        return q, ev.value
+
+    def sizes(self):
+        out = np.zeros(self.num_reader, np.int32)
+        check(min(0, self.L.elfrq_sizes(self._h, out.ctypes.data)))
+        return out
+
+    def draw(self, num_acts, num_future_actions=1):
+        """num_acts x 64 draws of GoGameTrain::act -> (slot, move_to, d4) int32 arrays"""
+        k = 64 * int(num_acts)
+        out = np.zeros((3, k), np.int32)
+        check(self.L.elfrq_draw(self._h, int(num_acts), int(num_future_actions), out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+        return out[0], out[1], out[2]
+
+    def draw_into(self, host, num_acts, num_future_actions=1):
+        """the same into a (pinned) int32 host tensor [3, >= num_acts * 64]"""
+        k = 64 * int(num_acts)
+        if host.dtype != torch.int32 or host.dim() != 2 or host.shape[0] != 3 or host.shape[1] < k or not host.is_contiguous():
+            raise ValueError("host must be a contiguous int32 tensor [3, >= num_acts * 64]")
+        check(self.L.elfrq_draw(self._h, int(num_acts), int(num_future_actions), host[0].data_ptr(), host[1].data_ptr(), host[2].data_ptr()))
+
+
+class ReplayBuffer:
+    """The trainer's replay buffer as the reference keeps and samples it: records arrive (TrainCtrl::OnReceive ->
+    InsertWithParity), live in ReaderQueues until their queue drops them, and train batches are what GoGameTrain game threads
+    draw from the queues -- here the records sit in an HBM store (ReplayLoader), the queues hold their slots, and one
+    k_replay_extract launch produces the rows of `acts` acts (64 rows each)."""
+
+    def __init__(self, board_size=19, num_reader=50, queue_min_size=10, queue_max_size=1000, batchsize=2048, batches_per_launch=1,
+                 insert_seed=0, num_threads=None, seed=0, job_id="", **loader_kw):
+        if batchsize % 64:
+            raise ValueError("batchsize must be a multiple of 64 (GoGameTrain sends 64 states per act)")
+        capacity = int(num_reader) * int(queue_max_size) + 1     # a slot is freed only after the insert that evicts it
+        self.loader = ReplayLoader(board_size=board_size, capacity=capacity, batchsize=batchsize, batches_per_launch=batches_per_launch,
+                                   **loader_kw)
+        self.queues = ReaderQueues(num_reader, queue_min_size, queue_max_size, insert_seed,
+                                   num_threads if num_threads is not None else batchsize // 64, seed, job_id)
+        self._free = list(range(capacity - 1, -1, -1))
+        # draws go host -> device through a small ring of pinned staging tensors: the host draws the next launch's samples while the
+        # device still replays the current one (nothing here waits for the stream)
+        B = self.loader.batchsize * self.loader.batches_per_launch
+        self._ring = [(torch.zeros((3, B), dtype=torch.int32).pin_memory(), torch.zeros((3, B), dtype=torch.int32, device=self.loader.device),
+                       torch.cuda.Event()) for _ in range(3)]
+        self._turn = 0
+
+    def close(self):
+        self.queues.close()
+        self.loader.close()
+
+    def insert(self, rec):
+        """one finished game (Record JSON text / dict) -> the queue it went to"""
+        r = rec if isinstance(rec, dict) and "moves" in rec else parse_record(self.loader.n, rec)
+        slot = self._free.pop()
+        self.loader.put(slot, r)
+        q, ev = self.queues.insert(slot, len(r["moves"]), r["reward"] > 0)
+        if ev >= 0:
+            self._free.append(ev)
+        return q
+
+    def sample(self, acts=None, out=None, events=None):
+        """the rows of `acts` acts (default: one train batch = batchsize / 64 acts), in the order the game threads drew them;
+        events = (start, end) torch.cuda.Events recorded around the extraction kernel"""
+        acts = int(acts or self.loader.batchsize // 64)
+        k = 64 * acts
+        host, dev, done = self._ring[self._turn]
+        self._turn = (self._turn + 1) % len(self._ring)
+        if k > host.shape[1]:
+            raise ValueError("more samples than the loader's batchsize x batches_per_launch")
+        done.synchronize()                       # the copy that last read this staging tensor (three launches ago)
+        self.queues.draw_into(host, acts, self.loader.nfa)
+        dev[:, :k].copy_(host[:, :k], non_blocking=True)
+        done.record(torch.cuda.current_stream(self.loader.device))
+        if events:
+            events[0].record()
+        b = self.loader.extract(dev[0, :k], dev[1, :k], dev[2, :k], out=out)
+        if events:
+            events[1].record()
+        return b
+
+    def sample_batches(self, k=None, out=None):
+        """k train batches (default batches_per_launch) from one launch -> list of k batch dicts (views of one allocation)"""
+        k = int(k or self.loader.batches_per_launch)
+        B = self.loader.batchsize
+        big = self.sample(k * B // 64, out=out)
+        return [{key: t[i * B:(i + 1) * B] for key, t in big.items()} for i in range(k)]

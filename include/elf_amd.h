@@ -407,6 +407,28 @@ int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_mov
 /* GoGameTrain::act's draws for n samples with the store's std::mt19937 (seeded at create): record, move_to =
  * rng() % (num_moves - num_future_actions + 1), D4 code = rng() % 8; results into device int32 [n] arrays */
 int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec, int32_t* move_to, int32_t* d4, void* stream);
+/* The trainer's replay buffer and GoGameTrain::act's draws, host only: elf::shared::ReaderQueuesT<Record>
+ * (elf/distributed/shared_reader.h:165-340) -- num_reader (even) queues, each a deque bounded by queue_max_size, filled as
+ * TrainCtrl::OnReceive does with InsertWithParity(record, rng, reward > 0) (train/game_ctrl.h:306-311): games Black won go to the odd
+ * queues, the others to the even ones -- and the draws of GoGameTrain::act (train/game_train.cc:23-58) over it.  A record is a
+ * handle: the slot of an ElfReplay store the caller keeps the record in.  insert_seed seeds TrainCtrl's generator (0 = time(NULL),
+ * the reference's rule). */
+typedef struct ElfReaderQueues ElfReaderQueues;
+int elfrq_create(int num_reader, int queue_min_size, int queue_max_size, uint32_t insert_seed, ElfReaderQueues** out);
+int elfrq_destroy(ElfReaderQueues* q);
+/* InsertWithParity: queue 2 * (rng() % (num_reader / 2)) + black_win, push_back, the queue's oldest record dropped when it holds
+ * more than queue_max_size (*evicted <- its handle, -1 = none: the caller may reuse that slot).  Returns the queue index. */
+int elfrq_insert(ElfReaderQueues* q, int32_t slot, int32_t num_moves, int black_win, int32_t* evicted);
+int elfrq_sizes(const ElfReaderQueues* q, int32_t* per_queue);
+/* one std::mt19937 per GoGameTrain game thread (GoGameBase, common/game_base.h:32-38): seed != 0 -> thread t gets seed + t (the
+ * reference gives all of them `seed`: identical streams); seed == 0 -> elf_utils::get_seed(t ^ job_hash), time-based */
+int elfrq_set_threads(ElfReaderQueues* q, int num_threads, int64_t seed, uint64_t job_hash);
+/* num_acts acts of GoGameTrain::act, the threads taking turns, 64 states each (kNumState): getSamplerWithParity (queue pair
+ * rng() % (nq / 2), the odd queue if uniform_real(0, 1) > even_ratio clamped to [0.45, 0.55]: Black's and White's wins are drawn
+ * about equally often), Sampler::sample (rng() % queue size), switchRandomMove (a record shorter than num_future_actions is drawn
+ * again; move_to = rng() % (num_moves - num_future_actions + 1)), generateD4Code (rng() % 8).  Host int32 arrays of num_acts * 64:
+ * feed them to elftrain_extract.  ELFGO_E_BADARG while a queue holds fewer than queue_min_size records (the reference waits). */
+int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t* slot, int32_t* move_to, int32_t* d4);
 /* one launch: replay record rec[i] up to move_to[i] (switchBeforeMove), then every extractor of the "train" batch under
  * D4 code d4[i] (NULL = 0).  rec/move_to/d4 device int32 [n]; n <= elfgo_capacity(e) */
 int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, const int32_t* d4, int n, const ElfTrainBatch* out,

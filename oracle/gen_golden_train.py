@@ -161,8 +161,39 @@ def dump_case(name, n, kw):
     return exact
 
 
+# the reference's trainer input path end to end (reftrain_act: ReaderQueuesT<Record> + one real GoGameTrain thread + the "train"
+# batch group): (board size, replay-buffer shape, seeds, acts of 64 rows, num_future_actions)
+TRAIN_ACT_CASES = {
+    "train_act_9": (9, dict(num_reader=4, q_min_size=1, q_max_size=1000, insert_seed=3, game_seed=11, num_acts=3, num_future_actions=1)),
+    "train_act_9_evict": (9, dict(num_reader=2, q_min_size=2, q_max_size=4, insert_seed=5, game_seed=12, num_acts=2, num_future_actions=3)),
+    "train_act_19": (19, dict(num_reader=2, q_min_size=1, q_max_size=50, insert_seed=7, game_seed=13, num_acts=1, num_future_actions=1)),
+}
+
+
+def dump_train_act(name, n, kw):
+    """records = those of train_<n>.npz, each given its own black_ver (1000 + index) so that a row's selfplay_ver names its record"""
+    if "--missing" in sys.argv and os.path.exists(os.path.join(OUT, name + ".npz")):
+        return
+    src = np.load(os.path.join(OUT, "train_%d.npz" % n))
+    recs = []
+    for i, t in enumerate(src["records"]):
+        j = json.loads(str(t))
+        j["request"]["vers"]["black_ver"] = 1000 + i
+        recs.append(json.dumps(j, separators=(",", ":")))
+    R = RefSelfPlay(n)
+    a, b = R.train_act(recs, **kw), R.train_act(recs, **kw)
+    assert all(np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)) for k in a), name + ": reference not deterministic"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), board_size=np.int32(n), records=np.array(recs),
+                        cfg_keys=np.array(list(kw.keys())), cfg_vals=np.array([int(v) for v in kw.values()], np.int64),
+                        rec=(a["selfplay_ver"] - 1000).astype(np.int32), s=np.packbits(a["s"].reshape(len(a["s"]), -1), axis=1),
+                        **{k: a[k] for k in ("offline_a", "winner", "mcts_scores", "move_idx", "num_move", "aug_code", "selfplay_ver")})
+    print(name, "rows", len(a["winner"]), "records used", sorted(set((a["selfplay_ver"] - 1000).tolist())))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    for name, (n, kw) in TRAIN_ACT_CASES.items():
+        dump_train_act(name, n, kw)
     for name, (n, kw) in RECORD_CASES_R3.items():
         dump_case(name, n, kw)
     if "--only-r3" in sys.argv:

@@ -348,6 +348,24 @@ class RefSelfPlay:
                     move_idx=mi.value, num_move=nm.value, aug_code=ac.value, selfplay_ver=sv.value)
 
 
+    def train_act(self, records, num_reader=4, q_min_size=1, q_max_size=1000, insert_seed=1, game_seed=7, num_acts=2, num_future_actions=1):
+        """The reference's trainer input path end to end (oracle/ref_selfplay.cc reftrain_act): records (list of Record JSON texts)
+        inserted into a ReaderQueuesT<Record> with InsertWithParity, one real GoGameTrain thread, num_acts "train" batches of 64
+        rows -> dict of arrays [num_acts * 64, ...]"""
+        n, na, rows = self.n, self.na, 64 * num_acts
+        s = np.zeros((rows, 18, n, n), np.uint8); oa = np.zeros((rows, num_future_actions), np.int64)
+        w = np.zeros(rows, np.float32); ms = np.zeros((rows, na), np.float32)
+        mi = np.zeros(rows, np.int32); nm = np.zeros(rows, np.int32); ac = np.zeros(rows, np.int32); sv = np.zeros(rows, np.int64)
+        text = "[" + ",".join(records) + "]"
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self.L.reftrain_act(text.encode(), C.c_int(num_reader), C.c_int(q_min_size), C.c_int(q_max_size), C.c_uint32(insert_seed),
+                                 C.c_int64(game_seed), C.c_int(num_acts), C.c_int(num_future_actions), p(s), p(oa), p(w), p(ms), p(mi), p(nm),
+                                 p(ac), p(sv))
+        if rc != rows:
+            raise RuntimeError("reftrain_act failed (%d)" % rc)
+        return dict(s=s, offline_a=oa, winner=w, mcts_scores=ms, move_idx=mi, num_move=nm, aug_code=ac, selfplay_ver=sv)
+
+
 class PortSelfPlay:
     """The CPU restatement of the search + self-play loop (oracle/mcts_oracle.cc over go_oracle.c); same run() interface and
     result layout as RefSelfPlay, which it is pinned against (tests/test_oracle_mcts.py)."""
@@ -380,12 +398,7 @@ class PortSelfPlay:
                              prior.ctypes.data_as(C.c_void_p), reward.ctypes.data_as(C.c_void_p), stats)
         if k < 0:
             raise RuntimeError("orcsp_run failed: %d" % k)
-        self.L.refsp_last_prompts.restype = C.c_int64
-        npr = int(self.L.refsp_last_prompts(None, C.c_int64(0)))
-        prompts = np.zeros((npr, 18, self.n, self.n), np.uint8)
-        if npr:
-            self.L.refsp_last_prompts(prompts.ctypes.data_as(C.c_void_p), C.c_int64(prompts.size))
-        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k], prompts=prompts,
+        return dict(search=list(S)[:k], coord=coord[:k], visits=visits[:k], prior=prior[:k], reward=reward[:k],
                     batches=int(stats[0]), rows=int(stats[1]))
 
 

@@ -33,6 +33,7 @@
 #include "elfgames/go/common/game_feature.h"
 #include "elfgames/go/common/game_selfplay.h"
 #include "elfgames/go/common/go_game_specific.h"
+#include "elfgames/go/train/game_train.h"
 
 #include "stub_net.h"
 
@@ -466,6 +467,95 @@ int reftrain_sample(const char* record_json, int move_to, int d4, int num_future
     return 0;
   } catch (const std::exception& e) {
     fprintf(stderr, "reftrain_sample: %s\n", e.what());
+    return -1;
+  }
+}
+
+// The trainer's input path as the reference runs it: a ReaderQueuesT<Record> replay buffer (elf/distributed/shared_reader.h) filled the
+// way TrainCtrl::OnReceive fills it (InsertWithParity(Record, &rng, reward > 0), train/game_ctrl.h:306-311) and ONE real GoGameTrain
+// game thread whose act() (train/game_train.cc:23-58: getSamplerWithParity, sample, fromRecord, switchRandomMove, generateD4Code, 64
+// states per act) feeds the "train" batch group (game.py:403-409) of a real elf::Context.  One game thread and batchsize 64: every
+// act is one batch, so the rows come out in the order the thread drew them.  Outputs hold num_acts * 64 rows.  Returns rows, < 0 on error.
+int reftrain_act(const char* records_json_array, int num_reader, int q_min_size, int q_max_size, uint32_t insert_seed, int64_t game_seed,
+                 int num_acts, int num_future_actions, uint8_t* s_bits, int64_t* offline_a, float* winner, float* mcts_scores,
+                 int32_t* move_idx, int32_t* num_move, int32_t* aug_code, int64_t* selfplay_ver) {
+  try {
+    std::vector<Record> recs = Record::createBatchFromJson(std::string(records_json_array));
+    if (recs.empty() || num_reader < 2 || (num_reader & 1)) return -1;
+    elf::shared::RQCtrl rq;
+    rq.num_reader = num_reader;
+    rq.ctrl.queue_min_size = (size_t)q_min_size;
+    rq.ctrl.queue_max_size = (size_t)q_max_size;
+    elf::shared::ReaderQueuesT<Record> reader(rq);
+    std::mt19937 insert_rng(insert_seed);
+    for (const Record& r : recs) reader.InsertWithParity(Record(r), &insert_rng, r.result.reward > 0);
+    for (size_t q = 0; q < reader.nqueue(); ++q)
+      if (reader[q]->size() < (size_t)q_min_size) return -2;   // the reference would sleep for minutes (wait_for_sufficient_data)
+
+    const int B = 64, NA = BOARD_NUM_ACTION, PL = MAX_NUM_AGZ_FEATURE * BOARD_SIZE * BOARD_SIZE;
+    ContextOptions co;
+    co.num_games = 1;
+    co.batchsize = B;
+    GameOptions opt;
+    opt.mode = "train";
+    opt.seed = game_seed;
+    opt.num_future_actions = num_future_actions;
+    elf::Context ctx;
+    GoFeature gf(opt);
+    gf.registerExtractor(B, ctx.getExtractor());
+    std::unique_ptr<GoGameTrain> game(new GoGameTrain(0, ctx.getClient(), co, opt, &reader));
+    ctx.setStartCallback(1, [&](int, elf::GameClient*) { game->mainLoop(); });
+    const std::vector<std::string> keys = {"s", "offline_a", "winner", "mcts_scores", "move_idx", "selfplay_ver", "aug_code", "num_move"};
+    struct TB { std::vector<float> s, winner, ms; std::vector<int64_t> oa, ver; std::vector<int32_t> mi, ac, nm; };
+    std::vector<TB> tb(2);
+    std::vector<int> idx2tb;
+    for (int r = 0; r < 2; ++r) {
+      auto smo = ctx.createSharedMemOptions("train", B);
+      smo.setTimeout(0);
+      elf::SharedMem& sm = ctx.allocateSharedMem(smo, keys);
+      const int idx = sm.getSharedMemOptions().getIdx();
+      if ((int)idx2tb.size() <= idx) idx2tb.resize(idx + 1, -1);
+      idx2tb[idx] = r;
+      TB& b = tb[r];
+      for (const auto& k : keys) {
+        elf::AnyP* p = sm[k];
+        const auto& f = p->field();
+        const size_t ne = f.getSize().nelement();
+        void* addr = nullptr;
+        if (k == "s") { b.s.assign(ne, 0.f); addr = b.s.data(); }
+        else if (k == "winner") { b.winner.assign(ne, 0.f); addr = b.winner.data(); }
+        else if (k == "mcts_scores") { b.ms.assign(ne, 0.f); addr = b.ms.data(); }
+        else if (k == "offline_a") { b.oa.assign(ne, 0); addr = b.oa.data(); }
+        else if (k == "selfplay_ver") { b.ver.assign(ne, 0); addr = b.ver.data(); }
+        else if (k == "move_idx") { b.mi.assign(ne, 0); addr = b.mi.data(); }
+        else if (k == "aug_code") { b.ac.assign(ne, 0); addr = b.ac.data(); }
+        else if (k == "num_move") { b.nm.assign(ne, 0); addr = b.nm.data(); }
+        p->setAddress((uint64_t)addr, f.getSize().getContinuousStrides(f.getSizeOfType()).vec());
+      }
+    }
+    ctx.start();
+    int rows = 0;
+    for (int a = 0; a < num_acts;) {
+      const elf::SharedMem* sm = ctx.wait(100000);
+      if (sm == nullptr) continue;
+      const int eb = sm->getEffectiveBatchSize();
+      if (sm->getSharedMemOptions().getLabel() == "train") {
+        if (eb != B) { ctx.step(); ctx.stop(); return -3; }
+        const TB& b = tb[idx2tb[sm->getSharedMemOptions().getIdx()]];
+        for (int i = 0; i < eb; ++i, ++rows) {
+          for (int j = 0; j < PL; ++j) s_bits[(size_t)rows * PL + j] = b.s[(size_t)i * PL + j] != 0.f ? 1 : 0;
+          for (int j = 0; j < num_future_actions; ++j) offline_a[(size_t)rows * num_future_actions + j] = b.oa[(size_t)i * num_future_actions + j];
+          for (int j = 0; j < NA; ++j) mcts_scores[(size_t)rows * NA + j] = b.ms[(size_t)i * NA + j];
+          winner[rows] = b.winner[i]; move_idx[rows] = b.mi[i]; num_move[rows] = b.nm[i]; aug_code[rows] = b.ac[i]; selfplay_ver[rows] = b.ver[i];
+        }
+        ++a;
+      }
+      ctx.step();
+    }
+    ctx.stop();
+    return rows;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "reftrain_act: %s\n", e.what());
     return -1;
   }
 }

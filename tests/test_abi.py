@@ -10,7 +10,7 @@ from conftest import ROOT
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "elf_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(elf(?:go|mcts|sp|net|train|rec)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(elf(?:go|mcts|sp|net|train|rec|rq)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(built):

@@ -57,6 +57,37 @@ def test_train_batch_matches_reference_rows(elf, n, fmt):
         ld.close()
 
 
+@pytest.mark.parametrize("name", ["train_act_9", "train_act_9_evict", "train_act_19"])
+def test_replay_buffer_batches_equal_the_reference_trainer_path(elf, name):
+    """The trainer's input path end to end against the REAL one: the fixture is what one real GoGameTrain game thread
+    (train/game_train.cc:23-58) sent to the "train" batch group from a real ReaderQueuesT<Record> filled with InsertWithParity
+    (oracle/ref_selfplay.cc reftrain_act).  ReplayBuffer given the same records in the same order, the same queue shape and
+    seeds: same rows in the same order -- record and move drawn, D4 code, the 18 planes, offline_a, winner, mcts_scores, move_idx,
+    num_move, selfplay_ver -- including evictions from a full queue and records too short for num_future_actions."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [int(v) for v in g["cfg_vals"]]))
+    n, recs = int(g["board_size"]), [str(t) for t in g["records"]]
+    rows = 64 * cfg["num_acts"]
+    for fmt in ("f32_nchw", "f16_nhwc"):
+        rb = elf.ReplayBuffer(board_size=n, num_reader=cfg["num_reader"], queue_min_size=cfg["q_min_size"], queue_max_size=cfg["q_max_size"],
+                              batchsize=rows, insert_seed=cfg["insert_seed"], num_threads=1, seed=cfg["game_seed"],
+                              num_future_actions=cfg["num_future_actions"], feature_format=fmt)
+        for t in recs:
+            rb.insert(t)
+        b = rb.sample(cfg["num_acts"])
+        torch.cuda.synchronize()
+        want_s = np.unpackbits(g["s"], axis=1)[:, : 18 * n * n].reshape(rows, 18, n, n).astype(np.float32)
+        assert np.array_equal(b["s"].float().cpu().numpy(), want_s)
+        for k in ("offline_a", "winner", "move_idx", "num_move", "aug_code", "selfplay_ver"):
+            assert np.array_equal(b[k].cpu().numpy(), g[k]), (name, k)
+        ms, want = b["mcts_scores"].cpu().numpy(), g["mcts_scores"]
+        np.testing.assert_array_equal(ms, want)
+        fin = np.isfinite(want)
+        assert np.array_equal(ms[fin].view(np.uint32), want[fin].view(np.uint32))
+        rb.close()
+
+
 def test_replayed_positions_and_draws(elf):
     """sample(): draws within range and reproducible for a seed; replayed boards equal the oracle's replay (hash, legal mask)."""
     import torch

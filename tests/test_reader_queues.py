@@ -1,0 +1,95 @@
+"""The trainer's replay buffer and GoGameTrain::act's draws (elfrq_*, host-only code of libelf_amd.so) against the REAL reference:
+tests/golden/train_act_*.npz hold the "train" batches one real GoGameTrain game thread produced from a real ReaderQueuesT<Record>
+(oracle/ref_selfplay.cc reftrain_act, oracle/gen_golden_train.py).  CPU: the draws (record, move, D4 code); the rows themselves are
+compared on the GPU (tests/test_gpu_train.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pyoracle import RefSelfPlay, sgfstr2coords
+
+CASES = ["train_act_9", "train_act_9_evict", "train_act_19"]
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [int(v) for v in g["cfg_vals"]]))
+    return g, cfg, int(g["board_size"]), [str(t) for t in g["records"]]
+
+
+def fill(queues, n, recs):
+    """TrainCtrl::OnReceive: InsertWithParity(record, rng, reward > 0), in arrival order; the handle of record i is i"""
+    for i, t in enumerate(recs):
+        j = json.loads(t)
+        queues.insert(i, len(sgfstr2coords(n, j["result"]["content"])), j["result"]["reward"] > 0)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_draws_equal_the_reference_game_thread(built, name):
+    import elf_amd
+    g, cfg, n, recs = load_case(name)
+    q = elf_amd.ReaderQueues(cfg["num_reader"], cfg["q_min_size"], cfg["q_max_size"], cfg["insert_seed"], num_threads=1, seed=cfg["game_seed"])
+    fill(q, n, recs)
+    slot, move_to, d4 = q.draw(cfg["num_acts"], cfg["num_future_actions"])
+    assert np.array_equal(slot, g["rec"]), "records drawn (queue pair, parity, index)"
+    assert np.array_equal(d4, g["aug_code"]), "generateD4Code"
+    # extractMoveIdx is getPly() - 1 = move_to, except for the one record whose illegal moves the replay skips (the last one)
+    ok = slot != len(recs) - 1
+    assert ok.sum() > 32 and np.array_equal(move_to[ok], g["move_idx"][ok]), "switchRandomMove"
+    # every drawn record is long enough for num_future_actions, and short ones exist in the buffer (they were drawn again)
+    lens = np.array([len(sgfstr2coords(n, json.loads(t)["result"]["content"])) for t in recs])
+    assert (lens[slot] >= cfg["num_future_actions"]).all()
+    sizes = q.sizes()
+    assert sizes.max() <= cfg["q_max_size"] and sizes.sum() == min(len(recs), sizes.sum())
+    if name == "train_act_9_evict":
+        assert sizes.sum() < len(recs)           # the even queue overflowed: its oldest records are gone ...
+        assert 0 not in set(slot.tolist())       # ... and are never drawn
+    q.close()
+
+
+def test_parity_keeps_black_and_white_wins_balanced(built):
+    """getSamplerWithParity: whatever the share of Black's wins in the buffer (here 1 in 10), the odd (Black won) queues are
+    drawn 45 .. 55 % of the time (kSafeMargin, shared_reader.h:256-269)"""
+    import elf_amd
+    q = elf_amd.ReaderQueues(4, 1, 1000, insert_seed=9, num_threads=4, seed=21)
+    for i in range(400):
+        q.insert(i, 30, i % 10 == 0)
+    sizes = q.sizes()
+    assert sizes[1::2].sum() == 40 and sizes[0::2].sum() == 360
+    slot, move_to, d4 = q.draw(64, 1)
+    black = (slot % 10 == 0).mean()
+    assert 0.40 < black < 0.50, black            # 1 - even_ratio = 0.45 of the draws
+    assert move_to.min() == 0 and move_to.max() == 29 and set(d4.tolist()) == set(range(8))
+    q.close()
+
+
+def test_queue_arguments(built):
+    import elf_amd
+    L = elf_amd.lib()
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.elfrq_create(3, 1, 10, 1, C.byref(h)) == -1          # num_reader must be even (shared_reader.h:178)
+    assert L.elfrq_create(2, 0, 10, 1, C.byref(h)) == -1
+    q = elf_amd.ReaderQueues(2, 2, 10, insert_seed=1)
+    q.insert(0, 20, True)
+    q.insert(1, 20, False)
+    with pytest.raises(elf_amd.ElfGoError):                        # a queue below queue_min_size: the reference waits, we refuse
+        q.draw(1, 1)
+    q.insert(2, 20, True)
+    q.insert(3, 20, False)
+    with pytest.raises(elf_amd.ElfGoError):                        # no record long enough for 21 future actions
+        q.draw(1, 22)
+    s, m, d = q.draw(1, 3)
+    assert s.shape == (64,) and m.max() <= 17
+    q.close()
+
+
+def test_reference_reproduces_fixture():
+    g, cfg, n, recs = load_case("train_act_9_evict")
+    if not RefSelfPlay.available(n):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    a = RefSelfPlay(n).train_act(recs, **cfg)
+    assert np.array_equal(a["selfplay_ver"] - 1000, g["rec"]) and np.array_equal(a["move_idx"], g["move_idx"])
