@@ -14,3 +14,4 @@ __version__ = "0.1"
 from .selfplay import SelfPlay, MctsOptions, SpOptions  # noqa: F401,E402
 from . import compat  # noqa: F401,E402
 from .train import ReplayLoader, ReaderQueues, ReplayBuffer, parse_record, sgfstr_to_coords, coords_to_sgfstr  # noqa: F401,E402
+from .client import ClientRecords, parse_request_seq, request_seq_to_json  # noqa: F401,E402

@@ -74,6 +74,15 @@ SIGNATURES = {
     "elfsp_end_step2": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "elfsp_last_rows2": (_i, [_vp, _vp]),
     "elfsp_set_request2": (_i, [_vp, _vp]),
+    "elfrec_client_create": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "elfrec_client_destroy": (_i, [_vp]),
+    "elfrec_client_feed": (_i, [_vp, C.c_char_p]),
+    "elfrec_client_update_state": (_i, [_vp, _vp]),
+    "elfrec_client_size": (_i, [_vp]),
+    "elfrec_client_dump_and_clear": (_i64, [_vp, C.c_char_p, _sz]),
+    "elfrec_parse_request_seq": (_i, [C.c_char_p, _vp, C.POINTER(_i64), _vp]),
+    "elfrec_request_seq_to_json": (_i64, [_vp, _vp, _i64, C.c_char_p, _sz]),
+    "elfsp_thread_states": (_i, [_vp, _vp, _i]),
     "elfrq_create": (_i, [_i, _i, _i, C.c_uint32, C.POINTER(_vp)]),
     "elfrq_destroy": (_i, [_vp]),
     "elfrq_insert": (_i, [_vp, C.c_int32, C.c_int32, _i, C.POINTER(C.c_int32)]),

@@ -14,6 +14,9 @@
 #include <algorithm>
 #include <deque>
 #include <random>
+#include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/elf_amd.h"
@@ -217,15 +220,13 @@ SpRecordMeta elfrec_meta_from_options(const ElfSpOptions& o) {
   return m;
 }
 
-std::string elfrec_record_json(const SpRecordMeta& m, const SpRecord& r) {
-  std::string o;
-  o.reserve(4096 + r.policies.size() * 3);
-  const int P = (m.board_size + 2) * (m.board_size + 2);
-  o += "{\"offline\":false,\"pri\":0.0,\"request\":{\"client_ctrl\":{\"async\":";
+// MsgRequest::setJsonFields (record.h:119-127): {"client_ctrl":{...},"vers":{...}} as nlohmann dumps it (keys in std::map order)
+static void put_request(std::string& o, const SpRecordMeta& m) {
+  o += "{\"client_ctrl\":{\"async\":";
   put_bool(o, m.async);
   o += ",\"black_resign_thres\":";
   put_float(o, m.black_resign_thres);
-  o += ",\"client_type\":1,\"never_resign_prob\":"; put_float(o, m.never_resign_prob);
+  o += ",\"client_type\":" + std::to_string(m.client_type) + ",\"never_resign_prob\":"; put_float(o, m.never_resign_prob);
   o += ",\"num_game_thread_used\":" + std::to_string(m.num_game_thread_used);
   o += ",\"player_swap\":"; put_bool(o, m.player_swap);
   o += ",\"white_resign_thres\":"; put_float(o, m.white_resign_thres);
@@ -241,7 +242,16 @@ std::string elfrec_record_json(const SpRecordMeta& m, const SpRecord& r) {
   put_float(o, m.root_alpha);
   o += ",\"root_epsilon\":"; put_float(o, m.root_epsilon);
   o += ",\"seed\":0,\"verbose\":false,\"verbose_time\":false,\"virtual_loss\":" + std::to_string(m.virtual_loss);
-  o += "},\"white_ver\":" + std::to_string(m.white_ver) + "}},\"result\":{\"black_never_resign\":"; put_bool(o, r.never_resign);
+  o += "},\"white_ver\":" + std::to_string(m.white_ver) + "}}";
+}
+
+std::string elfrec_record_json(const SpRecordMeta& m, const SpRecord& r) {
+  std::string o;
+  o.reserve(4096 + r.policies.size() * 3);
+  const int P = (m.board_size + 2) * (m.board_size + 2);
+  o += "{\"offline\":false,\"pri\":0.0,\"request\":";
+  put_request(o, m);
+  o += ",\"result\":{\"black_never_resign\":"; put_bool(o, r.never_resign);
   o += ",\"content\":\"";
   {
     std::vector<char> buf(r.moves.size() * 6 + 8);
@@ -375,6 +385,7 @@ int elfrec_record_to_json2(const ElfSpOptions* opt, const ElfSpRequest* request,
     m.black_resign_thres = request->black_resign_thres; m.white_resign_thres = request->white_resign_thres;
     m.never_resign_prob = request->never_resign_prob; m.num_game_thread_used = request->num_game_thread_used;
     m.player_swap = request->player_swap != 0; m.async = request->async != 0;
+    m.client_type = request->client_type != 0 ? request->client_type : 1;
   }
   const std::string t = elfrec_record_json(m, r);
   if (out && cap > t.size()) { memcpy(out, t.data(), t.size()); out[t.size()] = 0; }
@@ -530,6 +541,290 @@ int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t
     }
   }
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The client's wire formats (train/distri_client.h): what it sends -- Records = {identity, states, records} (common/record.h:401-470),
+// kept and dumped by GuardedRecords (:111-170) -- and what it receives, MsgRequestSeq (common/record.h:152-171).  Text as
+// nlohmann::json::dump() writes it: compact, object keys in std::map order.
+namespace {
+
+void put_json_string(std::string& o, const std::string& t) {   // nlohmann escape_string, ensure_ascii = false
+  o += '"';
+  for (unsigned char ch : t) {
+    switch (ch) {
+      case '"': o += "\\\""; break;
+      case '\\': o += "\\\\"; break;
+      case '\b': o += "\\b"; break;
+      case '\f': o += "\\f"; break;
+      case '\n': o += "\\n"; break;
+      case '\r': o += "\\r"; break;
+      case '\t': o += "\\t"; break;
+      default:
+        if (ch < 0x20) { char t8[8]; snprintf(t8, sizeof(t8), "\\u%04x", ch); o += t8; }
+        else o += (char)ch;
+    }
+  }
+  o += '"';
+}
+
+// a reader for the JSON the reference's server sends: objects, arrays, strings, numbers, true / false / null
+struct JValue {
+  enum Kind { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
+  bool b = false;
+  double num = 0;
+  int64_t inum = 0;
+  bool is_int = false;
+  std::string str;
+  std::vector<JValue> arr;
+  std::vector<std::pair<std::string, JValue>> obj;
+  const JValue* get(const char* key) const {
+    if (kind != OBJ) return nullptr;
+    for (const auto& kv : obj) if (kv.first == key) return &kv.second;
+    return nullptr;
+  }
+};
+
+struct JReader {
+  const char* p;
+  const char* end;
+  bool ok = true;
+  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+  bool lit(const char* t) { const size_t n = strlen(t); if ((size_t)(end - p) >= n && !memcmp(p, t, n)) { p += n; return true; } return false; }
+  JValue value(int depth = 0) {
+    JValue v;
+    ws();
+    if (p >= end || depth > 32) { ok = false; return v; }
+    if (*p == '{') {
+      v.kind = JValue::OBJ; ++p; ws();
+      if (p < end && *p == '}') { ++p; return v; }
+      while (ok) {
+        ws();
+        JValue k = value(depth + 1);
+        if (!ok || k.kind != JValue::STR) { ok = false; break; }
+        ws();
+        if (p >= end || *p != ':') { ok = false; break; }
+        ++p;
+        v.obj.emplace_back(k.str, value(depth + 1));
+        ws();
+        if (p < end && *p == ',') { ++p; continue; }
+        if (p < end && *p == '}') { ++p; break; }
+        ok = false;
+      }
+    } else if (*p == '[') {
+      v.kind = JValue::ARR; ++p; ws();
+      if (p < end && *p == ']') { ++p; return v; }
+      while (ok) {
+        v.arr.push_back(value(depth + 1));
+        ws();
+        if (p < end && *p == ',') { ++p; continue; }
+        if (p < end && *p == ']') { ++p; break; }
+        ok = false;
+      }
+    } else if (*p == '"') {
+      v.kind = JValue::STR; ++p;
+      while (p < end && *p != '"') {
+        if (*p == '\\' && p + 1 < end) {
+          ++p;
+          switch (*p) {
+            case 'n': v.str += '\n'; break; case 't': v.str += '\t'; break; case 'r': v.str += '\r'; break;
+            case 'b': v.str += '\b'; break; case 'f': v.str += '\f'; break;
+            case 'u': {
+              if (end - p < 5) { ok = false; return v; }
+              unsigned code = 0;
+              for (int i = 1; i <= 4; ++i) { const char c = p[i]; code = code * 16 + (c <= '9' ? c - '0' : (c | 32) - 'a' + 10); }
+              p += 4;
+              if (code < 0x80) v.str += (char)code;                        // the BMP as UTF-8 (identities are ASCII in practice)
+              else if (code < 0x800) { v.str += (char)(0xC0 | (code >> 6)); v.str += (char)(0x80 | (code & 63)); }
+              else { v.str += (char)(0xE0 | (code >> 12)); v.str += (char)(0x80 | ((code >> 6) & 63)); v.str += (char)(0x80 | (code & 63)); }
+              break;
+            }
+            default: v.str += *p;
+          }
+          ++p;
+        } else v.str += *p++;
+      }
+      if (p >= end) { ok = false; return v; }
+      ++p;
+    } else if (lit("true")) { v.kind = JValue::BOOL; v.b = true; }
+    else if (lit("false")) { v.kind = JValue::BOOL; v.b = false; }
+    else if (lit("null")) { v.kind = JValue::NUL; }
+    else {
+      char* q = nullptr;
+      v.kind = JValue::NUM;
+      v.num = strtod(p, &q);
+      if (q == p) { ok = false; return v; }
+      v.is_int = true;
+      for (const char* c = p; c < q; ++c) if (*c == '.' || *c == 'e' || *c == 'E') v.is_int = false;
+      v.inum = v.is_int ? strtoll(p, nullptr, 10) : (int64_t)v.num;
+      p = q;
+    }
+    return v;
+  }
+};
+
+bool jnum(const JValue* o, const char* k, double* out) { const JValue* v = o ? o->get(k) : nullptr; if (!v || v->kind != JValue::NUM) return false; *out = v->num; return true; }
+bool jint(const JValue* o, const char* k, int64_t* out) { const JValue* v = o ? o->get(k) : nullptr; if (!v || v->kind != JValue::NUM) return false; *out = v->inum; return true; }
+bool jbool(const JValue* o, const char* k, bool* out) {   // nlohmann converts numbers to bool on assignment as well
+  const JValue* v = o ? o->get(k) : nullptr;
+  if (!v) return false;
+  if (v->kind == JValue::BOOL) { *out = v->b; return true; }
+  if (v->kind == JValue::NUM) { *out = v->num != 0; return true; }
+  return false;
+}
+
+}  // namespace
+
+struct ElfClientRecords {
+  std::string identity;
+  std::unordered_map<int, ElfThreadState> states;   // the reference's own container: its iteration order is the order of "states"
+  std::vector<std::string> records;                 // Record JSON texts
+};
+
+int elfrec_client_create(const char* identity, ElfClientRecords** out) {
+  if (!out) return ELFGO_E_BADARG;
+  ElfClientRecords* c = new ElfClientRecords();
+  c->identity = identity ? identity : "";
+  *out = c;
+  return 0;
+}
+
+int elfrec_client_destroy(ElfClientRecords* c) {
+  delete c;
+  return 0;
+}
+
+// GuardedRecords::feed (distri_client.h:118-121): records_.addRecord(s.dumpRecord()); record_json = one Record as elfsp_pop_record /
+// elfrec_record_to_json give it
+int elfrec_client_feed(ElfClientRecords* c, const char* record_json) {
+  if (!c || !record_json || record_json[0] != '{') return ELFGO_E_BADARG;
+  c->records.emplace_back(record_json);
+  return 0;
+}
+
+// Records::updateState (record.h:422-424): states[ts.thread_id] = ts
+int elfrec_client_update_state(ElfClientRecords* c, const ElfThreadState* ts) {
+  if (!c || !ts) return ELFGO_E_BADARG;
+  c->states[ts->thread_id] = *ts;
+  return 0;
+}
+
+int elfrec_client_size(const ElfClientRecords* c) { return c ? (int)c->records.size() : ELFGO_E_BADARG; }
+
+// GuardedRecords::dumpAndClear (distri_client.h:156-169): Records::dumpJsonString() (record.h:426-439,459-463), then clear().
+// Returns the length of the text; with out == NULL nothing is cleared (a size query); with a buffer too small ELFGO_E_BADSIZE.
+int64_t elfrec_client_dump_and_clear(ElfClientRecords* c, char* out, size_t cap) {
+  if (!c) return ELFGO_E_BADARG;
+  std::string o = "{\"identity\":";
+  put_json_string(o, c->identity);
+  if (!c->records.empty()) {
+    o += ",\"records\":[";
+    for (size_t i = 0; i < c->records.size(); ++i) { if (i) o += ','; o += c->records[i]; }
+    o += ']';
+  }
+  if (!c->states.empty()) {
+    o += ",\"states\":[";
+    bool first = true;
+    for (const auto& t : c->states) {
+      if (!first) o += ',';
+      first = false;
+      const ElfThreadState& ts = t.second;
+      o += "{\"black\":" + std::to_string(ts.black) + ",\"move_idx\":" + std::to_string(ts.move_idx) + ",\"seq\":" + std::to_string(ts.seq) +
+           ",\"thread_id\":" + std::to_string(ts.thread_id) + ",\"white\":" + std::to_string(ts.white) + "}";
+    }
+    o += ']';
+  }
+  o += '}';
+  if (!out) return (int64_t)o.size();
+  if (cap <= o.size()) return ELFGO_E_BADSIZE;
+  memcpy(out, o.data(), o.size());
+  out[o.size()] = 0;
+  c->states.clear();      // Records::clear: the maps keep their bucket counts, as the reference's do
+  c->records.clear();
+  return (int64_t)o.size();
+}
+
+// MsgRequestSeq::createFromJson (record.h:161-166) -> MsgRequest::createFromJson (:129-134) -> ModelPair (black_ver, white_ver,
+// mcts_opt = TSOptions::createFromJson, tree_search_options.h:196-213) and ClientCtrl::createFromJson (record.h:49-66: player_swap
+// may be missing in a self-play request, async may be missing always).  A missing mandatory field is the reference's
+// "... cannot not be found!" exception: ELFGO_E_BADARG here.
+int elfrec_parse_request_seq(const char* text, ElfSpRequest* request, int64_t* seq, ElfTsOptions* mcts_opt) {
+  if (!text || !request) return ELFGO_E_BADARG;
+  JReader rd{text, text + strlen(text)};
+  const JValue root = rd.value();
+  rd.ws();
+  if (!rd.ok || rd.p != rd.end || root.kind != JValue::OBJ) return ELFGO_E_BADARG;
+  const JValue* req = root.get("request");
+  const JValue* vers = req ? req->get("vers") : nullptr;
+  const JValue* ctrl = req ? req->get("client_ctrl") : nullptr;
+  const JValue* mo = vers ? vers->get("mcts_opt") : nullptr;
+  const JValue* alg = mo ? mo->get("alg_opt") : nullptr;
+  int64_t sq = -1, i64 = 0;
+  if (!vers || !ctrl || !mo || !alg || !jint(&root, "seq", &sq)) return ELFGO_E_BADARG;
+  ElfSpRequest q;
+  memset(&q, 0, sizeof(q));
+  if (!jint(vers, "black_ver", &q.black_ver) || !jint(vers, "white_ver", &q.white_ver)) return ELFGO_E_BADARG;
+  ElfTsOptions t;
+  memset(&t, 0, sizeof(t));
+  double d = 0;
+  bool b = false;
+#define NEED_INT(obj, key, dst) do { if (!jint(obj, key, &i64)) return ELFGO_E_BADARG; dst = (decltype(dst))i64; } while (0)
+#define NEED_FLT(obj, key, dst) do { if (!jnum(obj, key, &d)) return ELFGO_E_BADARG; dst = (float)d; } while (0)
+#define NEED_BOOL(obj, key, dst) do { if (!jbool(obj, key, &b)) return ELFGO_E_BADARG; dst = b ? 1 : 0; } while (0)
+  NEED_INT(mo, "max_num_moves", t.max_num_moves); NEED_INT(mo, "num_threads", t.num_threads);
+  NEED_INT(mo, "num_rollouts_per_thread", t.num_rollouts_per_thread); NEED_INT(mo, "num_rollouts_per_batch", t.num_rollouts_per_batch);
+  NEED_BOOL(mo, "verbose", t.verbose); NEED_BOOL(mo, "verbose_time", t.verbose_time); NEED_INT(mo, "seed", t.seed);
+  NEED_BOOL(mo, "persistent_tree", t.persistent_tree);
+  {
+    const JValue* pm = mo->get("pick_method");
+    const JValue* lp = mo->get("log_prefix");
+    if (!pm || pm->kind != JValue::STR || !lp || lp->kind != JValue::STR) return ELFGO_E_BADARG;
+    t.pick_method = pm->str == "most_visited" ? ELFSP_PICK_MOST_VISITED : pm->str == "strongest_prior" ? ELFSP_PICK_STRONGEST_PRIOR :
+                    pm->str == "uniform_random" ? ELFSP_PICK_UNIFORM_RANDOM : -1;   // -1: the search would throw "Unknown pick method"
+    snprintf(t.log_prefix, sizeof(t.log_prefix), "%s", lp->str.c_str());
+  }
+  NEED_FLT(mo, "root_epsilon", t.root_epsilon); NEED_FLT(mo, "root_alpha", t.root_alpha); NEED_INT(mo, "virtual_loss", t.virtual_loss);
+  NEED_BOOL(alg, "use_prior", t.use_prior); NEED_FLT(alg, "c_puct", t.c_puct);
+  NEED_BOOL(alg, "unexplored_q_zero", t.unexplored_q_zero); NEED_BOOL(alg, "root_unexplored_q_zero", t.root_unexplored_q_zero);
+  NEED_INT(ctrl, "client_type", q.client_type); NEED_INT(ctrl, "num_game_thread_used", q.num_game_thread_used);
+  NEED_FLT(ctrl, "black_resign_thres", q.black_resign_thres); NEED_FLT(ctrl, "white_resign_thres", q.white_resign_thres);
+  NEED_FLT(ctrl, "never_resign_prob", q.never_resign_prob);
+  const bool is_selfplay = q.black_ver >= 0 && q.white_ver == -1;           // ModelPair::is_selfplay
+  if (jbool(ctrl, "player_swap", &b)) q.player_swap = b ? 1 : 0;
+  else if (!is_selfplay) return ELFGO_E_BADARG;                              // JSON_LOAD, not _OPTIONAL, for evaluation requests
+  if (jbool(ctrl, "async", &b)) q.async = b ? 1 : 0;
+#undef NEED_INT
+#undef NEED_FLT
+#undef NEED_BOOL
+  *request = q;
+  if (seq) *seq = sq;
+  if (mcts_opt) *mcts_opt = t;
+  return 0;
+}
+
+// MsgRequestSeq::dumpJsonString (record.h:167-171): {"request":{...},"seq":n} -- what the reference's server writes
+int64_t elfrec_request_seq_to_json(const ElfSpRequest* request, const ElfTsOptions* t, int64_t seq, char* out, size_t cap) {
+  if (!request || !t) return ELFGO_E_BADARG;
+  SpRecordMeta m{};
+  m.board_size = 0;
+  m.black_ver = request->black_ver; m.white_ver = request->white_ver;
+  m.num_threads = t->num_threads; m.num_rollouts_per_thread = t->num_rollouts_per_thread; m.num_rollouts_per_batch = t->num_rollouts_per_batch;
+  m.virtual_loss = t->virtual_loss; m.persistent_tree = t->persistent_tree != 0; m.use_prior = t->use_prior != 0;
+  m.unexplored_q_zero = t->unexplored_q_zero != 0; m.root_unexplored_q_zero = t->root_unexplored_q_zero != 0;
+  m.c_puct = t->c_puct; m.root_epsilon = t->root_epsilon; m.root_alpha = t->root_alpha;
+  m.black_resign_thres = request->black_resign_thres; m.white_resign_thres = request->white_resign_thres;
+  m.never_resign_prob = request->never_resign_prob; m.num_game_thread_used = request->num_game_thread_used;
+  m.player_swap = request->player_swap != 0; m.async = request->async != 0; m.pick_method = t->pick_method;
+  m.client_type = request->client_type != 0 ? request->client_type : 1;
+  if (t->max_num_moves != 0 || t->seed != 0 || t->verbose || t->verbose_time || t->log_prefix[0]) return ELFGO_E_BADARG;   // not representable by the writer
+  std::string o = "{\"request\":";
+  put_request(o, m);
+  o += ",\"seq\":" + std::to_string(seq) + "}";
+  if (!out) return (int64_t)o.size();
+  if (cap <= o.size()) return ELFGO_E_BADSIZE;
+  memcpy(out, o.data(), o.size());
+  out[o.size()] = 0;
+  return (int64_t)o.size();
 }
 
 }  // extern "C"

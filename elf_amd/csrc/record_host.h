@@ -17,6 +17,7 @@ struct SpRecordMeta {          // the MsgRequest half of a Record (record.h:119-
   int num_game_thread_used;
   bool player_swap = false, async = false;
   int pick_method = 0;       // ELFSP_PICK_*
+  int client_type = 1;       // ClientCtrl.client_type as the server sent it (CLIENT_SELFPLAY_ONLY = 1, record.h:24-29)
 };
 
 struct SpRecord {              // the MsgResult half (record.h:184-234) + Record's own fields (:236-262)

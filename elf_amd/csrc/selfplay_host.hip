@@ -52,6 +52,7 @@ struct SpRequest {          // MsgRequest (common/record.h:119-149): ModelPair +
   float black_thres = 0.f, white_thres = 0.f, never_resign_prob = 0.f;
   bool async = false, player_swap = false;
   int thread_used = -1;
+  int client_type = 1;         // ClientCtrl.client_type: carried into the records only
   int id = 0;
   bool wait() const { return black_ver < 0; }                           // ModelPair::wait
   bool is_selfplay() const { return black_ver >= 0 && white_ver == -1; }
@@ -176,6 +177,7 @@ static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {
   m.black_resign_thres = gm.req.black_thres; m.white_resign_thres = gm.req.white_thres; m.never_resign_prob = gm.req.never_resign_prob;
   m.num_game_thread_used = gm.req.thread_used;
   m.player_swap = gm.req.player_swap; m.async = gm.req.async;
+  m.client_type = gm.req.client_type;
   return m;
 }
 
@@ -189,7 +191,7 @@ static void sp_finish_record(ElfSelfPlay* sp, int g, float final_value, int fina
     r.reward = final_value;                      // _state.getFinalValue()
     r.never_resign = gm.never_resign;
     r.num_move = final_ply - 1;                  // _state.getPly() - 1
-    r.thread_id = (uint64_t)g;
+    r.thread_id = (uint64_t)(sp->opt.game_idx_base + g);   // _game_idx: the same id the game's ThreadState carries (elfsp_thread_states)
     r.seq = gm.seq;                              // _seq: ctor restart() -> 1, first request restart() -> 2, then +1 per game
     r.using_models.assign(gm.using_models.begin(), gm.using_models.end());
     r.timestamp = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
@@ -937,6 +939,7 @@ int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* q) {
   r.black_thres = q->black_resign_thres; r.white_thres = q->white_resign_thres; r.never_resign_prob = q->never_resign_prob;
   r.async = q->async != 0; r.player_swap = q->player_swap != 0;
   r.thread_used = q->num_game_thread_used;
+  r.client_type = q->client_type != 0 ? q->client_type : 1;
   if (!sp->explicit_request && sp->n_steps == 0 && !sp->step_open && !sp->mailbox.empty() && sp->cur_done) {
     // nothing has been played yet: this request replaces the implicit one of elfsp_create (the reference's games wait for their
     // first request, game_selfplay.cc:277-279)
@@ -948,7 +951,7 @@ int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* q) {
   const bool have_last = !sp->mailbox.empty() || sp->cur.id != 0;
   if (have_last && last.black_ver == r.black_ver && last.white_ver == r.white_ver && last.black_thres == r.black_thres &&
       last.white_thres == r.white_thres && last.never_resign_prob == r.never_resign_prob && last.async == r.async &&
-      last.player_swap == r.player_swap && last.thread_used == r.thread_used)
+      last.player_swap == r.player_swap && last.thread_used == r.thread_used && last.client_type == r.client_type)
     return 0;
   sp_push_request(sp, r);
   if (!sp->step_open) {                              // games between two searches may look at their mailbox now
@@ -977,6 +980,22 @@ int elfsp_take_game_starts(ElfSelfPlay* sp, int64_t* black_ver, int64_t* white_v
   if (black_ver) *black_ver = sp->start_black;
   if (white_ver) *white_ver = sp->start_white;
   return n;
+}
+
+// GoStateExt::getThreadState (go_state_ext.h:149-157) of every game; host-only
+int elfsp_thread_states(const ElfSelfPlay* sp, ElfThreadState* out, int capacity) {
+  if (!sp || !out || capacity < sp->G) return ELFGO_E_BADARG;
+  for (int g = 0; g < sp->G; ++g) {
+    const SpGame& gm = sp->games[g];
+    ElfThreadState& t = out[g];
+    t.thread_id = sp->opt.game_idx_base + g;
+    t.seq = gm.seq;
+    t.move_idx = gm.ply - 1;
+    t.reserved = 0;
+    t.black = gm.req.black_ver;
+    t.white = gm.req.white_ver;
+  }
+  return sp->G;
 }
 
 int elfsp_set_pick_seed(ElfSelfPlay* sp, uint32_t seed) {

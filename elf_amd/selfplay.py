@@ -43,7 +43,7 @@ class SpRequest(C.Structure):
     """ElfSpRequest"""
     _fields_ = [("black_ver", C.c_int64), ("white_ver", C.c_int64), ("black_resign_thres", C.c_float),
                 ("white_resign_thres", C.c_float), ("never_resign_prob", C.c_float), ("num_game_thread_used", C.c_int32),
-                ("player_swap", C.c_int32), ("async_", C.c_int32)]
+                ("player_swap", C.c_int32), ("async_", C.c_int32), ("client_type", C.c_int32)]
 
 
 PICK_METHODS = {"most_visited": 0, "strongest_prior": 1, "uniform_random": 2}

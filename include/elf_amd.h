@@ -301,6 +301,8 @@ typedef struct ElfSpRequest {
   int32_t num_game_thread_used;       /* ClientCtrl.num_game_thread_used, -1 = all games */
   int32_t player_swap;                /* ClientCtrl.player_swap */
   int32_t async;                      /* ClientCtrl.async */
+  int32_t client_type;                /* ClientCtrl.client_type as the server sent it (record.h:24-29); it only travels into the
+                                         Records the games dump.  0 = unset: CLIENT_SELFPLAY_ONLY (1) */
 } ElfSpRequest;
 int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* request);
 /* the same with both thresholds equal, every game used, no swap */
@@ -407,6 +409,42 @@ int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_mov
 /* GoGameTrain::act's draws for n samples with the store's std::mt19937 (seeded at create): record, move_to =
  * rng() % (num_moves - num_future_actions + 1), D4 code = rng() % 8; results into device int32 [n] arrays */
 int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec, int32_t* move_to, int32_t* d4, void* stream);
+/* ---- the client's wire formats (train/distri_client.h), host only --------------------------------------------------------------
+ * What a self-play client sends to the reference's server: Records = {identity, states, records} (common/record.h:401-470) as
+ * GuardedRecords keeps and dumps them (distri_client.h:111-170) -- and what it receives: MsgRequestSeq (record.h:152-171).  Texts
+ * are byte-identical to nlohmann::json::dump() of the reference's objects, so its server parses them and its tests read them. */
+typedef struct ElfThreadState {       /* ThreadState (record.h:354-380) = GoStateExt::getThreadState (go_state_ext.h:149-157) */
+  int32_t thread_id, seq, move_idx, reserved;
+  int64_t black, white;
+} ElfThreadState;
+typedef struct ElfTsOptions {         /* TSOptions + SearchAlgoOptions as they travel in a request (tree_search_options.h:23-75,77-213) */
+  int32_t max_num_moves, num_threads, num_rollouts_per_thread, num_rollouts_per_batch;
+  int32_t verbose, verbose_time, persistent_tree, pick_method /* ELFSP_PICK_*, -1 = a name the search does not know */;
+  int64_t seed;
+  float root_epsilon, root_alpha;
+  int32_t virtual_loss;
+  int32_t use_prior, unexplored_q_zero, root_unexplored_q_zero;
+  float c_puct;
+  char log_prefix[60];
+} ElfTsOptions;
+typedef struct ElfClientRecords ElfClientRecords;
+int elfrec_client_create(const char* identity, ElfClientRecords** out);
+int elfrec_client_destroy(ElfClientRecords* c);
+int elfrec_client_feed(ElfClientRecords* c, const char* record_json);              /* GuardedRecords::feed: one finished game */
+int elfrec_client_update_state(ElfClientRecords* c, const ElfThreadState* state);  /* Records::updateState (GameNotifier::OnStateUpdate) */
+int elfrec_client_size(const ElfClientRecords* c);                                  /* records waiting */
+/* GuardedRecords::dumpAndClear: the message for the server.  Returns the text length; out == NULL only queries it (nothing is
+ * cleared); ELFGO_E_BADSIZE when cap <= length. */
+int64_t elfrec_client_dump_and_clear(ElfClientRecords* c, char* out, size_t cap);
+/* the server's reply: MsgRequestSeq::createFromJson.  *mcts_opt <- the TSOptions the server dictates (GoGameSelfPlay::restart builds
+ * its AIs from request.vers.mcts_opt, game_selfplay.cc:166-180: a client checks them against the context it runs).  ELFGO_E_BADARG
+ * for malformed JSON or a missing mandatory field (the reference throws "... cannot not be found!"). */
+int elfrec_parse_request_seq(const char* json_text, ElfSpRequest* request, int64_t* seq, ElfTsOptions* mcts_opt);
+/* MsgRequestSeq::dumpJsonString: what the reference's server writes for this request */
+int64_t elfrec_request_seq_to_json(const ElfSpRequest* request, const ElfTsOptions* mcts_opt, int64_t seq, char* out, size_t cap);
+/* GoStateExt::getThreadState of every game of a self-play context (thread_id = the job-wide game index, seq, move_idx = ply - 1,
+ * black / white = the versions of the game's current request): what GameNotifier::OnStateUpdate reports at every fifth act */
+int elfsp_thread_states(const ElfSelfPlay* sp, ElfThreadState* out, int capacity);
 /* The trainer's replay buffer and GoGameTrain::act's draws, host only: elf::shared::ReaderQueuesT<Record>
  * (elf/distributed/shared_reader.h:165-340) -- num_reader (even) queues, each a deque bounded by queue_max_size, filled as
  * TrainCtrl::OnReceive does with InsertWithParity(record, rng, reward > 0) (train/game_ctrl.h:306-311): games Black won go to the odd

@@ -348,6 +348,57 @@ class RefSelfPlay:
                     move_idx=mi.value, num_move=nm.value, aug_code=ac.value, selfplay_ver=sv.value)
 
 
+    # ---- the client's wire formats: the real Records / MsgRequestSeq (oracle/ref_selfplay.cc refrec_*)
+    def _text(self, fn, *args):
+        fn.restype = C.c_int64
+        n = int(fn(*args, None, C.c_int64(0)))
+        if n < 0:
+            return None
+        buf = C.create_string_buffer(n + 1)
+        fn(*args, buf, C.c_int64(n + 1))
+        return buf.raw[:n].decode("latin-1")
+
+    def client_reset(self, identity):
+        self.L.refrec_client_reset(identity.encode())
+
+    def client_feed(self, record_json):
+        assert self.L.refrec_client_feed(record_json.encode("latin-1")) == 0
+
+    def client_update_state(self, thread_id, seq, move_idx, black, white):
+        self.L.refrec_client_update_state(C.c_int(thread_id), C.c_int(seq), C.c_int(move_idx), C.c_int64(black), C.c_int64(white))
+
+    def client_dump(self, cap=1 << 24):
+        """GuardedRecords::dumpAndClear"""
+        self.L.refrec_client_dump_and_clear.restype = C.c_int64
+        buf = C.create_string_buffer(cap)
+        n = int(self.L.refrec_client_dump_and_clear(buf, C.c_int64(cap)))
+        assert 0 <= n < cap
+        return buf.raw[:n].decode("latin-1")
+
+    def records_parse(self, text):
+        """the server's Records::createFromJsonString -> (records, states, sum of move_idx, identity) or None if it throws"""
+        out3 = (C.c_int64 * 3)()
+        self.L.refrec_records_parse.restype = C.c_int64
+        buf = C.create_string_buffer(4096)
+        n = int(self.L.refrec_records_parse(text.encode("latin-1"), out3, buf, C.c_int64(4096)))
+        if n < 0:
+            return None
+        return int(out3[0]), int(out3[1]), int(out3[2]), buf.raw[:n].decode("latin-1")
+
+    def request_seq_dump(self, black_ver, white_ver, client_type=1, num_game_thread_used=-1, black_thres=0.0, white_thres=0.0,
+                         never_resign_prob=0.0, player_swap=0, async_=0, seq=0, **kw):
+        """MsgRequestSeq::dumpJsonString, TSOptions from the MCTS_DEFAULTS-style keywords"""
+        cfg = dict(MCTS_DEFAULTS)
+        cfg.update(kw)
+        c = RefSpConfig(**cfg)
+        return self._text(self.L.refrec_request_seq_dump, C.byref(c), C.c_int64(black_ver), C.c_int64(white_ver), C.c_int(client_type),
+                          C.c_int(num_game_thread_used), C.c_float(black_thres), C.c_float(white_thres), C.c_float(never_resign_prob),
+                          C.c_int(player_swap), C.c_int(async_), C.c_int64(seq))
+
+    def request_seq_roundtrip(self, text):
+        """text -> MsgRequestSeq -> text, None when the reference throws"""
+        return self._text(self.L.refrec_request_seq_roundtrip, text.encode("latin-1"))
+
     def train_act(self, records, num_reader=4, q_min_size=1, q_max_size=1000, insert_seed=1, game_seed=7, num_acts=2, num_future_actions=1):
         """The reference's trainer input path end to end (oracle/ref_selfplay.cc reftrain_act): records (list of Record JSON texts)
         inserted into a ReaderQueuesT<Record> with InsertWithParity, one real GoGameTrain thread, num_acts "train" batches of 64

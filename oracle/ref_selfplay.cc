@@ -560,6 +560,64 @@ int reftrain_act(const char* records_json_array, int num_reader, int q_min_size,
   }
 }
 
+// ---- the client's wire formats: the real Records / ThreadState / MsgRequestSeq (common/record.h) ---------------------------------
+// Records as GuardedRecords (train/distri_client.h:111-170) keeps it: one object, fed and dumped repeatedly (clear() keeps the
+// unordered_map's buckets, which the order of "states" in later messages depends on)
+static std::unique_ptr<Records> g_client_records;
+static int64_t copy_out(const std::string& t, char* buf, int64_t cap) {
+  if (buf && cap > 0) { const int64_t k = std::min<int64_t>((int64_t)t.size(), cap - 1); memcpy(buf, t.data(), (size_t)k); buf[k] = 0; }
+  return (int64_t)t.size();
+}
+void refrec_client_reset(const char* identity) { g_client_records.reset(new Records(identity ? identity : "")); }
+int refrec_client_feed(const char* record_json) {
+  try { g_client_records->addRecord(Record::createFromJson(json::parse(record_json))); return 0; }
+  catch (const std::exception& e) { fprintf(stderr, "refrec_client_feed: %s\n", e.what()); return -1; }
+}
+void refrec_client_update_state(int thread_id, int seq, int move_idx, int64_t black, int64_t white) {
+  ThreadState ts;
+  ts.thread_id = thread_id; ts.seq = seq; ts.move_idx = move_idx; ts.black = black; ts.white = white;
+  g_client_records->updateState(ts);
+}
+int64_t refrec_client_dump_and_clear(char* buf, int64_t cap) {     // GuardedRecords::dumpAndClear :156-169
+  const std::string t = g_client_records->dumpJsonString();
+  g_client_records->clear();
+  return copy_out(t, buf, cap);
+}
+// the server's side of the same message (TrainCtrl::OnReceive, train/game_ctrl.h:288): Records::createFromJsonString; out3 =
+// {records, states, sum of the states' move_idx}; identity copied to buf.  < 0 when the reference throws.
+int64_t refrec_records_parse(const char* text, int64_t* out3, char* buf, int64_t cap) {
+  try {
+    Records rs = Records::createFromJsonString(std::string(text));
+    int64_t mv = 0;
+    for (const auto& t : rs.states) mv += t.second.move_idx;
+    out3[0] = (int64_t)rs.records.size(); out3[1] = (int64_t)rs.states.size(); out3[2] = mv;
+    return copy_out(rs.identity, buf, cap);
+  } catch (const std::exception& e) { fprintf(stderr, "refrec_records_parse: %s\n", e.what()); return -1; }
+}
+// what the reference's server sends: MsgRequestSeq::dumpJsonString with the TSOptions of cfg
+int64_t refrec_request_seq_dump(const RefSpConfig* cfg, int64_t black_ver, int64_t white_ver, int client_type, int num_game_thread_used,
+                                float black_thres, float white_thres, float never_resign_prob, int player_swap, int async, int64_t seq,
+                                char* buf, int64_t cap) {
+  MsgRequestSeq m;
+  m.seq = seq;
+  m.request.vers.black_ver = black_ver; m.request.vers.white_ver = white_ver;
+  auto& ts = m.request.vers.mcts_opt;
+  ts.num_threads = cfg->mcts_threads; ts.num_rollouts_per_thread = cfg->rollouts_per_thread; ts.num_rollouts_per_batch = cfg->rollouts_per_batch;
+  ts.virtual_loss = cfg->virtual_loss; ts.persistent_tree = cfg->persistent_tree != 0; ts.root_epsilon = cfg->root_epsilon;
+  ts.root_alpha = cfg->root_alpha; ts.alg_opt.use_prior = cfg->use_prior != 0; ts.alg_opt.c_puct = cfg->c_puct;
+  ts.alg_opt.unexplored_q_zero = cfg->unexplored_q_zero != 0; ts.alg_opt.root_unexplored_q_zero = cfg->root_unexplored_q_zero != 0;
+  ts.pick_method = cfg->pick_method == 1 ? "strongest_prior" : cfg->pick_method == 2 ? "uniform_random" : "most_visited";
+  auto& c = m.request.client_ctrl;
+  c.client_type = (ClientType)client_type; c.num_game_thread_used = num_game_thread_used; c.black_resign_thres = black_thres;
+  c.white_resign_thres = white_thres; c.never_resign_prob = never_resign_prob; c.player_swap = player_swap != 0; c.async = async != 0;
+  return copy_out(m.dumpJsonString(), buf, cap);
+}
+// text -> MsgRequestSeq -> text; < 0 when the reference throws (a missing field)
+int64_t refrec_request_seq_roundtrip(const char* text, char* buf, int64_t cap) {
+  try { return copy_out(MsgRequestSeq::createFromJson(json::parse(text)).dumpJsonString(), buf, cap); }
+  catch (const std::exception& e) { return -1; }
+}
+
 // CPU baseline of the trainer's input pipeline: what GoGameTrain::act does per sample (fromRecord, switchRandomMove,
 // generateD4Code, then every "train" extractor the batcher would call on the sending thread), records parsed once,
 // `threads` host threads each producing samples into its own row buffers.  Returns the number of board steps replayed.

@@ -88,6 +88,41 @@ def test_replay_buffer_batches_equal_the_reference_trainer_path(elf, name):
         rb.close()
 
 
+def test_client_message_of_a_selfplay_context_is_read_by_the_reference_server(elf):
+    """The loop of a self-play client (train/distri_client.h): games play, their thread states and finished games collect in a
+    ClientRecords (GuardedRecords), and the message it dumps is parsed by the REAL Records::createFromJsonString -- the call
+    TrainCtrl::OnReceive makes on the training server -- into the same number of records and states."""
+    import torch
+    from pyoracle import RefSelfPlay
+    n, G = 9, 4
+    sp = elf.SelfPlay(board_size=n, num_games=G, mcts_rollout_per_thread=32, mcts_rollout_per_batch=16, seed=17, move_cutoff=12,
+                      keep_records=16, nodes_per_game=1024, model_ver=6, game_idx_base=100)
+    c = elf.ClientRecords("mi355x-0")
+    finished = 0
+    while finished < 6:
+        rows = sp.begin_step()
+        pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), 4, 0)
+        sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device), torch.full((rows,), 6, dtype=torch.int64, device=sp.device))
+        before = len(c)
+        c.update_from(sp)
+        finished += len(c) - before
+    plies = sp.board_engine().info_host()["ply"][:G]
+    text = c.dump_and_clear()
+    j = json.loads(text)
+    assert j["identity"] == "mi355x-0" and len(j["records"]) == finished and len(j["states"]) == G
+    by_id = {t["thread_id"]: t for t in j["states"]}
+    assert sorted(by_id) == [100, 101, 102, 103]
+    for g in range(G):
+        t = by_id[100 + g]
+        assert t["move_idx"] == int(plies[g]) - 1 and t["black"] == 6 and t["white"] == -1 and t["seq"] >= 2
+    assert all(r["request"]["vers"]["black_ver"] == 6 and r["thread_id"] in by_id for r in j["records"])
+    if RefSelfPlay.available(n):
+        got = RefSelfPlay(n).records_parse(text)
+        assert got == (finished, G, sum(t["move_idx"] for t in j["states"]), "mi355x-0")
+    sp.close()
+    c.close()
+
+
 def test_replayed_positions_and_draws(elf):
     """sample(): draws within range and reproducible for a seed; replayed boards equal the oracle's replay (hash, legal mask)."""
     import torch

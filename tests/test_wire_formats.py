@@ -1,0 +1,89 @@
+"""CPU: the client's wire formats (elfrec_client_*, elfrec_parse_request_seq, elfrec_request_seq_to_json; host-only code of
+libelf_amd.so) against texts written by the REAL reference objects -- Records / ThreadState / MsgRequestSeq of
+src_cpp/elfgames/go/common/record.h (tests/golden/wire_formats.json, oracle/gen_golden_wire.py)."""
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN
+from pyoracle import MCTS_DEFAULTS, RefSelfPlay
+
+
+@pytest.fixture(scope="module")
+def wire():
+    with open(os.path.join(GOLDEN, "wire_formats.json")) as fh:
+        return json.load(fh)
+
+
+def test_records_messages_equal_the_reference_s(built, wire):
+    """GuardedRecords sessions: the same state updates and finished games in the same order give the same message text at every
+    dumpAndClear -- identity escaping, "records" / "states" present only when non-empty, and the order of "states" (the iteration
+    order of the reference's std::unordered_map<int, ThreadState>, which survives clear() with its buckets)."""
+    import elf_amd
+    for ses in wire["sessions"]:
+        c = elf_amd.ClientRecords(ses["identity"])
+        dumps = iter(ses["dumps"])
+        for op in ses["ops"]:
+            if op["op"] == "state":
+                c.update_state(op["thread_id"], op["seq"], op["move_idx"], op["black"], op["white"])
+            elif op["op"] == "feed":
+                c.feed(wire["records"][op["rec"]])
+            else:
+                want = next(dumps)
+                got = c.dump_and_clear()
+                assert got == want, (ses["identity"], got[:200], want[:200])
+                assert len(c) == 0
+        c.close()
+
+
+def test_request_texts(built, wire):
+    """MsgRequestSeq: the server's text is parsed into the request / TSOptions it was written from, written back byte for byte, and
+    a text with a field removed is accepted or refused exactly as MsgRequestSeq::createFromJson accepts it or throws."""
+    import elf_amd
+    for r in wire["requests"]:
+        p = dict(MCTS_DEFAULTS)
+        p.update(black_ver=0, white_ver=-1, client_type=1, num_game_thread_used=-1, black_thres=0.0, white_thres=0.0, never_resign_prob=0.0,
+                 player_swap=0, async_=0, seq=0)
+        p.update(r["params"])
+        q, seq, t = elf_amd.parse_request_seq(r["text"])
+        assert (q.black_ver, q.white_ver, q.client_type, q.num_game_thread_used, q.player_swap, q.async_, seq) == \
+            (p["black_ver"], p["white_ver"], p["client_type"], p["num_game_thread_used"], p["player_swap"], p["async_"], p["seq"])
+        import numpy as np
+        f32 = lambda v: float(np.float32(v))
+        assert (q.black_resign_thres, q.white_resign_thres, q.never_resign_prob) == (f32(p["black_thres"]), f32(p["white_thres"]), f32(p["never_resign_prob"]))
+        assert (t.num_threads, t.num_rollouts_per_thread, t.num_rollouts_per_batch, t.virtual_loss, t.persistent_tree, t.pick_method) == \
+            (p["mcts_threads"], p["rollouts_per_thread"], p["rollouts_per_batch"], p["virtual_loss"], p["persistent_tree"], p["pick_method"])
+        assert (t.c_puct, t.root_epsilon, t.root_alpha) == (f32(p["c_puct"]), f32(p["root_epsilon"]), f32(p["root_alpha"]))
+        assert (t.use_prior, t.unexplored_q_zero, t.root_unexplored_q_zero) == (p["use_prior"], p["unexplored_q_zero"], p["root_unexplored_q_zero"])
+        assert (t.max_num_moves, t.seed, t.verbose, t.verbose_time, t.log_prefix) == (0, 0, 0, 0, b"")
+        assert elf_amd.request_seq_to_json(q, t, seq) == r["text"]
+        for v in r["variants"]:
+            if v["roundtrip"] is None:
+                with pytest.raises(elf_amd.ElfGoError):
+                    elf_amd.parse_request_seq(v["text"])
+            else:
+                q2, seq2, t2 = elf_amd.parse_request_seq(v["text"])
+                assert elf_amd.request_seq_to_json(q2, t2, seq2) == v["roundtrip"], v["removed"]
+    for bad in ("", "{", "[]", '{"seq":1}', '{"request":{},"seq":1}', r["text"] + "x", r["text"][:-1]):
+        with pytest.raises(elf_amd.ElfGoError):
+            elf_amd.parse_request_seq(bad)
+
+
+def test_reference_server_reads_our_messages(built, wire):
+    """Records::createFromJsonString (TrainCtrl::OnReceive) on messages built here"""
+    if not RefSelfPlay.available(9):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    import elf_amd
+    R = RefSelfPlay(9)
+    c = elf_amd.ClientRecords("box-1")
+    for t in range(6):
+        c.update_state(t, 2 + t, 10 * t, 7, -1)
+    c.feed(wire["records"][0])
+    c.feed(wire["records"][3])
+    text = c.dump_and_clear()
+    assert R.records_parse(text) == (2, 6, sum(10 * t for t in range(6)), "box-1")
+    assert R.records_parse(c.dump_and_clear()) == (0, 0, 0, "box-1")      # nothing collected: {"identity":"box-1"}
+    q, seq, t = elf_amd.parse_request_seq(wire["requests"][1]["text"])
+    assert R.request_seq_roundtrip(elf_amd.request_seq_to_json(q, t, seq + 1)) == wire["requests"][1]["text"].replace('"seq":%d' % seq, '"seq":%d' % (seq + 1))
+    c.close()
