@@ -220,6 +220,17 @@ SpRecordMeta elfrec_meta_from_options(const ElfSpOptions& o) {
   return m;
 }
 
+namespace { void put_json_string(std::string& o, const std::string& t); }
+
+void elfrec_meta_set_ts(SpRecordMeta* m, const ElfTsOptions& t) {
+  m->num_threads = t.num_threads; m->num_rollouts_per_thread = t.num_rollouts_per_thread; m->num_rollouts_per_batch = t.num_rollouts_per_batch;
+  m->virtual_loss = t.virtual_loss; m->persistent_tree = t.persistent_tree != 0; m->use_prior = t.use_prior != 0;
+  m->unexplored_q_zero = t.unexplored_q_zero != 0; m->root_unexplored_q_zero = t.root_unexplored_q_zero != 0;
+  m->c_puct = t.c_puct; m->root_epsilon = t.root_epsilon; m->root_alpha = t.root_alpha; m->pick_method = t.pick_method;
+  m->max_num_moves = t.max_num_moves; m->ts_seed = t.seed; m->verbose = t.verbose != 0; m->verbose_time = t.verbose_time != 0;
+  m->log_prefix.assign(t.log_prefix, strnlen(t.log_prefix, sizeof(t.log_prefix)));
+}
+
 // MsgRequest::setJsonFields (record.h:119-127): {"client_ctrl":{...},"vers":{...}} as nlohmann dumps it (keys in std::map order)
 static void put_request(std::string& o, const SpRecordMeta& m) {
   o += "{\"client_ctrl\":{\"async\":";
@@ -234,14 +245,17 @@ static void put_request(std::string& o, const SpRecordMeta& m) {
   o += ",\"root_unexplored_q_zero\":"; put_bool(o, m.root_unexplored_q_zero);
   o += ",\"unexplored_q_zero\":"; put_bool(o, m.unexplored_q_zero);
   o += ",\"use_prior\":"; put_bool(o, m.use_prior);
-  o += "},\"log_prefix\":\"\",\"max_num_moves\":0,\"num_rollouts_per_batch\":" + std::to_string(m.num_rollouts_per_batch);
+  o += "},\"log_prefix\":"; put_json_string(o, m.log_prefix);
+  o += ",\"max_num_moves\":" + std::to_string(m.max_num_moves) + ",\"num_rollouts_per_batch\":" + std::to_string(m.num_rollouts_per_batch);
   o += ",\"num_rollouts_per_thread\":" + std::to_string(m.num_rollouts_per_thread);
   o += ",\"num_threads\":" + std::to_string(m.num_threads) + ",\"persistent_tree\":"; put_bool(o, m.persistent_tree);
   o += std::string(",\"pick_method\":\"") + (m.pick_method == 1 ? "strongest_prior" : m.pick_method == 2 ? "uniform_random" : "most_visited") +
        "\",\"root_alpha\":";
   put_float(o, m.root_alpha);
   o += ",\"root_epsilon\":"; put_float(o, m.root_epsilon);
-  o += ",\"seed\":0,\"verbose\":false,\"verbose_time\":false,\"virtual_loss\":" + std::to_string(m.virtual_loss);
+  o += ",\"seed\":" + std::to_string(m.ts_seed) + ",\"verbose\":"; put_bool(o, m.verbose);
+  o += ",\"verbose_time\":"; put_bool(o, m.verbose_time);
+  o += ",\"virtual_loss\":" + std::to_string(m.virtual_loss);
   o += "},\"white_ver\":" + std::to_string(m.white_ver) + "}}";
 }
 
@@ -808,15 +822,11 @@ int64_t elfrec_request_seq_to_json(const ElfSpRequest* request, const ElfTsOptio
   SpRecordMeta m{};
   m.board_size = 0;
   m.black_ver = request->black_ver; m.white_ver = request->white_ver;
-  m.num_threads = t->num_threads; m.num_rollouts_per_thread = t->num_rollouts_per_thread; m.num_rollouts_per_batch = t->num_rollouts_per_batch;
-  m.virtual_loss = t->virtual_loss; m.persistent_tree = t->persistent_tree != 0; m.use_prior = t->use_prior != 0;
-  m.unexplored_q_zero = t->unexplored_q_zero != 0; m.root_unexplored_q_zero = t->root_unexplored_q_zero != 0;
-  m.c_puct = t->c_puct; m.root_epsilon = t->root_epsilon; m.root_alpha = t->root_alpha;
+  elfrec_meta_set_ts(&m, *t);
   m.black_resign_thres = request->black_resign_thres; m.white_resign_thres = request->white_resign_thres;
   m.never_resign_prob = request->never_resign_prob; m.num_game_thread_used = request->num_game_thread_used;
-  m.player_swap = request->player_swap != 0; m.async = request->async != 0; m.pick_method = t->pick_method;
+  m.player_swap = request->player_swap != 0; m.async = request->async != 0;
   m.client_type = request->client_type != 0 ? request->client_type : 1;
-  if (t->max_num_moves != 0 || t->seed != 0 || t->verbose || t->verbose_time || t->log_prefix[0]) return ELFGO_E_BADARG;   // not representable by the writer
   std::string o = "{\"request\":";
   put_request(o, m);
   o += ",\"seq\":" + std::to_string(seq) + "}";

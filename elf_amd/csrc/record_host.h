@@ -18,7 +18,14 @@ struct SpRecordMeta {          // the MsgRequest half of a Record (record.h:119-
   bool player_swap = false, async = false;
   int pick_method = 0;       // ELFSP_PICK_*
   int client_type = 1;       // ClientCtrl.client_type as the server sent it (CLIENT_SELFPLAY_ONLY = 1, record.h:24-29)
+  // TSOptions fields no search reads, echoed as the request carried them
+  int max_num_moves = 0;
+  int64_t ts_seed = 0;
+  bool verbose = false, verbose_time = false;
+  std::string log_prefix;
 };
+struct ElfTsOptions;
+void elfrec_meta_set_ts(SpRecordMeta* m, const ElfTsOptions& t);   // the TSOptions half of the meta from a request's mcts_opt
 
 struct SpRecord {              // the MsgResult half (record.h:184-234) + Record's own fields (:236-262)
   std::vector<uint16_t> moves;            // GoState::getAllMoves()

@@ -53,6 +53,7 @@ struct SpRequest {          // MsgRequest (common/record.h:119-149): ModelPair +
   bool async = false, player_swap = false;
   int thread_used = -1;
   int client_type = 1;         // ClientCtrl.client_type: carried into the records only
+  ElfTsOptions ts;             // ModelPair.mcts_opt: the search options the AIs of this request are built with
   int id = 0;
   bool wait() const { return black_ver < 0; }                           // ModelPair::wait
   bool is_selfplay() const { return black_ver >= 0 && white_ver == -1; }
@@ -129,6 +130,7 @@ struct ElfSelfPlay {
   int64_t start_black = 0, start_white = -1;   // versions of the last request that (re)started games
   int game_starts = 0;
   bool explicit_request = false;
+  ElfSpOptions opt0;             // the options at creation: the TSOptions of a request that names none (GameContext::setRequest)
   std::mt19937 pick_rng;         // MCTSResultT::addActions' static rng (tree_search_base.h:238), uniform_random only
   std::chrono::steady_clock::time_point t_after_drain;
   // statistics / capture
@@ -178,6 +180,7 @@ static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {
   m.num_game_thread_used = gm.req.thread_used;
   m.player_swap = gm.req.player_swap; m.async = gm.req.async;
   m.client_type = gm.req.client_type;
+  elfrec_meta_set_ts(&m, gm.req.ts);           // vers.mcts_opt as the request carried it
   return m;
 }
 
@@ -235,6 +238,31 @@ static int sp_forward_preload(ElfSelfPlay* sp, const std::vector<int32_t>& ids) 
 
 // effective options of the "actor_white" AI: init_ai's overrides (game_selfplay.cc:51-70) of GameOptions.white_puct /
 // white_mcts_rollout_per_batch / white_mcts_rollout_per_thread
+// TSOptions <-> the fields of ElfSpOptions they live in
+static ElfTsOptions sp_ts_of(const ElfSpOptions& o) {
+  ElfTsOptions t;
+  memset(&t, 0, sizeof(t));
+  t.num_threads = o.mcts.num_threads; t.num_rollouts_per_thread = o.num_rollouts_per_thread; t.num_rollouts_per_batch = o.mcts.num_rollouts_per_batch;
+  t.persistent_tree = o.persistent_tree != 0; t.pick_method = o.pick_method; t.root_epsilon = o.root_epsilon; t.root_alpha = o.root_alpha;
+  t.virtual_loss = o.mcts.virtual_loss; t.use_prior = o.mcts.use_prior != 0; t.unexplored_q_zero = o.mcts.unexplored_q_zero != 0;
+  t.root_unexplored_q_zero = o.mcts.root_unexplored_q_zero != 0; t.c_puct = o.mcts.c_puct;
+  return t;
+}
+static void sp_ts_into(const ElfTsOptions& t, ElfSpOptions* o) {
+  o->mcts.num_threads = t.num_threads; o->num_rollouts_per_thread = t.num_rollouts_per_thread; o->mcts.num_rollouts_per_batch = t.num_rollouts_per_batch;
+  o->persistent_tree = t.persistent_tree != 0; o->pick_method = t.pick_method; o->root_epsilon = t.root_epsilon; o->root_alpha = t.root_alpha;
+  o->mcts.virtual_loss = t.virtual_loss; o->mcts.use_prior = t.use_prior != 0; o->mcts.unexplored_q_zero = t.unexplored_q_zero != 0;
+  o->mcts.root_unexplored_q_zero = t.root_unexplored_q_zero != 0; o->mcts.c_puct = t.c_puct;
+}
+static bool sp_ts_equal(const ElfTsOptions& a, const ElfTsOptions& b) {      // TSOptions::operator== (tree_search_options.h:133-180)
+  return a.max_num_moves == b.max_num_moves && a.num_threads == b.num_threads && a.num_rollouts_per_thread == b.num_rollouts_per_thread &&
+         a.num_rollouts_per_batch == b.num_rollouts_per_batch && (a.verbose != 0) == (b.verbose != 0) && (a.verbose_time != 0) == (b.verbose_time != 0) &&
+         a.seed == b.seed && (a.persistent_tree != 0) == (b.persistent_tree != 0) && a.pick_method == b.pick_method &&
+         !strncmp(a.log_prefix, b.log_prefix, sizeof(a.log_prefix)) && a.root_epsilon == b.root_epsilon && a.root_alpha == b.root_alpha &&
+         a.virtual_loss == b.virtual_loss && (a.use_prior != 0) == (b.use_prior != 0) && a.c_puct == b.c_puct &&
+         (a.unexplored_q_zero != 0) == (b.unexplored_q_zero != 0) && (a.root_unexplored_q_zero != 0) == (b.root_unexplored_q_zero != 0);
+}
+
 static void sp_pool_options(const ElfSpOptions& o, int a, ElfMctsOptions* mo, int* rollouts_per_thread) {
   *mo = o.mcts;
   *rollouts_per_thread = o.num_rollouts_per_thread;
@@ -316,7 +344,7 @@ static int sp_restart_games(ElfSelfPlay* sp, const std::vector<int32_t>& ids) {
 static bool sp_on_receive(ElfSelfPlay* sp, int g, const SpRequest& r, bool* model_changed) {
   SpGame& gm = sp->games[g];
   const bool is_waiting = r.wait(), is_prev_waiting = gm.req.wait();
-  const bool same_vers = r.black_ver == gm.req.black_ver && r.white_ver == gm.req.white_ver;
+  const bool same_vers = r.black_ver == gm.req.black_ver && r.white_ver == gm.req.white_ver && sp_ts_equal(r.ts, gm.req.ts);   // ModelPair::operator==
   const bool same_swap = r.player_swap == gm.req.player_swap;
   const bool no_restart = (same_vers || r.async) && same_swap && !is_prev_waiting;
   gm.req = r;                                    // _state_ext.setRequest: thresholds follow the request (go_state_ext.h:57-66)
@@ -330,6 +358,27 @@ static bool sp_on_receive(ElfSelfPlay* sp, int g, const SpRequest& r, bool* mode
     if (!same_vers) *model_changed = true;       // UPDATE_MODEL_ASYNC
   }
   return false;
+}
+
+// New search options for the whole context (all playing games have just restarted and hold no tree): rebuild the tree pools
+static int sp_apply_ts(ElfSelfPlay* sp, const ElfTsOptions& t) {
+  HIPCHK(hipStreamSynchronize(sp->stream));
+  int fmt = 0;
+  const bool have_fmt = sp->pool[0].mcts && elfmcts_get_feature_format(sp->pool[0].mcts, &fmt) == 0;
+  const bool had_white = sp->pool[1].mcts != nullptr;
+  const int64_t old_w = sp->pool[0].W > 0 ? sp->pool[0].W : 1;
+  sp_pool_free(sp->pool[0]);
+  sp_pool_free(sp->pool[1]);
+  sp_ts_into(t, &sp->opt);
+  // the node pool was sized by the caller for the rollouts of the options it created the context with: keep the same head room
+  const int64_t new_w = (int64_t)((t.num_rollouts_per_thread + t.num_rollouts_per_batch - 1) / t.num_rollouts_per_batch) * t.num_rollouts_per_batch * t.num_threads;
+  if (new_w > old_w)   // (a multiple of 64: elfmcts_create)
+    sp->opt.nodes_per_game = (int)std::min<int64_t>((((int64_t)sp->opt.nodes_per_game * new_w / old_w + 63) / 64) * 64, (int64_t)1 << 30);
+  SPCHK(sp_pool_create(sp, 0));
+  if (have_fmt) SPCHK(elfmcts_set_feature_format(sp->pool[0].mcts, fmt));
+  if (had_white) SPCHK(sp_pool_create(sp, 1));
+  for (SpGame& gm : sp->games) gm.ai = -1;
+  return 0;
 }
 
 // What the dispatcher thread and the games' checkMessage calls do between two searches: deliver the current request to every
@@ -360,6 +409,9 @@ static int sp_poll_requests(ElfSelfPlay* sp) {
     if (sp->cur_restarted) {
       sp->game_starts++;
       sp->start_black = sp->cur.black_ver; sp->start_white = sp->cur.white_ver;
+      // the restarted games' AIs are built from the request's TSOptions (restart() :166-180): every restarted game is idle at the
+      // barrier now, the others wait for a request, so the pools can be rebuilt for other options
+      if (!sp_ts_equal(sp->cur.ts, sp_ts_of(sp->opt))) SPCHK(sp_apply_ts(sp, sp->cur.ts));
     }
     for (SpGame& gm : sp->games) if (gm.phase == PH_BARRIER) gm.phase = PH_PLAY;
     sp->cur_done = true;
@@ -767,6 +819,10 @@ int elfsp_create(const ElfSpOptions* o, int device, const uint64_t* zobrist_host
   r.black_ver = o->model_ver; r.white_ver = -1;
   r.black_thres = r.white_thres = o->resign_thres; r.never_resign_prob = o->never_resign_prob;
   r.thread_used = o->num_games;
+  sp->opt0 = *o;
+  r.ts = sp_ts_of(*o);
+  sp->cur.ts = r.ts;
+  for (SpGame& gm : sp->games) gm.req.ts = r.ts;
   sp_push_request(sp, r);
   *out = sp;
   return 0;
@@ -924,16 +980,25 @@ int elfsp_end_step(ElfSelfPlay* sp, const float* pi, int64_t pi_stride_floats, c
   return elfsp_end_step2(sp, pis, pi_stride_floats, vs, rvs, stream);
 }
 
-int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* q) {
+int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* q) { return elfsp_set_request3(sp, q, nullptr); }
+
+int elfsp_set_request3(ElfSelfPlay* sp, const ElfSpRequest* q, const ElfTsOptions* mcts_opt) {
   if (!sp || !q) return ELFGO_E_BADARG;
   if (q->white_ver >= 0 && q->black_ver < 0) return ELFGO_E_BADARG;
+  const ElfTsOptions ts = mcts_opt ? *mcts_opt : sp_ts_of(sp->opt0);
+  if (ts.num_threads < 1 || ts.num_rollouts_per_batch < 1 || ts.num_rollouts_per_thread < 1 || ts.pick_method < ELFSP_PICK_MOST_VISITED ||
+      ts.pick_method > ELFSP_PICK_UNIFORM_RANDOM || (int64_t)ts.num_rollouts_per_batch * ts.num_threads > elfmcts_max_rollouts_per_step())
+    return ELFGO_E_BADARG;
   if (q->white_ver >= 0) {
     // the second AI's tree pool must fit the leaf table of a step
+    ElfSpOptions o2 = sp->opt;
+    sp_ts_into(ts, &o2);
     ElfMctsOptions mo; int rpt;
-    sp_pool_options(sp->opt, 1, &mo, &rpt);
+    sp_pool_options(o2, 1, &mo, &rpt);
     if ((int64_t)mo.num_rollouts_per_batch * mo.num_threads > elfmcts_max_rollouts_per_step() || rpt <= 0) return ELFGO_E_BADARG;
   }
   SpRequest r;
+  r.ts = ts;
   r.black_ver = q->black_ver < 0 ? -1 : q->black_ver;
   r.white_ver = q->black_ver < 0 ? -1 : (q->white_ver < 0 ? -1 : q->white_ver);
   r.black_thres = q->black_resign_thres; r.white_thres = q->white_resign_thres; r.never_resign_prob = q->never_resign_prob;
@@ -951,7 +1016,7 @@ int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* q) {
   const bool have_last = !sp->mailbox.empty() || sp->cur.id != 0;
   if (have_last && last.black_ver == r.black_ver && last.white_ver == r.white_ver && last.black_thres == r.black_thres &&
       last.white_thres == r.white_thres && last.never_resign_prob == r.never_resign_prob && last.async == r.async &&
-      last.player_swap == r.player_swap && last.thread_used == r.thread_used && last.client_type == r.client_type)
+      last.player_swap == r.player_swap && last.thread_used == r.thread_used && last.client_type == r.client_type && sp_ts_equal(last.ts, r.ts))
     return 0;
   sp_push_request(sp, r);
   if (!sp->step_open) {                              // games between two searches may look at their mailbox now

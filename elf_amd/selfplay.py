@@ -180,21 +180,43 @@ class SelfPlay:
             check(self.L.elfsp_end_step(self._h, None, 0, None, None, self._stream()))
 
     def set_request(self, black_ver, white_ver=-1, resign_thres=0.0, never_resign_prob=0.0, async_=False, num_game_thread_used=-1,
-                    player_swap=False, white_resign_thres=None):
+                    player_swap=False, white_resign_thres=None, mcts_opt=None, client_type=0):
         """Client::setRequest (train/distri_client.h:318-331): every game receives it at the top of its next fifth act (at once
-        while it waits); white_ver >= 0 starts evaluation games with a second AI for White (step them with begin_step2 / end_step2)"""
+        while it waits); white_ver >= 0 starts evaluation games with a second AI for White (step them with begin_step2 / end_step2).
+        mcts_opt (elf_amd.client.TsOptions, e.g. from parse_request_seq): the search options the request carries -- the reference's
+        server dictates them (evaluation requests switch the Dirichlet noise off); None = the options the context was created with."""
         q = SpRequest(int(black_ver), int(white_ver), float(resign_thres), float(resign_thres if white_resign_thres is None else white_resign_thres),
-                      float(never_resign_prob), int(num_game_thread_used), int(player_swap), int(async_))
-        check(self.L.elfsp_set_request2(self._h, C.byref(q)))
+                      float(never_resign_prob), int(num_game_thread_used), int(player_swap), int(async_), int(client_type))
+        self.send_request(q, mcts_opt)
+
+    def send_request(self, request, mcts_opt=None):
+        """an SpRequest (+ TsOptions) as parse_request_seq returns them"""
+        if mcts_opt is not None:
+            # the rows of a step are num_games x threads x rollouts per batch: make room before the step that delivers the request
+            rows = self.num_games * int(mcts_opt.num_threads) * int(mcts_opt.num_rollouts_per_batch)
+            wk = int(self.opt.white_mcts_rollout_per_batch)
+            self._grow_rows(rows, self.num_games * int(mcts_opt.num_threads) * wk if wk > 0 else rows)
+        check(self.L.elfsp_set_request3(self._h, C.byref(request), C.byref(mcts_opt) if mcts_opt is not None else None))
+
+    def _grow_rows(self, rows, rows_white):
+        if rows > self.max_rows:
+            self.max_rows = rows
+            self.s = self._alloc_rows(rows)
+        self._want_white = max(getattr(self, "_want_white", 0), rows_white)
+        if getattr(self, "s_white", None) is not None and rows_white > self.max_rows_white:
+            self.max_rows_white = rows_white
+            self.s_white = self._alloc_rows(rows_white)
+
+    def _alloc_rows(self, rows):
+        if self.feature_format == "f16_nhwc":
+            return torch.zeros((rows, self.n, self.n, 18), dtype=torch.float16, device=self.device).permute(0, 3, 1, 2)
+        return torch.zeros((rows, 18, self.n, self.n), dtype=torch.float32, device=self.device)
 
     # ---- games with two AIs: rows of the "actor_black" AI in self.s, rows of the "actor_white" AI in self.s_white
     def _white_rows(self):
         if getattr(self, "s_white", None) is None:
-            rows = self.L.elfsp_max_rows_actor(self._h, 1)
-            if self.feature_format == "f16_nhwc":
-                self.s_white = torch.zeros((rows, self.n, self.n, 18), dtype=torch.float16, device=self.device).permute(0, 3, 1, 2)
-            else:
-                self.s_white = torch.zeros((rows, 18, self.n, self.n), dtype=torch.float32, device=self.device)
+            rows = max(self.L.elfsp_max_rows_actor(self._h, 1), getattr(self, "_want_white", 0))   # incl. a request still on its way
+            self.s_white = self._alloc_rows(rows)
             self.max_rows_white = rows
         return self.s_white
 

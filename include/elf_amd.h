@@ -295,6 +295,16 @@ int elfsp_last_rows2(ElfSelfPlay* sp, int* n_rows);
  * Restarted games stay idle until every game has received the request; then one "game_start" is due
  * (elfsp_take_game_starts) and they play.  Replies must carry the AI's version in "rv" unless async.
  * Requests queue: each is delivered to all games before the next one goes out (elf/base/dispatcher.h:104-152). */
+typedef struct ElfTsOptions {         /* TSOptions + SearchAlgoOptions as they travel in a request (tree_search_options.h:23-75,77-213) */
+  int32_t max_num_moves, num_threads, num_rollouts_per_thread, num_rollouts_per_batch;
+  int32_t verbose, verbose_time, persistent_tree, pick_method /* ELFSP_PICK_*, -1 = a name the search does not know */;
+  int64_t seed;
+  float root_epsilon, root_alpha;
+  int32_t virtual_loss;
+  int32_t use_prior, unexplored_q_zero, root_unexplored_q_zero;
+  float c_puct;
+  char log_prefix[60];
+} ElfTsOptions;
 typedef struct ElfSpRequest {
   int64_t black_ver, white_ver;       /* ModelPair */
   float black_resign_thres, white_resign_thres, never_resign_prob;   /* ClientCtrl; the resign check uses the mean of the two */
@@ -305,6 +315,19 @@ typedef struct ElfSpRequest {
                                          Records the games dump.  0 = unset: CLIENT_SELFPLAY_ONLY (1) */
 } ElfSpRequest;
 int elfsp_set_request2(ElfSelfPlay* sp, const ElfSpRequest* request);
+/* The same with the TSOptions the request carries (MsgRequest.vers.mcts_opt).  In the reference the SERVER dictates the search
+ * options: GoGameSelfPlay::restart builds its AIs from request.vers.mcts_opt (game_selfplay.cc:166-180), self-play requests carry the
+ * server's options (train/ctrl_selfplay.h:426), evaluation requests the same with the Dirichlet noise and both *_q_zero flags
+ * switched off (EvalSubCtrl, train/ctrl_eval.h:227-237), and ModelPair::operator== compares them, so a request that differs only
+ * in mcts_opt restarts the games as a new model does.  Here: the games restart, wait at the barrier, and when every game has
+ * received the request the tree pools are rebuilt for the new options (threads, rollouts per thread / per batch, virtual loss,
+ * persistent tree, pick method, root epsilon / alpha, c_puct, use_prior, both q_zero flags); ElfSpOptions.white_* overrides still
+ * apply on top for the second AI; an async request changes nothing until the next restart, as in the reference.
+ * elfsp_max_rows_actor may change with it: size the row destinations for the largest request you send BEFORE the step that
+ * delivers it.  mcts_opt == NULL: the context's options at creation (GameContext::setRequest, inference/game_context.h:83).
+ * ELFGO_E_BADARG for options the engine cannot run (threads x rollouts per batch above elfmcts_max_rollouts_per_step, an unknown
+ * pick method). */
+int elfsp_set_request3(ElfSelfPlay* sp, const ElfSpRequest* request, const ElfTsOptions* mcts_opt);
 /* the same with both thresholds equal, every game used, no swap */
 int elfsp_set_request(ElfSelfPlay* sp, int64_t black_ver, int64_t white_ver, float resign_thres, float never_resign_prob, int async);
 /* Seed of the uniform_random pick generator: MCTSResultT::addActions' `static std::mt19937 rng(time(NULL))`
@@ -417,16 +440,6 @@ typedef struct ElfThreadState {       /* ThreadState (record.h:354-380) = GoStat
   int32_t thread_id, seq, move_idx, reserved;
   int64_t black, white;
 } ElfThreadState;
-typedef struct ElfTsOptions {         /* TSOptions + SearchAlgoOptions as they travel in a request (tree_search_options.h:23-75,77-213) */
-  int32_t max_num_moves, num_threads, num_rollouts_per_thread, num_rollouts_per_batch;
-  int32_t verbose, verbose_time, persistent_tree, pick_method /* ELFSP_PICK_*, -1 = a name the search does not know */;
-  int64_t seed;
-  float root_epsilon, root_alpha;
-  int32_t virtual_loss;
-  int32_t use_prior, unexplored_q_zero, root_unexplored_q_zero;
-  float c_puct;
-  char log_prefix[60];
-} ElfTsOptions;
 typedef struct ElfClientRecords ElfClientRecords;
 int elfrec_client_create(const char* identity, ElfClientRecords** out);
 int elfrec_client_destroy(ElfClientRecords* c);

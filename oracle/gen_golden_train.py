@@ -56,6 +56,17 @@ RECORD_CASES_R3 = {
                                        black_ver=3, move_cutoff=14, req2_after_searches=7, req2_black_ver=4)),
     "records_9_req2_async": (9, dict(rollouts_per_thread=48, max_searches=44, policy_distri_cutoff=4, net_salt=75, num_games=1,
                                      black_ver=3, move_cutoff=14, req2_after_searches=7, req2_black_ver=4, req2_async=1)),
+    # the second request carries its own ModelPair.mcts_opt, as every request of the reference's server does: same model, other
+    # search options (restart because ModelPair::operator== compares mcts_opt); and an evaluation request as EvalSubCtrl writes it
+    # (train/ctrl_eval.h:227-237: white_ver >= 0, Dirichlet noise and both q_zero flags off)
+    "records_9_req2_ts": (9, dict(rollouts_per_thread=48, max_searches=44, policy_distri_cutoff=4, net_salt=79, num_games=1, black_ver=3,
+                                  move_cutoff=14, req2_after_searches=7, req2_black_ver=3, req2_ts=1, req2_rollouts_per_thread=32,
+                                  req2_rollouts_per_batch=8, req2_c_puct=0.9, req2_root_epsilon=0.0, req2_root_alpha=0.0)),
+    "records_9_req2_eval": (9, dict(rollouts_per_thread=48, max_searches=44, policy_distri_cutoff=4, net_salt=80, white_net_salt=82, num_games=1,
+                                    black_ver=3, move_cutoff=14, unexplored_q_zero=1, root_unexplored_q_zero=1, req2_after_searches=7,
+                                    req2_black_ver=4, req2_white_ver=3, req2_ts=1, req2_rollouts_per_thread=48, req2_rollouts_per_batch=16,
+                                    req2_c_puct=1.5, req2_root_epsilon=0.0, req2_root_alpha=0.0, req2_unexplored_q_zero=0,
+                                    req2_root_unexplored_q_zero=0)),
     # GameOptions.cheat_* (finish_game, game_selfplay.cc:122-129 -> GoStateExt::setFinalValue go_state_ext.h:86-99): the result of
     # a self-play game is a draw of the game's generator (also for a resigned game; the draw shifts the stream the next game
     # samples its moves from); the result of an evaluation game is the parity of a hash of the two version strings, negated

@@ -68,6 +68,9 @@ struct SpConfig {
   int32_t cheat_eval_new_model_wins_half, cheat_selfplay_random_result;
   int32_t online, following_pass, net_value_on;   // online mode: oracle/ref_selfplay.cc only
   float net_value;
+  int32_t req2_ts, req2_rollouts_per_thread, req2_rollouts_per_batch;   // the second request's own TSOptions and white_ver
+  float req2_c_puct, req2_root_epsilon, req2_root_alpha;
+  int32_t req2_unexplored_q_zero, req2_root_unexplored_q_zero, req2_white_ver;
 };
 struct SpSearch {
   int32_t game, move_played, best_action, total_visits, n_edges;
@@ -412,14 +415,16 @@ static int64_t g_fixed_time = 0;
 static bool g_reseed = true;
 void orcsp_set_time(int64_t t) { g_fixed_time = t; g_reseed = true; }
 
-int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search, int32_t* out_coord, int32_t* out_visits,
+int orcsp_run(const SpConfig* cfg_in, net_fn net, void* user, SpSearch* out_search, int32_t* out_coord, int32_t* out_visits,
               float* out_prior, float* out_reward, int64_t* stats) {
+  SpConfig cur_cfg = *cfg_in;                    // the request the game plays under: a second request may replace its versions / TSOptions
+  const SpConfig* cfg = &cur_cfg;
   const int n = orc_board_size(), na = n * n + 1, max_move = 2 * n * n;
   std::mt19937 game_rng;
   game_rng.seed(cfg->seed);                      // GoGameBase, common/game_base.h:32-38
   // GoGameSelfPlay::restart :158-200: "actor_black" first, then (white_ver >= 0) "actor_white" with the white_* overrides, each
   // seeded with the next draw of the game's generator (init_ai :45-47); player_swap exchanges the two
-  const bool two = cfg->white_ver >= 0;
+  bool two = cfg->white_ver >= 0;
   Actor actors[2];
   Search searches[2];
   int64_t batches_before = 0, rows_before = 0;
@@ -470,8 +475,24 @@ int orcsp_run(const SpConfig* cfg, net_fn net, void* user, SpSearch* out_search,
     // async -> the game goes on (the versions only show in the record)
     if (req2_pending && k > cfg->req2_after_searches && k % 5 == 0) {
       req2_pending = false;
-      if (!cfg->req2_async && cfg->req2_black_ver != cfg->black_ver) {
+      // ModelPair::operator== (record.h): versions and mcts_opt (TSOptions::operator==, every field)
+      const bool same_ts = !cfg->req2_ts || (cfg->req2_rollouts_per_thread == cfg->rollouts_per_thread && cfg->req2_rollouts_per_batch == cfg->rollouts_per_batch &&
+                                             cfg->req2_c_puct == cfg->c_puct && cfg->req2_root_epsilon == cfg->root_epsilon && cfg->req2_root_alpha == cfg->root_alpha &&
+                                             (cfg->req2_unexplored_q_zero != 0) == (cfg->unexplored_q_zero != 0) &&
+                                             (cfg->req2_root_unexplored_q_zero != 0) == (cfg->root_unexplored_q_zero != 0));
+      if (!cfg->req2_async && (cfg->req2_black_ver != cfg->black_ver || cfg->req2_white_ver != cfg->white_ver || !same_ts)) {
+        // restart() builds the AIs from the NEW request: its versions (a second AI if white_ver >= 0) and its TSOptions :166-180
+        cur_cfg.black_ver = cfg_in->req2_black_ver; cur_cfg.white_ver = cfg_in->req2_white_ver;
+        if (cfg_in->req2_ts) {
+          cur_cfg.rollouts_per_thread = cfg_in->req2_rollouts_per_thread; cur_cfg.rollouts_per_batch = cfg_in->req2_rollouts_per_batch;
+          cur_cfg.c_puct = cfg_in->req2_c_puct; cur_cfg.root_epsilon = cfg_in->req2_root_epsilon; cur_cfg.root_alpha = cfg_in->req2_root_alpha;
+          cur_cfg.unexplored_q_zero = cfg_in->req2_unexplored_q_zero; cur_cfg.root_unexplored_q_zero = cfg_in->req2_root_unexplored_q_zero;
+        }
+        two = cur_cfg.white_ver >= 0;
         init_ais();
+        ai = &searches[0];
+        ai2 = two ? &searches[1] : nullptr;
+        if (two && cfg->player_swap) std::swap(ai, ai2);
         orc_reset(st); moves.clear();
         never_resign = false; has_never = false;
         sgf_iter = 0;

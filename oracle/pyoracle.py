@@ -211,7 +211,10 @@ class RefSpConfig(C.Structure):
          ("pick_method", C.c_int32), ("black_policy_only", C.c_int32), ("white_policy_only", C.c_int32), ("thread_used", C.c_int32),
          ("req2_after_searches", C.c_int32), ("req2_black_ver", C.c_int32), ("req2_async", C.c_int32),
          ("cheat_eval_new_model_wins_half", C.c_int32), ("cheat_selfplay_random_result", C.c_int32),
-         ("online", C.c_int32), ("following_pass", C.c_int32), ("net_value_on", C.c_int32), ("net_value", C.c_float)]
+         ("online", C.c_int32), ("following_pass", C.c_int32), ("net_value_on", C.c_int32), ("net_value", C.c_float),
+         ("req2_ts", C.c_int32), ("req2_rollouts_per_thread", C.c_int32), ("req2_rollouts_per_batch", C.c_int32), ("req2_c_puct", C.c_float),
+         ("req2_root_epsilon", C.c_float), ("req2_root_alpha", C.c_float), ("req2_unexplored_q_zero", C.c_int32),
+         ("req2_root_unexplored_q_zero", C.c_int32), ("req2_white_ver", C.c_int32)]
 
 
 class RefSpSearch(C.Structure):
@@ -227,7 +230,8 @@ MCTS_DEFAULTS = dict(num_games=1, batchsize=16, mcts_threads=1, rollouts_per_thr
                      white_rollouts_per_thread=-1, white_net_salt=8, pick_method=0, black_policy_only=0, white_policy_only=0,
                      thread_used=0, req2_after_searches=0, req2_black_ver=0, req2_async=0,
                      cheat_eval_new_model_wins_half=0, cheat_selfplay_random_result=0, online=0, following_pass=0, net_value_on=0,
-                     net_value=0.0)
+                     net_value=0.0, req2_ts=0, req2_rollouts_per_thread=0, req2_rollouts_per_batch=0, req2_c_puct=0.0, req2_root_epsilon=0.0,
+                     req2_root_alpha=0.0, req2_unexplored_q_zero=0, req2_root_unexplored_q_zero=0, req2_white_ver=-1)
 
 
 class RefSelfPlay:

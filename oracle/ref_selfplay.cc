@@ -88,6 +88,13 @@ struct RefSpConfig {
   int32_t following_pass;       // GameOptions.following_pass (mcts_update_info :104-111)
   int32_t net_value_on;         // stub net: V = net_value for every row (a position the AI is sure about)
   float net_value;
+  // the second request's own ModelPair.mcts_opt (the reference's server dictates the search options: ctrl_selfplay.h:426, and for
+  // evaluation games ctrl_eval.h:227-237 with the noise and both q_zero flags off) and white_ver
+  int32_t req2_ts;              // 1 = the fields below replace the context's TSOptions in the second request
+  int32_t req2_rollouts_per_thread, req2_rollouts_per_batch;
+  float req2_c_puct, req2_root_epsilon, req2_root_alpha;
+  int32_t req2_unexplored_q_zero, req2_root_unexplored_q_zero;
+  int32_t req2_white_ver;       // white_ver of the second request (-1 = self-play)
 };
 
 // One record per finished search (MCTSAI_T::act), in completion order.
@@ -318,6 +325,7 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
     g_white_rows = 0;
     g_game_starts = 0;
     int64_t cur_black_rv = cfg->black_ver;   // the version the "actor_black" model answers with: follows the game_start batches
+    int64_t cur_white_rv = cfg->white_ver;
     bool req2_sent = false;
     const auto t0 = std::chrono::steady_clock::now();
     const int NA = BOARD_NUM_ACTION;
@@ -334,6 +342,7 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
         if (g_game_starts < 8) g_start_vers[g_game_starts] = b.black_ver[0];
         g_game_starts++;
         cur_black_rv = b.black_ver[0];
+        cur_white_rv = b.white_ver[0];
       }
       if (label == "human_actor") {
         for (size_t i = 0; i < (size_t)18 * BOARD_SIZE * BOARD_SIZE; ++i) g_prompts.push_back(b.s[i] != 0.f ? 1 : 0);
@@ -352,8 +361,15 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
         if (cfg->req2_after_searches > 0 && !req2_sent && cap.count.load() >= cfg->req2_after_searches) {
           MsgRequest req2;
           req2.vers.black_ver = cfg->req2_black_ver;
-          req2.vers.white_ver = -1;
+          req2.vers.white_ver = cfg->req2_white_ver;
           req2.vers.mcts_opt = co.mcts_options;
+          if (cfg->req2_ts) {
+            auto& t2 = req2.vers.mcts_opt;
+            t2.num_rollouts_per_thread = cfg->req2_rollouts_per_thread; t2.num_rollouts_per_batch = cfg->req2_rollouts_per_batch;
+            t2.alg_opt.c_puct = cfg->req2_c_puct; t2.root_epsilon = cfg->req2_root_epsilon; t2.root_alpha = cfg->req2_root_alpha;
+            t2.alg_opt.unexplored_q_zero = cfg->req2_unexplored_q_zero != 0;
+            t2.alg_opt.root_unexplored_q_zero = cfg->req2_root_unexplored_q_zero != 0;
+          }
           req2.client_ctrl.black_resign_thres = cfg->resign_thres;
           req2.client_ctrl.white_resign_thres = cfg->resign_thres;
           req2.client_ctrl.never_resign_prob = cfg->never_resign_prob;
@@ -366,7 +382,7 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
         if (net) net(b.s.data(), eb, b.pi.data(), b.V.data(), net_user);
         else stubnet_eval(b.s.data(), eb, BOARD_SIZE, white_group ? cfg->white_net_salt : cfg->net_salt, cfg->net_tie_levels, b.pi.data(), b.V.data());
         if (cfg->net_value_on) for (int i = 0; i < eb; ++i) b.V[i] = cfg->net_value;
-        for (int i = 0; i < eb; ++i) { b.rv[i] = white_group ? cfg->white_ver : cur_black_rv; b.a[i] = 0; }
+        for (int i = 0; i < eb; ++i) { b.rv[i] = white_group ? cur_white_rv : cur_black_rv; b.a[i] = 0; }
         if (white_group) g_white_rows += eb;
         (void)NA;
         batches++; rows += eb;

@@ -40,15 +40,17 @@ def sp_from_fixture_cfg(elf_amd, n, cfg, **over):
 def drive_stub(sp, n, cfg, done, on_step=None, black_ver=None):
     """serve batches with the stub nets of the fixture until done(sp); two-AI games through begin_step2 / end_step2 with the
     "actor_white" rows evaluated by the second stub net and every reply carrying its model's version in rv (black_ver: a callable
-    giving the version the "actor_black" model has now, for runs in which a later request changes it)"""
+    giving the (black, white) versions the models have now, for runs in which a later request changes them)"""
     import torch
     salt, ties = int(cfg["net_salt"]), int(cfg["net_tie_levels"])
-    two = int(cfg.get("white_ver", -1)) >= 0
+    two = int(cfg.get("white_ver", -1)) >= 0 or int(cfg.get("req2_white_ver", -1)) >= 0
     bv, wv = int(cfg.get("black_ver", 0)), int(cfg.get("white_ver", -1))
     rows_total = [0, 0]
     while not done(sp):
         if two:
             rb, rw = sp.begin_step2()
+            if black_ver is not None:          # a later request changes the models: (black, white) versions now
+                bv, wv = black_ver()
             rep = [None, None]
             for a, (rows, s, sl, ver) in enumerate(((rb, sp.s, salt, bv), (rw, sp.s_white, int(cfg["white_net_salt"]), wv))):
                 if rows:
@@ -63,7 +65,7 @@ def drive_stub(sp, n, cfg, done, on_step=None, black_ver=None):
             if rows:
                 pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), salt, ties)
                 sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device),
-                            torch.full((rows,), bv if black_ver is None else black_ver(), dtype=torch.int64, device=sp.device))
+                            torch.full((rows,), bv if black_ver is None else black_ver()[0], dtype=torch.int64, device=sp.device))
             else:
                 sp.end_step(None, None)
         if on_step:

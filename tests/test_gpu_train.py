@@ -119,6 +119,39 @@ def test_client_message_of_a_selfplay_context_is_read_by_the_reference_server(el
     if RefSelfPlay.available(n):
         got = RefSelfPlay(n).records_parse(text)
         assert got == (finished, G, sum(t["move_idx"] for t in j["states"]), "mi355x-0")
+    # the server's reply: a MsgRequestSeq text with a new model and other search options (more rollouts per step than the context
+    # was created with: the row buffer grows) -> parsed -> sent to the games -> they restart under it
+    import ctypes as C
+    from elf_amd.client import TsOptions
+    from elf_amd.selfplay import SpRequest
+    reply = elf.request_seq_to_json(SpRequest(7, -1, 0.05, 0.05, 0.1, -1, 0, 0, 1),
+                                    TsOptions(0, 2, 24, 12, 0, 0, 1, 0, 0, 0.0, 0.0, 2, 1, 0, 0, 0.75, b""), 41)
+    if RefSelfPlay.available(n):
+        assert RefSelfPlay(n).request_seq_roundtrip(reply) == reply          # the reference reads and rewrites it unchanged
+    q, seq, ts = elf.parse_request_seq(reply)
+    assert seq == 41 and q.black_ver == 7
+    L = elf.lib()
+    bv, wv = C.c_int64(0), C.c_int64(0)
+    L.elfsp_take_game_starts(sp._h, C.byref(bv), C.byref(wv))
+    sp.send_request(q, ts)
+    assert sp.max_rows >= G * 2 * 12
+    ver, guard = 6, 0
+    while sp.progress()["searches"] < 200 and guard < 400:
+        rows = sp.begin_step()
+        if L.elfsp_take_game_starts(sp._h, C.byref(bv), C.byref(wv)):
+            ver = bv.value
+        pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), 4, 0)
+        sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device), torch.full((rows,), ver, dtype=torch.int64, device=sp.device))
+        c.update_from(sp)
+        guard += 1
+        if ver == 7 and len(c) >= 2:
+            break
+    assert ver == 7 and rows == G * 2 * 12                                    # every game plays under the new options: T x K rows each
+    j2 = json.loads(c.dump_and_clear())
+    new = [r for r in j2["records"] if r["request"]["vers"]["black_ver"] == 7]
+    assert new and all(r["request"]["vers"]["mcts_opt"]["num_rollouts_per_thread"] == 24 and r["request"]["vers"]["mcts_opt"]["num_threads"] == 2
+                       and r["request"]["client_ctrl"]["black_resign_thres"] == float(np.float32(0.05)) for r in new)
+    assert all(t["black"] == 7 for t in j2["states"])
     sp.close()
     c.close()
 
@@ -237,13 +270,16 @@ def _check_run_against_fixture(sp, g, got, want, name):
         assert t2 == str(g["records"][got.index(t)])   # text-identical to the reference's json::dump()
 
 
-@pytest.mark.parametrize("name", ["records_9_req2_restart", "records_9_req2_async"])
+@pytest.mark.parametrize("name", ["records_9_req2_restart", "records_9_req2_async", "records_9_req2_ts", "records_9_req2_eval"])
 def test_second_request_while_a_game_plays_equals_reference(elf, name):
     """The reference run of the fixture got a second request (black_ver 3 -> 4) into the game's mailbox during its eighth search
     (oracle/ref_selfplay.cc req2_*).  GoGameSelfPlay::act reads the mailbox at every fifth act only (game_selfplay.cc:273-289), so
     searches 8 and 9 still run under the old request; at the eleventh act OnReceive (:222-270) either restarts the game from the
     empty board with new AIs, nothing recorded, seq advanced (other versions) or lets it go on (async; the record then names both
-    models).  Same search log, same record texts, same "game_start" batches as the reference."""
+    models).  Same search log, same record texts, same "game_start" batches as the reference.
+    *_ts: the second request has the same model but other search options (ModelPair.mcts_opt: the reference's server dictates them);
+    *_eval: it is an evaluation request as EvalSubCtrl writes it (train/ctrl_eval.h:227-237: a second AI, Dirichlet noise and the
+    q_zero flags off) -- the games restart and search with the request's options."""
     import ctypes as C
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
@@ -253,20 +289,30 @@ def test_second_request_while_a_game_plays_equals_reference(elf, name):
     L = elf.lib()
     got, starts, state = [], [], dict(sent=False, ver=int(cfg["black_ver"]))
 
+    state["wver"] = int(cfg["white_ver"])
+
     def model_version():
         # a request restarts the games at the top of an act, i.e. inside begin_step: the "game_start" it makes due comes before the
-        # rows of the new games are answered (its callback loads the model the batch names, selfplay.py)
+        # rows of the new games are answered (its callback loads the models the batch names, selfplay.py)
         bv, wv = C.c_int64(-9), C.c_int64(-9)
         for _ in range(L.elfsp_take_game_starts(sp._h, C.byref(bv), C.byref(wv))):
             starts.append(bv.value)
-            state["ver"] = bv.value
-        return state["ver"]
+            state["ver"], state["wver"] = bv.value, wv.value
+        return state["ver"], state["wver"]
 
     def on_step(sp, rows_total):
         got.extend(sp.pop_records())
         if not state["sent"] and sp.progress()["searches"] >= int(cfg["req2_after_searches"]):
-            sp.set_request(int(cfg["req2_black_ver"]), -1, float(np.float32(cfg["resign_thres"])), float(np.float32(cfg["never_resign_prob"])),
-                           async_=bool(cfg["req2_async"]), num_game_thread_used=1)
+            ts = None
+            if int(cfg.get("req2_ts", 0)):
+                from elf_amd.client import TsOptions
+                f32 = lambda k: float(np.float32(cfg[k]))
+                ts = TsOptions(0, int(cfg["mcts_threads"]), int(cfg["req2_rollouts_per_thread"]), int(cfg["req2_rollouts_per_batch"]), 0, 0,
+                               int(cfg["persistent_tree"]), int(cfg["pick_method"]), 0, f32("req2_root_epsilon"), f32("req2_root_alpha"),
+                               int(cfg["virtual_loss"]), int(cfg["use_prior"]), int(cfg["req2_unexplored_q_zero"]),
+                               int(cfg["req2_root_unexplored_q_zero"]), f32("req2_c_puct"), b"")
+            sp.set_request(int(cfg["req2_black_ver"]), int(cfg.get("req2_white_ver", -1)), float(np.float32(cfg["resign_thres"])),
+                           float(np.float32(cfg["never_resign_prob"])), async_=bool(cfg["req2_async"]), num_game_thread_used=1, mcts_opt=ts)
             state["sent"] = True
 
     drive_stub(sp, n, cfg, lambda sp: len(got) >= len(want) and sp.progress()["searches"] >= int(g["searches"]), on_step,

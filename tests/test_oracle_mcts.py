@@ -67,7 +67,7 @@ def test_reference_reproduces_fixture(name):
 
 RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
                "records_19_cutoff", "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart", "records_9_req2_async",
-               "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap"]
+               "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval"]
 
 
 @pytest.mark.parametrize("name", CASES + CASES_R3 + RECORD_RUNS)
@@ -79,7 +79,8 @@ def test_restatement_matches_reference_fixture(built, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
     n = int(g["board_size"])
-    fl = ("c_puct", "root_epsilon", "root_alpha", "komi", "resign_thres", "never_resign_prob", "white_puct")
+    fl = ("c_puct", "root_epsilon", "root_alpha", "komi", "resign_thres", "never_resign_prob", "white_puct", "net_value", "req2_c_puct",
+          "req2_root_epsilon", "req2_root_alpha")
     kw = {k: (float(np.float32(v)) if k in fl else int(v)) for k, v in cfg.items()}
     m = len(g["move_played"])
     if name == "mcts_19_r8192":
