@@ -646,7 +646,11 @@ struct JReader {
             case 'u': {
               if (end - p < 5) { ok = false; return v; }
               unsigned code = 0;
-              for (int i = 1; i <= 4; ++i) { const char c = p[i]; code = code * 16 + (c <= '9' ? c - '0' : (c | 32) - 'a' + 10); }
+              for (int i = 1; i <= 4; ++i) {
+                const char c = p[i];
+                if (!((c >= '0' && c <= '9') || ((c | 32) >= 'a' && (c | 32) <= 'f'))) { ok = false; return v; }
+                code = code * 16 + (c <= '9' ? c - '0' : (c | 32) - 'a' + 10);
+              }
               p += 4;
               if (code < 0x80) v.str += (char)code;                        // the BMP as UTF-8 (identities are ASCII in practice)
               else if (code < 0x800) { v.str += (char)(0xC0 | (code >> 6)); v.str += (char)(0x80 | (code & 63)); }
