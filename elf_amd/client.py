@@ -65,6 +65,10 @@ class ClientRecords:
 
     def update_from(self, sp):
         """GameNotifier::OnStateUpdate for every game of a SelfPlay context, in game order; also feeds its finished games"""
+        if hasattr(sp, "groups"):            # PipelinedSelfPlay: every group is a context
+            for g in sp.groups:
+                self.update_from(g)
+            return
         n = sp.num_games
         buf = (ThreadState * n)()
         k = self.L.elfsp_thread_states(sp._h, buf, n)

@@ -104,6 +104,73 @@ class PipelinedSelfPlay:
             self._begin(i)                                           # next step's select, behind the expansion on the same stream
         return total if self.wait_rows else None
 
+    # ---- requests and evaluation games (two AIs): the same pipeline through begin_step2 / end_step2 -------------------------------
+    def set_request(self, *args, **kw):
+        """SelfPlay.set_request for every group (each group is a context of its own: it restarts at its own barrier)"""
+        for g in self.groups:
+            g.set_request(*args, **kw)
+
+    def send_request(self, request, mcts_opt=None):
+        for g in self.groups:
+            g.send_request(request, mcts_opt)
+
+    def pop_records(self):
+        return [r for g in self.groups for r in g.pop_records()]
+
+    def _begin2(self, i):
+        import ctypes as C
+        g, st = self.groups[i], self.search_streams[i]
+        with torch.cuda.stream(st):
+            self._rows2[i] = g.begin_step2()        # select + features of both AIs; the row counts are waited for
+            bv, wv = C.c_int64(0), C.c_int64(0)
+            if g.L.elfsp_take_game_starts(g._h, C.byref(bv), C.byref(wv)):   # the "game_start" batch of this group
+                self.versions[i] = (bv.value, wv.value)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._ev_sel[i] = ev
+
+    def step2(self, net_fns):
+        """One batch for every group, for contexts that receive requests and may play evaluation games.  net_fns = (black_fn,
+        white_fn); fn(s, rows, version) -> (pi, V) evaluates rows `s[:rows]` with the model of that version (the versions of the
+        group's last "game_start"; groups restart under a request at different steps).  Replies carry the version in rv.
+        Returns the number of net rows of the step."""
+        n = len(self.groups)
+        if not getattr(self, "_primed2", False):
+            if self._primed:
+                raise RuntimeError("step() and step2() cannot be mixed on one pipeline")
+            self._rows2 = [(0, 0)] * n
+            self.versions = [(g.opt.model_ver, -1) for g in self.groups]
+            for i in range(n):
+                self._begin2(i)
+            self._primed2 = True
+        total = 0
+        for i in range(n):
+            g = self.groups[i]
+            ns = self.net_streams[i % len(self.net_streams)]
+            rows = self._rows2[i]
+            replies = [None, None]
+            with torch.cuda.stream(ns):
+                ns.wait_event(self._ev_sel[i])
+                for a in range(2):
+                    if rows[a]:
+                        s = g.s if a == 0 else g.s_white
+                        ver = self.versions[i][a]
+                        pi, v = net_fns[a](s, rows[a], ver)
+                        replies[a] = (pi, v, torch.full((rows[a],), ver, dtype=torch.int64, device=self.device))
+                ev_net = torch.cuda.Event()
+                ev_net.record(ns)
+            st = self.search_streams[i]
+            with torch.cuda.stream(st):
+                st.wait_event(ev_net)
+                g.end_step2(replies)
+                for r in replies:
+                    if r is not None:
+                        for t in r:
+                            t.record_stream(st)
+            total += rows[0] + rows[1]
+            self._begin2(i)
+        return total
+
     def synchronize(self):
         for st in self.search_streams:
             st.synchronize()

@@ -199,6 +199,8 @@ class SelfPlay:
         check(self.L.elfsp_set_request3(self._h, C.byref(request), C.byref(mcts_opt) if mcts_opt is not None else None))
 
     def _grow_rows(self, rows, rows_white):
+        if rows > self.max_rows or (getattr(self, "s_white", None) is not None and rows_white > self.max_rows_white):
+            torch.cuda.synchronize(self.device)      # nothing may still be reading the row tensors that are replaced
         if rows > self.max_rows:
             self.max_rows = rows
             self.s = self._alloc_rows(rows)

@@ -550,3 +550,51 @@ def test_async_request_changes_the_model_without_restarting_the_games(elf):
     assert j["result"]["using_models"] == [3, 8] and j["request"]["vers"]["black_ver"] == 8 and j["request"]["client_ctrl"]["async"] is True
     assert j["result"]["num_move"] == 13           # one uninterrupted game to the cutoff
     sp.close()
+
+
+def test_pipelined_groups_with_requests_and_evaluation_games(elf):
+    """PipelinedSelfPlay.step2: game groups pipelined against the net while requests arrive -- self-play, then an evaluation request
+    with its own search options (second AI, noise off), then self-play with the next model.  Every group restarts at its own
+    barrier; replies carry the versions of the group's last "game_start"; the records name the models they were played with."""
+    import json
+    import torch
+    from elf_amd.client import TsOptions
+    from elf_amd.selfplay import SpRequest
+    n = 9
+    from elf_amd.pipeline import PipelinedSelfPlay
+    pl = PipelinedSelfPlay(groups=2, seed=31, board_size=n, num_games=3, mcts_rollout_per_thread=32, mcts_rollout_per_batch=16,
+                           move_cutoff=10, keep_records=32, nodes_per_game=1024, model_ver=1)
+    seen = set()
+
+    def make(salt_of):
+        def fn(s, rows, ver):
+            seen.add(ver)
+            pi, v = stub_net(n, s[:rows].cpu().numpy(), salt_of(ver), 0)
+            return torch.from_numpy(pi).to(pl.device), torch.from_numpy(v).to(pl.device)
+        return fn
+
+    fns = (make(lambda ver: 100 + ver), make(lambda ver: 200 + ver))
+    out = elf.ClientRecords("pipelined")
+    ts = TsOptions(0, 1, 32, 16, 0, 0, 1, 0, 0, 0.25, 0.03, 1, 1, 0, 0, 1.5, b"")
+    ts_eval = TsOptions.from_buffer_copy(ts)
+    ts_eval.root_epsilon = ts_eval.root_alpha = 0.0
+    ts_eval.num_rollouts_per_thread = 48                      # other search options than the context was created with
+    plan = {60: (SpRequest(2, 1, 0.0, 0.0, 0.0, -1, 0, 0, 2), ts_eval), 160: (SpRequest(2, -1, 0.0, 0.0, 0.0, -1, 0, 0, 1), ts)}
+    recs = []
+    for step in range(260):
+        if step in plan:
+            pl.send_request(*plan[step])
+        assert pl.step2(fns) >= 0
+        out.update_from(pl)
+        if step % 50 == 49:
+            recs += json.loads(out.dump_and_clear()).get("records", [])
+    pl.synchronize()
+    kinds = {(r["request"]["vers"]["black_ver"], r["request"]["vers"]["white_ver"]) for r in recs}
+    assert kinds == {(1, -1), (2, 1), (2, -1)}, kinds
+    ev = [r for r in recs if r["request"]["vers"]["white_ver"] == 1]
+    assert all(r["request"]["vers"]["mcts_opt"]["num_rollouts_per_thread"] == 48 and r["request"]["vers"]["mcts_opt"]["root_epsilon"] == 0.0
+               and r["result"]["using_models"] == [1, 2] and r["request"]["client_ctrl"]["client_type"] == 2 for r in ev)
+    assert seen == {1, 2} and {r["thread_id"] for r in recs} == set(range(6))      # both groups' games (job-wide thread ids)
+    assert pl.versions == [(2, -1), (2, -1)]
+    pl.close()
+    out.close()
