@@ -173,7 +173,7 @@ static void sp_for_games(const std::vector<int32_t>& ids, F fn) {
 }
 
 static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {
-  // Record.request = curr_request_ (go_state_ext.h:134): the game's own request, mcts_opt = the context's TSOptions
+  // Record.request = curr_request_ (go_state_ext.h:134): the game's own request incl. the mcts_opt it carried
   SpRecordMeta m = elfrec_meta_from_options(sp->opt);
   m.black_ver = gm.req.black_ver; m.white_ver = gm.req.white_ver;
   m.black_resign_thres = gm.req.black_thres; m.white_resign_thres = gm.req.white_thres; m.never_resign_prob = gm.req.never_resign_prob;

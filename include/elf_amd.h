@@ -450,7 +450,7 @@ int elfrec_client_size(const ElfClientRecords* c);                              
  * cleared); ELFGO_E_BADSIZE when cap <= length. */
 int64_t elfrec_client_dump_and_clear(ElfClientRecords* c, char* out, size_t cap);
 /* the server's reply: MsgRequestSeq::createFromJson.  *mcts_opt <- the TSOptions the server dictates (GoGameSelfPlay::restart builds
- * its AIs from request.vers.mcts_opt, game_selfplay.cc:166-180: a client checks them against the context it runs).  ELFGO_E_BADARG
+ * its AIs from request.vers.mcts_opt, game_selfplay.cc:166-180: hand both to elfsp_set_request3).  ELFGO_E_BADARG
  * for malformed JSON or a missing mandatory field (the reference throws "... cannot not be found!"). */
 int elfrec_parse_request_seq(const char* json_text, ElfSpRequest* request, int64_t* seq, ElfTsOptions* mcts_opt);
 /* MsgRequestSeq::dumpJsonString: what the reference's server writes for this request */
