@@ -167,6 +167,18 @@ class ReplayLoader:
         return [{key: t[i * B:(i + 1) * B] for key, t in big.items()} for i in range(k)]
 
 
+def records_of_message(text):
+    """Records::createFromJsonString (common/record.h:465-475), what TrainCtrl::OnReceive does with a client's message or with the
+    content of an offline data file (DistriServer::loadOfflineSelfplayData): an object with "identity" is a Records message, anything
+    else a plain array of Records.  -> (identity, list of Record dicts)"""
+    j = json.loads(text)
+    if isinstance(j, dict) and "identity" in j:
+        return j["identity"], list(j.get("records", []))
+    if not isinstance(j, list):
+        raise ValueError("neither a Records message nor an array of Records")
+    return "", list(j)
+
+
 class ReaderQueues:
     """elf::shared::ReaderQueuesT<Record> + the draws of GoGameTrain::act over it (elfrq_*, host only): see include/elf_amd.h.
     Records are handles (slots of a ReplayLoader)."""
@@ -255,6 +267,17 @@ class ReplayBuffer:
         if ev >= 0:
             self._free.append(ev)
         return q
+
+    def insert_message(self, text, keep=None):
+        """a client's message or an offline data file: every record goes into the buffer, in order (the reference's server first
+        asks its model-version bookkeeping whether to keep a record, ctrl_selfplay.h: pass keep(record_dict) -> bool for that).
+        -> number of records inserted"""
+        k = 0
+        for r in records_of_message(text)[1]:
+            if keep is None or keep(r):
+                self.insert(r)
+                k += 1
+        return k
 
     def sample(self, acts=None, out=None, events=None):
         """the rows of `acts` acts (default: one train batch = batchsize / 64 acts), in the order the game threads drew them;

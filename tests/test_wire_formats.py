@@ -87,3 +87,16 @@ def test_reference_server_reads_our_messages(built, wire):
     q, seq, t = elf_amd.parse_request_seq(wire["requests"][1]["text"])
     assert R.request_seq_roundtrip(elf_amd.request_seq_to_json(q, t, seq + 1)) == wire["requests"][1]["text"].replace('"seq":%d' % seq, '"seq":%d' % (seq + 1))
     c.close()
+
+
+def test_records_of_message(built, wire):
+    """the two texts TrainCtrl::OnReceive accepts: a client's Records message and a plain array of Records (offline data files)"""
+    from elf_amd.train import records_of_message
+    ses = wire["sessions"][0]
+    ident, recs = records_of_message(ses["dumps"][0])
+    assert ident == ses["identity"] and len(recs) == sum(1 for op in ses["ops"][: [i for i, o in enumerate(ses["ops"]) if o["op"] == "dump"][0]] if op["op"] == "feed")
+    ident, recs = records_of_message("[" + ",".join(wire["records"][:3]) + "]")
+    assert ident == "" and [r["seq"] for r in recs] == [json.loads(t)["seq"] for t in wire["records"][:3]]
+    assert records_of_message('{"identity":"x"}') == ("x", [])
+    with pytest.raises(ValueError):
+        records_of_message('{"records":[]}')
