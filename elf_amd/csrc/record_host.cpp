@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <deque>
 #include <random>
+#include <sstream>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -335,6 +336,46 @@ int elfrec_coords_to_sgfstr(int board_size, const uint16_t* coords, int n, char*
   if (out && len < cap) out[len] = 0;
   if (out && len >= cap) return ELFGO_E_BADSIZE;
   return (int)len;
+}
+
+// GoStateExt::dumpSgf (go_state_ext.cc:26-82): the SGF text finish_game writes to <dump_record_prefix>_<game>_<seq>_<B|W>.sgf
+// (game_selfplay.cc:133-135, go_state_ext.h:48-56): result, player names, komi, every move with its predicted value.  The same
+// iostream / std::to_string calls as the reference, so that the numbers print alike.  git_hash / git_staged: the two lines of the
+// opening comment (the reference prints its build's GIT_COMMIT_HASH / GIT_STAGED); NULL = this library's version and "0".
+int64_t elfrec_game_sgf(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const float* values, int num_values,
+                        float final_value, const char* filename, const char* git_hash, const char* git_staged, char* out, size_t cap) {
+  if (!opt || num_moves < 0 || num_values < 0 || (num_moves && !moves) || (num_values && !values) || !filename) return ELFGO_E_BADARG;
+  const int S = opt->board_size + 2;
+  std::stringstream ss;
+  const float value = final_value;
+  std::string result;
+  if (std::abs(value) == 1.0) result = (value > 0.0 ? "B+R" : "W+R");
+  else result = (value > 0.0 ? "B+" + std::to_string(value) : "W+" + std::to_string(-value));
+  std::stringstream cm;
+  cm << "Filename: " << filename << std::endl;
+  cm << "Git hash: " << (git_hash ? git_hash : elfgo_version()) << std::endl;
+  cm << "Staged: " << (git_staged ? git_staged : "0") << std::endl;
+  ss << "(;SZ[" << opt->board_size << "]RE[" << result << "]C[" + cm.str() + "]";
+  std::string black_name = "MCTS", white_name = "MCTS";      // use_mcts: this engine's AIs always search
+  if (opt->black_use_policy_network_only) black_name += "(policy only)";
+  if (opt->white_use_policy_network_only) white_name += "(policy only)";
+  ss << "PB[" << black_name << "]PW[" << white_name << "]KM[" << opt->mcts.komi << "]";
+  for (int i = 0; i < num_moves; ++i) {
+    const int c = moves[i];
+    std::string mv;                                           // coord2str (sgf/sgf.h:48-57)
+    if (c != 0 /* M_PASS */) { mv += (char)('a' + X(c, S)); mv += (char)('a' + Y(c, S)); }
+    ss << ";" << (i % 2 == 0 ? "B" : "W") << "[" << mv << "]";
+    std::string comments = std::to_string(i + 1) + ": ";
+    if (i < num_values) comments += "PredV: " + std::to_string(values[i]);
+    ss << "C[" << comments << "]";
+  }
+  ss << ")";
+  const std::string t = ss.str();
+  if (!out) return (int64_t)t.size();
+  if (cap <= t.size()) return ELFGO_E_BADSIZE;
+  memcpy(out, t.data(), t.size());
+  out[t.size()] = 0;
+  return (int64_t)t.size();
 }
 
 // sgfstr2coords (sgf/sgf.h:97-125) with str2coord (:21-46); returns the number of moves (all of them are counted, the

@@ -82,9 +82,10 @@ class SelfPlay:
                  mcts_threads=1, game_idx_base=0, job_id="", required_version=-1, white_puct=-1.0, white_mcts_rollout_per_batch=-1,
                  white_mcts_rollout_per_thread=-1, black_use_policy_network_only=False, white_use_policy_network_only=False,
                  mcts_pick_method="most_visited", cheat_eval_new_model_wins_half=False, cheat_selfplay_random_result=False,
-                 following_pass=False):
+                 following_pass=False, dump_record_prefix=""):
         if not torch.cuda.is_available():
             raise RuntimeError("elf_amd.SelfPlay needs a ROCm GPU (no CPU fallback exists)")
+        self.dump_record_prefix = dump_record_prefix      # pop_records() also writes every finished game as SGF (needs keep_records)
         self.L = _lib.lib()
         self.n = int(board_size)
         self.num_games = int(num_games)
@@ -340,6 +341,13 @@ class SelfPlay:
             buf = C.create_string_buffer(need.value + 1)
             check(self.L.elfsp_pop_record(self._h, buf, need.value + 1, C.byref(need)))
             out.append(buf.raw[:need.value].decode())
+        if getattr(self, "dump_record_prefix", ""):
+            # GameOptions.dump_record_prefix: finish_game writes every finished game as SGF (game_selfplay.cc:133-135)
+            from .train import record_to_sgf, sgf_file_name
+            for r in out:
+                name = sgf_file_name(self.dump_record_prefix, r)
+                with open(name, "w") as fh:
+                    fh.write(record_to_sgf(self.n, r, self.opt, name) + "\n")
         return out
 
     def search_log(self):

@@ -167,6 +167,29 @@ class ReplayLoader:
         return [{key: t[i * B:(i + 1) * B] for key, t in big.items()} for i in range(k)]
 
 
+def record_to_sgf(board_size, rec, opt, filename, git_hash=None, git_staged=None):
+    """GoStateExt::dumpSgf (go_state_ext.cc:26-82) for a finished game: rec = Record JSON text / dict, opt = the SpOptions the game
+    was played under (komi, policy-only flags) -> SGF text (result, player names, komi, every move with its predicted value)"""
+    L = _lib.lib()
+    j = json.loads(rec) if isinstance(rec, (str, bytes)) else rec
+    mv = sgfstr_to_coords(board_size, j["result"]["content"])
+    val = np.asarray(j["result"]["values"], np.float32)
+    args = (C.byref(opt), mv.ctypes.data, mv.size, val.ctypes.data if val.size else None, val.size, float(j["result"]["reward"]),
+            filename.encode(), git_hash.encode() if git_hash is not None else None, git_staged.encode() if git_staged is not None else None)
+    n = L.elfrec_game_sgf(*args, None, 0)
+    if n < 0:
+        check(int(n))
+    buf = C.create_string_buffer(n + 1)
+    L.elfrec_game_sgf(*args, buf, n + 1)
+    return buf.raw[:n].decode("latin-1")
+
+
+def sgf_file_name(prefix, rec):
+    """the file finish_game writes the game to (GoStateExt::dumpSgf(), go_state_ext.h:48-56): <prefix>_<game>_<seq>_<B|W>.sgf"""
+    j = json.loads(rec) if isinstance(rec, (str, bytes)) else rec
+    return "%s_%d_%d_%s.sgf" % (prefix, j["thread_id"], j["seq"], "B" if j["result"]["reward"] > 0 else "W")
+
+
 def records_of_message(text):
     """Records::createFromJsonString (common/record.h:465-475), what TrainCtrl::OnReceive does with a client's message or with the
     content of an offline data file (DistriServer::loadOfflineSelfplayData): an object with "identity" is a Records message, anything

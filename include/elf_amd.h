@@ -432,6 +432,13 @@ int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_mov
 /* GoGameTrain::act's draws for n samples with the store's std::mt19937 (seeded at create): record, move_to =
  * rng() % (num_moves - num_future_actions + 1), D4 code = rng() % 8; results into device int32 [n] arrays */
 int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec, int32_t* move_to, int32_t* d4, void* stream);
+/* GoStateExt::dumpSgf (go_state_ext.cc:26-82): the SGF text the reference's finish_game writes for a finished game when
+ * GameOptions.dump_record_prefix is set (file <prefix>_<game>_<seq>_<B|W>.sgf, go_state_ext.h:48-56): RE[] from the final value
+ * ("B+R" / "W+R" for +-1, else the margin), PB / PW ("MCTS", "(policy only)" appended), KM, every move with "C[<n>: PredV: <v>]".
+ * moves / values / final_value = Record.result.content (as Coords), .values, .reward.  git_hash / git_staged: the two lines of the
+ * opening comment, NULL = this library's version and "0".  Returns the length; out == NULL queries it. */
+int64_t elfrec_game_sgf(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const float* values, int num_values,
+                        float final_value, const char* filename, const char* git_hash, const char* git_staged, char* out, size_t cap);
 /* ---- the client's wire formats (train/distri_client.h), host only --------------------------------------------------------------
  * What a self-play client sends to the reference's server: Records = {identity, states, records} (common/record.h:401-470) as
  * GuardedRecords keeps and dumps them (distri_client.h:111-170) -- and what it receives: MsgRequestSeq (record.h:152-171).  Texts

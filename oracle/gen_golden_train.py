@@ -77,6 +77,12 @@ RECORD_CASES_R3 = {
                                      black_ver=11, white_ver=12, move_cutoff=18, cheat_eval_new_model_wins_half=1)),
     "records_9_cheat_eval_swap": (9, dict(rollouts_per_thread=32, max_searches=60, policy_distri_cutoff=4, net_salt=77, white_net_salt=78,
                                           black_ver=14, white_ver=12, player_swap=1, move_cutoff=18, cheat_eval_new_model_wins_half=1)),
+    # GoStateExt::dumpSgf of every finished game (what dump_record_prefix writes; the `sgfs` array of fixtures generated from here
+    # on): resigned and scored games, a policy-only White
+    "records_9_sgf": (9, dict(rollouts_per_thread=32, max_searches=220, policy_distri_cutoff=4, net_salt=91, num_games=1,
+                              resign_thres=0.95, move_cutoff=60, komi=6.5)),
+    "records_9_sgf_policy_only": (9, dict(rollouts_per_thread=32, max_searches=60, policy_distri_cutoff=4, net_salt=92, num_games=1,
+                                          move_cutoff=12, white_policy_only=1)),
     # GameOptions.mode = "online": the human_actor prompts of GoGameSelfPlay::act :290-330 answered from a script (a move, the same
     # move again = illegal and prompted again, SKIP = the AI searches and moves, PASS, CLEAR, RESIGN), every prompt's feature planes
     # kept; following_pass (mcts_update_info :104-111) with a stub net that is sure White wins / sure Black wins
@@ -166,7 +172,8 @@ def dump_case(name, n, kw):
                         n_edges=np.array([s.n_edges for s in r["search"]], np.int32),
                         root_value=np.array([s.root_value for s in r["search"]], np.float32),
                         coord=r["coord"].astype(np.int16), visits=r["visits"], prior=r["prior"], reward=r["reward"],
-                        game_starts=np.int32(r["game_starts"]), start_versions=np.array(r["start_versions"], np.int64), **extra)
+                        game_starts=np.int32(r["game_starts"]), start_versions=np.array(r["start_versions"], np.int64),
+                        sgfs=np.array(R.last_sgfs()), **extra)
     print(name, "records", len(exact), [(j["seq"], j["result"]["num_move"], j["result"]["reward"], len(j["result"].get("policies", [])))
                                         for j in recs])
     return exact

@@ -315,6 +315,11 @@ class RefSelfPlay:
         """JSON array text: Record of every game that finished during the last run()"""
         return self._text(self.L.refsp_last_records)
 
+    def last_sgfs(self):
+        """GoStateExt::dumpSgf of every game that finished during the last run() (what dump_record_prefix writes), list of texts"""
+        import json
+        return json.loads(self._text(self.L.refsp_last_sgfs))
+
     def record_roundtrip(self, record_json):
         return self._text(self.L.reftrain_record_roundtrip, record_json.encode())
 

@@ -156,6 +156,7 @@ struct Capture : public GameNotifierBase {
     count++;
   }
   std::vector<std::string> records;   // Record JSON of every finished game, in completion order
+  std::vector<std::string> sgfs;      // GoStateExt::dumpSgf of the same games
   void OnGameEnd(const GoStateExt& s) override {
     std::lock_guard<std::mutex> l(m);
     // searches past max_searches run while the driver is already shutting the context down (replies are FAILED batches):
@@ -164,6 +165,11 @@ struct Capture : public GameNotifierBase {
     json j;
     s.dumpRecord().setJsonFields(j);
     records.push_back(j.dump());
+    // what finish_game writes when GameOptions.dump_record_prefix is set (:133-135 -> GoStateExt::dumpSgf, go_state_ext.cc:26-82)
+    const ThreadState ts = s.getThreadState();
+    const std::string fname = "game_" + std::to_string(ts.thread_id) + "_" + std::to_string(s.seq()) + "_" +
+                              (s.state().getFinalValue() > 0 ? "B" : "W") + ".sgf";
+    sgfs.push_back(s.dumpSgf(fname));
   }
 };
 
@@ -178,6 +184,7 @@ struct GameCapture : public GameNotifierBase {
 std::string g_preload_sgf;     // GameOptions.preload_sgf for the next refsp_run ("" = none)
 int g_preload_move_to = -1;
 std::string g_last_records;   // JSON array text of the records of the last refsp_run
+std::string g_last_sgfs;      // JSON array of the dumpSgf texts of the same games
 int64_t g_white_rows = 0;     // rows served to the "actor_white" group by the last refsp_run
 std::vector<int64_t> g_human_script;   // answers to the "human_actor" prompts of an online run
 std::vector<uint8_t> g_prompts;         // "s" of every prompt of the last online run, one byte per plane point
@@ -399,6 +406,9 @@ int refsp_run(const RefSpConfig* cfg, refsp_net_fn net, void* net_user, RefSpSea
       g_last_records = "[";
       for (size_t i = 0; i < cap.records.size(); ++i) g_last_records += (i ? "," : "") + cap.records[i];
       g_last_records += "]";
+      json js = json::array();
+      for (const auto& t : cap.sgfs) js.push_back(t);
+      g_last_sgfs = js.dump();
     }
 
     const int k = (int)cap.searches.size();
@@ -454,6 +464,26 @@ void refsp_set_preload(const char* path, int move_to) {
 int64_t refsp_last_records(char* buf, int64_t cap) {
   const int64_t n = (int64_t)g_last_records.size();
   if (buf && cap > 0) memcpy(buf, g_last_records.data(), (size_t)std::min(n, cap));
+  return n;
+}
+
+// dumpSgf's header for a given final value (which overload of abs() decides between "B+R" and "B+1.500000"?)
+int64_t refsp_sgf_of_value(float final_value, float komi, char* buf, int64_t cap) {
+  GameOptions opt;
+  opt.komi = komi;
+  struct Open : public GoStateExt {
+    using GoStateExt::GoStateExt;
+    GoState& board() { return _state; }
+  } st(0, opt);
+  st.board().setFinalValue(final_value);
+  const std::string t = st.dumpSgf("f.sgf");
+  if (buf && cap > 0) { const int64_t k = std::min<int64_t>((int64_t)t.size(), cap - 1); memcpy(buf, t.data(), (size_t)k); buf[k] = 0; }
+  return (int64_t)t.size();
+}
+
+int64_t refsp_last_sgfs(char* buf, int64_t cap) {
+  const int64_t n = (int64_t)g_last_sgfs.size();
+  if (buf && cap > 0) memcpy(buf, g_last_sgfs.data(), (size_t)std::min(n, cap));
   return n;
 }
 

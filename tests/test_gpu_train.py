@@ -216,7 +216,7 @@ def test_loader_argument_errors(elf):
 
 @pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff",
                                   "records_9_eval", "records_9_eval_swap_resign",
-                                  "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap"])
+                                  "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_sgf_policy_only"])
 def test_selfplay_records_equal_reference_dump(elf, name):
     """GPU self-play under the fixture's configuration leaves the same Record JSON text as the reference's
     GoStateExt::dumpRecord for every finished game (content, quantised policies, predicted values, reward, seq), timestamp aside."""

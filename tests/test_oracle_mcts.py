@@ -67,7 +67,7 @@ def test_reference_reproduces_fixture(name):
 
 RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
                "records_19_cutoff", "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart", "records_9_req2_async",
-               "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval"]
+               "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval", "records_9_sgf", "records_9_sgf_policy_only"]
 
 
 @pytest.mark.parametrize("name", CASES + CASES_R3 + RECORD_RUNS)

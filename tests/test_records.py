@@ -159,3 +159,50 @@ def test_float_text_fuzz_against_reference(built):
             vals = (np.tanh(rng.standard_normal(3000)) * rng.choice([1, 1e-3, 1e3, 1e-6])).astype(np.float32)
         t, _ = _values_text(elf_amd, vals)
         assert R.record_roundtrip(t) == t      # the reference parses our text and dumps the same text
+
+
+@pytest.mark.parametrize("name", ["records_9_sgf", "records_9_sgf_policy_only"])
+def test_game_sgf_equals_reference_dumpSgf(built, name):
+    """GameOptions.dump_record_prefix: the SGF text finish_game writes for a finished game (GoStateExt::dumpSgf,
+    go_state_ext.cc:26-82) rebuilt from the game's Record: RE[] ("B+R" / "W+R" / margin), PB / PW with "(policy only)", KM, every
+    move with its predicted value -- equal to what the reference's dumpSgf returned for the same game."""
+    import elf_amd
+    from elf_amd.train import record_to_sgf, sgf_file_name
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = int(g["board_size"])
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    opt = sp_options(elf_amd, n, cfg)
+    opt.black_use_policy_network_only, opt.white_use_policy_network_only = int(cfg["black_policy_only"]), int(cfg["white_policy_only"])
+    assert len(g["sgfs"]) == len(g["records"]) >= 2
+    for t, want in zip(g["records"], g["sgfs"]):
+        t, want = str(t), str(want)
+        fname = sgf_file_name("game", t)
+        assert ("Filename: " + fname + "\n") in want                      # <prefix>_<game>_<seq>_<B|W>.sgf
+        got = record_to_sgf(n, t, opt, fname, git_hash="GIT_COMMIT_HASH", git_staged="GIT_STAGED")   # the harness build's two lines
+        assert got == want
+    ours = record_to_sgf(n, str(g["records"][0]), opt, "x.sgf")
+    assert "Git hash: elf_amd" in ours and "Staged: 0" in ours
+    if name == "records_9_sgf":
+        assert any("RE[B+R]" in str(x) for x in g["sgfs"]) and any("RE[W+R]" in str(x) for x in g["sgfs"]) and "KM[6.5]" in str(g["sgfs"][0])
+    else:
+        assert all("RE[W+6.500000]" in str(x) and "PW[MCTS(policy only)]" in str(x) for x in g["sgfs"])
+
+
+def test_game_sgf_result_strings(built):
+    """RE[] for values the fixtures do not reach, against the reference's dumpSgf where oracle/_ref is present: |value| == 1 is a
+    resignation, anything else a margin printed with std::to_string; komi through an ostream"""
+    import elf_amd
+    from elf_amd.train import record_to_sgf
+    g = np.load(os.path.join(GOLDEN, "records_9_sgf.npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    R = RefSelfPlay(9) if RefSelfPlay.available(9) else None
+    for v, komi, want in ((1.5, 7.5, "RE[B+1.500000]"), (-1.5, 0.5, "RE[W+1.500000]"), (1.0, 7.5, "RE[B+R]"), (-1.0, 6.5, "RE[W+R]"),
+                          (0.0, 7.0, "RE[W+-0.000000]"), (12.25, 7.125, "RE[B+12.250000]"), (-361.0, 1234567.0, "RE[W+361.000000]")):
+        opt = sp_options(elf_amd, 9, cfg)
+        opt.mcts.komi = komi
+        rec = dict(result=dict(content="()", values=[], reward=v), thread_id=0, seq=1)
+        got = record_to_sgf(9, rec, opt, "f.sgf", "GIT_COMMIT_HASH", "GIT_STAGED")
+        assert want in got
+        if R is not None:
+            ref = R._text(R.L.refsp_sgf_of_value, C.c_float(v), C.c_float(komi))
+            assert got == ref.replace("PB[Policy]PW[Policy]", "PB[MCTS]PW[MCTS]")      # the harness state has use_mcts = false
