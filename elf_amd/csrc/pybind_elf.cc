@@ -472,6 +472,7 @@ class Context {
     o.resign_thres = 0.0f;             // ClientCtrl defaults until a request arrives (common/record.h:36-38)
     o.never_resign_prob = 0.0f;
     o.keep_records = go_.keep_records;
+    if (!go_.dump_record_prefix.empty() && o.keep_records < co_.num_games) o.keep_records = co_.num_games;   // the SGF is written from the record
     o.log_searches = go_.log_searches;
     o.policy_distri_training_for_all = go_.policy_distri_training_for_all;
     o.model_ver = 0;
@@ -503,6 +504,7 @@ class Context {
     if (dev < 0) chk(elfgo_get_device(&dev), "hipGetDevice");
     device_ = dev;
     chk(elfsp_create(&o, dev, zob.data(), &sp_), "elfsp_create");
+    opt_ = o;
     NA_ = n * n + 1;
     row_floats_ = 18 * n * n;
     // device staging: one step of leaf rows, and the replies of one step ("actor_white" staging is made by the first request
@@ -647,15 +649,36 @@ class Context {
   std::vector<std::string> popRecords() {
     std::vector<std::string> out;
     if (!sp_) return out;
+    drain_records();
+    out.assign(kept_records_.begin(), kept_records_.end());
+    kept_records_.clear();
+    return out;
+  }
+  // finished games' records out of the device context; GameOptions.dump_record_prefix: finish_game writes each as an SGF file
+  // (game_selfplay.cc:133-135 -> GoStateExt::dumpSgf)
+  void drain_records() {
     while (elfsp_records_pending(sp_) > 0) {
       size_t len = 0;
       elfsp_pop_record(sp_, nullptr, 0, &len);
       std::string buf(len + 1, '\0');
       chk(elfsp_pop_record(sp_, &buf[0], len + 1, &len), "elfsp_pop_record");
       buf.resize(len);
-      out.push_back(buf);
+      if (!go_.dump_record_prefix.empty()) {
+        char name[1024];
+        const int64_t n = elfrec_record_to_sgf(&opt_, buf.c_str(), go_.dump_record_prefix.c_str(), name, sizeof(name), nullptr, 0);
+        if (n > 0) {
+          std::string text((size_t)n + 1, '\0');
+          if (elfrec_record_to_sgf(&opt_, buf.c_str(), go_.dump_record_prefix.c_str(), name, sizeof(name), &text[0], (size_t)n + 1) == n) {
+            text.resize((size_t)n);
+            std::ofstream oo(name);
+            oo << text << std::endl;
+          }
+        }
+      }
+      kept_records_.push_back(std::move(buf));
+      const size_t cap = (size_t)std::max(opt_.keep_records, 1);
+      while (kept_records_.size() > cap) kept_records_.pop_front();
     }
-    return out;
   }
   void setStream(uint64_t s) { stream_ = reinterpret_cast<void*>(s); }
   int device() const { return device_; }
@@ -830,6 +853,7 @@ class Context {
   }
 
   void note_finished(int done) {
+    if (!go_.dump_record_prefix.empty()) drain_records();
     std::vector<float> fv((size_t)done + 8);
     const int k = elfsp_take_finished(sp_, fv.data(), (int)fv.size());
     for (int i = 0; i < k; ++i) stats_.wr.feed(fv[i]);
@@ -936,6 +960,8 @@ class Context {
   std::map<std::string, int> rr_;
   std::vector<GameView> views_;
   GameStats stats_;
+  ElfSpOptions opt_{};                       // the options the device context was created with
+  std::deque<std::string> kept_records_;     // records taken out of the device context, waiting for popRecords()
   ElfSelfPlay* sp_ = nullptr;
   void* stream_ = nullptr;
   int device_ = 0, max_rows_[2] = {0, 0}, NA_ = 0, row_floats_ = 0;

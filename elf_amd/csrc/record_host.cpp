@@ -861,6 +861,36 @@ int elfrec_parse_request_seq(const char* text, ElfSpRequest* request, int64_t* s
   return 0;
 }
 
+// The SGF file of a finished game from its Record text (what elfsp_pop_record returns): name = <prefix>_<thread_id>_<seq>_<B|W>.sgf
+// (GoStateExt::dumpSgf(), go_state_ext.h:48-56), text = elfrec_game_sgf.  Returns the text length; ELFGO_E_BADARG for a text that
+// is not a Record.
+int64_t elfrec_record_to_sgf(const ElfSpOptions* opt, const char* record_json, const char* prefix, char* name_out, size_t name_cap,
+                             char* out, size_t cap) {
+  if (!opt || !record_json || !prefix) return ELFGO_E_BADARG;
+  JReader rd{record_json, record_json + strlen(record_json)};
+  const JValue root = rd.value();
+  if (!rd.ok || root.kind != JValue::OBJ) return ELFGO_E_BADARG;
+  const JValue* res = root.get("result");
+  const JValue* content = res ? res->get("content") : nullptr;
+  const JValue* vals = res ? res->get("values") : nullptr;
+  double reward = 0;
+  int64_t seq = 0, thread_id = 0;
+  if (!content || content->kind != JValue::STR || !jnum(res, "reward", &reward) || !jint(&root, "seq", &seq) || !jint(&root, "thread_id", &thread_id))
+    return ELFGO_E_BADARG;
+  const int nm = elfrec_sgfstr_to_coords(opt->board_size, content->str.c_str(), nullptr, 0);
+  if (nm < 0) return nm;
+  std::vector<uint16_t> moves((size_t)nm + 1);
+  elfrec_sgfstr_to_coords(opt->board_size, content->str.c_str(), moves.data(), nm);
+  std::vector<float> values;
+  if (vals && vals->kind == JValue::ARR) for (const JValue& v : vals->arr) values.push_back((float)v.num);
+  const std::string name = std::string(prefix) + "_" + std::to_string(thread_id) + "_" + std::to_string(seq) + "_" + ((float)reward > 0 ? "B" : "W") + ".sgf";
+  if (name_out) {
+    if (name_cap <= name.size()) return ELFGO_E_BADSIZE;
+    memcpy(name_out, name.data(), name.size() + 1);
+  }
+  return elfrec_game_sgf(opt, moves.data(), nm, values.data(), (int)values.size(), (float)reward, name.c_str(), nullptr, nullptr, out, cap);
+}
+
 // MsgRequestSeq::dumpJsonString (record.h:167-171): {"request":{...},"seq":n} -- what the reference's server writes
 int64_t elfrec_request_seq_to_json(const ElfSpRequest* request, const ElfTsOptions* t, int64_t seq, char* out, size_t cap) {
   if (!request || !t) return ELFGO_E_BADARG;

@@ -439,6 +439,10 @@ int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec, int
  * opening comment, NULL = this library's version and "0".  Returns the length; out == NULL queries it. */
 int64_t elfrec_game_sgf(const ElfSpOptions* opt, const uint16_t* moves, int num_moves, const float* values, int num_values,
                         float final_value, const char* filename, const char* git_hash, const char* git_staged, char* out, size_t cap);
+/* the same from the Record text of a finished game (elfsp_pop_record): *name_out <- <prefix>_<thread_id>_<seq>_<B|W>.sgf, the file
+ * name GoStateExt::dumpSgf() uses (go_state_ext.h:48-56) */
+int64_t elfrec_record_to_sgf(const ElfSpOptions* opt, const char* record_json, const char* prefix, char* name_out, size_t name_cap,
+                             char* out, size_t cap);
 /* ---- the client's wire formats (train/distri_client.h), host only --------------------------------------------------------------
  * What a self-play client sends to the reference's server: Records = {identity, states, records} (common/record.h:401-470) as
  * GuardedRecords keeps and dumps them (distri_client.h:111-170) -- and what it receives: MsgRequestSeq (record.h:152-171).  Texts

@@ -431,13 +431,15 @@ def test_reply_version_is_checked(mods):
 
 
 @pytest.mark.gpu
-def test_game_end_batches_and_game_stats(mods):
-    """finished games: one game_end batch each (GameNotifier::OnGameEnd, distri_client.h:228-240), WinRateStats fed, records kept"""
+def test_game_end_batches_and_game_stats(mods, tmp_path):
+    """finished games: one game_end batch each (GameNotifier::OnGameEnd, distri_client.h:228-240), WinRateStats fed, records kept;
+    GameOptions.dump_record_prefix: every finished game is written as SGF (finish_game :133-135 -> GoStateExt::dumpSgf)"""
     import json
     from pyoracle import MCTS_DEFAULTS
     cfg = dict(MCTS_DEFAULTS)
     cfg.update(num_games=3, rollouts_per_thread=16, seed=88, net_salt=3, move_cutoff=5, policy_distri_cutoff=2)
-    log, ev = _session(mods, cfg, 3 * 9, n=9, force_restated=True, keep_records=16)
+    prefix = str(tmp_path / "dump")
+    log, ev = _session(mods, cfg, 3 * 9, n=9, force_restated=True, keep_records=16, dump_record_prefix=prefix)
     GC = ev["GC"]
     wr = GC.getClient().getGameStats().getWinRateStats()
     assert wr.total_games >= 3 and wr.total_games == wr.black_wins + wr.white_wins
@@ -451,6 +453,17 @@ def test_game_end_batches_and_game_stats(mods):
     j = json.loads(recs[0])
     assert j["result"]["num_move"] == 4 and j["request"]["vers"]["black_ver"] == 0 and j["request"]["vers"]["mcts_opt"]["num_rollouts_per_thread"] == 16
     assert GC.getClient().getGameStats().getPlayedGames() == []
+    import elf_amd
+    from elf_amd.train import sgf_file_name
+    files = sorted(os.listdir(str(tmp_path)))
+    assert len(files) >= len(recs) >= 3
+    for t in recs:
+        name = sgf_file_name(prefix, t)                         # <prefix>_<game>_<seq>_<B|W>.sgf
+        text = open(name).read()
+        jr = json.loads(t)
+        assert text.startswith("(;SZ[9]RE[") and ("Filename: " + name) in text and "PB[MCTS]PW[MCTS]KM[7.5]" in text and text.endswith(")\n")
+        assert text.count(";B[") + text.count(";W[") == jr["result"]["num_move"]
+        assert ("C[1: PredV: %f]" % jr["result"]["values"][0]) in text
     ev["gcw"].stop()
 
 
