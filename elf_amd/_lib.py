@@ -75,6 +75,7 @@ SIGNATURES = {
     "elfsp_last_rows2": (_i, [_vp, _vp]),
     "elfsp_set_request2": (_i, [_vp, _vp]),
     "elfsp_set_request3": (_i, [_vp, _vp, _vp]),
+    "elfrec_sgf_parse": (_i, [_i, C.c_char_p, _vp, _vp, _i, _vp]),
     "elfrec_game_sgf": (_i64, [_vp, _vp, _i, _vp, _i, _f, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, _sz]),
     "elfrec_record_to_sgf": (_i64, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, _sz, C.c_char_p, _sz]),
     "elfrec_client_create": (_i, [C.c_char_p, C.POINTER(_vp)]),

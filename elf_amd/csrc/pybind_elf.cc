@@ -328,37 +328,20 @@ struct GameStats {             // common/game_stats.h:19-68 (the counters this e
   std::vector<std::string> getPlayedGames() const { return {}; }   // feedSgf is never called by the reference either (distri_client.h:236)
 };
 
-// Sgf::load main line -> reference Coords (sgf/sgf.cc; "" and, up to 19x19, "tt" are passes)
+// Sgf::load + iterator (sgf/sgf.cc) -> the Coords GoGameSelfPlay::restart forwards / follows (game_selfplay.cc:202-219,392-405: only
+// the entries' moves are used, not their colours).  Entries without a move (uninitialised in the reference) are left out.
 std::vector<uint16_t> sgf_main_line(const std::string& path, int n) {
   std::ifstream f(path);
   if (!f) throw std::runtime_error("preload_sgf: cannot open " + path);
   std::stringstream ss;
   ss << f.rdbuf();
   const std::string t = ss.str();
-  std::vector<uint16_t> out;
-  const int S = n + 2;
-  int depth = 0;
-  for (size_t i = 0; i + 2 < t.size(); ++i) {
-    if (t[i] == '(') { ++depth; continue; }
-    if (t[i] == ')') { if (--depth <= 0 && !out.empty()) break; continue; }   // main line = first variation at every branch
-    if (t[i] != ';') continue;
-    size_t j = i + 1;
-    while (j < t.size() && isspace((unsigned char)t[j])) ++j;
-    if (j + 1 >= t.size() || (t[j] != 'B' && t[j] != 'W') || isalpha((unsigned char)t[j + 1])) continue;
-    size_t k = j + 1;
-    while (k < t.size() && isspace((unsigned char)t[k])) ++k;
-    if (k >= t.size() || t[k] != '[') continue;
-    size_t e = t.find(']', k);
-    if (e == std::string::npos) break;
-    const std::string mv = t.substr(k + 1, e - k - 1);
-    if (mv.size() < 2 || (mv == "tt" && n <= 19)) out.push_back(0);
-    else {
-      const int x = mv[0] - 'a', y = mv[1] - 'a';
-      if (x < 0 || x >= n || y < 0 || y >= n) throw std::runtime_error("preload_sgf: move off board: " + mv);
-      out.push_back((uint16_t)((y + 1) * S + (x + 1)));
-    }
-    i = e;
-  }
+  const int k = elfrec_sgf_parse(n, t.c_str(), nullptr, nullptr, 0, nullptr);
+  if (k <= 0) throw std::runtime_error("preload_sgf: " + path + " is not an SGF game");
+  std::vector<int32_t> players((size_t)k);
+  std::vector<uint16_t> coords((size_t)k), out;
+  elfrec_sgf_parse(n, t.c_str(), players.data(), coords.data(), k, nullptr);
+  for (int i = 0; i < k; ++i) if (players[(size_t)i] != 0) out.push_back(coords[(size_t)i]);
   return out;
 }
 

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <functional>
 #include <random>
 #include <sstream>
 #include <string>
@@ -336,6 +337,112 @@ int elfrec_coords_to_sgfstr(int board_size, const uint16_t* coords, int n, char*
   if (out && len < cap) out[len] = 0;
   if (out && len >= cap) return ELFGO_E_BADSIZE;
   return (int)len;
+}
+
+// Sgf::load(filename, game_string) + the iterator over its entries (sgf/sgf.cc:28-57,72-127,129-240, sgf/sgf.h:21-46,125-245), restated:
+//  * the header is the node after the first ';': its key/value pairs up to the next ';' or ')' (RE, SZ, KM, HA are read here);
+//  * every following ';' starts an entry whose B[..] / W[..] property (the last one, if several) is the move; any other key --
+//    and the second, third ... value of a multi-value property such as AB[gc][cg], whose key is then empty -- is ignored;
+//  * '(' and ')' do not nest: a key/value scan stops at ';' or ')' and the next entry starts at the next ';' wherever it is, so
+//    the variations of a file follow each other as if they were one line of play;
+//  * a backslash hides the character after it from the scanner (an escaped ']' does not end a value);
+//  * keys and values are trimmed by sgf.cc's own trim (blanks and newlines; its right end only when the left needed none);
+//  * str2coord: fewer than two characters = pass; blanks and newlines before each letter are skipped; off the board (e.g. "tt" on
+//    19x19) = M_INVALID (3), which GoState::forward refuses.
+// An entry without a move has uninitialised fields in the reference; here it is reported as (player 0, M_INVALID).
+// Returns the number of entries (all are counted, the first `cap` stored); 0 when the text has no header or no entry
+// (Sgf::load returns false).
+int elfrec_sgf_parse(int board_size, const char* text, int32_t* players, uint16_t* coords, int cap, ElfSgfHeader* header) {
+  if (board_size < 1 || !text || cap < 0 || (cap > 0 && (!players || !coords))) return ELFGO_E_BADARG;
+  const int N = board_size, S = N + 2;
+  const int len = (int)strlen(text);
+  const char* s = text;
+  // sgf.cc:15-24 trim: blanks and newlines off both ends -- except that it returns substr(l, r + 1), a COUNT of r + 1 characters
+  // from l, so the right end is only trimmed when nothing was trimmed on the left
+  auto trim = [](const std::string& t) {
+    int l = 0;
+    while (l < (int)t.size() && (t[l] == ' ' || t[l] == '\n')) l++;
+    int r = (int)t.size() - 1;
+    while (r >= 0 && (t[r] == ' ' || t[r] == '\n')) r--;
+    return t.substr((size_t)l, (size_t)(r + 1));
+  };
+  auto str2coord = [&](const std::string& v) -> int {
+    if (v.size() < 2) return 0;                          // M_PASS
+    size_t i = 0;
+    while (i < v.size() && (v[i] == '\n' || v[i] == ' ')) i++;
+    if (i == v.size()) return 3;                         // M_INVALID
+    const int x = v[i] - 'a';
+    i++;
+    while (i < v.size() && (v[i] == '\n' || v[i] == ' ')) i++;
+    if (i == v.size()) return 3;
+    const int y = v[i] - 'a';
+    if (x < 0 || x >= N || y < 0 || y >= N) return 3;
+    return (y + 1) * S + (x + 1);
+  };
+  // get_key_values: calls cb(key, value) for every pair from `from`; returns where the scan stopped
+  auto scan = [&](int from, const std::function<void(const std::string&, const std::string&)>& cb) {
+    int i, start = from, k0 = 0, k1 = 0;
+    bool in_value = false, done = false, backslash = false;
+    for (i = from; i < len && !done; ++i) {
+      if (s[i] == '\\') { backslash = !backslash; continue; }
+      if (backslash) { backslash = false; continue; }
+      const char c = s[i];
+      if (!in_value) {
+        if (c == '[') { k0 = start; k1 = i; start = i + 1; in_value = true; }
+        else if (c == ';' || c == ')') { --i; done = true; }
+      } else if (c == ']') {
+        cb(std::string(s + k0, (size_t)(k1 - k0)), std::string(s + start, (size_t)(i - start)));
+        start = i + 1;
+        in_value = false;
+      }
+    }
+    return i;
+  };
+  ElfSgfHeader h;
+  h.size = N; h.komi = 7.5f; h.handi = 0; h.winner = 3 /* S_OFF_BOARD */; h.win_margin = 0.0f;
+  int i = 0;
+  while (i < len && s[i] != ';') i++;
+  if (i >= len) return 0;
+  i++;
+  int next = scan(i, [&](const std::string& key, const std::string& value) {
+    const std::string v = trim(value), k = trim(key);
+    if (k == "RE") {
+      if (!v.empty()) {
+        h.winner = (v[0] == 'B' || v[0] == 'b') ? 1 : 2;
+        if (v.size() >= 3) {                             // stof(v.substr(2)), or a reason such as "R" / "id"
+          const std::string m = v.substr(2);
+          char* e = nullptr;
+          const float f = strtof(m.c_str(), &e);
+          if (e != m.c_str()) h.win_margin = f;
+        }
+      }
+    } else if (k == "SZ") h.size = atoi(v.c_str());
+    else if (k == "KM") h.komi = strtof(v.c_str(), nullptr);
+    else if (k == "HA") h.handi = atoi(v.c_str());
+  });
+  int count = 0;
+  while (true) {
+    int j = next;
+    while (j < len && s[j] != ';') ++j;
+    if (j >= len) break;
+    ++j;
+    int player = 0, move = 3;
+    if (j < len && s[j] == '(') {
+      // ";(": the reference descends into a child list it never iterates and keeps this entry without a move; the siblings go on
+      // after the matching scan.  Not met in practice; reported as an entry without a move.
+      next = j + 1;
+    } else {
+      next = scan(j, [&](const std::string& key, const std::string& value) {
+        const std::string v = trim(value), k = trim(key);
+        if (k.size() == 1 && (k[0] == 'B' || k[0] == 'W')) { player = k[0] == 'B' ? 1 : 2; move = str2coord(v); }
+      });
+    }
+    if (count < cap) { players[count] = player; coords[count] = (uint16_t)move; }
+    ++count;
+  }
+  if (count == 0) return 0;
+  if (header) *header = h;
+  return count;
 }
 
 // GoStateExt::dumpSgf (go_state_ext.cc:26-82): the SGF text finish_game writes to <dump_record_prefix>_<game>_<seq>_<B|W>.sgf

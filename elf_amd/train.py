@@ -167,6 +167,27 @@ class ReplayLoader:
         return [{key: t[i * B:(i + 1) * B] for key, t in big.items()} for i in range(k)]
 
 
+class SgfHeader(C.Structure):
+    """ElfSgfHeader"""
+    _fields_ = [("size", C.c_int32), ("handi", C.c_int32), ("winner", C.c_int32), ("komi", C.c_float), ("win_margin", C.c_float)]
+
+
+def parse_sgf(board_size, text):
+    """Sgf::load + iterator (sgf/sgf.cc) -> (players int32 [k] (1 Black, 2 White), coords uint16 [k] (0 pass, 3 invalid), header dict),
+    or None where the reference's loader fails (no header / no entry)"""
+    L = _lib.lib()
+    raw = text.encode("latin-1") if isinstance(text, str) else text
+    h = SgfHeader()
+    k = L.elfrec_sgf_parse(int(board_size), raw, None, None, 0, C.byref(h))
+    if k < 0:
+        check(k)
+    if k == 0:
+        return None
+    pl, mv = np.zeros(k, np.int32), np.zeros(k, np.uint16)
+    L.elfrec_sgf_parse(int(board_size), raw, pl.ctypes.data, mv.ctypes.data, k, C.byref(h))
+    return pl, mv, dict(size=h.size, komi=h.komi, handi=h.handi, winner=h.winner, win_margin=h.win_margin)
+
+
 def record_to_sgf(board_size, rec, opt, filename, git_hash=None, git_staged=None):
     """GoStateExt::dumpSgf (go_state_ext.cc:26-82) for a finished game: rec = Record JSON text / dict, opt = the SpOptions the game
     was played under (komi, policy-only flags) -> SGF text (result, player names, komi, every move with its predicted value)"""

@@ -432,6 +432,16 @@ int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_mov
 /* GoGameTrain::act's draws for n samples with the store's std::mt19937 (seeded at create): record, move_to =
  * rng() % (num_moves - num_future_actions + 1), D4 code = rng() % 8; results into device int32 [n] arrays */
 int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec, int32_t* move_to, int32_t* d4, void* stream);
+/* Sgf::load + its iterator (sgf/sgf.cc:28-240, sgf/sgf.h:21-46,125-245), host only: the entries of an SGF text as (player, Coord) --
+ * player 1 = Black, 2 = White; Coord 0 = pass, 3 = M_INVALID (off the board, e.g. "tt" on 19x19: GoState::forward refuses it) -- with
+ * the reference's reading of the format: the first node is the header (SZ, KM, HA, RE), setup stones (AB / AW) are not moves,
+ * variations are not nested but follow each other, a backslash hides the next character.  Returns the number of entries (the first
+ * `cap` are stored), 0 where Sgf::load returns false.  This is what GameOptions.preload_sgf and the ladder suite are read with. */
+typedef struct ElfSgfHeader {
+  int32_t size, handi, winner /* Stone: 1 Black, 2 White, 3 none */;
+  float komi, win_margin;
+} ElfSgfHeader;
+int elfrec_sgf_parse(int board_size, const char* text, int32_t* players, uint16_t* coords, int cap, ElfSgfHeader* header);
 /* GoStateExt::dumpSgf (go_state_ext.cc:26-82): the SGF text the reference's finish_game writes for a finished game when
  * GameOptions.dump_record_prefix is set (file <prefix>_<game>_<seq>_<B|W>.sgf, go_state_ext.h:48-56): RE[] from the final value
  * ("B+R" / "W+R" for +-1, else the margin), PB / PW ("MCTS", "(policy only)" appended), KM, every move with "C[<n>: PredV: <v>]".

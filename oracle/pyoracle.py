@@ -189,6 +189,17 @@ class Ref(_Engine):
             raise IOError(path)
         return mv[:k].copy(), pl[:k].copy()
 
+    def sgf_parse(self, text):
+        """Sgf::load(filename, game_string) -> (moves, players, dict(size, komi, handi, winner, win_margin)) or None (load failed)"""
+        mv = np.zeros(4096, np.int32)
+        pl = np.zeros(4096, np.int32)
+        h = np.zeros(5, np.float32)
+        k = self.L.ref_sgf_parse(C.c_char_p(text.encode("latin-1")), mv.ctypes.data_as(C.c_void_p), pl.ctypes.data_as(C.c_void_p), C.c_int(4096),
+                                 h.ctypes.data_as(C.c_void_p))
+        if k < 0:
+            return None
+        return mv[:k].copy(), pl[:k].copy(), dict(size=int(h[0]), komi=float(h[1]), handi=int(h[2]), winner=int(h[3]), win_margin=float(h[4]))
+
     def zobrist(self):
         z = np.zeros((self.n + 2) ** 2, np.uint64)
         self.L.ref_zobrist.argtypes = [C.c_void_p]

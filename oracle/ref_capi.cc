@@ -104,6 +104,23 @@ int ref_sgf_moves(const char* path, int32_t* moves, int32_t* players, int cap) {
   return n;
 }
 
+// the same from a game string (Sgf::load(filename, game_string), sgf.cc:28-57) + the header fields; header5 = {size, komi, handi,
+// winner (Stone), win_margin}
+int ref_sgf_parse(const char* text, int32_t* moves, int32_t* players, int cap, float* header5) {
+  Sgf sgf;
+  if (!sgf.load("", std::string(text))) return -1;
+  int n = 0;
+  for (auto it = sgf.begin(); !it.done() && n < cap; ++it) {
+    auto m = it.getCurrMove();
+    moves[n] = m.move; players[n] = m.player; ++n;
+  }
+  if (header5) {
+    const SgfHeader& h = sgf.getHeader();
+    header5[0] = (float)h.size; header5[1] = h.komi; header5[2] = (float)h.handi; header5[3] = (float)h.winner; header5[4] = h.win_margin;
+  }
+  return n;
+}
+
 // ---- config-2 protocol: random legal non-true-eye play to game end -------------
 // Counter-based RNG shared verbatim with the HIP kernel and oracle/go_oracle.c.
 static inline uint32_t fmix32(uint32_t h) {
