@@ -428,9 +428,10 @@ int elfrec_sgf_parse(int board_size, const char* text, int32_t* players, uint16_
     ++j;
     int player = 0, move = 3;
     if (j < len && s[j] == '(') {
-      // ";(": the reference descends into a child list it never iterates and keeps this entry without a move; the siblings go on
-      // after the matching scan.  Not met in practice; reported as an entry without a move.
-      next = j + 1;
+      // ";(": the reference parses a child list from here to the end of the text, then looks for ')' at the offset its last,
+      // failing load call has reset to 0 -- finds '(' there, calls the file corrupted and drops this entry and everything after
+      // it (sgf.cc:216-226): the list of entries ends here
+      break;
     } else {
       next = scan(j, [&](const std::string& key, const std::string& value) {
         const std::string v = trim(value), k = trim(key);

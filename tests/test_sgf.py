@@ -97,3 +97,36 @@ def test_differential_against_the_reference_loader(built):
         ok = pl != 0                    # (a trailing node without a move is uninitialised memory in the reference)
         assert len(mv) == len(wm) and np.array_equal(mv[ok], wm[ok]) and np.array_equal(pl[ok], wp[ok]) and h == pytest.approx(wh), f
         assert ok.sum() >= len(mv) - 1
+
+
+def test_random_texts_against_the_reference_loader(built):
+    """800 random SGF-like texts (blanks and newlines inside moves, lower-case and two-letter keys, comments with brackets and
+    escapes, stray parentheses, ";(" -- where the reference calls the file corrupted and drops the rest): same entries, same header"""
+    if not Ref.available(9):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    from elf_amd.train import parse_sgf
+    R = Ref(9)
+    rng = np.random.default_rng(1)
+    letters = "abcdefghij t"
+
+    def mv():
+        if rng.integers(0, 6) == 0:
+            return ""
+        a, b = letters[rng.integers(0, len(letters))], letters[rng.integers(0, len(letters))]
+        return ["", " ", "\n", "  "][rng.integers(0, 4)] + a + ["", " ", "\n"][rng.integers(0, 3)] + b + ["", " ", "\n"][rng.integers(0, 3)]
+
+    pieces = [lambda: ";", lambda: "B[%s]" % mv(), lambda: "W[%s]" % mv(), lambda: "C[te;xt ) ( \\] more]", lambda: "AB[aa][bb]",
+              lambda: "(", lambda: ")", lambda: " ", lambda: "\n", lambda: "B [%s]" % mv(), lambda: "b[aa]", lambda: "BB[aa]",
+              lambda: ";B[%s]" % mv(), lambda: ";W[%s]" % mv(), lambda: "\nW[%s]" % mv()]
+    for _ in range(800):
+        t = "(;SZ[9]KM[%s]" % ["6.5", "0.5", " 7", "5.50"][rng.integers(0, 4)] + ["", "RE[B+R]", "RE[W+2.5]", "RE[b+10]", "HA[2]", "\nHA[3]"][rng.integers(0, 6)]
+        for _ in range(rng.integers(1, 14)):
+            t += pieces[rng.integers(0, len(pieces))]()
+        want, got = R.sgf_parse(t), parse_sgf(9, t)
+        assert (want is None) == (got is None), repr(t)
+        if want is None:
+            continue
+        wm, wp, wh = want
+        ok = got[0] != 0
+        assert len(got[0]) == len(wm) and np.array_equal(got[1][ok], wm[ok]) and np.array_equal(got[0][ok], wp[ok]), repr(t)
+        assert got[2] == pytest.approx(wh), repr(t)
