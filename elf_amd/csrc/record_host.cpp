@@ -239,7 +239,7 @@ static void put_request(std::string& o, const SpRecordMeta& m) {
   put_bool(o, m.async);
   o += ",\"black_resign_thres\":";
   put_float(o, m.black_resign_thres);
-  o += ",\"client_type\":" + std::to_string(m.client_type) + ",\"never_resign_prob\":"; put_float(o, m.never_resign_prob);
+  o += ",\"client_type\":" + std::to_string((uint32_t)m.client_type) + ",\"never_resign_prob\":"; put_float(o, m.never_resign_prob);
   o += ",\"num_game_thread_used\":" + std::to_string(m.num_game_thread_used);
   o += ",\"player_swap\":"; put_bool(o, m.player_swap);
   o += ",\"white_resign_thres\":"; put_float(o, m.white_resign_thres);
@@ -830,15 +830,53 @@ struct JReader {
   }
 };
 
-bool jnum(const JValue* o, const char* k, double* out) { const JValue* v = o ? o->get(k) : nullptr; if (!v || v->kind != JValue::NUM) return false; *out = v->num; return true; }
-bool jint(const JValue* o, const char* k, int64_t* out) { const JValue* v = o ? o->get(k) : nullptr; if (!v || v->kind != JValue::NUM) return false; *out = v->inum; return true; }
-bool jbool(const JValue* o, const char* k, bool* out) {   // nlohmann converts numbers to bool on assignment as well
-  const JValue* v = o ? o->get(k) : nullptr;
-  if (!v) return false;
-  if (v->kind == JValue::BOOL) { *out = v->b; return true; }
-  if (v->kind == JValue::NUM) { *out = v->num != 0; return true; }
-  return false;
+// nlohmann's implicit conversions as the reference's JSON_LOAD uses them (target.field = j["field"]), by target type:
+//   int          numbers (a float is truncated) and booleans (1 / 0)
+//   int64_t      numbers only (it is the library's own integer type: no conversion from a boolean)
+//   float        numbers and booleans
+//   bool         booleans only
+//   std::string  strings only
+//   ClientType   numbers only, stored in the enum's unsigned underlying type
+// Return: 1 = converted, 0 = the key is absent, -1 = present with a type the conversion throws on.
+int jget(const JValue* o, const char* k, const JValue** v) { *v = o ? o->get(k) : nullptr; return *v ? 1 : 0; }
+int jint32(const JValue* o, const char* k, int32_t* out) {
+  const JValue* v;
+  if (!jget(o, k, &v)) return 0;
+  if (v->kind == JValue::NUM) { *out = v->is_int ? (int32_t)v->inum : (int32_t)v->num; return 1; }
+  if (v->kind == JValue::BOOL) { *out = v->b ? 1 : 0; return 1; }
+  return -1;
 }
+int jint64(const JValue* o, const char* k, int64_t* out) {
+  const JValue* v;
+  if (!jget(o, k, &v)) return 0;
+  if (v->kind != JValue::NUM) return -1;
+  *out = v->is_int ? v->inum : (int64_t)v->num;
+  return 1;
+}
+int jfloat(const JValue* o, const char* k, float* out) {
+  const JValue* v;
+  if (!jget(o, k, &v)) return 0;
+  if (v->kind == JValue::NUM) { *out = (float)v->num; return 1; }
+  if (v->kind == JValue::BOOL) { *out = v->b ? 1.0f : 0.0f; return 1; }
+  return -1;
+}
+int jbool(const JValue* o, const char* k, bool* out) {
+  const JValue* v;
+  if (!jget(o, k, &v)) return 0;
+  if (v->kind != JValue::BOOL) return -1;
+  *out = v->b;
+  return 1;
+}
+int jenum(const JValue* o, const char* k, int32_t* out) {
+  const JValue* v;
+  if (!jget(o, k, &v)) return 0;
+  if (v->kind != JValue::NUM) return -1;
+  *out = (int32_t)(uint32_t)(v->is_int ? v->inum : (int64_t)v->num);
+  return 1;
+}
+// the number / reward fields of a Record this library wrote itself
+bool jnum(const JValue* o, const char* k, double* out) { const JValue* v = o ? o->get(k) : nullptr; if (!v || v->kind != JValue::NUM) return false; *out = v->num; return true; }
+bool jint(const JValue* o, const char* k, int64_t* out) { return jint64(o, k, out) == 1; }
 
 }  // namespace
 
@@ -926,18 +964,20 @@ int elfrec_parse_request_seq(const char* text, ElfSpRequest* request, int64_t* s
   const JValue* ctrl = req ? req->get("client_ctrl") : nullptr;
   const JValue* mo = vers ? vers->get("mcts_opt") : nullptr;
   const JValue* alg = mo ? mo->get("alg_opt") : nullptr;
-  int64_t sq = -1, i64 = 0;
-  if (!vers || !ctrl || !mo || !alg || !jint(&root, "seq", &sq)) return ELFGO_E_BADARG;
+  int64_t sq = -1;
+  if (!vers || vers->kind != JValue::OBJ || !ctrl || ctrl->kind != JValue::OBJ || !mo || mo->kind != JValue::OBJ || !alg ||
+      alg->kind != JValue::OBJ || jint64(&root, "seq", &sq) != 1)
+    return ELFGO_E_BADARG;
   ElfSpRequest q;
   memset(&q, 0, sizeof(q));
-  if (!jint(vers, "black_ver", &q.black_ver) || !jint(vers, "white_ver", &q.white_ver)) return ELFGO_E_BADARG;
+  if (jint64(vers, "black_ver", &q.black_ver) != 1 || jint64(vers, "white_ver", &q.white_ver) != 1) return ELFGO_E_BADARG;
   ElfTsOptions t;
   memset(&t, 0, sizeof(t));
-  double d = 0;
   bool b = false;
-#define NEED_INT(obj, key, dst) do { if (!jint(obj, key, &i64)) return ELFGO_E_BADARG; dst = (decltype(dst))i64; } while (0)
-#define NEED_FLT(obj, key, dst) do { if (!jnum(obj, key, &d)) return ELFGO_E_BADARG; dst = (float)d; } while (0)
-#define NEED_BOOL(obj, key, dst) do { if (!jbool(obj, key, &b)) return ELFGO_E_BADARG; dst = b ? 1 : 0; } while (0)
+  int32_t i32 = 0;
+#define NEED_INT(obj, key, dst) do { if (jint32(obj, key, &i32) != 1) return ELFGO_E_BADARG; dst = i32; } while (0)
+#define NEED_FLT(obj, key, dst) do { if (jfloat(obj, key, &dst) != 1) return ELFGO_E_BADARG; } while (0)
+#define NEED_BOOL(obj, key, dst) do { if (jbool(obj, key, &b) != 1) return ELFGO_E_BADARG; dst = b ? 1 : 0; } while (0)
   NEED_INT(mo, "max_num_moves", t.max_num_moves); NEED_INT(mo, "num_threads", t.num_threads);
   NEED_INT(mo, "num_rollouts_per_thread", t.num_rollouts_per_thread); NEED_INT(mo, "num_rollouts_per_batch", t.num_rollouts_per_batch);
   NEED_BOOL(mo, "verbose", t.verbose); NEED_BOOL(mo, "verbose_time", t.verbose_time); NEED_INT(mo, "seed", t.seed);
@@ -953,13 +993,21 @@ int elfrec_parse_request_seq(const char* text, ElfSpRequest* request, int64_t* s
   NEED_FLT(mo, "root_epsilon", t.root_epsilon); NEED_FLT(mo, "root_alpha", t.root_alpha); NEED_INT(mo, "virtual_loss", t.virtual_loss);
   NEED_BOOL(alg, "use_prior", t.use_prior); NEED_FLT(alg, "c_puct", t.c_puct);
   NEED_BOOL(alg, "unexplored_q_zero", t.unexplored_q_zero); NEED_BOOL(alg, "root_unexplored_q_zero", t.root_unexplored_q_zero);
-  NEED_INT(ctrl, "client_type", q.client_type); NEED_INT(ctrl, "num_game_thread_used", q.num_game_thread_used);
+  if (jenum(ctrl, "client_type", &q.client_type) != 1) return ELFGO_E_BADARG;
+  NEED_INT(ctrl, "num_game_thread_used", q.num_game_thread_used);
   NEED_FLT(ctrl, "black_resign_thres", q.black_resign_thres); NEED_FLT(ctrl, "white_resign_thres", q.white_resign_thres);
   NEED_FLT(ctrl, "never_resign_prob", q.never_resign_prob);
   const bool is_selfplay = q.black_ver >= 0 && q.white_ver == -1;           // ModelPair::is_selfplay
-  if (jbool(ctrl, "player_swap", &b)) q.player_swap = b ? 1 : 0;
-  else if (!is_selfplay) return ELFGO_E_BADARG;                              // JSON_LOAD, not _OPTIONAL, for evaluation requests
-  if (jbool(ctrl, "async", &b)) q.async = b ? 1 : 0;
+  {
+    const int r = jbool(ctrl, "player_swap", &b);
+    if (r < 0 || (r == 0 && !is_selfplay)) return ELFGO_E_BADARG;            // JSON_LOAD, not _OPTIONAL, for evaluation requests
+    if (r == 1) q.player_swap = b ? 1 : 0;
+  }
+  {
+    const int r = jbool(ctrl, "async", &b);
+    if (r < 0) return ELFGO_E_BADARG;
+    if (r == 1) q.async = b ? 1 : 0;
+  }
 #undef NEED_INT
 #undef NEED_FLT
 #undef NEED_BOOL
@@ -1009,7 +1057,7 @@ int64_t elfrec_request_seq_to_json(const ElfSpRequest* request, const ElfTsOptio
   m.black_resign_thres = request->black_resign_thres; m.white_resign_thres = request->white_resign_thres;
   m.never_resign_prob = request->never_resign_prob; m.num_game_thread_used = request->num_game_thread_used;
   m.player_swap = request->player_swap != 0; m.async = request->async != 0;
-  m.client_type = request->client_type != 0 ? request->client_type : 1;
+  m.client_type = request->client_type;          // as given (a parsed request is written back unchanged)
   std::string o = "{\"request\":";
   put_request(o, m);
   o += ",\"seq\":" + std::to_string(seq) + "}";

@@ -100,3 +100,56 @@ def test_records_of_message(built, wire):
     assert records_of_message('{"identity":"x"}') == ("x", [])
     with pytest.raises(ValueError):
         records_of_message('{"records":[]}')
+
+
+def test_random_request_texts_against_the_reference_parser(built, wire):
+    """2000 server replies with fields removed or given another JSON type (number for a flag, flag for a number, string, null,
+    array ...): accepted or refused exactly as MsgRequestSeq::createFromJson does -- nlohmann's conversions by target type (int
+    takes numbers and booleans, int64_t numbers only, float numbers and booleans, bool only booleans, the enum only numbers) --
+    and, when accepted, written back to the same text"""
+    if not RefSelfPlay.available(9):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    import copy
+    import numpy as np
+    import elf_amd
+    R = RefSelfPlay(9)
+    rng = np.random.default_rng(3)
+    alts = [True, False, 0, 1, -1, 2, 1.5, 0.25, -0.75, 1e-3, 40000, "most_visited", "strongest_prior", "x", None, [], {}]
+
+    def leaves(d, path=()):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from leaves(v, path + (k,))
+            else:
+                yield path + (k,)
+
+    accepted = refused = 0
+    for _ in range(2000):
+        j = copy.deepcopy(json.loads(wire["requests"][rng.integers(0, len(wire["requests"]))]["text"]))
+        paths = list(leaves(j))
+        for _ in range(rng.integers(1, 4)):
+            p = paths[rng.integers(0, len(paths))]
+            d = j
+            for k in p[:-1]:
+                d = d.get(k) if isinstance(d, dict) else None
+                if not isinstance(d, dict):
+                    break
+            if not isinstance(d, dict) or p[-1] not in d:
+                continue
+            if rng.random() < 0.25:
+                del d[p[-1]]
+            else:
+                d[p[-1]] = alts[rng.integers(0, len(alts))]
+        t = json.dumps(j, separators=[(",", ":"), (", ", ": ")][rng.integers(0, 2)])
+        want = R.request_seq_roundtrip(t)
+        try:
+            q, seq, ts = elf_amd.parse_request_seq(t)
+        except elf_amd.ElfGoError:
+            assert want is None, t
+            refused += 1
+            continue
+        assert want is not None, t
+        accepted += 1
+        if ts.pick_method >= 0:                      # (an unknown method name is kept as code -1: it cannot be written back)
+            assert elf_amd.request_seq_to_json(q, ts, seq) == want, t
+    assert accepted > 300 and refused > 300
