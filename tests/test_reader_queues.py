@@ -93,3 +93,35 @@ def test_reference_reproduces_fixture():
         pytest.skip("oracle/_ref not built (no /root/reference here)")
     a = RefSelfPlay(n).train_act(recs, **cfg)
     assert np.array_equal(a["selfplay_ver"] - 1000, g["rec"]) and np.array_equal(a["move_idx"], g["move_idx"])
+
+
+def test_live_differential_over_queue_shapes_and_seeds(built):
+    """the same comparison live (oracle/_ref present): other numbers of queues, queue bounds small enough to evict, other seeds,
+    num_future_actions 1..3 -- draws of one real GoGameTrain thread vs elfrq_draw"""
+    if not RefSelfPlay.available(9):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    import elf_amd
+    g, _, n, recs = load_case("train_act_9")
+    R = RefSelfPlay(n)
+    lens = [len(sgfstr2coords(n, json.loads(t)["result"]["content"])) for t in recs]
+    rng = np.random.default_rng(8)
+    done = 0
+    for trial in range(12):
+        cfg = dict(num_reader=int(rng.choice([2, 4, 6])), q_min_size=1, q_max_size=int(rng.choice([3, 5, 1000])),
+                   insert_seed=int(rng.integers(1, 1 << 30)), game_seed=int(rng.integers(1, 1 << 30)), num_acts=2,
+                   num_future_actions=int(rng.integers(1, 4)))
+        try:
+            a = R.train_act(recs, **cfg)
+        except RuntimeError:
+            continue                      # a queue stayed below q_min_size: the reference would wait for more data
+        q = elf_amd.ReaderQueues(cfg["num_reader"], cfg["q_min_size"], cfg["q_max_size"], cfg["insert_seed"], num_threads=1, seed=cfg["game_seed"])
+        fill(q, n, recs)
+        slot, move_to, d4 = q.draw(cfg["num_acts"], cfg["num_future_actions"])
+        assert np.array_equal(slot, a["selfplay_ver"] - 1000), cfg
+        assert np.array_equal(d4, a["aug_code"]), cfg
+        ok = slot != len(recs) - 1
+        assert np.array_equal(move_to[ok], a["move_idx"][ok]), cfg
+        assert all(lens[s_] >= cfg["num_future_actions"] for s_ in slot)
+        q.close()
+        done += 1
+    assert done >= 6
