@@ -153,3 +153,31 @@ def test_random_request_texts_against_the_reference_parser(built, wire):
         if ts.pick_method >= 0:                      # (an unknown method name is kept as code -1: it cannot be written back)
             assert elf_amd.request_seq_to_json(q, ts, seq) == want, t
     assert accepted > 300 and refused > 300
+
+
+def test_live_differential_of_client_messages(built, wire):
+    """random GuardedRecords sessions against the real Records object (oracle/_ref): thread ids up to 5000 in random order (the
+    unordered_map rehashes several times and keeps its buckets across clear()), repeated updates, dumps with and without records"""
+    if not RefSelfPlay.available(9):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    import numpy as np
+    import elf_amd
+    R = RefSelfPlay(9)
+    rng = np.random.default_rng(12)
+    for ses in range(4):
+        ident = "client-%d" % ses
+        R.client_reset(ident)
+        c = elf_amd.ClientRecords(ident)
+        for rnd in range(6):
+            k = int(rng.choice([0, 3, 40, 700, 2500]))
+            ids = rng.integers(0, 5000, size=k)
+            for t in ids:
+                st = (int(t), int(rng.integers(1, 50)), int(rng.integers(-1, 400)), int(rng.integers(0, 90)), int(rng.integers(-1, 90)))
+                R.client_update_state(*st)
+                c.update_state(*st)
+            for _ in range(int(rng.integers(0, 3))):
+                r = wire["records"][int(rng.integers(0, len(wire["records"])))]
+                R.client_feed(r)
+                c.feed(r)
+            assert c.dump_and_clear() == R.client_dump(), (ses, rnd)
+        c.close()
