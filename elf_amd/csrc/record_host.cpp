@@ -787,26 +787,41 @@ struct JReader {
     } else if (*p == '"') {
       v.kind = JValue::STR; ++p;
       while (p < end && *p != '"') {
+        if ((unsigned char)*p < 0x20) { ok = false; return v; }   // raw control characters are not JSON (nlohmann: parse_error 101)
         if (*p == '\\' && p + 1 < end) {
           ++p;
           switch (*p) {
             case 'n': v.str += '\n'; break; case 't': v.str += '\t'; break; case 'r': v.str += '\r'; break;
             case 'b': v.str += '\b'; break; case 'f': v.str += '\f'; break;
+            case '"': case '\\': case '/': v.str += *p; break;
             case 'u': {
-              if (end - p < 5) { ok = false; return v; }
+              auto hex4 = [&](const char* q, unsigned* out) -> bool {
+                if (end - q < 4) return false;
+                unsigned code = 0;
+                for (int i = 0; i < 4; ++i) {
+                  const char c = q[i];
+                  if (!((c >= '0' && c <= '9') || ((c | 32) >= 'a' && (c | 32) <= 'f'))) return false;
+                  code = code * 16 + (c <= '9' ? c - '0' : (c | 32) - 'a' + 10);
+                }
+                *out = code;
+                return true;
+              };
               unsigned code = 0;
-              for (int i = 1; i <= 4; ++i) {
-                const char c = p[i];
-                if (!((c >= '0' && c <= '9') || ((c | 32) >= 'a' && (c | 32) <= 'f'))) { ok = false; return v; }
-                code = code * 16 + (c <= '9' ? c - '0' : (c | 32) - 'a' + 10);
-              }
+              if (!hex4(p + 1, &code)) { ok = false; return v; }
               p += 4;
-              if (code < 0x80) v.str += (char)code;                        // the BMP as UTF-8 (identities are ASCII in practice)
+              if (code >= 0xD800 && code <= 0xDBFF) {                      // a high surrogate must be followed by \uDC00..DFFF
+                unsigned lo = 0;
+                if (end - p < 7 || p[1] != '\\' || p[2] != 'u' || !hex4(p + 3, &lo) || lo < 0xDC00 || lo > 0xDFFF) { ok = false; return v; }
+                p += 6;
+                code = 0x10000 + ((code - 0xD800) << 10) + (lo - 0xDC00);
+              } else if (code >= 0xDC00 && code <= 0xDFFF) { ok = false; return v; }
+              if (code < 0x80) v.str += (char)code;
               else if (code < 0x800) { v.str += (char)(0xC0 | (code >> 6)); v.str += (char)(0x80 | (code & 63)); }
-              else { v.str += (char)(0xE0 | (code >> 12)); v.str += (char)(0x80 | ((code >> 6) & 63)); v.str += (char)(0x80 | (code & 63)); }
+              else if (code < 0x10000) { v.str += (char)(0xE0 | (code >> 12)); v.str += (char)(0x80 | ((code >> 6) & 63)); v.str += (char)(0x80 | (code & 63)); }
+              else { v.str += (char)(0xF0 | (code >> 18)); v.str += (char)(0x80 | ((code >> 12) & 63)); v.str += (char)(0x80 | ((code >> 6) & 63)); v.str += (char)(0x80 | (code & 63)); }
               break;
             }
-            default: v.str += *p;
+            default: ok = false; return v;                                 // unknown escape
           }
           ++p;
         } else v.str += *p++;
@@ -817,13 +832,30 @@ struct JReader {
     else if (lit("false")) { v.kind = JValue::BOOL; v.b = false; }
     else if (lit("null")) { v.kind = JValue::NUL; }
     else {
+      // the JSON number grammar first: -?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][+-]?[0-9]+)?  (strtod alone also takes hex, inf / nan, a leading
+      // '+' and leading zeros, all of which nlohmann refuses)
+      const char* c = p;
+      if (c < end && *c == '-') ++c;
+      if (c >= end || *c < '0' || *c > '9') { ok = false; return v; }
+      if (*c == '0') ++c; else while (c < end && *c >= '0' && *c <= '9') ++c;
+      v.is_int = true;
+      if (c < end && *c == '.') {
+        v.is_int = false; ++c;
+        if (c >= end || *c < '0' || *c > '9') { ok = false; return v; }
+        while (c < end && *c >= '0' && *c <= '9') ++c;
+      }
+      if (c < end && (*c == 'e' || *c == 'E')) {
+        v.is_int = false; ++c;
+        if (c < end && (*c == '+' || *c == '-')) ++c;
+        if (c >= end || *c < '0' || *c > '9') { ok = false; return v; }
+        while (c < end && *c >= '0' && *c <= '9') ++c;
+      }
+      const std::string tok(p, c);                  // the text need not be NUL-terminated at `end`
       char* q = nullptr;
       v.kind = JValue::NUM;
-      v.num = strtod(p, &q);
-      if (q == p) { ok = false; return v; }
-      v.is_int = true;
-      for (const char* c = p; c < q; ++c) if (*c == '.' || *c == 'e' || *c == 'E') v.is_int = false;
-      v.inum = v.is_int ? strtoll(p, nullptr, 10) : (int64_t)v.num;
+      v.num = strtod(tok.c_str(), &q);
+      v.inum = v.is_int ? strtoll(tok.c_str(), nullptr, 10) : (int64_t)v.num;
+      q = const_cast<char*>(c);
       p = q;
     }
     return v;
@@ -903,6 +935,12 @@ int elfrec_client_destroy(ElfClientRecords* c) {
 // elfrec_record_to_json give it
 int elfrec_client_feed(ElfClientRecords* c, const char* record_json) {
   if (!c || !record_json || record_json[0] != '{') return ELFGO_E_BADARG;
+  {                                               // the text is spliced into the message verbatim: it has to be one JSON object
+    JReader rd{record_json, record_json + strlen(record_json)};
+    const JValue v = rd.value();
+    rd.ws();
+    if (!rd.ok || v.kind != JValue::OBJ || rd.p != rd.end) return ELFGO_E_BADARG;
+  }
   c->records.emplace_back(record_json);
   return 0;
 }

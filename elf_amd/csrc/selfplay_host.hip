@@ -20,6 +20,7 @@
 // very same library: std::gamma_distribution (Dirichlet noise), std::uniform_real_distribution (move sampling,
 // never-resign draw), std::mt19937 streams per game and per actor.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -31,6 +32,8 @@
 #include <vector>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <deque>
 #include <functional>
 #include <string>
@@ -125,7 +128,8 @@ struct ElfSelfPlay {
   // requests: `cur` is the one being delivered (every game must receive it before the next one goes out, dispatcher.h:104-152)
   std::deque<SpRequest> mailbox;
   SpRequest cur;
-  bool cur_done = true, cur_restarted = false;
+  bool cur_done = true, cur_restarted = false;   // cur_restarted: the request changed the model of some game ("game_start" is due)
+  int cur_n_restart = 0;                         // games that actually restarted under `cur` (RestartReply::UPDATE_MODEL)
   int next_req_id = 1;
   int64_t start_black = 0, start_white = -1;   // versions of the last request that (re)started games
   int game_starts = 0;
@@ -157,19 +161,75 @@ struct ElfSelfPlay {
   } while (0)
 
 // Per-game host work of a move boundary (gamma draws for the Dirichlet noise, the D4 draws of the coming search) touches only
-// that game's generators: spread over a few host threads when many games are at the boundary together.
+// that game's generators: spread over a few host threads when many games are at the boundary together.  The threads are a
+// process-wide pool created at the first use and parked on a condition variable in between (a move boundary every 200 steps
+// would otherwise pay for 16 thread creations + joins each time).
+class SpWorkers {
+ public:
+  static SpWorkers& get() { static SpWorkers w; return w; }
+  // fn(i) for i in [0, n), strided over `nt` participants (the caller is participant 0); returns when all of them are done
+  void run(size_t n, unsigned nt, const std::function<void(size_t)>& fn) {
+    std::unique_lock<std::mutex> call(call_mu_);          // one parallel region at a time (contexts on several host threads)
+    ensure(nt - 1);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; n_ = n; nt_ = nt; pending_ = nt - 1; ++epoch_;
+    }
+    cv_.notify_all();
+    for (size_t i = 0; i < n; i += nt) fn(i);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+  ~SpWorkers() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+ private:
+  void ensure(unsigned k) {
+    while (th_.size() < k) {
+      const unsigned id = (unsigned)th_.size() + 1;        // participant index of this worker
+      // a worker created during a later region must not mistake that region for a new epoch before it is asked to run
+      const uint64_t seen0 = epoch_;
+      th_.emplace_back([this, id, seen0] {
+        uint64_t seen = seen0;
+        for (;;) {
+          const std::function<void(size_t)>* fn; size_t n; unsigned nt;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+            if (stop_) return;
+            seen = epoch_; fn = fn_; n = n_; nt = nt_;
+          }
+          if (id < nt) {
+            for (size_t i = id; i < n; i += nt) (*fn)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_one();
+          }
+        }
+      });
+    }
+  }
+  std::mutex call_mu_, mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> th_;
+  const std::function<void(size_t)>* fn_ = nullptr;
+  size_t n_ = 0;
+  unsigned nt_ = 0, pending_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+
 template <class F>
 static void sp_for_games(const std::vector<int32_t>& ids, F fn) {
   const size_t n = ids.size();
   unsigned nt = std::thread::hardware_concurrency();
+  if (const char* e = getenv("ELF_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) nt = (unsigned)v; }   // e.g. nproc / ranks on a shared node
   if (nt > 16) nt = 16;
   if (n < 16 || nt < 2) { for (int g : ids) fn(g); return; }
   if (nt > n / 4) nt = (unsigned)(n / 4);
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (unsigned t = 0; t < nt; ++t)
-    th.emplace_back([&, t]() { for (size_t i = t; i < n; i += nt) fn(ids[i]); });
-  for (auto& x : th) x.join();
+  SpWorkers::get().run(n, nt, [&](size_t i) { fn(ids[i]); });
 }
 
 static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {
@@ -253,6 +313,14 @@ static void sp_ts_into(const ElfTsOptions& t, ElfSpOptions* o) {
   o->persistent_tree = t.persistent_tree != 0; o->pick_method = t.pick_method; o->root_epsilon = t.root_epsilon; o->root_alpha = t.root_alpha;
   o->mcts.virtual_loss = t.virtual_loss; o->mcts.use_prior = t.use_prior != 0; o->mcts.unexplored_q_zero = t.unexplored_q_zero != 0;
   o->mcts.root_unexplored_q_zero = t.root_unexplored_q_zero != 0; o->mcts.c_puct = t.c_puct;
+}
+// the fields of a request's TSOptions that the tree pools are built from (what sp_ts_into stores): max_num_moves, seed, verbose*,
+// log_prefix take part in ModelPair::operator== (sp_ts_equal) but never in the shape of a pool
+static bool sp_ts_pool_equal(const ElfTsOptions& a, const ElfTsOptions& b) {
+  return a.num_threads == b.num_threads && a.num_rollouts_per_thread == b.num_rollouts_per_thread && a.num_rollouts_per_batch == b.num_rollouts_per_batch &&
+         (a.persistent_tree != 0) == (b.persistent_tree != 0) && a.pick_method == b.pick_method && a.root_epsilon == b.root_epsilon &&
+         a.root_alpha == b.root_alpha && a.virtual_loss == b.virtual_loss && (a.use_prior != 0) == (b.use_prior != 0) && a.c_puct == b.c_puct &&
+         (a.unexplored_q_zero != 0) == (b.unexplored_q_zero != 0) && (a.root_unexplored_q_zero != 0) == (b.root_unexplored_q_zero != 0);
 }
 static bool sp_ts_equal(const ElfTsOptions& a, const ElfTsOptions& b) {      // TSOptions::operator== (tree_search_options.h:133-180)
   return a.max_num_moves == b.max_num_moves && a.num_threads == b.num_threads && a.num_rollouts_per_thread == b.num_rollouts_per_thread &&
@@ -390,7 +458,7 @@ static int sp_poll_requests(ElfSelfPlay* sp) {
       if (sp->mailbox.empty()) return 0;
       sp->cur = sp->mailbox.front();
       sp->mailbox.pop_front();
-      sp->cur_done = false; sp->cur_restarted = false;
+      sp->cur_done = false; sp->cur_restarted = false; sp->cur_n_restart = 0;
     }
     std::vector<int32_t> restart;
     int pending = 0;
@@ -403,15 +471,20 @@ static int sp_poll_requests(ElfSelfPlay* sp) {
       if (r.thread_used >= 0 && g >= r.thread_used) r.set_wait();   // DispatcherCallback::OnFirstSend :28-44
       if (sp_on_receive(sp, g, r, &sp->cur_restarted)) restart.push_back(g);
     }
+    sp->cur_n_restart += (int)restart.size();
     SPCHK(sp_restart_games(sp, restart));
     if (pending) return 0;
     // every game has replied: OnReply :46-103
     if (sp->cur_restarted) {
       sp->game_starts++;
       sp->start_black = sp->cur.black_ver; sp->start_white = sp->cur.white_ver;
-      // the restarted games' AIs are built from the request's TSOptions (restart() :166-180): every restarted game is idle at the
-      // barrier now, the others wait for a request, so the pools can be rebuilt for other options
-      if (!sp_ts_equal(sp->cur.ts, sp_ts_of(sp->opt))) SPCHK(sp_apply_ts(sp, sp->cur.ts));
+      // the restarted games' AIs are built from the request's TSOptions (restart() :166-180).  The pools belong to the whole
+      // context, so they are rebuilt for other options only when some game actually restarted (an async model update restarts
+      // nobody: setAsync :150-156 only clears required_version, the AIs keep the TSOptions they were built with) and no game is
+      // in the middle of play under the old options -- then every playing game is idle at the barrier and holds no tree.
+      bool playing_on = false;
+      for (const SpGame& gm : sp->games) playing_on = playing_on || gm.phase == PH_PLAY;
+      if (sp->cur_n_restart > 0 && !playing_on && !sp_ts_pool_equal(sp->cur.ts, sp_ts_of(sp->opt))) SPCHK(sp_apply_ts(sp, sp->cur.ts));
     }
     for (SpGame& gm : sp->games) if (gm.phase == PH_BARRIER) gm.phase = PH_PLAY;
     sp->cur_done = true;

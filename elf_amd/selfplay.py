@@ -200,15 +200,23 @@ class SelfPlay:
         check(self.L.elfsp_set_request3(self._h, C.byref(request), C.byref(mcts_opt) if mcts_opt is not None else None))
 
     def _grow_rows(self, rows, rows_white):
-        if rows > self.max_rows or (getattr(self, "s_white", None) is not None and rows_white > self.max_rows_white):
-            torch.cuda.synchronize(self.device)      # nothing may still be reading the row tensors that are replaced
-        if rows > self.max_rows:
+        grow_b = rows > self.max_rows
+        grow_w = getattr(self, "s_white", None) is not None and rows_white > self.max_rows_white
+        if grow_b or grow_w:
+            torch.cuda.synchronize(self.device)      # nothing may still be reading or writing the row tensors that are replaced
+        if grow_b:
+            # a step may be open (PipelinedSelfPlay has always run begin_step for the next step already): its rows sit in the old
+            # tensor and the coming end_step evaluates self.s[:rows] -- they move into the front of the new one
+            new = self._alloc_rows(rows)
+            new[:self.max_rows].copy_(self.s)
             self.max_rows = rows
-            self.s = self._alloc_rows(rows)
+            self.s = new
         self._want_white = max(getattr(self, "_want_white", 0), rows_white)
-        if getattr(self, "s_white", None) is not None and rows_white > self.max_rows_white:
+        if grow_w:
+            new = self._alloc_rows(rows_white)
+            new[:self.max_rows_white].copy_(self.s_white)
             self.max_rows_white = rows_white
-            self.s_white = self._alloc_rows(rows_white)
+            self.s_white = new
 
     def _alloc_rows(self, rows):
         if self.feature_format == "f16_nhwc":

@@ -306,7 +306,11 @@ class ReplayBuffer:
         """one finished game (Record JSON text / dict) -> the queue it went to"""
         r = rec if isinstance(rec, dict) and "moves" in rec else parse_record(self.loader.n, rec)
         slot = self._free.pop()
-        self.loader.put(slot, r)
+        try:
+            self.loader.put(slot, r)
+        except Exception:
+            self._free.append(slot)              # a refused record (too long, malformed policies) must not leak its slot
+            raise
         q, ev = self.queues.insert(slot, len(r["moves"]), r["reward"] > 0)
         if ev >= 0:
             self._free.append(ev)

@@ -383,7 +383,7 @@ def test_config3_real_net_against_the_real_reference_stack(elf):
         assert res["searches_compared"] == moves
         assert res["decision_diverged"] == 0, res
         assert res["bit_equal"] + res["reward_ulps_only"] == moves, res
-        assert res["max_reward_ulps"] <= 64, res
+        assert res["max_reward_ulps"] <= 2, res   # 1 ulp is the most ever seen (3 of 138 searches, profiles/r03a_, r03m_): hazard H2
         assert engine_only_rows == 0          # the engine asked the net for positions the reference asked for, nothing else
         for k in range(moves):
             assert ref[0][k]["total_visits"] == got[0][k]["total_visits"]

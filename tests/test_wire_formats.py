@@ -68,6 +68,22 @@ def test_request_texts(built, wire):
     for bad in ("", "{", "[]", '{"seq":1}', '{"request":{},"seq":1}', r["text"] + "x", r["text"][:-1]):
         with pytest.raises(elf_amd.ElfGoError):
             elf_amd.parse_request_seq(bad)
+    # the JSON grammar itself, as nlohmann enforces it: numbers (no hex, no leading '+' or zeros, no inf / nan, digits after '.' and
+    # the exponent mark), string escapes (known ones only, no raw control characters, well-formed surrogate pairs)
+    good = r["text"]
+    assert '"seq":' in good
+    head, tail = good.rsplit('"seq":', 1)
+    num_end = len(tail) - len(tail.lstrip("-0123456789"))
+    for lit in ("0x10", "+1", "01", "1.", ".5", "1e", "1e+", "inf", "nan", "-", "--1"):
+        with pytest.raises(elf_amd.ElfGoError):
+            elf_amd.parse_request_seq(head + '"seq":' + lit + tail[num_end:])
+    for lit in ("7", "-0", "1e2", "1.5E+1", "12.25"):
+        elf_amd.parse_request_seq(head + '"seq":' + lit + tail[num_end:])
+    for strbad in ('"a\\qb"', '"a\tb"', '"\\ud83d"', '"\\ude00"', '"\\ud83d\\u0041"', '"\\u12g4"'):
+        with pytest.raises(elf_amd.ElfGoError):
+            elf_amd.parse_request_seq(good[:-1] + ',"extra":' + strbad + "}")
+    for strok in ('"a\\/b\\"c\\\\"', '"\\ud83d\\ude00"', '"\\u00e9"'):
+        elf_amd.parse_request_seq(good[:-1] + ',"extra":' + strok + "}")
 
 
 def test_reference_server_reads_our_messages(built, wire):
