@@ -272,29 +272,63 @@ def self_spawn(n):
     os.execv(sys.executable, cmd)
 
 
+DIST_INFO = {}
+
+
 def init_dist(args):
+    """-> (rank, device index, world, dist).  One process per GPU (SURVEY.md 8e: independent games per GPU, no data-path collective);
+    the process group only carries the barrier and the max-time / sum-count reduction of the report.  ELF_BENCH_SHARE_GPU=1 maps
+    every rank onto the visible GPUs round-robin (two ranks on the one GPU of a development box: the world > 1 code path on real
+    kernels) and moves the process group to gloo (RCCL refuses two ranks on one device)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    share = os.environ.get("ELF_BENCH_SHARE_GPU", "0") == "1"
+    device = local_rank
+    if share and torch.cuda.is_available():
+        device = local_rank % torch.cuda.device_count()
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("ELF_BENCH_BACKEND", "nccl")   # "gloo" only in the CPU test of this path
+        # every rank tunes and caches its convolutions in its own MIOpen user database: N concurrent finds on one sqlite file
+        # serialise on its lock (and have been seen to corrupt it)
+        mi = os.path.join(os.environ.get("TMPDIR", "/tmp"), "elf_amd_miopen", "rank%d" % rank)
+        os.makedirs(mi, exist_ok=True)
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", mi)
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", mi)
+        # the host side of a rank (boundary threads, torch's intra-op pool) gets its own slice of the cores, as one client process
+        # per GPU would be pinned on a node (README.rst:132-134)
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // max(1, local_world))
+        mine = cores[(local_rank % local_world) * per:(local_rank % local_world + 1) * per] or cores
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            mine = cores
+        os.environ.setdefault("ELF_AMD_HOST_THREADS", str(max(1, min(16, len(mine)))))
+        torch.set_num_threads(max(1, len(mine)))
+        backend = os.environ.get("ELF_BENCH_BACKEND", "gloo" if share else "nccl")   # "gloo": the CPU test of this path / shared GPU
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
+        DIST_INFO.update(backend=backend, host_cores_per_rank=len(mine), ranks_share_one_gpu=bool(share),
+                         miopen_user_db="per rank (%s)" % os.path.dirname(mi))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-    if world > 1:
-        # one process per GPU on one node: keep the host-side thread pools of the ranks from oversubscribing the cores
-        torch.set_num_threads(max(1, len(os.sched_getaffinity(0)) // world))
-    return rank, local_rank, world, dist
+        torch.cuda.set_device(device)
+    return rank, device, world, dist
+
+
+def _reduce_dev(dist, dev):
+    """gloo reduces host tensors (its device support is optional in a ROCm build); RCCL reduces on the rank's GPU"""
+    return torch.device("cpu") if (dist is not None and dist.get_backend() != "nccl") else dev
 
 
 def reduce_max_sum(dist, dev, dt, count):
+    dev = _reduce_dev(dist, dev)
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
     s_all = torch.tensor([count], dtype=torch.int64, device=dev)
     if dist is not None:
@@ -306,7 +340,7 @@ def reduce_max_sum(dist, dev, dt, count):
 def gather_per_rank(dist, dev, value, world):
     if dist is None:
         return [value]
-    t = torch.zeros(world, dtype=torch.float64, device=dev)
+    t = torch.zeros(world, dtype=torch.float64, device=_reduce_dev(dist, dev))
     t[dist.get_rank()] = value
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t.tolist()]
@@ -320,8 +354,11 @@ def scaling_report(world, value, per_rank, key):
     return {"n_gpus": world, "per_rank": per_rank, "sum_over_ranks": float(sum(per_rank)) if per_rank else None,
             "n1_reference": ref, "n1_reference_source": load_profile_json("headline_n1.json").get("source"),
             "per_gpu_fraction_of_n1": (value / world / ref) if (ref and world) else None,
-            "measured_curve": "none: no multi-GPU node was available to the builder; N > 1 is covered by the gloo tests and, on a node, by "
-                              "running this command with --gpus 2/4/8"}
+            "process_group": dict(DIST_INFO),
+            "measured_curve": "none: no multi-GPU node was available to the builder.  The N > 1 path has run on real kernels with two ranks "
+                              "sharing ONE GPU (ELF_BENCH_SHARE_GPU=1, gloo; profiles/r04*_two_ranks_one_gpu.json: that line exercises the "
+                              "world > 1 code, its per-GPU fraction says nothing about scaling) and in the gloo tests; on a node, run this "
+                              "command with --gpus 2/4/8"}
 
 
 def make_barrier(dist):

@@ -53,3 +53,35 @@ def test_bench_spawns_its_own_ranks():
     assert sr["n_gpus"] == 2 and len(sr["per_rank"]) == 2 and abs(sr["sum_over_ranks"] - sum(sr["per_rank"])) < 1e-6
     assert set(sr) >= {"per_rank", "sum_over_ranks", "n1_reference", "per_gpu_fraction_of_n1", "measured_curve"}
     assert "no multi-GPU node" in sr["measured_curve"]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_on_the_real_workloads():
+    """The world > 1 branches of run_mcts / run_games on real kernels: two ranks on the one GPU of this box (ELF_BENCH_SHARE_GPU=1,
+    process group over gloo), a small net and few rollouts.  Each rank plays its own games (game_idx_base = rank x games), the line
+    carries the slowest rank's time, the sum of the rollouts and of the finished games, and the per-rank values."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ELF_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "both", "--games", "32", "--groups", "2",
+                        "--rollouts", "64", "--steps", "6", "--warmup", "2", "--net-blocks", "2", "--net-dim", "32",
+                        "--games-rollouts", "16", "--games-cutoff", "6", "--games-generations", "2"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 2 and rep["steps"] == 6 and rep["scaling"] == "weak"
+    cfg = rep["config"]
+    assert cfg["games_per_gpu"] == 32 and cfg["rollouts_per_step"] == 32 * 16
+    # value = rollouts of BOTH ranks / the slowest rank's time
+    assert abs(rep["value"] - 2 * 32 * 16 * 6 / (rep["ms_per_step"] * 6 / 1e3)) < 1e-6 * rep["value"]
+    sr = cfg["scaling_report"]
+    assert len(sr["per_rank"]) == 2 and all(v > 0 for v in sr["per_rank"])
+    assert sr["process_group"]["backend"] == "gloo" and sr["process_group"]["ranks_share_one_gpu"] is True
+    assert rep["cpu_baseline"] is None                      # timed on rank 0 at N = 1 only
+    gm = rep["selfplay_games"]
+    assert gm["n_gpus"] == 2 and len(gm["per_rank_games_per_sec"]) == 2
+    assert gm["games_finished"] >= 2 * 32                   # both ranks finished at least one generation of their games

@@ -1,0 +1,133 @@
+// GPU-box tool (not part of the library): instruction-issue roofs of one gfx950 CU, measured -- scalar ALU, vector ALU and the two
+// together, with 1 / 2 / 4 / 8 resident waves per SIMD.  The board kernels live in LDS and registers and move their control to
+// SGPRs on purpose (169 SALU beside 236 VALU instructions per 19x19 board step), so the scalar unit -- ONE per CU, shared by the
+// four SIMDs (MI355X_MICROARCH.md "Terms") -- may be the binding roof; bench.py prices the kernels against both.
+//   hipcc --offload-arch=gfx950 -O2 tools/issue_probe.hip -o build/issue_probe && build/issue_probe > profiles/r04_issue_probe.json
+// Every kernel runs ITER iterations of a straight-line block of 128 instructions of one kind (8 independent register chains, so the
+// chains never bind); the loop adds 3 scalar instructions + 1 branch per 128 (1.6 %, counted).  Rate = instructions / shader clock /
+// CU, from the wall time of the launch (hipEvents) at the clock the launch really ran at (GRBM-free estimate: s_memtime deltas of
+// every wave, which tick at the shader clock on this part, give cycles per wave; wall time x 2.4 GHz is printed beside it).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+
+#define REP8(x) x x x x x x x x
+#define REP16(x) REP8(x) REP8(x)
+
+enum { M_SADD = 0, M_SAND64, M_SMUL, M_SLSHL64, M_SBCNT64, M_SCSEL, M_VADD, M_VAND_OR, M_VCMP, M_READLANE, M_MIX11, M_MIX21, M_MIX12, M_DEP_VADD, M_DEP_SADD, M_COUNT };
+static const char* kNames[M_COUNT] = {"s_add_u32", "s_and_b64", "s_mul_i32", "s_lshl_b64", "s_bcnt1_i32_b64", "s_cselect_b32", "v_add_u32", "v_and_or_b32",
+                                      "v_cmp_eq_u32 (VALU writing an SGPR pair)", "v_readlane_b32", "mix 1 SALU : 1 VALU", "mix 2 SALU : 1 VALU",
+                                      "mix 1 SALU : 2 VALU", "v_add_u32 dependent chain", "s_add_u32 dependent chain"};
+static const int kSalu[M_COUNT] = {128, 128, 128, 128, 128, 128, 0, 0, 0, 0, 64, 86, 43, 0, 128};   // per 128-instruction block (mixes below)
+static const int kValu[M_COUNT] = {0, 0, 0, 0, 0, 0, 128, 128, 128, 128, 64, 42, 85, 128, 0};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_probe(unsigned long long* cyc, unsigned* sink, int iters) {
+  unsigned s0 = blockIdx.x, s1 = 1, s2 = 2, s3 = 3, s4 = 4, s5 = 5, s6 = 6, s7 = 7;
+  unsigned v0 = threadIdx.x, v1 = 1, v2 = 2, v3 = 3, v4 = 4, v5 = 5, v6 = 6, v7 = 7;
+  unsigned long long q0 = blockIdx.x + 1, q1 = 3, q2 = 5, q3 = 7;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == M_SADD) {
+      asm volatile(REP16("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n")
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : : "scc");
+    } else if (MODE == M_DEP_SADD) {
+      asm volatile(REP16(REP8("s_add_u32 %0, %0, 1\n")) : "+s"(s0) : : "scc");
+    } else if (MODE == M_SAND64) {
+      asm volatile(REP16("s_and_b64 %0, %0, %1\n s_and_b64 %1, %1, %2\n s_and_b64 %2, %2, %3\n s_and_b64 %3, %3, %0\n s_or_b64 %0, %0, %1\n s_or_b64 %1, %1, %2\n s_or_b64 %2, %2, %3\n s_or_b64 %3, %3, %0\n")
+                   : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3) : : "scc");
+    } else if (MODE == M_SMUL) {
+      asm volatile(REP16("s_mul_i32 %0, %0, 3\n s_mul_i32 %1, %1, 3\n s_mul_i32 %2, %2, 3\n s_mul_i32 %3, %3, 3\n s_mul_i32 %4, %4, 3\n s_mul_i32 %5, %5, 3\n s_mul_i32 %6, %6, 3\n s_mul_i32 %7, %7, 3\n")
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7));
+    } else if (MODE == M_SLSHL64) {
+      asm volatile(REP16("s_lshl_b64 %0, %0, 1\n s_lshr_b64 %1, %1, 1\n s_lshl_b64 %2, %2, 1\n s_lshr_b64 %3, %3, 1\n s_lshl_b64 %0, %0, 1\n s_lshr_b64 %1, %1, 1\n s_lshl_b64 %2, %2, 1\n s_lshr_b64 %3, %3, 1\n")
+                   : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3) : : "scc");
+    } else if (MODE == M_SBCNT64) {
+      asm volatile(REP16("s_bcnt1_i32_b64 %0, %4\n s_bcnt1_i32_b64 %1, %5\n s_bcnt1_i32_b64 %2, %6\n s_bcnt1_i32_b64 %3, %7\n s_bcnt1_i32_b64 %0, %4\n s_bcnt1_i32_b64 %1, %5\n s_bcnt1_i32_b64 %2, %6\n s_bcnt1_i32_b64 %3, %7\n")
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "s"(q0), "s"(q1), "s"(q2), "s"(q3) : "scc");
+    } else if (MODE == M_SCSEL) {
+      asm volatile(REP16("s_cmp_lg_u32 %0, 0\n s_cselect_b32 %1, %2, %3\n s_cmp_lg_u32 %1, 0\n s_cselect_b32 %4, %5, %6\n s_cmp_lg_u32 %4, 0\n s_cselect_b32 %7, %2, %3\n s_cmp_lg_u32 %7, 0\n s_cselect_b32 %0, %5, %6\n")
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : : "scc");
+    } else if (MODE == M_VADD) {
+      asm volatile(REP16("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_DEP_VADD) {
+      asm volatile(REP16(REP8("v_add_u32 %0, %0, 1\n")) : "+v"(v0));
+    } else if (MODE == M_VAND_OR) {
+      asm volatile(REP16("v_and_or_b32 %0, %0, %1, %2\n v_and_or_b32 %1, %1, %2, %3\n v_and_or_b32 %2, %2, %3, %4\n v_and_or_b32 %3, %3, %4, %5\n v_and_or_b32 %4, %4, %5, %6\n v_and_or_b32 %5, %5, %6, %7\n v_and_or_b32 %6, %6, %7, %0\n v_and_or_b32 %7, %7, %0, %1\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_VCMP) {
+      asm volatile(REP16("v_cmp_eq_u32 %0, %4, %5\n v_cmp_eq_u32 %1, %5, %6\n v_cmp_eq_u32 %2, %6, %7\n v_cmp_eq_u32 %3, %7, %4\n v_cmp_ne_u32 %0, %4, %5\n v_cmp_ne_u32 %1, %5, %6\n v_cmp_ne_u32 %2, %6, %7\n v_cmp_ne_u32 %3, %7, %4\n")
+                   : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+    } else if (MODE == M_READLANE) {
+      asm volatile(REP16("v_readlane_b32 %0, %8, 0\n v_readlane_b32 %1, %9, 1\n v_readlane_b32 %2, %10, 2\n v_readlane_b32 %3, %11, 3\n v_readlane_b32 %4, %8, 4\n v_readlane_b32 %5, %9, 5\n v_readlane_b32 %6, %10, 6\n v_readlane_b32 %7, %11, 7\n")
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+    } else if (MODE == M_MIX11) {
+      asm volatile(REP16("s_add_u32 %0, %0, 1\n v_add_u32 %4, %4, 1\n s_add_u32 %1, %1, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %2, %2, 1\n v_add_u32 %6, %6, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %7, %7, 1\n")
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "scc");
+    } else if (MODE == M_MIX21) {   // 42 x (2 SALU + 1 VALU) + 2 SALU = 86 SALU + 42 VALU
+      asm volatile(REP8("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n v_add_u32 %4, %4, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n v_add_u32 %6, %6, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %7, %7, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n v_add_u32 %4, %4, 1\n")
+                   "s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n v_add_u32 %6, %6, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "scc");
+    } else if (MODE == M_MIX12) {   // 42 x (1 SALU + 2 VALU) + 1 SALU + 1 VALU = 43 SALU + 85 VALU
+      asm volatile(REP8("s_add_u32 %0, %0, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %1, %1, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n s_add_u32 %2, %2, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n s_add_u32 %0, %0, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n")
+                   "s_add_u32 %1, %1, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n s_add_u32 %2, %2, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %6, %6, 1\n"
+                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "scc");
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+  const unsigned r = s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7 ^ v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7 ^ (unsigned)(q0 ^ q1 ^ q2 ^ q3);
+  if (r == 0x12345678u) sink[0] = r;   // keeps every chain alive
+}
+
+typedef void (*kern_t)(unsigned long long*, unsigned*, int);
+static kern_t kKernels[M_COUNT] = {k_probe<0>, k_probe<1>, k_probe<2>, k_probe<3>, k_probe<4>, k_probe<5>, k_probe<6>, k_probe<7>, k_probe<8>, k_probe<9>,
+                                   k_probe<10>, k_probe<11>, k_probe<12>, k_probe<13>, k_probe<14>};
+
+int main() {
+  hipDeviceProp_t pr;
+  hipGetDeviceProperties(&pr, 0);
+  const int cus = pr.multiProcessorCount;
+  const int iters = 2000;
+  unsigned long long* d_cyc; unsigned* d_sink;
+  const int max_waves = cus * 32;
+  hipMalloc((void**)&d_cyc, 8 * (size_t)max_waves); hipMalloc((void**)&d_sink, 64);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz_prop\": %d, \"block\": \"128 instructions x %d iterations per wave; 256-thread workgroups, W workgroups per CU = W waves per SIMD\",\n \"rows\": [\n", pr.gcnArchName, cus, pr.clockRate / 1000, iters);
+  bool first = true;
+  for (int m = 0; m < M_COUNT; ++m) {
+    for (int w : {1, 2, 4, 8}) {
+      const int wgs = cus * w;
+      float best_ms = 1e30f;
+      std::vector<unsigned long long> h(wgs * 4);
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kKernels[m], dim3(wgs), dim3(256), 0, 0, d_cyc, d_sink, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best_ms) best_ms = ms;
+      }
+      hipMemcpy(h.data(), d_cyc, 8 * (size_t)wgs * 4, hipMemcpyDeviceToHost);
+      double cyc_mean = 0; unsigned long long cyc_max = 0;
+      for (auto c : h) { cyc_mean += (double)c; if (c > cyc_max) cyc_max = c; }
+      cyc_mean /= (double)h.size();
+      const double per_wave = (double)iters * 132.0;           // 128 + s_add / s_cmp / s_cbranch + (uncounted) loop bookkeeping ~ 4
+      const double salu_w = (double)iters * (kSalu[m] + 3), valu_w = (double)iters * kValu[m];
+      const double waves_per_cu = 4.0 * w;
+      // per CU and shader clock, clock taken from the slowest wave's own cycle counter (all waves of a CU run concurrently)
+      const double salu_clk_cu = salu_w * waves_per_cu / (double)cyc_max, valu_clk_cu = valu_w * waves_per_cu / (double)cyc_max;
+      const double wall_cycles_24 = best_ms * 1e-3 * 2.4e9;
+      printf("%s  {\"kind\": \"%s\", \"waves_per_simd\": %d, \"wall_ms\": %.4f, \"wave_cycles_mean\": %.0f, \"wave_cycles_max\": %llu, \"cycles_per_instruction_per_wave\": %.3f,"
+             " \"salu_per_clk_per_cu\": %.4f, \"valu_per_clk_per_cu\": %.4f, \"valu_per_clk_per_simd\": %.4f, \"wall_x_2.4GHz_cycles\": %.0f}",
+             first ? "" : ",\n", kNames[m], w, best_ms, cyc_mean, cyc_max, cyc_mean / per_wave, salu_clk_cu, valu_clk_cu, valu_clk_cu / 4.0, wall_cycles_24);
+      first = false;
+    }
+  }
+  printf("\n ]}\n");
+  return 0;
+}
