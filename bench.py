@@ -43,6 +43,13 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz max clock
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s = 1228.8
+# The scalar ALU: ONE per CU, shared by its four SIMDs.  Measured on this part (tools/issue_probe.hip, profiles/r04a_issue_probe.json):
+# 1.00 scalar instruction per clock per CU for every SALU class tried (s_add / s_and_b64 / s_mul_i32 / s_lshl_b64 / s_bcnt1 / s_cselect),
+# reached from 4 waves per CU on; a VALU stream issues beside it at full rate.  The same probe puts the VALU peak at 1.82 per clock and
+# CU for plain VOP2 (v_add_u32; the 2-cycle wave64 rate would be 2.0) but at 1.0 per clock and CU -- one per 4 cycles per SIMD -- for
+# 3-source VOP3 (v_and_or_b32), vector compares that write an SGPR pair and v_readlane, which the board kernels are full of; and a single
+# wave issues at most one instruction per 4.1 - 4.2 cycles whatever its kind.
+SALU_PEAK_GINST = 256 * 1.0 * 2.4       # G scalar instructions / s = 614.4
 STEP_BYTES = {19: 8730, 9: 4450}  # reference state in + out + legal mask, per board step
 FEAT_BYTES = {("f32", 19): 26728, ("f32", 9): 6008, ("f16", 19): 13732, ("f16", 9): 3092}   # row written + 16 history bit-planes read
 # SURVEY.md 8d, algorithmic bytes of one MCTS rollout: per visited node 362 x 20 B edge read + 12 B vloss write + 12 B backup
@@ -109,7 +116,15 @@ def issue_roof(kernel, units_per_launch, kernel_s):
                 "note": "profiles/pmc_issue.json was measured on other kernel sources than the tree holds (kernel_source_hash differs): "
                         "no issue-roof fraction is derived from stale instruction counts; re-run tools/gpu_r3_pmc.sh + tools/update_issue.py"}
     ach = units_per_launch * valu / kernel_s / 1e9
+    salu = per.get("salu_per_unit")
+    salu_ach = units_per_launch * salu / kernel_s / 1e9 if salu else None
+    salu_frac = salu_ach / SALU_PEAK_GINST if salu_ach else None
+    binding = "salu" if (salu_frac is not None and salu_frac > ach / VALU_PEAK_GINST) else "valu"
     return {"bound": "issue", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": ach / VALU_PEAK_GINST,
+            "salu_issue": {"achieved": salu_ach, "peak": SALU_PEAK_GINST, "unit": "G scalar instructions/s", "frac": salu_frac,
+                           "note": "one scalar ALU per CU at a measured 1.00 instruction per clock (profiles/r04a_issue_probe.json): "
+                                   "SQ_INSTS_SALU per unit x units/s / (256 CUs x 2.4 GHz)"},
+            "salu_issue_frac": salu_frac, "binding_issue_roof": binding, "binding_frac": max(ach / VALU_PEAK_GINST, salu_frac or 0.0),
             "traffic": load_traffic(kernel), "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "valu_per_unit": valu, "pmc_source_match": True,
             "pmc_source_hash": load_profile_json("pmc_issue.json").get("_source", {}).get("kernel_source_hash"),
             "salu_per_unit": per.get("salu_per_unit"), "lds_per_unit": per.get("lds_per_unit"),
@@ -666,7 +681,6 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl]
                    + (", one HIP graph per net call" if args.net_graph else ""), feat_fmt)
                 if net is not None else "NO conv net (--net %s: search kernels only)" % args.net)
-    moves_per_game = 250.0
     res = {
         "metric": "mcts_rollouts_per_sec (self-play, %dx%d Go, %d rollouts/move, bs %d)" % (n, n, args.rollouts * T, K),
         "value": roll_all / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -691,9 +705,9 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                          "first waited for the steps the host had queued ahead (pipeline depth; the GPU is busy meanwhile). Both "
                                          "are inside ms_per_step" % Gg,
                    "moves_per_sec": roll_all / dt_max / (args.rollouts * T),
-                   "games_per_sec_estimated": roll_all / dt_max / (args.rollouts * T) / moves_per_game,
-                   "games_per_sec_note": "ESTIMATED, not measured: rollouts/s / (rollouts per move x 250 moves per game) -- a 19x19 game at "
-                                         "8192 rollouts/move takes hours; measured games/s on a shortened configuration: selfplay_games",
+                   "games_per_sec_note": "games/s of this configuration is MEASURED in the sub-result selfplay_games: moves/s at plies 0 / 60 / 120 / "
+                                         "180 of recorded games over the measured length of games played to their natural end (no assumed game "
+                                         "length; round 3 divided by an assumed 250 moves)",
                    "per_rank_rollouts_per_sec": per_rank,
                    "scaling_report": scaling_report(world, roll_all / dt_max, per_rank, "mcts_rollouts_per_sec"),
                    "parity_note": PARITY_NOTE,
@@ -824,14 +838,119 @@ def run_games(args, rank, local_rank, world, dist):
     dt_max, games_all = reduce_max_sum(dist, dev, dt, st["games"])
     per_rank = gather_per_rank(dist, dev, st["games"] / dt, world)
     sp.close()
+    graphs.clear()
+
+    def graphed(spx):
+        """net_fn for a fresh PipelinedSelfPlay: one HIP graph per group's row tensor, as in the headline"""
+        gr = {}
+        if net is not None and args.net_graph:
+            from elf_amd.net import GraphedNet
+            try:
+                for g in spx.groups:
+                    gr[g.s.data_ptr()] = GraphedNet(net, g.s)
+            except Exception:
+                gr = {}
+            torch.cuda.synchronize()
+
+        def fn(s, rows):
+            if net is None:
+                return rnd()
+            gn = gr.get(s.data_ptr())
+            if gn is not None:
+                o = gn()
+            else:
+                with torch.no_grad():
+                    o = net({"s": s})
+            return o["pi"], o["V"]
+        return fn, gr
+
+    # ---- moves/s of the HEADLINE configuration (BASELINE configs[2]: 8192 rollouts/move) by game phase: the games of each group
+    # are put on a recorded 19x19 game (GameOptions.preload_sgf: two of the ladder-suite SGFs with >= 199 moves per phase, one per
+    # group, tests/golden/ladder_suite.npz) at ply 0 / 60 / 120 / 180 and search there for a fixed window.  moves/s = measured
+    # rollouts/s / rollouts per move: what a full-length game costs per move at that stage (legal moves thin out, trees deepen).
+    phases, by_phase = (0, 60, 120, 180), {}
+    lad = np.load(os.path.join(ROOT, "tests", "golden", "ladder_suite.npz")) if n == 19 else None
+    T = max(1, args.mcts_threads)
+    if lad is not None and args.phase_steps > 0:
+        lens = np.diff(lad["offsets"])
+        long_ = [i for i in range(len(lens)) if lens[i] >= 199]
+        for pi_, ply in enumerate(phases):
+            spx = PipelinedSelfPlay(groups=groups, seed=1234 + ply, game_idx_base=rank * G, wait_rows=False, net_streams=args.net_streams, board_size=n,
+                                    num_games=Gg, device=local_rank, mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5,
+                                    mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0,
+                                    policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt, mcts_threads=args.mcts_threads)
+            for gi, g in enumerate(spx.groups):
+                k = long_[(pi_ * groups + gi) % len(long_)]
+                g.preload(lad["moves"][lad["offsets"][k]:lad["offsets"][k + 1]].astype(np.uint16), ply)
+            fn, gr = graphed(spx)
+            for _ in range(max(2, args.phase_steps // 4)):
+                spx.step(fn)
+            spx.synchronize()
+            barrier()
+            tp = time.perf_counter()
+            for _ in range(args.phase_steps):
+                spx.step(fn)
+            spx.synchronize()
+            barrier()
+            dtp = time.perf_counter() - tp
+            dtp_max, roll_p = reduce_max_sum(dist, dev, dtp, Gg * groups * K * T * args.phase_steps)
+            stp = spx.stats()
+            by_phase[str(ply)] = {"rollouts_per_sec": roll_p / dtp_max, "moves_per_sec": roll_p / dtp_max / (args.rollouts * T),
+                                  "ms_per_step": dtp_max / args.phase_steps * 1e3, "net_rows_per_step": stp["rows"] / max(stp["steps"], 1) * groups}
+            spx.close()
+            gr.clear()
+    # ---- how long a game is when nothing cuts it short: the same loop with 16 rollouts per move and few games, no move cutoff, played
+    # to the natural end (two passes, the move limit 2 N^2, or a resignation at resign_thres 0.05) -- MEASURED with the random-init
+    # net this benchmark has (a trained net ends its games much earlier; the number is what this run's games really are)
+    length = None
+    if args.length_games > 0:
+        Gl = max(1, args.length_games // groups)
+        spl = PipelinedSelfPlay(groups=groups, seed=97, game_idx_base=rank * Gl * groups, wait_rows=False, board_size=n, num_games=Gl, device=local_rank,
+                                mcts_rollout_per_thread=K, mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1, mcts_persistent_tree=True,
+                                mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, policy_distri_cutoff=30, resign_thres=0.05, nodes_per_game=2048,
+                                feature_format=feat_fmt, keep_records=0)
+        fn, gr = graphed(spl)
+        limit = 2 * n * n + 8
+        tl = time.perf_counter()
+        for _ in range(limit):
+            spl.step(fn)
+            if _ % 32 == 31 and spl.stats()["games"] >= Gl * groups:
+                break
+        spl.synchronize()
+        stl = spl.stats()
+        length = {"games_finished": stl["games"], "moves_played": stl["moves"], "seconds": time.perf_counter() - tl,
+                  "mean_game_length": (stl["moves"] / stl["games"]) if stl["games"] else None,
+                  "config": "%d games, %d rollouts/move (one step per move), no move cutoff, resign_thres 0.05, random-init net: games end by two "
+                            "passes, the move limit %d, or resignation" % (Gl * groups, K, 2 * n * n)}
+        spl.close()
+        gr.clear()
+    games_from_phases = None
+    if by_phase and length and length["mean_game_length"]:
+        # seconds per game = sum over the plies of a game of 1 / moves_per_sec(phase of that ply): plies [0,60) at the rate measured at
+        # ply 0, [60,120) at ply 60, [120,180) at ply 120, the rest at ply 180; x games in flight = the whole job's games/s
+        Lm, sec, edges = length["mean_game_length"], 0.0, list(phases) + [1e9]
+        for i, ply in enumerate(phases):
+            span = max(0.0, min(Lm, edges[i + 1]) - ply)
+            sec += span / by_phase[str(ply)]["moves_per_sec"]
+        games_from_phases = 1.0 / sec if sec > 0 else None    # moves/s is the job's aggregate over its games in flight: games/s = 1 / sum over a game's plies of 1 / (moves/s)
     if rank != 0:
         return None
-    return {"metric": "selfplay_games_per_sec (MEASURED, shortened configuration)", "value": games_all / dt_max, "unit": "games/s",
-            "n_gpus": world, "games_finished": games_all, "seconds": dt_max, "moves": st["moves"], "records_kept": recs,
+    return {"metric": "selfplay_games_per_sec", "value": games_from_phases if games_from_phases is not None else games_all / dt_max, "unit": "games/s",
+            "n_gpus": world,
+            "value_note": ("headline configuration (%d rollouts/move): measured moves/s by game phase (moves_per_sec_by_phase) over the MEASURED mean "
+                           "game length of this run's games (game_length); no assumed length enters" % (args.rollouts * T)) if games_from_phases is not None
+                          else "measured on the shortened configuration (shortened_run); the phase / length legs were switched off",
+            "moves_per_sec_by_phase": by_phase, "game_length": length,
+            "shortened_run": {"games_per_sec": games_all / dt_max, "games_finished": games_all, "seconds": dt_max, "moves": st["moves"], "records_kept": recs,
+                              "rollouts_per_move": roll, "move_cutoff": cutoff, "games_per_gpu": G,
+                              "workload": "the headline's self-play loop with %d rollouts/move (bs %d) and move_cutoff %d: %d games per GPU, %d generations "
+                                          "of games played to the cutoff, scored, recorded and restarted" % (roll, K, cutoff, G, args.games_generations)},
+            "games_finished": games_all, "seconds": dt_max, "moves": st["moves"], "records_kept": recs,
             "per_rank_games_per_sec": per_rank, "scaling_report": scaling_report(world, games_all / dt_max, per_rank, "selfplay_games_per_sec"),
-            "config": {"workload": "the headline's self-play loop with %d rollouts/move (bs %d) and move_cutoff %d: %d games per GPU, "
-                                   "%d generations of games played to the cutoff, scored, recorded and restarted" % (roll, K, cutoff, G, args.games_generations),
-                       "rollouts_per_move": roll, "move_cutoff": cutoff, "games_per_gpu": G, "net": "resnet" if net is not None else args.net}}
+            "config": {"workload": "games/s of BASELINE configs[2]: measured moves/s at plies 0/60/120/180 of recorded games (%d steps each) and the "
+                                   "measured length of games played to their natural end; beside it the shortened configuration played end to end "
+                                   "(%d rollouts/move, move_cutoff %d, %d generations)" % (args.phase_steps, roll, cutoff, args.games_generations),
+                       "rollouts_per_move": args.rollouts * T, "games_per_gpu": G, "net": "resnet" if net is not None else args.net}}
 
 
 def run_client(args, rank, local_rank, world, dist):
@@ -1175,6 +1294,8 @@ def main():
     ap.add_argument("--games-rollouts", type=int, default=32)
     ap.add_argument("--games-cutoff", type=int, default=40)
     ap.add_argument("--games-generations", type=int, default=2)
+    ap.add_argument("--phase-steps", type=int, default=16, help="timed steps per game phase (plies 0/60/120/180) of the games/s leg; 0 = off")
+    ap.add_argument("--length-games", type=int, default=32, help="games played to their natural end to measure the game length; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="headline only (no sub-results)")
     args = ap.parse_args()

@@ -119,6 +119,8 @@ SIGNATURES = {
     "elftrain_max_moves": (_i, [_vp]),
     "elftrain_num_records": (_i, [_vp]),
     "elftrain_put": (_i, [_vp, _i, _vp, _i, _f, _i64, _vp, _i, _vp, _i]),
+    "elftrain_put_async": (_i, [_vp, _i, _vp, _i, _f, _i64, _vp, _i, _vp, _i, _vp]),
+    "elftrain_set_keep_states": (_i, [_vp, _i]),
     "elftrain_draw": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "elftrain_extract": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "elfrec_coords_to_sgfstr": (_i, [_i, _vp, _i, _vp, _sz]),

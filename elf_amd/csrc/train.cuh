@@ -2,6 +2,12 @@
 // sampled ply with the board engine of go_board.cuh (position in LDS for the whole replay) and emits every field of the
 // reference's "train" batch in one launch.
 //
+// The reference replays every sample from the empty board (switchBeforeMove: reset + forward x move_to, ~160 forwards per sample).
+// The result of that replay is a pure function of (record, move_to), so the store keeps, per record, the state after every
+// CK_INTERVAL-th move (written once, by k_replay_checkpoint when the record is put) and the superko records of the whole game;
+// a sample then loads the checkpoint below its move_to and forwards at most CK_INTERVAL - 1 moves -- same state, same rows, a
+// tenth of the board steps.  HBM is 288 GB: 22 checkpoints x 3840 B + 724 x 104 B of superko records = 160 KB per 19x19 record.
+//
 // Replaces, for a batch of n samples, what one reference game thread does per sample:
 //   src_cpp/elfgames/go/train/game_train.cc          GoGameTrain::act :23-58
 //   src_cpp/elfgames/go/common/go_state_ext.h        GoStateExtOffline::fromRecord :248-258, switchBeforeMove :283-290
@@ -25,8 +31,52 @@ struct ReplayStore {
   int32_t* num_pol;      // [capacity] Record.result.policies.size()
   float* values;         // [capacity][max_moves] Record.result.values
   int32_t* num_values;   // [capacity]
-  int capacity, max_moves;
+  void* ckpt;            // [capacity][nck] Slot<N>: the state after the first (j + 1) * CK_INTERVAL moves of the record
+  u64* skrec;            // [capacity][max_moves + 2][SKW] superko records of the record's whole game (GoState::_board_hashes)
+  int capacity, max_moves, nck;
 };
+constexpr int CK_INTERVAL = 32;
+#define REPLAY_WAVES_CK 4
+
+// Superko records of a REPLAYED record: every pre-move position of the game is already in the store (k_replay_checkpoint wrote
+// them when the record was put), so a replay from a checkpoint stores nothing and consults them only on a Bloom hit --
+// same hit rule as go_state.cc:96-111.
+template <int N>
+struct ReplaySK {
+  const u64* rec;
+  __device__ __forceinline__ void record(int, u64, u64, u64, int) const {}
+  __device__ __forceinline__ bool exact_hit(int sk_len, u64 hash, u64 Bw, u64 Ww, int lane) const {
+    return GameSK<N>::scan(rec, sk_len, hash, sk_record_word<N>(hash, Bw, Ww, lane), lane);
+  }
+};
+
+// One wave per record, once per put (launched by the next elftrain_extract for every record put since the last one): the whole
+// game from the empty board (exactly the loop of switchBeforeMove), the superko records into the store, the board slot into a
+// checkpoint after every CK_INTERVAL-th move.
+template <int N, class PoolT>
+__global__ __launch_bounds__(64 * REPLAY_WAVES_CK) void k_replay_checkpoint(PoolT pool, ReplayStore st, const int32_t* slots, int n) {
+  using G = Geo<N>;
+  __shared__ Slot<N> lds_all[REPLAY_WAVES_CK];
+  __shared__ u64 zlds[G::P];
+  for (int j = threadIdx.x; j < G::P; j += 64 * REPLAY_WAVES_CK) zlds[j] = pool.zob[j];
+  __syncthreads();
+  const int wv = rfl((int)(threadIdx.x >> 6));
+  const int i = blockIdx.x * REPLAY_WAVES_CK + wv;
+  if (i >= n) return;
+  const int r = rfl(slots[i]);
+  const int nm = rfl(st.num_moves[r]);
+  const u16* mv = st.moves + (size_t)r * st.max_moves;
+  Board<N> bd;
+  bd.init(&lds_all[wv], pool.zob, st.skrec + (size_t)r * (st.max_moves + 2) * G::SKW);
+  bd.reset();
+  bd.playout_begin(zlds);
+  Slot<N>* ck = reinterpret_cast<Slot<N>*>(st.ckpt) + (size_t)r * st.nck;
+  for (int t = 0; t < nm; ++t) {
+    const int c = rfl((int)mv[t]);
+    if (c != M_INVALID) bd.forward(c);           // a refused move is skipped like any other (see k_replay_extract)
+    if ((t + 1) % CK_INTERVAL == 0 && (t + 1) / CK_INTERVAL <= st.nck) bd.store(&ck[(t + 1) / CK_INTERVAL - 1]);
+  }
+}
 
 struct TrainBatch {   // device pointers; any of them except `s` may be NULL
   void* s; int64_t s_stride; int fmt;
@@ -56,7 +106,10 @@ __device__ __forceinline__ int coord_to_action(int c, int d4) {
 // is a dependent latency chain per wave (a replay of ~160 plies), so what it needs is resident waves: elftrain_extract takes
 // any number of samples per launch (several train batches at once: the trainer prefetches).
 #define REPLAY_WAVES 4
-template <int N, class PoolT>
+// KEEP = true: the reference's own procedure (from the empty board, superko records of sample i into board slot i's record area,
+// the replayed GoState stored in board slot i of the engine, where elfgo_* can look at it).  KEEP = false (the trainer's mode):
+// from the record's checkpoint, nothing but the batch is written.
+template <int N, class PoolT, bool KEEP>
 __global__ __launch_bounds__(64 * REPLAY_WAVES) void k_replay_extract(PoolT pool, ReplayStore st, const int32_t* rec, const int32_t* move_to,
                                                                        const int32_t* d4s, int n, TrainBatch o) {
   using G = Geo<N>;
@@ -79,15 +132,31 @@ __global__ __launch_bounds__(64 * REPLAY_WAVES) void k_replay_extract(PoolT pool
   if (mt > nm) mt = nm;   // the reference asserts move_to < size (go_state_ext.h:284)
   const u16* mv = st.moves + (size_t)r * st.max_moves;
   Board<N> bd;
-  bd.init(&lds, pool.zob, pool.skr(i));
-  bd.reset();                                   // _state.reset()
-  bd.playout_begin(zlds);
-  for (int t = 0; t < mt; ++t) {                // switchBeforeMove: for (i < move_to) _state.forward(moves[i])
-    const int c = rfl((int)mv[t]);
-    if (c == M_INVALID) continue;               // the reference throws here (go_state.cc:75-77); a refused move is skipped like any other
-    bd.forward(c);
+  if (KEEP) {
+    bd.init(&lds, pool.zob, pool.skr(i));
+    bd.reset();                                   // _state.reset()
+    bd.playout_begin(zlds);
+    for (int t = 0; t < mt; ++t) {                // switchBeforeMove: for (i < move_to) _state.forward(moves[i])
+      const int c = rfl((int)mv[t]);
+      if (c == M_INVALID) continue;               // the reference throws here (go_state.cc:75-77); a refused move is skipped like any other
+      bd.forward(c);
+    }
+    bd.store(&pool.slots[i]);                     // the replayed GoState stays inspectable through elfgo_* (slot i)
+  } else {
+    const u64* skr = st.skrec + (size_t)r * (st.max_moves + 2) * G::SKW;
+    bd.init(&lds, pool.zob, const_cast<u64*>(skr));
+    int ck = mt / CK_INTERVAL;                    // checkpoints at or below move_to
+    if (ck > st.nck) ck = st.nck;
+    if (ck > 0) bd.load(reinterpret_cast<const Slot<N>*>(st.ckpt) + (size_t)r * st.nck + (ck - 1));
+    else bd.reset();
+    bd.playout_begin(zlds);
+    const ReplaySK<N> sk{skr};
+    for (int t = ck * CK_INTERVAL; t < mt; ++t) {
+      const int c = rfl((int)mv[t]);
+      if (c == M_INVALID) continue;
+      bd.forward(c, sk);
+    }
   }
-  bd.store(&pool.slots[i]);                     // the replayed GoState stays inspectable through elfgo_* (slot i)
   // "s": extractStateExtAGZ -> BoardFeature::extractAGZ under the sample's D4 code.  After the store only the history ring of the
   // LDS image is still needed: it moves into the (dead) Bloom words, and the extraction's scratch takes the front of the slot
   // (header + labels + liberties + old ring = 2624 B >= AGZ_SCRATCH_BYTES at 19x19) -- no scratch of its own, so 8 instead of 5

@@ -19,6 +19,11 @@ struct ElfReplay {
   std::vector<uint8_t> is_filled;
   std::mt19937 rng;                     // GoGameBase::_rng of the sampling thread (game_base.h:32-38)
   std::vector<int32_t> h_draw;
+  // records put since the last extraction: their checkpoints are written by ONE launch at the head of the next elftrain_extract
+  std::vector<int32_t> dirty;
+  std::vector<uint8_t> is_dirty;
+  int32_t* d_dirty = nullptr;           // [capacity]
+  int keep_states = 1;                  // elftrain_set_keep_states
 };
 
 extern "C" {
@@ -39,7 +44,13 @@ int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_polici
   A(st.black_ver, sizeof(int64_t) * capacity); A(st.num_pol, sizeof(int32_t) * capacity);
   A(st.values, cm * sizeof(float)); A(st.num_values, sizeof(int32_t) * capacity);
   if (with_policies) A(st.pol, cm * (size_t)r->P);
+  st.nck = max_moves / CK_INTERVAL;
+  const size_t skw = e->n == 19 ? Geo<19>::SKW : Geo<9>::SKW;
+  if (st.nck > 0) A(st.ckpt, (size_t)capacity * st.nck * e->slot_bytes);
+  A(st.skrec, (size_t)capacity * (max_moves + 2) * skw * sizeof(u64));
+  A(r->d_dirty, sizeof(int32_t) * capacity);
 #undef A
+  r->is_dirty.assign(capacity, 0);
   r->h_num_moves.assign(capacity, 0);
   r->is_filled.assign(capacity, 0);
   r->rng.seed(seed);
@@ -50,7 +61,8 @@ int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_polici
 int elftrain_destroy(ElfReplay* r) {
   if (!r) return ELFGO_E_BADARG;
   DevGuard _dg(r->eng->device);
-  void* ptrs[] = {r->st.moves, r->st.num_moves, r->st.winner, r->st.black_ver, r->st.pol, r->st.num_pol, r->st.values, r->st.num_values};
+  void* ptrs[] = {r->st.moves, r->st.num_moves, r->st.winner, r->st.black_ver, r->st.pol, r->st.num_pol, r->st.values, r->st.num_values,
+                  r->st.ckpt, r->st.skrec, r->d_dirty};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete r;
   return 0;
@@ -60,27 +72,47 @@ int elftrain_capacity(const ElfReplay* r) { return r ? r->st.capacity : ELFGO_E_
 int elftrain_max_moves(const ElfReplay* r) { return r ? r->st.max_moves : ELFGO_E_BADARG; }
 int elftrain_num_records(const ElfReplay* r) { return r ? (int)r->filled.size() : ELFGO_E_BADARG; }
 
-int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
-                 const uint8_t* policies_host, int num_policies, const float* values_host, int num_values) {
+// Stream-ordered: the copies are queued on `stream` (host buffers may be reused on return: pageable memory is staged by the
+// runtime before the call returns), so a put that reuses the slot of an evicted record cannot overtake an extraction queued on
+// the same stream that still reads it.
+int elftrain_put_async(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
+                       const uint8_t* policies_host, int num_policies, const float* values_host, int num_values, void* stream) {
   if (!r || slot < 0 || slot >= r->st.capacity || num_moves < 0 || num_moves > r->st.max_moves) return ELFGO_E_BADARG;
   if ((num_moves > 0 && !moves_host) || num_policies < 0 || num_policies > r->st.max_moves || num_values < 0 ||
       num_values > r->st.max_moves) return ELFGO_E_BADARG;
   if ((num_policies > 0 && (!policies_host || !r->st.pol)) || (num_values > 0 && !values_host)) return ELFGO_E_BADARG;
   DevGuard _dg(r->eng->device);
   ReplayStore& st = r->st;
+  hipStream_t s = (hipStream_t)stream;
   const size_t base = (size_t)slot * st.max_moves;
-  if (num_moves) HIPCHK(hipMemcpy(st.moves + base, moves_host, sizeof(u16) * num_moves, hipMemcpyHostToDevice));
-  if (num_policies) HIPCHK(hipMemcpy(st.pol + base * r->P, policies_host, (size_t)num_policies * r->P, hipMemcpyHostToDevice));
-  if (num_values) HIPCHK(hipMemcpy(st.values + base, values_host, sizeof(float) * num_values, hipMemcpyHostToDevice));
+  if (num_moves) HIPCHK(hipMemcpyAsync(st.moves + base, moves_host, sizeof(u16) * num_moves, hipMemcpyHostToDevice, s));
+  if (num_policies) HIPCHK(hipMemcpyAsync(st.pol + base * r->P, policies_host, (size_t)num_policies * r->P, hipMemcpyHostToDevice, s));
+  if (num_values) HIPCHK(hipMemcpyAsync(st.values + base, values_host, sizeof(float) * num_values, hipMemcpyHostToDevice, s));
   const float w = reward > 0 ? 1.0f : -1.0f;   // fromRecord, go_state_ext.h:250
   const int32_t nm = num_moves, np = num_policies, nv = num_values;
-  HIPCHK(hipMemcpy(st.num_moves + slot, &nm, 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(st.num_pol + slot, &np, 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(st.num_values + slot, &nv, 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(st.winner + slot, &w, 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(st.black_ver + slot, &black_ver, 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(st.num_moves + slot, &nm, 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(st.num_pol + slot, &np, 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(st.num_values + slot, &nv, 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(st.winner + slot, &w, 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(st.black_ver + slot, &black_ver, 8, hipMemcpyHostToDevice, s));
   r->h_num_moves[slot] = num_moves;
   if (!r->is_filled[slot]) { r->is_filled[slot] = 1; r->filled.push_back(slot); }
+  if (!r->is_dirty[slot]) { r->is_dirty[slot] = 1; r->dirty.push_back(slot); }   // checkpoints: at the head of the next extraction
+  return 0;
+}
+
+int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
+                 const uint8_t* policies_host, int num_policies, const float* values_host, int num_values) {
+  const int rc = elftrain_put_async(r, slot, moves_host, num_moves, reward, black_ver, policies_host, num_policies, values_host, num_values, nullptr);
+  if (rc) return rc;
+  DevGuard _dg(r->eng->device);
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
+int elftrain_set_keep_states(ElfReplay* r, int on) {
+  if (!r) return ELFGO_E_BADARG;
+  r->keep_states = on != 0;
   return 0;
 }
 
@@ -111,7 +143,7 @@ int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec_dev,
 }
 
 int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, const int32_t* d4, int n, const ElfTrainBatch* b, void* stream) {
-  if (!r || !rec || !move_to || !b || n < 0 || n > r->eng->capacity) return ELFGO_E_BADARG;
+  if (!r || !rec || !move_to || !b || n < 0 || (r->keep_states && n > r->eng->capacity)) return ELFGO_E_BADARG;
   if (n == 0) return 0;
   DevGuard _dg(r->eng->device);
   const int nn = r->eng->n;
@@ -122,8 +154,23 @@ int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, c
   o.offline_a = b->offline_a; o.nfa = b->num_future_actions;
   o.winner = b->winner; o.mcts_scores = b->mcts_scores; o.predicted_value = b->predicted_value;
   o.move_idx = b->move_idx; o.num_move = b->num_move; o.aug_code = b->aug_code; o.selfplay_ver = b->selfplay_ver;
-  DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_extract<N, Pool<N>>), dim3((n + REPLAY_WAVES - 1) / REPLAY_WAVES), dim3(64 * REPLAY_WAVES), 0, (hipStream_t)stream, pool_of<N>(r->eng), r->st,
-                                      rec, move_to, d4, n, o));
+  hipStream_t s = (hipStream_t)stream;
+  if (!r->dirty.empty()) {
+    // the records put since the last extraction get their checkpoints and superko records now, ahead of the samples that use them
+    const int nd = (int)r->dirty.size();
+    HIPCHK(hipMemcpyAsync(r->d_dirty, r->dirty.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
+    DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_checkpoint<N, Pool<N>>), dim3((nd + REPLAY_WAVES_CK - 1) / REPLAY_WAVES_CK), dim3(64 * REPLAY_WAVES_CK), 0, s,
+                                        pool_of<N>(r->eng), r->st, r->d_dirty, nd));
+    HIPCHK(hipGetLastError());
+    for (int32_t sl : r->dirty) r->is_dirty[sl] = 0;
+    r->dirty.clear();
+  }
+  const dim3 grid((n + REPLAY_WAVES - 1) / REPLAY_WAVES), block(64 * REPLAY_WAVES);
+  if (r->keep_states) {
+    DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_extract<N, Pool<N>, true>), grid, block, 0, s, pool_of<N>(r->eng), r->st, rec, move_to, d4, n, o));
+  } else {
+    DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_extract<N, Pool<N>, false>), grid, block, 0, s, pool_of<N>(r->eng), r->st, rec, move_to, d4, n, o));
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

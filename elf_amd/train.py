@@ -65,10 +65,13 @@ def parse_record(board_size, rec):
 
 
 class ReplayLoader:
-    """HBM-resident replay store + one-launch batch extraction (k_replay_extract)."""
+    """HBM-resident replay store + one-launch batch extraction (k_replay_extract).
+    keep_states=False (default, the trainer's mode): a sample replays from its record's checkpoint (the state after every 32nd
+    move, written once per put) -- at most 31 board steps instead of ~160, the same rows.  keep_states=True: the reference's own
+    procedure (reset + forward x move_to), and the replayed GoState of sample i stays in board slot i of `self.engine`."""
 
     def __init__(self, board_size=19, capacity=1024, batchsize=2048, device=0, max_moves=None, with_policies=True,
-                 num_future_actions=1, seed=0, feature_format="f32_nchw", batches_per_launch=1):
+                 num_future_actions=1, seed=0, feature_format="f32_nchw", batches_per_launch=1, keep_states=False):
         if not torch.cuda.is_available():
             raise RuntimeError("elf_amd.ReplayLoader needs a ROCm GPU (no CPU fallback exists)")
         self.L = _lib.lib()
@@ -83,11 +86,14 @@ class ReplayLoader:
         # the trainer prefetches: `batches_per_launch` train batches are drawn and extracted by ONE launch (sample_batches); the
         # replay of a sample is a dependent chain of ~160 board steps, so the kernel wants many samples in flight
         self.batches_per_launch = max(1, int(batches_per_launch))
-        self.engine = GoEngine(self.n, self.batchsize * self.batches_per_launch, device)   # replay scratch: sample i replays in board slot i
+        # keep_states: sample i's replayed GoState lives in board slot i of this engine; otherwise the engine only lends its constants
+        self.engine = GoEngine(self.n, self.batchsize * self.batches_per_launch if keep_states else 1, device)
         self.device = self.engine.device
         h = C.c_void_p()
         check(self.L.elftrain_create(self.engine._h, int(capacity), self.max_moves, int(with_policies), int(seed) & 0xFFFFFFFF, C.byref(h)))
         self._h = h
+        self.keep_states = bool(keep_states)
+        check(self.L.elftrain_set_keep_states(self._h, int(self.keep_states)))
         B, dev = self.batchsize * self.batches_per_launch, self.device
         self._draw = torch.zeros((3, B), dtype=torch.int32, device=dev)
 
@@ -115,9 +121,10 @@ class ReplayLoader:
         mv = np.ascontiguousarray(r["moves"], np.uint16)
         pol = np.ascontiguousarray(r["policies"], np.uint8)
         val = np.ascontiguousarray(r["values"], np.float32)
-        check(self.L.elftrain_put(self._h, int(slot), mv.ctypes.data, mv.size, float(r["reward"]), int(r["black_ver"]),
-                                  pol.ctypes.data if pol.size else None, pol.shape[0] if pol.size else 0,
-                                  val.ctypes.data if val.size else None, val.size))
+        # ordered on the stream the extractions run on: a put into the slot of an evicted record waits for the samples that still read it
+        check(self.L.elftrain_put_async(self._h, int(slot), mv.ctypes.data, mv.size, float(r["reward"]), int(r["black_ver"]),
+                                        pol.ctypes.data if pol.size else None, pol.shape[0] if pol.size else 0,
+                                        val.ctypes.data if val.size else None, val.size, self._stream()))
 
     def _alloc(self, n):
         dev = self.device

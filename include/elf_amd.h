@@ -429,6 +429,16 @@ int elftrain_num_records(const ElfReplay* r);
  * Host pointers; synchronous. */
 int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
                  const uint8_t* policies_host, int num_policies, const float* values_host, int num_values);
+/* the same, ordered on `stream` instead of the default stream: a put that reuses the slot of an evicted record cannot overtake an
+ * extraction queued on that stream.  The host arrays may be reused on return. */
+int elftrain_put_async(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
+                       const uint8_t* policies_host, int num_policies, const float* values_host, int num_values, void* stream);
+/* on != 0 (the default): elftrain_extract does what switchBeforeMove does (go_state_ext.h:283-290: reset, forward x move_to) and
+ * leaves the replayed GoState of sample i in board slot i of the engine (elfgo_info / elfgo_legal_mask / ... can look at it;
+ * n <= elfgo_capacity).  on == 0 (the trainer's mode): a sample starts from the record's checkpoint below move_to -- the state
+ * after every 32nd move is written once per put, by the next extraction, together with the game's superko records -- and
+ * forwards at most 31 moves; rows are identical, no board slot is written, n is not limited by the engine's capacity. */
+int elftrain_set_keep_states(ElfReplay* r, int on);
 /* GoGameTrain::act's draws for n samples with the store's std::mt19937 (seeded at create): record, move_to =
  * rng() % (num_moves - num_future_actions + 1), D4 code = rng() % 8; results into device int32 [n] arrays */
 int elftrain_draw(ElfReplay* r, int n, int num_future_actions, int32_t* rec, int32_t* move_to, int32_t* d4, void* stream);

@@ -208,8 +208,61 @@ def dump_train_act(name, n, kw):
     print(name, "rows", len(a["winner"]), "records used", sorted(set((a["selfplay_ver"] - 1000).tolist())))
 
 
+# A 9x9 game that ends by positional superko at move 107 (found with the restated board engine: uniformly random legal moves, eye
+# fills included, until GoState::terminated() by repetition), followed by 32 more recorded moves.  GoState::forward refuses every
+# move after the repetition (go_state.cc:78-79), so a replay to any later move_to stays on the position of ply 108 -- which is what
+# a loader that replays from stored checkpoints must reproduce (round 4: k_replay_checkpoint / k_replay_extract<KEEP = false>).
+SUPERKO_GAME_9 = [60, 95, 48, 108, 83, 94, 18, 15, 41, 46, 96, 89, 71, 40, 67, 25, 79, 58, 86, 103, 17, 82, 107, 59, 106, 53, 63, 36, 69, 28, 34, 12,
+                  102, 56, 51, 68, 105, 80, 20, 27, 81, 39, 70, 35, 29, 50, 92, 78, 91, 37, 75, 30, 42, 38, 45, 62, 47, 57, 61, 84, 100, 64, 85, 104,
+                  13, 31, 14, 19, 93, 72, 23, 16, 103, 18, 101, 90, 73, 52, 82, 67, 97, 41, 104, 42, 62, 49, 94, 84, 12, 26, 74, 29, 108, 48, 95, 24,
+                  80, 45, 14, 12, 23, 17, 72, 20, 13, 12, 14]
+
+
+def dump_superko():
+    n = 9
+    R = RefSelfPlay(n)
+    port = Port(n)
+    st = port.new()
+    for c in SUPERKO_GAME_9:
+        assert port.forward(st, c) == 1
+    assert port.terminated(st) and port.info(st)[0] == len(SUPERKO_GAME_9) + 1 < 2 * n * n      # ended by repetition, not by the move limit
+    port.free(st)
+    rng = np.random.default_rng(4109)
+    rec = synth_record(n, playout_seeds(1, base=4109)[0], rng, with_policies=True)
+    tail = [int(c) for c in R.sgfstr2coords(rec["result"]["content"])][:32]
+    mv = SUPERKO_GAME_9 + tail
+    k = len(mv)
+    P = (n + 2) ** 2
+    pol = np.zeros((k, P), np.uint8)
+    for i in range(k):
+        idx = rng.integers(0, P, size=int(rng.integers(1, 40)))
+        pol[i, idx] = rng.integers(1, 256, size=idx.size)
+    rec["result"].update(content=R.coords2sgfstr(mv), num_move=k, policies=pol.tolist(),
+                         values=[float(np.float32(v)) for v in np.round(np.tanh(rng.standard_normal(k)) * 1e4) / 1e4])
+    t = json.dumps(rec, separators=(",", ":"))
+    rows = []
+    for nfa in (1, 3):
+        for ci, mt in enumerate([0, 1, 31, 32, 33, 63, 64, 65, 95, 96, 97, 100, 105, 106, 107, 108, 109, 120, 127, 128, 129, 136, k - 3, k - 1]):
+            if mt > k - nfa:
+                continue
+            d4 = (ci + nfa) % 8
+            o = R.train_sample(t, mt, d4, nfa)
+            oa = np.zeros(3, np.int64)
+            oa[:nfa] = o["offline_a"]
+            rows.append(dict(rec=0, move_to=mt, d4=d4, nfa=nfa, s=np.packbits(o["s"].astype(np.uint8).ravel()), offline_a=oa,
+                             winner=o["winner"], mcts_scores=o["mcts_scores"], predicted_value=o["predicted_value"],
+                             move_idx=o["move_idx"], num_move=o["num_move"], aug_code=o["aug_code"], selfplay_ver=o["selfplay_ver"]))
+    late = [r for r in rows if r["move_to"] > len(SUPERKO_GAME_9)]
+    assert late and all(int(r["move_idx"]) == len(SUPERKO_GAME_9) for r in late)   # the replay stopped at the repetition
+    np.savez_compressed(os.path.join(OUT, "train_9_superko.npz"), board_size=np.int32(n), records=np.array([t]),
+                        **{kk: np.array([r[kk] for r in rows]) for kk in rows[0].keys()})
+    print("train_9_superko: %d rows, %d of them beyond the repetition" % (len(rows), len(late)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--superko" in sys.argv:
+        return dump_superko()
     for name, (n, kw) in TRAIN_ACT_CASES.items():
         dump_train_act(name, n, kw)
     for name, (n, kw) in RECORD_CASES_R3.items():

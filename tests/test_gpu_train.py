@@ -20,18 +20,22 @@ def elf(built):
 
 
 def load_rows(n):
-    g = np.load(os.path.join(GOLDEN, "train_%d.npz" % n))
+    g = np.load(os.path.join(GOLDEN, "train_%s.npz" % n))
     return g, [str(t) for t in g["records"]]
 
 
-@pytest.mark.parametrize("n", [9, 19])
+# keep: the reference's own procedure (reset + forward x move_to; the replayed state stays in the engine) / the trainer's mode
+# (from the record's checkpoint, at most 31 forwards).  "9_superko": a record that continues past a positional repetition
+@pytest.mark.parametrize("n", [9, 19, "9_superko"])
 @pytest.mark.parametrize("fmt", ["f32_nchw", "f16_nhwc"])
-def test_train_batch_matches_reference_rows(elf, n, fmt):
+@pytest.mark.parametrize("keep", [False, True])
+def test_train_batch_matches_reference_rows(elf, n, fmt, keep):
     import torch
     g, recs = load_rows(n)
+    n = int(g["board_size"])
     for nfa in (1, 3):
         sel = np.nonzero(g["nfa"] == nfa)[0]
-        ld = elf.ReplayLoader(board_size=n, capacity=len(recs) + 3, batchsize=len(sel), num_future_actions=nfa, feature_format=fmt)
+        ld = elf.ReplayLoader(board_size=n, capacity=len(recs) + 3, batchsize=len(sel), num_future_actions=nfa, feature_format=fmt, keep_states=keep)
         for i, t in enumerate(recs):
             ld.put(i + 2, t)                       # slots need not start at 0
         assert len(ld) == len(recs)
@@ -51,9 +55,19 @@ def test_train_batch_matches_reference_rows(elf, n, fmt):
         np.testing.assert_array_equal(ms, want)    # NaN rows (all-zero recorded policy: 0/0 in the reference too) compare equal
         fin = np.isfinite(want)
         assert np.array_equal(ms[fin].view(np.uint32), want[fin].view(np.uint32))
-        # the replayed GoState of sample i sits in board slot i of the loader's engine
-        info = ld.engine.info(n=len(sel)).cpu().numpy()
-        assert np.array_equal(info[:, 0] - 1, g["move_idx"][sel])
+        if keep:
+            # the replayed GoState of sample i sits in board slot i of the loader's engine
+            info = ld.engine.info(n=len(sel)).cpu().numpy()
+            assert np.array_equal(info[:, 0] - 1, g["move_idx"][sel])
+        # a record put again (other slot, then the same slot): its checkpoints are rewritten, the rows stay
+        if not keep and nfa == 1:
+            ld.put(0, recs[0])
+            ld.put(2, recs[0])
+            first = np.nonzero(g["rec"][sel] == 0)[0]
+            b2 = ld.extract(np.concatenate([np.zeros(len(first), np.int32), np.full(len(first), 2, np.int32)]),
+                            np.tile(g["move_to"][sel][first], 2), np.tile(g["d4"][sel][first], 2))
+            s2 = b2["s"].float().cpu().numpy()
+            assert np.array_equal(s2[: len(first)], want_s[first]) and np.array_equal(s2[len(first):], want_s[first])
         ld.close()
 
 
@@ -166,7 +180,8 @@ def test_replayed_positions_and_draws(elf):
     nfa = 2
     outs = []
     for rep in range(2):
-        ld = elf.ReplayLoader(board_size=n, capacity=len(recs), batchsize=96, num_future_actions=nfa, seed=42)
+        # rep 0: the reference's procedure with the states kept for inspection; rep 1: from the checkpoints -- same draws, same batch
+        ld = elf.ReplayLoader(board_size=n, capacity=len(recs), batchsize=96, num_future_actions=nfa, seed=42, keep_states=(rep == 0))
         for i, t in enumerate(recs):
             ld.put(i, t)
         b = ld.sample(96)

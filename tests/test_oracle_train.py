@@ -12,7 +12,7 @@ from pyoracle import Port, RefSelfPlay, port_train_sample, sgfstr2coords
 
 
 def rows_of(n):
-    g = np.load(os.path.join(GOLDEN, "train_%d.npz" % n))
+    g = np.load(os.path.join(GOLDEN, "train_%s.npz" % n))
     recs = [json.loads(str(t)) for t in g["records"]]
     return g, recs
 
@@ -37,6 +37,21 @@ def test_restatement_matches_reference_rows(built, n):
     for i in range(len(g["rec"])):
         o = port_train_sample(port, recs[int(g["rec"][i])], int(g["move_to"][i]), int(g["d4"][i]), int(g["nfa"][i]))
         check_row(n, g, i, o)
+
+
+def test_restatement_on_a_record_that_continues_past_a_superko_repetition(built):
+    """train_9_superko.npz (oracle/gen_golden_train.py --superko): the game ends by positional superko at move 107, the record holds
+    32 more moves; GoState::forward refuses them (go_state.cc:78-79), so rows drawn beyond the repetition show the position of ply 108."""
+    g, recs = rows_of("9_superko")
+    port = Port(9)
+    late = 0
+    for i in range(len(g["rec"])):
+        o = port_train_sample(port, recs[0], int(g["move_to"][i]), int(g["d4"][i]), int(g["nfa"][i]))
+        check_row(9, g, i, o)
+        if g["move_to"][i] > 107:
+            late += 1
+            assert g["move_idx"][i] == 107
+    assert late >= 10
 
 
 @pytest.mark.parametrize("n", [9, 19])

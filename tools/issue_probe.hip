@@ -16,18 +16,21 @@
 #define REP8(x) x x x x x x x x
 #define REP16(x) REP8(x) REP8(x)
 
-enum { M_SADD = 0, M_SAND64, M_SMUL, M_SLSHL64, M_SBCNT64, M_SCSEL, M_VADD, M_VAND_OR, M_VCMP, M_READLANE, M_MIX11, M_MIX21, M_MIX12, M_DEP_VADD, M_DEP_SADD, M_COUNT };
+enum { M_SADD = 0, M_SAND64, M_SMUL, M_SLSHL64, M_SBCNT64, M_SCSEL, M_VADD, M_VAND_OR, M_VCMP, M_READLANE, M_MIX11, M_MIX21, M_MIX12, M_DEP_VADD, M_DEP_SADD, M_VAND, M_VCNDMASK, M_VCMP_VCC, M_VCMP_SDWA, M_DPP, M_ALIGNBIT, M_LSHL_ADD, M_OR3, M_WRITELANE, M_LSHL64, M_MUL24, M_BFE, M_COUNT };
 static const char* kNames[M_COUNT] = {"s_add_u32", "s_and_b64", "s_mul_i32", "s_lshl_b64", "s_bcnt1_i32_b64", "s_cselect_b32", "v_add_u32", "v_and_or_b32",
                                       "v_cmp_eq_u32 (VALU writing an SGPR pair)", "v_readlane_b32", "mix 1 SALU : 1 VALU", "mix 2 SALU : 1 VALU",
-                                      "mix 1 SALU : 2 VALU", "v_add_u32 dependent chain", "s_add_u32 dependent chain"};
-static const int kSalu[M_COUNT] = {128, 128, 128, 128, 128, 128, 0, 0, 0, 0, 64, 86, 43, 0, 128};   // per 128-instruction block (mixes below)
-static const int kValu[M_COUNT] = {0, 0, 0, 0, 0, 0, 128, 128, 128, 128, 64, 42, 85, 128, 0};
+                                      "mix 1 SALU : 2 VALU", "v_add_u32 dependent chain", "s_add_u32 dependent chain",
+                                      "v_and_b32 (VOP2)", "v_cndmask_b32 (SGPR-pair mask)", "v_cmp_eq_u32 -> vcc (VOPC)", "v_cmp_eq_u32_sdwa -> vcc", "v_mov_b32_dpp row_shr:1",
+                                      "v_alignbit_b32", "v_lshl_add_u32", "v_or3_b32", "v_writelane_b32", "v_lshlrev_b64", "v_mul_u32_u24", "v_bfe_u32"};
+static const int kSalu[M_COUNT] = {128, 128, 128, 128, 128, 128, 0, 0, 0, 0, 64, 86, 43, 0, 128, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // per 128-instruction block (mixes below)
+static const int kValu[M_COUNT] = {0, 0, 0, 0, 0, 0, 128, 128, 128, 128, 64, 42, 85, 128, 0, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_probe(unsigned long long* cyc, unsigned* sink, int iters) {
   unsigned s0 = blockIdx.x, s1 = 1, s2 = 2, s3 = 3, s4 = 4, s5 = 5, s6 = 6, s7 = 7;
   unsigned v0 = threadIdx.x, v1 = 1, v2 = 2, v3 = 3, v4 = 4, v5 = 5, v6 = 6, v7 = 7;
   unsigned long long q0 = blockIdx.x + 1, q1 = 3, q2 = 5, q3 = 7;
+  unsigned long long w0 = threadIdx.x + 1, w1 = 3, w2 = 5, w3 = 7;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < iters; ++i) {
     if (MODE == M_SADD) {
@@ -75,17 +78,54 @@ __global__ __launch_bounds__(256) void k_probe(unsigned long long* cyc, unsigned
       asm volatile(REP8("s_add_u32 %0, %0, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %1, %1, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n s_add_u32 %2, %2, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n s_add_u32 %0, %0, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n")
                    "s_add_u32 %1, %1, 1\n v_add_u32 %6, %6, 1\n v_add_u32 %7, %7, 1\n s_add_u32 %2, %2, 1\n v_add_u32 %4, %4, 1\n v_add_u32 %5, %5, 1\n s_add_u32 %3, %3, 1\n v_add_u32 %6, %6, 1\n"
                    : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "scc");
+    } else if (MODE == M_VAND) {
+      asm volatile(REP16("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %5\n v_and_b32 %2, %2, %6\n v_and_b32 %3, %3, %7\n v_and_b32 %4, %4, %0\n v_and_b32 %5, %5, %1\n v_and_b32 %6, %6, %2\n v_and_b32 %7, %7, %3\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_VCNDMASK) {
+      asm volatile(REP16("v_cndmask_b32 %0, %0, %4, %8\n v_cndmask_b32 %1, %1, %5, %9\n v_cndmask_b32 %2, %2, %6, %10\n v_cndmask_b32 %3, %3, %7, %11\n v_cndmask_b32 %4, %4, %0, %8\n v_cndmask_b32 %5, %5, %1, %9\n v_cndmask_b32 %6, %6, %2, %10\n v_cndmask_b32 %7, %7, %3, %11\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(q0), "s"(q1), "s"(q2), "s"(q3));
+    } else if (MODE == M_VCMP_VCC) {
+      asm volatile(REP16("v_cmp_eq_u32 vcc, %0, %1\n v_cmp_eq_u32 vcc, %1, %2\n v_cmp_eq_u32 vcc, %2, %3\n v_cmp_eq_u32 vcc, %3, %0\n v_cmp_ne_u32 vcc, %0, %1\n v_cmp_ne_u32 vcc, %1, %2\n v_cmp_ne_u32 vcc, %2, %3\n v_cmp_ne_u32 vcc, %3, %0\n")
+                   : : "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "vcc");
+    } else if (MODE == M_VCMP_SDWA) {
+      asm volatile(REP16("v_cmp_eq_u32_sdwa vcc, %0, %1 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_eq_u32_sdwa vcc, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_eq_u32_sdwa vcc, %3, %0 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_eq_u32_sdwa vcc, %0, %1 src0_sel:WORD_1 src1_sel:DWORD\n v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:WORD_1 src1_sel:DWORD\n v_cmp_eq_u32_sdwa vcc, %2, %3 src0_sel:WORD_1 src1_sel:DWORD\n v_cmp_eq_u32_sdwa vcc, %3, %0 src0_sel:WORD_1 src1_sel:DWORD\n")
+                   : : "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "vcc");
+    } else if (MODE == M_DPP) {
+      asm volatile(REP16("v_mov_b32_dpp %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %2 row_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %3 row_shl:1 row_mask:0xf bank_mask:0xf\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_ALIGNBIT) {
+      asm volatile(REP16("v_alignbit_b32 %0, %0, %4, 7\n v_alignbit_b32 %1, %1, %5, 7\n v_alignbit_b32 %2, %2, %6, 7\n v_alignbit_b32 %3, %3, %7, 7\n v_alignbit_b32 %4, %4, %0, 7\n v_alignbit_b32 %5, %5, %1, 7\n v_alignbit_b32 %6, %6, %2, 7\n v_alignbit_b32 %7, %7, %3, 7\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_LSHL_ADD) {
+      asm volatile(REP16("v_lshl_add_u32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 1, %5\n v_lshl_add_u32 %2, %2, 1, %6\n v_lshl_add_u32 %3, %3, 1, %7\n v_lshl_add_u32 %4, %4, 1, %0\n v_lshl_add_u32 %5, %5, 1, %1\n v_lshl_add_u32 %6, %6, 1, %2\n v_lshl_add_u32 %7, %7, 1, %3\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_OR3) {
+      asm volatile(REP16("v_or3_b32 %0, %0, %4, %5\n v_or3_b32 %1, %1, %5, %6\n v_or3_b32 %2, %2, %6, %7\n v_or3_b32 %3, %3, %7, %4\n v_or3_b32 %4, %4, %0, %1\n v_or3_b32 %5, %5, %1, %2\n v_or3_b32 %6, %6, %2, %3\n v_or3_b32 %7, %7, %3, %0\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_WRITELANE) {
+      asm volatile(REP16("v_writelane_b32 %0, %8, 0\n v_writelane_b32 %1, %9, 1\n v_writelane_b32 %2, %10, 2\n v_writelane_b32 %3, %11, 3\n v_writelane_b32 %4, %8, 4\n v_writelane_b32 %5, %9, 5\n v_writelane_b32 %6, %10, 6\n v_writelane_b32 %7, %11, 7\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "s"(s0), "s"(s1), "s"(s2), "s"(s3));
+    } else if (MODE == M_LSHL64) {
+      asm volatile(REP16("v_lshlrev_b64 %0, 1, %0\n v_lshlrev_b64 %1, 1, %1\n v_lshlrev_b64 %2, 1, %2\n v_lshlrev_b64 %3, 1, %3\n v_lshrrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 1, %1\n v_lshrrev_b64 %2, 1, %2\n v_lshrrev_b64 %3, 1, %3\n")
+                   : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+    } else if (MODE == M_MUL24) {
+      asm volatile(REP16("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %5\n v_mul_u32_u24 %2, %2, %6\n v_mul_u32_u24 %3, %3, %7\n v_mul_u32_u24 %4, %4, %0\n v_mul_u32_u24 %5, %5, %1\n v_mul_u32_u24 %6, %6, %2\n v_mul_u32_u24 %7, %7, %3\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+    } else if (MODE == M_BFE) {
+      asm volatile(REP16("v_bfe_u32 %0, %0, 1, 31\n v_bfe_u32 %1, %1, 1, 31\n v_bfe_u32 %2, %2, 1, 31\n v_bfe_u32 %3, %3, 1, 31\n v_bfe_u32 %4, %4, 1, 31\n v_bfe_u32 %5, %5, 1, 31\n v_bfe_u32 %6, %6, 1, 31\n v_bfe_u32 %7, %7, 1, 31\n")
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
-  const unsigned r = s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7 ^ v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7 ^ (unsigned)(q0 ^ q1 ^ q2 ^ q3);
+  const unsigned r = s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7 ^ v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7 ^ (unsigned)(q0 ^ q1 ^ q2 ^ q3) ^ (unsigned)(w0 ^ w1 ^ w2 ^ w3);
   if (r == 0x12345678u) sink[0] = r;   // keeps every chain alive
 }
 
 typedef void (*kern_t)(unsigned long long*, unsigned*, int);
 static kern_t kKernels[M_COUNT] = {k_probe<0>, k_probe<1>, k_probe<2>, k_probe<3>, k_probe<4>, k_probe<5>, k_probe<6>, k_probe<7>, k_probe<8>, k_probe<9>,
-                                   k_probe<10>, k_probe<11>, k_probe<12>, k_probe<13>, k_probe<14>};
+                                   k_probe<10>, k_probe<11>, k_probe<12>, k_probe<13>, k_probe<14>, k_probe<15>, k_probe<16>, k_probe<17>, k_probe<18>, k_probe<19>,
+                                   k_probe<20>, k_probe<21>, k_probe<22>, k_probe<23>, k_probe<24>, k_probe<25>, k_probe<26>};
 
 int main() {
   hipDeviceProp_t pr;
@@ -123,8 +163,9 @@ int main() {
       const double salu_clk_cu = salu_w * waves_per_cu / (double)cyc_max, valu_clk_cu = valu_w * waves_per_cu / (double)cyc_max;
       const double wall_cycles_24 = best_ms * 1e-3 * 2.4e9;
       printf("%s  {\"kind\": \"%s\", \"waves_per_simd\": %d, \"wall_ms\": %.4f, \"wave_cycles_mean\": %.0f, \"wave_cycles_max\": %llu, \"cycles_per_instruction_per_wave\": %.3f,"
-             " \"salu_per_clk_per_cu\": %.4f, \"valu_per_clk_per_cu\": %.4f, \"valu_per_clk_per_simd\": %.4f, \"wall_x_2.4GHz_cycles\": %.0f}",
-             first ? "" : ",\n", kNames[m], w, best_ms, cyc_mean, cyc_max, cyc_mean / per_wave, salu_clk_cu, valu_clk_cu, valu_clk_cu / 4.0, wall_cycles_24);
+             " \"salu_per_clk_per_cu\": %.4f, \"valu_per_clk_per_cu\": %.4f, \"valu_per_clk_per_simd\": %.4f, \"wall_x_2.4GHz_cycles\": %.0f, \"inst_per_clk_per_cu_wall_2.4GHz\": %.4f}",
+             first ? "" : ",\n", kNames[m], w, best_ms, cyc_mean, cyc_max, cyc_mean / per_wave, salu_clk_cu, valu_clk_cu, valu_clk_cu / 4.0, wall_cycles_24,
+             per_wave * waves_per_cu / wall_cycles_24);
       first = false;
     }
   }
