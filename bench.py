@@ -1197,6 +1197,8 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     out = ld._alloc(B)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     mt_sum = torch.zeros((), dtype=torch.int64, device=dev)
+    fwd_sum = torch.zeros((), dtype=torch.int64, device=dev)     # plies forwarded from the checkpoints (move_idx mod 32)
+    ck_sum = torch.zeros((), dtype=torch.int64, device=dev)      # samples that load a checkpoint (move_idx >= 32)
     barrier = make_barrier(dist)
     d = ld._draw
     for i in range(warmup):
@@ -1213,6 +1215,8 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
             ld.extract(d[0, :B], d[1, :B], d[2, :B], out=out)          # the dominant kernel, on torch's current stream
             ev[i][1].record()
         mt_sum += out["move_idx"].sum()
+        fwd_sum += (out["move_idx"] % 32).sum()
+        ck_sum += (out["move_idx"] >= 32).sum()
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -1223,6 +1227,13 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         return None
     per_sample = replayed / (B * steps) * STEP_BYTES[n] + (26728 if n == 19 else 6008) + P + 4 * (n * n + 1) + 40
     kname = "k_replay_extract<%d>" % n
+    # what THIS kernel has to move per sample: the record's checkpoint slot in (3840 B at 19x19, none below ply
+    # 32), the <= 31 moves it forwards, the quantised policy row in; the feature row, the normalised policy, offline_a and 36 B of scalars out
+    slot_b = 3840 if n == 19 else 1024
+    row_b = 18 * n * n * (2 if ld.f16 else 4)
+    fwd_mean = float(fwd_sum.item()) / (B * steps)
+    ck_share = float(ck_sum.item()) / (B * steps)
+    own_bytes = ck_share * slot_b + 2 * fwd_mean + P + row_b + 4 * (n * n + 1) + 8 * nfa + 36
     res = {
         "metric": "train_samples_per_sec (%dx%d replay to a random ply + every field of the reference's train batch)" % (n, n),
         "value": samples_all / dt_max, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -1230,23 +1241,35 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "data": "synthetic",
         "config": {"workload": "SURVEY.md 8f-1 trainer input pipeline: train batches of %d samples, %d batches drawn + extracted per launch (one "
                                "step = one launch: the trainer prefetches), %d records of %d plies (random legal play on the device engine), one "
-                               "MCTS policy per ply, num_future_actions %d, s rows %s" % (B1, KB, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
+                               "MCTS policy per ply, num_future_actions %d, s rows %s; every sample starts from its record's checkpoint (the state "
+                               "after every 32nd move, written once per record) and forwards the rest"
+                               % (B1, KB, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
                    "batch": B1, "batches_per_launch": KB, "samples_per_launch": B, "records": R, "board_size": n,
                    "sampler": ("reference replay buffer: %d ReaderQueues (q_min 10, q_max 1000) filled with InsertWithParity, draws of "
                                "GoGameTrain::act by %d game threads taking turns (64 states per act)" % (args.train_readers, B1 // 64)) if queues
                    else "uniform over the records (elftrain_draw)",
                    "mean_replayed_plies": replayed / (B * steps),
+                   "mean_forwarded_plies": fwd_mean,
+                   "replay_note": "mean_replayed_plies = the forwards the reference's switchBeforeMove makes per sample (reset + forward x "
+                                  "move_to); mean_forwarded_plies = what k_replay_extract forwards from the checkpoint below move_to",
                    "replayed_board_steps_per_sec": replayed / dt,
                    "algorithmic_GBps": B * per_sample / (kern_ms / 1e3) / 1e9,
                    "algorithmic_note": "SURVEY.md 8d bytes per sample (replayed plies x 8730 B + features + policy row + scores): the data "
-                                       "movement of the reference's formulation; NOT this kernel's roof (the replay runs in LDS)",
+                                       "movement of the reference's formulation; NOT this kernel's roof",
+                   "host_side": "value = samples / wall time of the timed loop, which includes the host's draws (ReaderQueues + mt19937) and "
+                                "index uploads; roofline.avg_kernel_ms is the kernel alone",
                    "parallelism": "independent samples per GPU, no collective"},
     }
-    roof = issue_roof(kname, replayed / steps, kern_ms / 1e3)   # unit = one replayed board step
-    if roof is None:
-        roof = {"bound": "issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
-                "traffic": load_traffic(kname), "kernel": kname, "avg_kernel_ms": kern_ms,
-                "note": "profiles/pmc_issue.json has no VALU count for this kernel"}
+    ach = B * own_bytes / (kern_ms / 1e3) / 1e9
+    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": load_traffic(kname), "kernel": kname, "avg_kernel_ms": kern_ms, "bytes_per_sample": own_bytes,
+            "samples_per_sec_kernel_only": B / (kern_ms / 1e3),
+            "note": "with <= 31 forwards per sample the kernel is an HBM stream: per sample %.0f B = checkpoint slot in (%d B x %.2f of the "
+                    "samples) + moves + policy row in, feature row (%d B) + normalised policy + offline_a + scalars out; achieved = samples "
+                    "per launch x that / the kernel's mean HIP-event time" % (own_bytes, slot_b, ck_share, row_b)}
+    issue = issue_roof(kname, fwd_sum.item() / steps, kern_ms / 1e3)   # unit = one forwarded board step
+    if issue is not None:
+        roof["issue"] = issue
     res["roofline"] = roof
     res["cpu_baseline"] = cpu_baseline_train(n, "[" + ",".join(recs_json) + "]", nfa) if with_cpu else None
     return res
