@@ -43,7 +43,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz max clock
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s = 1228.8
-# The scalar ALU: ONE per CU, shared by its four SIMDs.  Measured on this part (tools/issue_probe.hip, profiles/r04a_issue_probe.json):
+# The scalar ALU: ONE per CU, shared by its four SIMDs.  Measured on this part (tools/issue_probe.hip, profiles/r04b_issue_probe.json):
 # 1.00 scalar instruction per clock per CU for every SALU class tried (s_add / s_and_b64 / s_mul_i32 / s_lshl_b64 / s_bcnt1 / s_cselect),
 # reached from 4 waves per CU on; a VALU stream issues beside it at full rate.  The same probe puts the VALU peak at 1.82 per clock and
 # CU for plain VOP2 (v_add_u32; the 2-cycle wave64 rate would be 2.0) but at 1.0 per clock and CU -- one per 4 cycles per SIMD -- for
@@ -122,7 +122,7 @@ def issue_roof(kernel, units_per_launch, kernel_s):
     binding = "salu" if (salu_frac is not None and salu_frac > ach / VALU_PEAK_GINST) else "valu"
     return {"bound": "issue", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": ach / VALU_PEAK_GINST,
             "salu_issue": {"achieved": salu_ach, "peak": SALU_PEAK_GINST, "unit": "G scalar instructions/s", "frac": salu_frac,
-                           "note": "one scalar ALU per CU at a measured 1.00 instruction per clock (profiles/r04a_issue_probe.json): "
+                           "note": "one scalar ALU per CU at a measured 1.00 instruction per clock (profiles/r04b_issue_probe.json): "
                                    "SQ_INSTS_SALU per unit x units/s / (256 CUs x 2.4 GHz)"},
             "salu_issue_frac": salu_frac, "binding_issue_roof": binding, "binding_frac": max(ach / VALU_PEAK_GINST, salu_frac or 0.0),
             "traffic": load_traffic(kernel), "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "valu_per_unit": valu, "pmc_source_match": True,

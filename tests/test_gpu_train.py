@@ -35,7 +35,7 @@ def test_train_batch_matches_reference_rows(elf, n, fmt, keep):
     n = int(g["board_size"])
     for nfa in (1, 3):
         sel = np.nonzero(g["nfa"] == nfa)[0]
-        ld = elf.ReplayLoader(board_size=n, capacity=len(recs) + 3, batchsize=len(sel), num_future_actions=nfa, feature_format=fmt, keep_states=keep)
+        ld = elf.ReplayLoader(board_size=n, capacity=len(recs) + 3, batchsize=2 * len(sel), num_future_actions=nfa, feature_format=fmt, keep_states=keep)
         for i, t in enumerate(recs):
             ld.put(i + 2, t)                       # slots need not start at 0
         assert len(ld) == len(recs)
