@@ -226,7 +226,7 @@ def cpu_baseline_mcts_stub(n, rollouts_per_batch):
                       "excluded), %.1f s" % (len(r["search"]), rollouts, rollouts_per_batch, cores, cores, dt)}
 
 
-def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=20.0):
+def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=24.0):
     """SURVEY.md 8d / BASELINE.md: the reference stack (its TreeSearchT + batcher, oracle/_ref/libelfsp) driving the SAME
     PyTorch-ROCm net through its batch interface (`refsp_net_fn` plays GCWrapper's part: pinned-host rows -> GPU -> net -> host),
     mcts_threads = 2, batchsize = 16 as in start_selfplay.sh, game threads sized to the host cores.  Bounded sample."""
@@ -237,7 +237,6 @@ def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=
     if not po.RefSelfPlay.available(n) or net is None:
         return {"value": None, "unit": "rollouts/s", "cores": 0, "kind": "unavailable", "sample": "oracle/_ref/libelfsp%d.so not built" % n}
     host = len(os.sched_getaffinity(0))
-    games = max(1, min(host // 3, 32))          # one game thread + two search threads each
     calls = [0, 0]
 
     def net_fn(s):
@@ -250,23 +249,36 @@ def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=
 
     R = po.RefSelfPlay(n)
     rollouts = 256
-    # calibrate on one search per game, then size the sample to the budget
-    t0 = time.time()
-    r = R.run(net=net_fn, num_games=games, mcts_threads=2, rollouts_per_thread=rollouts // 2, rollouts_per_batch=rollouts_per_batch,
-              batchsize=rollouts_per_batch, max_searches=games, seed=1234, timeout_usec=10)
-    dt0 = max(r["usec"] / 1e6, 1e-3)
-    per = dt0 / max(len(r["search"]), 1)
-    searches = int(max(games, min(64 * games, (budget_s - (time.time() - t0)) / max(per, 1e-4))))
-    calls[0] = calls[1] = 0
-    r = R.run(net=net_fn, num_games=games, mcts_threads=2, rollouts_per_thread=rollouts // 2, rollouts_per_batch=rollouts_per_batch,
-              batchsize=rollouts_per_batch, max_searches=searches, seed=1234, timeout_usec=10)
-    dt = r["usec"] / 1e6
-    done = len(r["search"]) * rollouts       # 2 search threads x rollouts/2 each (tree_search.h:472-476)
-    return {"value": done / dt, "unit": "rollouts/s", "cores": games * 3, "kind": "reference",
-            "sample": "%d searches of %d rollouts (2 search threads x %d, bs %d) by %d reference game threads, the same %s net on the "
-                      "GPU through the reference's batch interface (%d net calls, mean %.1f rows), net time INCLUDED, %.1f s"
-                      % (len(r["search"]), rollouts, rollouts // 2, rollouts_per_batch, games, str(dtype).replace("torch.", ""), calls[0],
-                         calls[1] / max(calls[0], 1), dt)}
+    # "num_games tuned to saturate host cores" -- swept, the best setting reported (one game thread + two search threads
+    # per game; start_client.sh:21 runs 32)
+    settings = [g for g in (32, 64, 128) if g == 32 or 3 * g <= 2 * host] or [max(1, min(host // 3, 32))]
+    sweep, best = [], None
+    for games in settings:
+        budget = budget_s / len(settings)
+        t0 = time.time()
+        # calibrate on one search per game, then size the sample to the budget
+        r = R.run(net=net_fn, num_games=games, mcts_threads=2, rollouts_per_thread=rollouts // 2, rollouts_per_batch=rollouts_per_batch,
+                  batchsize=rollouts_per_batch, max_searches=games, seed=1234, timeout_usec=10)
+        dt0 = max(r["usec"] / 1e6, 1e-3)
+        per = dt0 / max(len(r["search"]), 1)
+        searches = int(max(games, min(64 * games, (budget - (time.time() - t0)) / max(per, 1e-4))))
+        calls[0] = calls[1] = 0
+        r = R.run(net=net_fn, num_games=games, mcts_threads=2, rollouts_per_thread=rollouts // 2, rollouts_per_batch=rollouts_per_batch,
+                  batchsize=rollouts_per_batch, max_searches=searches, seed=1234, timeout_usec=10)
+        dt = r["usec"] / 1e6
+        done = len(r["search"]) * rollouts       # 2 search threads x rollouts/2 each (tree_search.h:472-476)
+        row = {"num_games": games, "rollouts_per_sec": done / dt, "searches": len(r["search"]), "seconds": dt, "net_calls": calls[0],
+               "mean_rows_per_call": calls[1] / max(calls[0], 1)}
+        sweep.append(row)
+        if best is None or row["rollouts_per_sec"] > best["rollouts_per_sec"]:
+            best = row
+    return {"value": best["rollouts_per_sec"], "unit": "rollouts/s", "cores": min(host, best["num_games"] * 3), "kind": "reference",
+            "num_games_sweep": sweep,
+            "sample": "best of num_games in %s: %d reference game threads, %d searches of %d rollouts (2 search threads x %d, bs %d), the same "
+                      "%s net on the GPU through the reference's batch interface (%d net calls, mean %.1f rows), net time INCLUDED, %.1f s; "
+                      "host has %d cores"
+                      % ([r_["num_games"] for r_ in sweep], best["num_games"], best["searches"], rollouts, rollouts // 2, rollouts_per_batch,
+                         str(dtype).replace("torch.", ""), best["net_calls"], best["mean_rows_per_call"], best["seconds"], host)}
 
 
 # ------------------------------------------------------------------------------------------------------------------- distributed
@@ -691,7 +703,12 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                "untimed steps so that the timed window is a search in progress that crosses a move boundary"
                                % (K, args.rollouts * T, net_desc, G, groups, pregrow),
                    "search_dtype": "f32 edge statistics (the reference's float), u16 board labels", "net_dtype": args.net_dtype if net is not None else None,
-                   "games_per_gpu": G, "board_size": n, "mcts_threads": T, "rollouts_per_step": G * K * T, "net_rows_per_step": my_rows / steps,
+                   "games_per_gpu": G, "board_size": n, "mcts_threads": T,
+                   "mcts_threads_note": None if T == 1 else ("mcts_threads = %d: the reference's search threads race on the shared tree (it is nondeterministic "
+                                                             "there, SURVEY H8); this engine runs ONE deterministic interleaving of them -- thread t's K descents see "
+                                                             "the virtual losses of threads < t -- which is checked against the same interleaving restated in "
+                                                             "oracle/mcts_oracle.cc, not against the reference" % T),
+                   "rollouts_per_step": G * K * T, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
                    "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups, "pregrow_steps": pregrow,
                    "host_wait_per_step": bool(args.wait_rows),
