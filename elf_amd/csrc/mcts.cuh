@@ -314,6 +314,14 @@ __device__ unsigned long long g_select_phase[4096][8];   // per block id: no ato
 
 __device__ __attribute__((noinline)) double sqrt_beyond_table(int v) { return sqrt((double)v); }
 
+// A/B switches (tools/gpu_r4_f.sh, gpu_r4_g.sh); measured: profiles/r04f_select_ab.txt, r04g_expand_ab.txt
+#ifndef ELF_EXP_BLOCKED
+#define ELF_EXP_BLOCKED 1    // k_mcts_expand sorts with the slots blocked 8 per lane (bitonic_sort512_blocked)
+#endif
+#ifndef ELF_SEL_D4PRE
+#define ELF_SEL_D4PRE 1      // the next 64 pre-drawn D4 codes are read once per launch (lane l = the l-th draw), not one dependent load per net leaf
+#endif
+
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
   using NR = NodeRec<N>;
@@ -342,6 +350,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   Board<N> bd;
   bd.init(&lds, pool.zob, nullptr);
 
+  // the D4 codes the coming net leaves draw: one coalesced read per launch (nothing draws besides this wave); beyond 64 draws the
+  // kernel falls back to the dependent load
+  const int rng_pos0 = rng_pos;
+  int d4_pre = 0;
+  if (ELF_SEL_D4PRE && cfg.rotation_flip) { const int ix = rng_pos0 + lane; d4_pre = ix < tp.W ? (int)tp.d4buf[(size_t)g * tp.W + ix] : 0; }
   int n_unique = 0, n_nn = 0, thread_start = 0;
   const float vl_f = (float)cfg.virtual_loss;
   int visited_nodes = 0;
@@ -544,6 +557,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           kind = LK_NN;
           if (cfg.rotation_flip) {                         // get_extractor :175-183: rng() % 8, one draw per NN leaf
             if (rng_pos >= tp.W) err |= MCTS_ERR_RNG;
+            else if (ELF_SEL_D4PRE && rng_pos - rng_pos0 < 64) d4 = rl(d4_pre, rng_pos - rng_pos0);
             else d4 = rfl((int)tp.d4buf[(size_t)g * tp.W + rng_pos]);
             ++rng_pos;
           }
@@ -768,6 +782,57 @@ __device__ __forceinline__ void bitonic_sort512(u64 (&sx)[8], int lane) {
 }
 
 
+// The same sort with the slots held BLOCKED, slot e = lane * 8 + k: the strides 1, 2, 4 of every merge are then exchanges between a
+// lane's own registers (24 of the 45 stages), and of the 21 stages that cross lanes those with lane distance 1, 2 and 8 ride the
+// DPP network (quad_perm / row_ror:8) -- 12 stages through the LDS crossbar instead of 39.  Any sorting network yields the same
+// result here: the keys are distinct (they embed the payload) except for the all-ones padding.
+template <int LS>
+__device__ __forceinline__ u64 xor_lane(u64 v) {
+  if (LS == 1) return dpp_u64<0xB1>(v);        // quad_perm [1,0,3,2]
+  if (LS == 2) return dpp_u64<0x4E>(v);        // quad_perm [2,3,0,1]
+  if (LS == 8) return dpp_u64<0x128>(v);       // row_ror:8
+  return __shfl_xor(v, LS, 64);
+}
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_stage_blocked(u64 (&sx)[8], int lane) {
+  if (STRIDE < 8) {
+    // in-register: slots k and k | STRIDE of the same lane
+    const bool dn_lane = SIZE >= 8 && SIZE < 512 && (lane & (SIZE >> 3)) != 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k & STRIDE) continue;
+      const int kp = k | STRIDE;
+      const u64 a = sx[k], b = sx[kp];
+      const bool dn = SIZE < 8 ? ((k & SIZE) != 0) : dn_lane;
+      const bool sw = (a > b) != dn;            // equal slots (padding) may swap: same value
+      sx[k] = sw ? b : a;
+      sx[kp] = sw ? a : b;
+    }
+  } else {
+    constexpr int LS = STRIDE >> 3;
+    const bool up = SIZE >= 512 || (lane & (SIZE >> 3)) == 0;
+    const bool keep_min = ((lane & LS) == 0) == up;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 y = xor_lane<LS>(sx[k]);
+      const bool less = sx[k] < y;
+      sx[k] = (keep_min == less) ? sx[k] : y;
+    }
+  }
+}
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge_blocked(u64 (&sx)[8], int lane) {
+  bitonic_stage_blocked<SIZE, STRIDE>(sx, lane);
+  if constexpr (STRIDE > 1) bitonic_merge_blocked<SIZE, STRIDE / 2>(sx, lane);
+}
+template <int SIZE>
+__device__ __forceinline__ void bitonic_sizes_blocked(u64 (&sx)[8], int lane) {
+  bitonic_merge_blocked<SIZE, SIZE / 2>(sx, lane);
+  if constexpr (SIZE < 512) bitonic_sizes_blocked<SIZE * 2>(sx, lane);
+}
+// ascending; slot e = lane * 8 + k
+__device__ __forceinline__ void bitonic_sort512_blocked(u64 (&sx)[8], int lane) { bitonic_sizes_blocked<2>(sx, lane); }
+
 // The introsort loop of std::sort(pairs, a.second > b.second) over L.key / L.prob [0, n), wave-parallel and exact: the
 // pairing formulation of stl_emul.h (sort_desc_pairing, checked against libstdc++ on the host).  One partition = flags + ranks by
 // ballots over the <= 6 rounds that overlap the range, positions through LDS scratch (the sprob area, not yet in use), parallel
@@ -902,7 +967,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
   int nvalid = 0;
 #pragma unroll
   for (int k = 0; k < SK; ++k) {
-    const int i = k * 64 + lane;
+    const int i = ELF_EXP_BLOCKED ? lane * SK + k : k * 64 + lane;   // sort slot <-> action id (any bijection does)
     bool valid = false;
     int coord = 0;
     float p = 0.0f;
@@ -933,6 +998,22 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
     n = 1;
   } else {
     n = nvalid;
+    if (ELF_EXP_BLOCKED) {
+      bitonic_sort512_blocked(sx, lane);
+      EXP_PHASE(3);   // register bitonic sort of 512 slots
+      // sorted element e = lane*8 + k: prior back from the key, coord from the payload; the rest of the kernel holds element
+      // k*64 + lane in sp[k], read back from LDS
+#pragma unroll
+      for (int k = 0; k < SK; ++k) {
+        const int e = lane * SK + k;
+        const u32 ukey = ~(u32)(sx[k] >> 32);
+        const u32 bits = (ukey & 0x80000000u) ? (ukey & 0x7FFFFFFFu) : ~ukey;
+        if (e < n) { L.sprob[e] = __uint_as_float(bits); L.skey[e] = (u16)(sx[k] & 0xFFFFu); }
+      }
+      Board<N>::wsync();
+#pragma unroll
+      for (int k = 0; k < R; ++k) { const int e = k * 64 + lane; sp[k] = e < n ? L.sprob[e] : 0.0f; }
+    } else {
     bitonic_sort512(sx, lane);
     EXP_PHASE(3);   // register bitonic sort of 512 slots
     // sorted element e = k*64 + lane (e < n <= N*N+1 <= 6*64): prior back from the key, coord from the payload
@@ -943,6 +1024,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
       const u32 bits = (ukey & 0x80000000u) ? (ukey & 0x7FFFFFFFu) : ~ukey;
       sp[k] = __uint_as_float(bits);
       if (e < n) { L.sprob[e] = sp[k]; L.skey[e] = (u16)(sx[k] & 0xFFFFu); }
+    }
     }
     Board<N>::wsync();
 #pragma unroll

@@ -5,6 +5,7 @@
 // and printed with the shortest round-trip digits in nlohmann's fixed/exponent layout), so that the reference's
 // Record::createFromJson reads it back field for field.
 #include "record_host.h"
+#include "host_workers.h"
 
 #include <math.h>
 #include <string.h>
@@ -679,30 +680,39 @@ int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t
   if (!any) return ELFGO_E_BADARG;
   const float kSafeMargin = 0.45;
   const int kNumState = 64;
-  for (int a = 0; a < num_acts; ++a) {
-    std::mt19937& rng = q->thread_rng[(size_t)(q->next_act++ % (int64_t)q->thread_rng.size())];
-    for (int i = 0; i < kNumState; ++i) {
-      const size_t o = (size_t)a * kNumState + i;
-      while (true) {
-        const int even = q->parity_sizes[0], odd = q->parity_sizes[1];
-        float even_ratio = static_cast<float>(even) / (even + odd + 1e-6);
-        even_ratio = std::max(even_ratio, kSafeMargin);
-        even_ratio = std::min(even_ratio, 1.0f - kSafeMargin);
-        std::uniform_real_distribution<> dis(0.0, 1.0);
-        int idx = (int)(rng() % (q->qs.size() / 2));
-        idx *= 2;
-        if (dis(rng) > even_ratio) idx++;
-        const std::deque<ElfReaderQueues::Rec>& buf = q->qs[(size_t)idx];
-        if (buf.size() < q->queue_min_size) continue;
-        const ElfReaderQueues::Rec& r = buf[rng() % buf.size()];
-        if (r.num_moves <= num_future_actions - 1) continue;
-        slot[o] = r.slot;
-        move_to[o] = (int32_t)(rng() % (size_t)(r.num_moves - num_future_actions + 1));
-        break;
+  // The acts go round the game threads; every thread draws from its own generator and only READS the queues, so the acts of
+  // different threads are independent of each other: thread tt's acts (in their order) are one unit of work for the host pool.
+  const int64_t T = (int64_t)q->thread_rng.size(), first = q->next_act;
+  auto acts_of_thread = [&](size_t tt) {
+    std::mt19937& rng = q->thread_rng[tt];
+    for (int64_t a = (((int64_t)tt - first) % T + T) % T; a < num_acts; a += T) {
+      for (int i = 0; i < kNumState; ++i) {
+        const size_t o = (size_t)a * kNumState + i;
+        while (true) {
+          const int even = q->parity_sizes[0], odd = q->parity_sizes[1];
+          float even_ratio = static_cast<float>(even) / (even + odd + 1e-6);
+          even_ratio = std::max(even_ratio, kSafeMargin);
+          even_ratio = std::min(even_ratio, 1.0f - kSafeMargin);
+          std::uniform_real_distribution<> dis(0.0, 1.0);
+          int idx = (int)(rng() % (q->qs.size() / 2));
+          idx *= 2;
+          if (dis(rng) > even_ratio) idx++;
+          const std::deque<ElfReaderQueues::Rec>& buf = q->qs[(size_t)idx];
+          if (buf.size() < q->queue_min_size) continue;
+          const ElfReaderQueues::Rec& r = buf[rng() % buf.size()];
+          if (r.num_moves <= num_future_actions - 1) continue;
+          slot[o] = r.slot;
+          move_to[o] = (int32_t)(rng() % (size_t)(r.num_moves - num_future_actions + 1));
+          break;
+        }
+        d4[o] = (int32_t)(rng() % 8);
       }
-      d4[o] = (int32_t)(rng() % 8);
     }
-  }
+  };
+  const unsigned nt = (unsigned)std::min<int64_t>(std::min<int64_t>(T, num_acts), host_worker_count(16));
+  if (nt < 2 || num_acts < 8) { for (int64_t tt = 0; tt < T; ++tt) acts_of_thread((size_t)tt); }
+  else HostWorkers::get().run((size_t)T, nt, acts_of_thread);
+  q->next_act += num_acts;
   return 0;
 }
 

@@ -40,6 +40,7 @@
 #include <thread>
 
 #include "engine_host.h"
+#include "host_workers.h"
 #include "record_host.h"
 
 struct ElfSpSearchRec {   // == ElfSpSearch in include/elf_amd.h
@@ -164,72 +165,13 @@ struct ElfSelfPlay {
 // that game's generators: spread over a few host threads when many games are at the boundary together.  The threads are a
 // process-wide pool created at the first use and parked on a condition variable in between (a move boundary every 200 steps
 // would otherwise pay for 16 thread creations + joins each time).
-class SpWorkers {
- public:
-  static SpWorkers& get() { static SpWorkers w; return w; }
-  // fn(i) for i in [0, n), strided over `nt` participants (the caller is participant 0); returns when all of them are done
-  void run(size_t n, unsigned nt, const std::function<void(size_t)>& fn) {
-    std::unique_lock<std::mutex> call(call_mu_);          // one parallel region at a time (contexts on several host threads)
-    ensure(nt - 1);
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn; n_ = n; nt_ = nt; pending_ = nt - 1; ++epoch_;
-    }
-    cv_.notify_all();
-    for (size_t i = 0; i < n; i += nt) fn(i);
-    std::unique_lock<std::mutex> lk(mu_);
-    done_.wait(lk, [&] { return pending_ == 0; });
-    fn_ = nullptr;
-  }
-  ~SpWorkers() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-  }
- private:
-  void ensure(unsigned k) {
-    while (th_.size() < k) {
-      const unsigned id = (unsigned)th_.size() + 1;        // participant index of this worker
-      // a worker created during a later region must not mistake that region for a new epoch before it is asked to run
-      const uint64_t seen0 = epoch_;
-      th_.emplace_back([this, id, seen0] {
-        uint64_t seen = seen0;
-        for (;;) {
-          const std::function<void(size_t)>* fn; size_t n; unsigned nt;
-          {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-            if (stop_) return;
-            seen = epoch_; fn = fn_; n = n_; nt = nt_;
-          }
-          if (id < nt) {
-            for (size_t i = id; i < n; i += nt) (*fn)(i);
-            std::lock_guard<std::mutex> lk(mu_);
-            if (--pending_ == 0) done_.notify_one();
-          }
-        }
-      });
-    }
-  }
-  std::mutex call_mu_, mu_;
-  std::condition_variable cv_, done_;
-  std::vector<std::thread> th_;
-  const std::function<void(size_t)>* fn_ = nullptr;
-  size_t n_ = 0;
-  unsigned nt_ = 0, pending_ = 0;
-  uint64_t epoch_ = 0;
-  bool stop_ = false;
-};
-
 template <class F>
 static void sp_for_games(const std::vector<int32_t>& ids, F fn) {
   const size_t n = ids.size();
-  unsigned nt = std::thread::hardware_concurrency();
-  if (const char* e = getenv("ELF_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) nt = (unsigned)v; }   // e.g. nproc / ranks on a shared node
-  if (nt > 16) nt = 16;
+  unsigned nt = host_worker_count(16);
   if (n < 16 || nt < 2) { for (int g : ids) fn(g); return; }
   if (nt > n / 4) nt = (unsigned)(n / 4);
-  SpWorkers::get().run(n, nt, [&](size_t i) { fn(ids[i]); });
+  HostWorkers::get().run(n, nt, [&](size_t i) { fn(ids[i]); });
 }
 
 static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {

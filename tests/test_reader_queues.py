@@ -125,3 +125,26 @@ def test_live_differential_over_queue_shapes_and_seeds(built):
         q.close()
         done += 1
     assert done >= 6
+
+
+def test_draws_do_not_depend_on_the_host_threads_that_make_them(built):
+    """elfrq_draw spreads the acts of different game threads (each with its own generator) over the host worker pool: the arrays
+    equal the one-thread result, act for act, also when the acts do not divide evenly among the game threads."""
+    import numpy as np
+    from elf_amd.train import ReaderQueues
+    outs = []
+    for host_threads in ("1", "8", "3"):
+        os.environ["ELF_AMD_HOST_THREADS"] = host_threads
+        try:
+            q = ReaderQueues(num_reader=4, queue_min_size=2, queue_max_size=50, insert_seed=5, num_threads=5, seed=21, job_id="")
+            rng = np.random.default_rng(3)
+            for s in range(40):
+                q.insert(s, int(rng.integers(1, 200)), bool(rng.integers(0, 2)))
+            a = q.draw(7, 2)            # fewer acts than the pool's threshold: serial path
+            b = q.draw(23, 2)           # 23 acts over 5 game threads, starting at thread 7 % 5
+            c = q.draw(16, 1)
+            outs.append(np.concatenate([np.asarray(x).ravel() for x in (*a, *b, *c)]))
+            q.close()
+        finally:
+            os.environ.pop("ELF_AMD_HOST_THREADS", None)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Refresh profiles/pmc_issue.json (instructions per unit of work of the LDS-resident kernels) from the PMC summaries of one
-tools/gpu_r3_pmc.sh visit.  usage: python tools/update_issue.py gpurun_out/<tag> <tag>
+tools/gpu_r4_pmc.sh visit.  usage: python tools/update_issue.py gpurun_out/<tag> <tag>
 Units per launch come from the bench line that ran under the same rocprofv3 pass (stats_<workload>.log)."""
 import json, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -27,7 +27,7 @@ p = os.path.join(root, "profiles", "pmc_issue.json")
 res = json.load(open(p)) if os.path.exists(p) else {}
 for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>", "board step", "board"),
                                        ("board9", "k_playout<9>", "k_playout<9>", "board step", "board9"),
-                                       ("train", "k_replay_extract<19>", "k_replay_extract<19>", "replayed board step", "train")):
+                                       ("train", "k_replay_extract<19>", "k_replay_extract<19>", "board step forwarded from the checkpoint", "train")):
     s = os.path.join(out, "summary_%s.txt" % wl)
     log = os.path.join(out, "stats_%s.log" % wl)
     if not (os.path.exists(s) and os.path.exists(log)):
@@ -37,7 +37,7 @@ for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>
     if d is None or "SQ_INSTS_VALU" not in c:
         continue
     cfg = d["config"]
-    units = cfg["board_steps_per_pass"] if wl.startswith("board") else cfg["mean_replayed_plies"] * cfg.get("samples_per_launch", cfg["batch"])
+    units = cfg["board_steps_per_pass"] if wl.startswith("board") else cfg.get("mean_forwarded_plies", cfg["mean_replayed_plies"]) * cfg.get("samples_per_launch", cfg["batch"])
     res[key] = {"valu_per_unit": c["SQ_INSTS_VALU"][0] / units, "salu_per_unit": c["SQ_INSTS_SALU"][0] / units,
                 "lds_per_unit": c.get("SQ_INSTS_LDS", (0.0, 0))[0] / units, "unit": unit,
                 # north_star: LDS-bank utilisation of the board step.  SQ_LDS_IDX_ACTIVE = cycles the LDS index pipe is busy,
@@ -49,7 +49,7 @@ for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>
                 "wave_wait_frac": (c["SQ_WAIT_ANY"][0] / c["SQ_WAVE_CYCLES"][0]) if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c else None,
                 "profile": "profiles/%s_%s_rocprofv3.txt" % (tag, profile),
                 "note": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS, mean over %d launches of the bench.py --workload %s run "
-                        "of tools/gpu_r3_pmc.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
+                        "of tools/gpu_r4_pmc.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
 sys.path.insert(0, root)
 from elf_amd._lib import KERNEL_SOURCES, kernel_source_hash   # noqa: E402
 res["_source"] = {"kernel_source_hash": kernel_source_hash(), "files": ["elf_amd/csrc/" + f for f in KERNEL_SOURCES], "visit": tag,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Refresh profiles/pmc_traffic.json from the PMC summaries of one tools/gpu_round.sh visit.
+"""Refresh profiles/pmc_traffic.json from the PMC summaries of one tools/gpu_r4_pmc.sh visit.
 usage: python tools/update_traffic.py gpurun_out/<tag> <tag>   (FETCH_SIZE doubled: MI355X_MICROARCH.md, gfx950 counts 128-B requests as 64 B)"""
 import json, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -38,7 +38,7 @@ if os.path.exists(t):
         if "k_replay_extract" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             res["k_replay_extract<19>"] = {"hbm_bytes_per_launch": hbm(c), "fetch_size_kib": c["FETCH_SIZE"][0], "write_size_kib": c["WRITE_SIZE"][0],
                                            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d launches of bench.py --workload train "
-                                                   "(32768 samples = 16 train batches of 2048 per launch, the bench default --train-prefetch 16, ~159 replayed plies each); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_train_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
+                                                   "(32768 samples = 16 train batches of 2048 per launch, the bench default --train-prefetch 16; each sample loads its record's checkpoint and forwards <= 31 plies); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_train_rocprofv3.txt" % (c["FETCH_SIZE"][1], tag)}
 for key, algo in (("f32", 26728), ("f16", 13732)):
     t = os.path.join(out, "summary_feat%s.txt" % ("32" if key == "f32" else "16"))
     if not os.path.exists(t):
