@@ -119,12 +119,27 @@ def issue_roof(kernel, units_per_launch, kernel_s):
     salu = per.get("salu_per_unit")
     salu_ach = units_per_launch * salu / kernel_s / 1e9 if salu else None
     salu_frac = salu_ach / SALU_PEAK_GINST if salu_ach else None
-    binding = "salu" if (salu_frac is not None and salu_frac > ach / VALU_PEAK_GINST) else "valu"
+    # class-weighted VALU roof: only plain VOP1/VOP2 issue at (nearly) the 2-cycle rate; VOP3 / VOPC / DPP / SDWA / lane access /
+    # 64-bit shifts / multiplies were measured at one per 4 cycles per SIMD (profiles/r04b_issue_probe.json).  The kernel's static mix
+    # (tools/valu_mix.py -> profiles/valu_mix.json) prices its instructions accordingly.
+    mixes = load_profile_json("valu_mix.json")
+    mix = None
+    if mixes.get("_source", {}).get("kernel_source_hash") == load_profile_json("pmc_issue.json").get("_source", {}).get("kernel_source_hash"):
+        base, size = kernel.split("<")[0], kernel.split("<")[1].rstrip(">")
+        for k, v in mixes.items():
+            if k.startswith(base + "<" + size) and not k.endswith("true>"):
+                mix = v
+    w_peak = mix["valu_peak_ginst"] if mix else None
+    w_frac = ach / w_peak if w_peak else None
+    binding = "salu" if (salu_frac is not None and salu_frac > (w_frac or ach / VALU_PEAK_GINST)) else "valu"
     return {"bound": "issue", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": ach / VALU_PEAK_GINST,
             "salu_issue": {"achieved": salu_ach, "peak": SALU_PEAK_GINST, "unit": "G scalar instructions/s", "frac": salu_frac,
                            "note": "one scalar ALU per CU at a measured 1.00 instruction per clock (profiles/r04b_issue_probe.json): "
                                    "SQ_INSTS_SALU per unit x units/s / (256 CUs x 2.4 GHz)"},
-            "salu_issue_frac": salu_frac, "binding_issue_roof": binding, "binding_frac": max(ach / VALU_PEAK_GINST, salu_frac or 0.0),
+            "valu_class_weighted": {"peak": w_peak, "frac": w_frac, "quarter_rate_share_static": mix["quarter_rate_share"] if mix else None,
+                                    "note": "VALU peak for this kernel's static instruction mix: plain VOP1/VOP2 at the measured 1.82 per clock and "
+                                            "CU, everything else at the measured 1.0 (profiles/valu_mix.json, r04b_issue_probe.json)"},
+            "salu_issue_frac": salu_frac, "binding_issue_roof": binding, "binding_frac": max(w_frac or ach / VALU_PEAK_GINST, salu_frac or 0.0),
             "traffic": load_traffic(kernel), "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "valu_per_unit": valu, "pmc_source_match": True,
             "pmc_source_hash": load_profile_json("pmc_issue.json").get("_source", {}).get("kernel_source_hash"),
             "salu_per_unit": per.get("salu_per_unit"), "lds_per_unit": per.get("lds_per_unit"),
