@@ -27,6 +27,10 @@ for W in board board9 mcts train feat32 feat16; do
   python tools/summarize_prof.py $OUT $W > $OUT/summary_$W.txt 2>&1
   grep -E "k_playout|k_mcts|k_replay|k_extract" $OUT/summary_$W.txt | head -12
 done
+echo "== rocprofv3 stats, search-only with 2048 games in two pipelined groups (215 GB of node records)"
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_mcts2048 -o stats --output-format csv -- python bench.py --workload mcts --net random --features f16 --games 2048 --groups 2 --nodes-per-game 8192 --rollouts 2048 --pregrow 0 --warmup 88 --steps 32 --no-cpu-baseline > $OUT/stats_mcts2048.log 2>&1
+python tools/summarize_prof.py $OUT mcts2048 > $OUT/summary_mcts2048.txt 2>&1
+head -8 $OUT/summary_mcts2048.txt
 echo "== rocprofv3 stats, headline (with the real net)"
 timeout 500 rocprofv3 --kernel-trace --stats -d $OUT/stats_mctsnet -o stats --output-format csv -- python bench.py --workload mcts --steps 20 --warmup 5 --no-cpu-baseline > $OUT/stats_mctsnet.log 2>&1
 python tools/summarize_prof.py $OUT mctsnet > $OUT/summary_mctsnet.txt 2>&1
