@@ -940,18 +940,20 @@ def run_games(args, rank, local_rank, world, dist):
         spl = PipelinedSelfPlay(groups=groups, seed=97, game_idx_base=rank * Gl * groups, wait_rows=False, board_size=n, num_games=Gl, device=local_rank,
                                 mcts_rollout_per_thread=K, mcts_rollout_per_batch=K, mcts_puct=1.5, mcts_virtual_loss=1, mcts_persistent_tree=True,
                                 mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, policy_distri_cutoff=30, resign_thres=0.05, nodes_per_game=2048,
-                                feature_format=feat_fmt, keep_records=0)
+                                feature_format=feat_fmt, keep_records=4 * Gl)
         fn, gr = graphed(spl)
         limit = 2 * n * n + 8
         tl = time.perf_counter()
         for _ in range(limit):
             spl.step(fn)
-            if _ % 32 == 31 and spl.stats()["games"] >= Gl * groups:
+            if _ % 16 == 15 and spl.stats()["games"] >= Gl * groups:
                 break
         spl.synchronize()
         stl = spl.stats()
-        length = {"games_finished": stl["games"], "moves_played": stl["moves"], "seconds": time.perf_counter() - tl,
-                  "mean_game_length": (stl["moves"] / stl["games"]) if stl["games"] else None,
+        # the length of every FINISHED game from its record (Record.result.num_move), not moves / games (games still running would count)
+        lens = [json.loads(r)["result"]["num_move"] for g in spl.groups for r in g.pop_records()]
+        length = {"games_finished": len(lens), "moves_played": stl["moves"], "seconds": time.perf_counter() - tl,
+                  "mean_game_length": float(np.mean(lens)) if lens else None, "min_max_game_length": [int(min(lens)), int(max(lens))] if lens else None,
                   "config": "%d games, %d rollouts/move (one step per move), no move cutoff, resign_thres 0.05, random-init net: games end by two "
                             "passes, the move limit %d, or resignation" % (Gl * groups, K, 2 * n * n)}
         spl.close()
