@@ -39,7 +39,8 @@ namespace elfgo {
 enum { NS_NOT_VISITED = 0, NS_EVAL_REQUESTED = 1, NS_VISITED = 2 };   // NodeT::VisitType
 enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2 };
 enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8, MCTS_ERR_VERSION = 16 };
-constexpr int MCTS_KMAX = 256;  // max rollouts per step = num_threads x rollouts_per_batch (leaf table of a step: LDS in select, 64-leaf chunks in backup)
+constexpr int MCTS_KMAX = 1024;  // max rollouts per step = num_threads x rollouts_per_batch: the stride of the per-game leaf / row tables in HBM.
+                                 // The leaf table of a step in LDS (k_mcts_select) is sized by the launch: 20 B per rollout of the step
 enum { GM_IDLE = 0, GM_SEARCH = 1, GM_POLICY_ONLY = 2 };   // per-game mask byte (elfmcts_set_game_mask)
 
 struct NodeHdr {          // 64 B
@@ -327,9 +328,15 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   using NR = NodeRec<N>;
   __shared__ Slot<N> lds;
   __shared__ __attribute__((aligned(16))) float uqs[64 + 8];   // unsigned child Qs of one round's visited edges, compacted
-  // the unique leaves of this step (unique per search thread), in first-occurrence order
-  __shared__ int lf_node[MCTS_KMAX], lf_count[MCTS_KMAX], lf_meta[MCTS_KMAX], lf_nn[MCTS_KMAX];
-  __shared__ float lf_value[MCTS_KMAX];
+  // the unique leaves of this step (unique per search thread), in first-occurrence order: five arrays of KTP entries in the launch's
+  // dynamic LDS (KTP = num_threads x rollouts_per_batch rounded up to 64; elfmcts_select passes 20 x KTP bytes)
+  extern __shared__ int lf_dyn[];
+  const int KTP = (cfg.rollouts_per_batch * cfg.num_threads + 63) & ~63;
+  int* const lf_node = lf_dyn;
+  int* const lf_count = lf_dyn + KTP;
+  int* const lf_meta = lf_dyn + 2 * KTP;
+  int* const lf_nn = lf_dyn + 3 * KTP;
+  float* const lf_value = reinterpret_cast<float*>(lf_dyn + 4 * KTP);
   const int g = blockIdx.x, lane = threadIdx.x;
   const int mode = rfl(tp.game_mode(g));
   if (mode == GM_IDLE) {                     // this game does not search in this step: no leaves, no rows

@@ -47,7 +47,7 @@ static TreePool<N> tree_of(const ElfMcts* m) {
 }
 
 static int cfg_from(const ElfMctsOptions* o, TreeCfg* c) {
-  // leaf table of a step: num_threads x num_rollouts_per_batch <= MCTS_KMAX = 256 (larger products are rejected, not truncated)
+  // leaf table of a step: num_threads x num_rollouts_per_batch <= MCTS_KMAX = 1024 (larger products are rejected, not truncated)
   if (!o || o->num_rollouts_per_batch <= 0 || o->num_threads <= 0 ||
       (int64_t)o->num_rollouts_per_batch * o->num_threads > MCTS_KMAX)
     return ELFGO_E_BADARG;
@@ -194,8 +194,8 @@ int elfmcts_select(ElfMcts* m, const int32_t* board_ids, void* s_dst, int64_t st
   DevGuard _dg(m->eng->device);
   const int KT = m->cfg.rollouts_per_batch * m->cfg.num_threads;
   DISPATCH(m->eng, {
-    hipLaunchKernelGGL((k_mcts_select<N, Pool<N>>), dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
-                       board_ids, m->cfg);
+    hipLaunchKernelGGL((k_mcts_select<N, Pool<N>>), dim3(m->G), dim3(64), (size_t)20 * ((KT + 63) & ~63), (hipStream_t)stream, tree_of<N>(m),
+                       pool_of<N>(m->eng), board_ids, m->cfg);
     hipLaunchKernelGGL(k_mcts_rowbase<N>, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree_of<N>(m), counts);
     hipLaunchKernelGGL(k_mcts_features<N>, dim3(m->G * KT), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), KT, s_dst, stride_elems,
                        m->feat_fmt, m->rowmap);

@@ -116,7 +116,7 @@ typedef struct ElfMctsOptions {
   int32_t num_threads;              /* TSOptions.num_threads: search threads per game (tree_search.h:345-368), >= 1; one step runs
                                      * their batch_rollouts in sequence on the shared tree, so a move costs
                                      * num_threads x num_rollouts_per_thread rollouts (tree_search.h:472-476).
-                                     * num_threads x num_rollouts_per_batch must be <= elfmcts_max_rollouts_per_step() = 256
+                                     * num_threads x num_rollouts_per_batch must be <= elfmcts_max_rollouts_per_step() = 1024
                                      * (the leaf table of one step; ELFGO_E_BADARG otherwise) */
   int32_t reserved0;
   int64_t required_version;         /* MCTSActorParams.required_version: < 0 = replies of any model version are accepted */
@@ -141,7 +141,7 @@ int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt);
  * ELFGO_FEAT_F16_NHWC s_dst points to halfs and the stride argument counts halfs. */
 int elfmcts_set_feature_format(ElfMcts* m, int fmt);
 int elfmcts_get_feature_format(const ElfMcts* m, int* fmt);
-/* largest num_threads x num_rollouts_per_batch a search step can hold (256) */
+/* largest num_threads x num_rollouts_per_batch a search step can hold (1024: the stride of the per-game leaf tables; the step's table in LDS is sized by the launch) */
 int elfmcts_max_rollouts_per_step(void);
 /* Which games the per-game launches that follow act on: mask = device bytes [num_games], 0 = the game is left alone (no root
  * check, no noise, no descents, no rows), 1 = it searches, 2 = TreeSearchT::runPolicyOnly (tree_search.h:385-407: the root is

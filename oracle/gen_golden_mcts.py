@@ -55,6 +55,9 @@ CASES = {
     "mcts_9_r256_bs128": (9, dict(rollouts_per_thread=256, rollouts_per_batch=128, batchsize=128, max_searches=20, net_salt=59,
                                   policy_distri_cutoff=4)),
     "mcts_19_r512_bs256": (19, dict(rollouts_per_thread=512, rollouts_per_batch=256, batchsize=256, max_searches=4, net_salt=60)),
+    # round 4: the leaf table of a step is sized by the launch (up to 1024 leaves): 512 rollouts per batch, and 2 search threads x 384
+    "mcts_9_r1024_bs512": (9, dict(rollouts_per_thread=1024, rollouts_per_batch=512, batchsize=512, max_searches=8, net_salt=64,
+                                   policy_distri_cutoff=4)),
     # TSOptions.pick_method = uniform_random (tree_search.h:514-517): random_idx = rng() % edges from MCTSResultT::addActions'
     # process-wide `static std::mt19937 rng(time(NULL))` (tree_search_base.h:238).  fixed_time = what time() returns to the
     # reference in the generating process (oracle/ref_selfplay.cc refsp_set_time); one game, so the draws have one order; the

@@ -85,9 +85,10 @@ def test_pick_method_uniform_random_matches_reference(elf):
     run_case(elf, "mcts_9_pick_uniform")
 
 
-@pytest.mark.parametrize("name", ["mcts_9_r256_bs128", "mcts_19_r512_bs256"])
+@pytest.mark.parametrize("name", ["mcts_9_r256_bs128", "mcts_19_r512_bs256", "mcts_9_r1024_bs512"])
 def test_more_than_64_rollouts_per_batch(elf, name):
-    """num_rollouts_per_batch 128 / 256 (tree_search_options.h:81 has no bound): the leaf table of a step holds up to 256 leaves."""
+    """num_rollouts_per_batch 128 / 256 / 512 (tree_search_options.h:81 has no bound): the leaf table of a step is sized by the
+    launch (up to 1024 leaves = num_threads x num_rollouts_per_batch)."""
     run_case(elf, name)
 
 

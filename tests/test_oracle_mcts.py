@@ -14,7 +14,7 @@ CASES = ["mcts_19_r8192", "mcts_19_r256_dir", "mcts_19_r256_ties", "mcts_19_r512
          "mcts_9_r64_ties", "mcts_19_r128_vl0", "mcts_19_r128_noprior", "mcts_9_r128_rootq0", "mcts_9_r96_bs4", "mcts_9_r128_bs64"]
 # round 3: evaluation games (two AIs), strongest_prior, policy-only play, more than 64 rollouts per batch
 CASES_R3 = ["mcts_9_eval_two_ai", "mcts_19_eval_swap", "mcts_9_pick_prior", "mcts_9_policy_only_white", "mcts_9_policy_only_eval",
-            "mcts_9_r256_bs128", "mcts_19_r512_bs256", "mcts_9_pick_uniform"]
+            "mcts_9_r256_bs128", "mcts_19_r512_bs256", "mcts_9_pick_uniform", "mcts_9_r1024_bs512"]
 
 
 @pytest.mark.parametrize("n", [19, 9])
