@@ -54,6 +54,9 @@ def test_mcts_bad_arguments_are_status_codes(built):
     assert L.elfsp_create(None, 0, None, ctypes.byref(h)) == -1
     assert L.elfsp_destroy(None) == -1
     assert L.elfsp_begin_step(None, None, 0, None, None) == -1
+    # the trainer-side entry points added in round 4: a null store is a status code
+    assert L.elftrain_set_keep_states(None, 1) == -1
+    assert L.elftrain_put_async(None, 0, None, 0, ctypes.c_float(1.0), 0, None, 0, None, 0, None) == -1
 
 
 def test_selfplay_refuses_to_run_without_gpu(built):

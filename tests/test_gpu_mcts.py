@@ -280,8 +280,8 @@ def test_search_threads_equal_their_restatement(elf, n, T, K, roll):
     assert 0.5 * T * roll < rec[0].total_visits <= T * roll - T * K
     assert sp.stats()["rollouts"] == m * T * ((roll + K - 1) // K) * K
     sp.close()
-    with pytest.raises(Exception):     # the leaf table of a step holds T x K <= 256 leaves, rejected loudly beyond
-        elf.SelfPlay(board_size=9, num_games=1, mcts_rollout_per_batch=32, mcts_threads=16)
+    with pytest.raises(Exception):     # the leaf tables hold T x K <= 1024 leaves per step, rejected loudly beyond
+        elf.SelfPlay(board_size=9, num_games=1, mcts_rollout_per_batch=64, mcts_threads=32)
 
 
 def test_backup_order_is_first_occurrence_with_unquantised_values(elf):
