@@ -1351,6 +1351,7 @@ def main():
     ap.add_argument("--games-rollouts", type=int, default=32)
     ap.add_argument("--games-cutoff", type=int, default=40)
     ap.add_argument("--games-generations", type=int, default=2)
+    ap.add_argument("--search-only-games", type=int, default=2048, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
     ap.add_argument("--phase-steps", type=int, default=16, help="timed steps per game phase (plies 0/60/120/180) of the games/s leg; 0 = off")
     ap.add_argument("--length-games", type=int, default=32, help="games played to their natural end to measure the game length; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1375,6 +1376,27 @@ def main():
         v = getattr(args, name)
         return v if (v is not None and args.workload != "both") else dflt
 
+    if sub and args.board_size == 19 and args.search_only_games > 0:
+        # the search kernels without the conv net, with as many games in flight as 288 GB of HBM hold at the headline's pool size
+        # (2048 games x 8192 node records x 12.5 KB = 215 GB): two waves per SIMD in the per-game kernels, two pipelined groups
+        try:
+            import copy
+            a2 = copy.copy(args)
+            a2.net, a2.features, a2.games, a2.groups, a2.nodes_per_game, a2.rollouts, a2.pregrow = "random", "f16", args.search_only_games, 2, 8192, 2048, 0
+            so = run_mcts(a2, rank, local_rank, world, dist, 32, 88, False)
+            if rank == 0:
+                c = so["config"]
+                res["search_only"] = {"metric": "mcts_rollouts_per_sec, search kernels only (random replies instead of the conv net)", "value": so["value"],
+                                      "unit": "rollouts/s", "ms_per_step": so["ms_per_step"], "games_per_gpu": c["games_per_gpu"], "groups": c["groups"],
+                                      "rollouts_per_step": c["rollouts_per_step"], "mean_depth": c["mean_depth"], "select_ms": c["select_ms"],
+                                      "expand_backup_ms": c["expand_backup_ms"], "roofline": so["roofline"],
+                                      "note": "same kernels, same tree shape (2048 rollouts per move on 8192-node pools, depth ~6.3) as the round-3 search-only "
+                                              "line, with 2048 instead of 1024 games per GPU: the per-game kernels are latency chains, a second resident "
+                                              "wave per SIMD hides them (1024 games, one group: profiles/r04z_bench_search_only.json)"}
+        except Exception as e:   # e.g. not enough free HBM beside another process
+            if rank == 0:
+                res["search_only"] = "unavailable: %r" % (e,)
+            torch.cuda.empty_cache()
     if args.workload == "board" or sub:
         b = run_board(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3), with_cpu)
         if args.workload == "board":
