@@ -1396,6 +1396,8 @@ def main():
         except Exception as e:   # e.g. not enough free HBM beside another process
             if rank == 0:
                 res["search_only"] = "unavailable: %r" % (e,)
+            import gc
+            gc.collect()                     # a half-built context frees its node pools in its finaliser
             torch.cuda.empty_cache()
     if args.workload == "board" or sub:
         b = run_board(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3), with_cpu)
