@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <functional>
@@ -16,6 +17,11 @@ class HostWorkers {
   // fn(i) for i in [0, n), strided over `nt` participants (the caller is participant 0); returns when all of them are done
   void run(size_t n, unsigned nt, const std::function<void(size_t)>& fn) {
     std::unique_lock<std::mutex> call(call_mu_);          // one parallel region at a time (contexts on several host threads)
+    if (owner_ != getpid()) {                              // a forked child inherits the object but not the threads: start over
+      (void)new std::vector<std::thread>(std::move(th_));   // abandoned, never destroyed: the handles name threads of the parent
+      th_.clear();
+      owner_ = getpid();
+    }
     ensure(nt - 1);
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -57,6 +63,7 @@ class HostWorkers {
       });
     }
   }
+  pid_t owner_ = getpid();
   std::mutex call_mu_, mu_;
   std::condition_variable cv_, done_;
   std::vector<std::thread> th_;

@@ -85,3 +85,24 @@ def test_two_ranks_share_the_gpu_on_the_real_workloads():
     gm = rep["selfplay_games"]
     assert gm["n_gpus"] == 2 and len(gm["per_rank_games_per_sec"]) == 2
     assert gm["games_finished"] >= 2 * 32                   # both ranks finished at least one generation of their games
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("board", ["--boards", "256", "--steps", "2", "--warmup", "1"]),
+                                            ("train", ["--train-batch", "256", "--train-prefetch", "2", "--train-records", "32", "--steps", "3", "--warmup", "1"])])
+def test_two_ranks_share_the_gpu_on_the_board_and_trainer_workloads(workload, extra):
+    """The world > 1 branches of run_board / run_train (per-rank seeds and records, max-over-ranks time, sum of the units) with two
+    ranks on this box's one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ELF_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload, "--no-cpu-baseline"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["value"] > 0
+    if workload == "board":
+        assert rep["parity_mismatches"] == 0 and rep["config"]["boards_per_gpu"] == 256
+    else:
+        assert rep["config"]["samples_per_launch"] == 512
