@@ -1200,7 +1200,9 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     if queues:
         # the reference's replay buffer and draws: ReaderQueues filled with InsertWithParity, GoGameTrain::act's draws by B / 64 game
         # threads per train batch (elf_amd.ReplayBuffer; bit-exact against the real GoGameTrain path, tests/test_gpu_train.py)
-        rb = elf_amd.ReplayBuffer(board_size=n, num_reader=args.train_readers, queue_min_size=10, queue_max_size=1000, batchsize=B,
+        # (queue_min_size 10 as in the reference's defaults, less when --train-records is too small to fill every queue that far)
+        rb = elf_amd.ReplayBuffer(board_size=n, num_reader=args.train_readers, queue_min_size=max(1, min(10, R // (4 * args.train_readers))),
+                                  queue_max_size=1000, batchsize=B,
                                   batches_per_launch=KB, insert_seed=77 + rank, seed=1234 + 1000 * rank, device=local_rank,
                                   num_future_actions=nfa, feature_format=fmt)
         ld = rb.loader

@@ -89,7 +89,7 @@ def test_two_ranks_share_the_gpu_on_the_real_workloads():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,extra", [("board", ["--boards", "256", "--steps", "2", "--warmup", "1"]),
-                                            ("train", ["--train-batch", "256", "--train-prefetch", "2", "--train-records", "32", "--steps", "3", "--warmup", "1"])])
+                                            ("train", ["--train-batch", "256", "--train-prefetch", "2", "--train-records", "128", "--steps", "3", "--warmup", "1"])])
 def test_two_ranks_share_the_gpu_on_the_board_and_trainer_workloads(workload, extra):
     """The world > 1 branches of run_board / run_train (per-rank seeds and records, max-over-ranks time, sum of the units) with two
     ranks on this box's one GPU."""
