@@ -691,66 +691,106 @@ struct ExpandLds {
 };
 static_assert(sizeof(ExpandLds<19>) <= 6400, "expand LDS per wave");
 
-// iteration order of the reference's unordered_map after inserting skey[0..n) (see stl_emul.h); result in L.seq
-template <int N>
-__device__ __forceinline__ void umap_order_wave(ExpandLds<N>& L, int n, int lane) {
+// inclusive prefix sum over the 64 lanes on the DPP network: Hillis-Steele inside each row of 16 (row_shr 1 / 2 / 4 / 8, zero fill),
+// then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  EXEC must be full.
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+// iteration order of the reference's unordered_map after inserting skey[0..n) (see stl_emul.h); result in L.seq.
+// One epoch = one bucket count of libstdc++'s rehash policy (13, 29, 59, 127, 257, 541): the elements so far, in their current
+// iteration order, followed by the epoch's new elements, re-grouped by bucket (groups in order of first appearance, members in
+// sequence order) and reversed.  The epochs are compiled one by one (round 4): the bucket count is a constant, so `key % nb` is a
+// multiply-shift, the scan of an element's residue class is a fixed number of independent LDS reads issued together (34 for 13
+// buckets, 2 for 257; as a run-time loop each read waited for the previous one), the early epochs (<= 59 elements) are one round
+// of 64 lanes with no loop around it, and the coord -> time table is cleared once (a coord that is present is rewritten by every
+// epoch, one that is absent never was written).
+template <int N, int EP>
+__device__ __forceinline__ void umap_epoch_wave(ExpandLds<N>& L, int n, int lane, int& have, int& done, u16*& cur, u16*& nxt) {
   constexpr int P = Geo<N>::P;     // coords are < (N+2)^2
   constexpr int NE = NodeRec<N>::NE;
-  int have = 0, done = 0;
-  for (int ep = 0; ep < stl_emul::kNumEpochs && done < n; ++ep) {
-    const int nb = stl_emul::epoch_buckets(ep);
-    const int take = (n < nb ? n : nb) - done;
-    const int m = have + take;
-    for (int t = have + lane; t < m; t += 64) L.seq[t] = (u16)(done + (t - have));
-    done += take;
-    Board<N>::wsync();
-    if (nb >= P) {
-      // every key has its own bucket: the epoch iterates as the plain reverse of its insertion sequence
-      for (int t = lane; t < m; t += 64) L.nseq[m - 1 - t] = L.seq[t];
-    } else {
-      for (int i = lane; i < ExpandLds<N>::PP; i += 64) L.tkey[i] = 0xFFFF;
-      Board<N>::wsync();
-      for (int t = lane; t < m; t += 64) L.tkey[L.skey[L.seq[t]]] = (u16)t;
-      Board<N>::wsync();
-      // per element: first time / size of its bucket and its rank inside the bucket, by scanning the
-      // (at most ceil(P/nb)) coords of its residue class; group sizes are prefix-summed over first times
-      constexpr int RR = (NE + 63) / 64;
-      int ftv[RR], rkv[RR];
-      int carry = 0;
+  constexpr int nb = stl_emul::epoch_buckets(EP);
+  if (done >= n) return;
+  const int take = (n < nb ? n : nb) - done;
+  const int m = have + take;
+  for (int t = have + lane; t < m; t += 64) cur[t] = (u16)(done + (t - have));
+  done += take;
+  Board<N>::wsync();
+  if (nb >= P) {
+    // every key has its own bucket: the epoch iterates as the plain reverse of its insertion sequence
+    for (int t = lane; t < m; t += 64) nxt[m - 1 - t] = cur[t];
+  } else {
+    constexpr int MAXM = nb < NE ? nb : NE;            // elements this epoch can hold
+    constexpr int RR = (MAXM + 63) / 64;               // rounds of 64 lanes
+    constexpr int CNT = (P + nb - 1) / nb;             // coords of one residue class
+    int kkv[RR];
 #pragma unroll
-      for (int k = 0; k < RR; ++k) {
-        ftv[k] = 0xFFFF; rkv[k] = 0;
-        if (k * 64 >= m) continue;   // wave-uniform: the early epochs hold at most 13 / 29 / 59 elements, one round of 64
-        const int t = k * 64 + lane;
-        int ft = 0xFFFF, cnt = 0, rk = 0;
-        if (t < m) {
-          const int kk = L.skey[L.seq[t]];
-          for (int c = kk % nb; c < P; c += nb) {
-            const int tt = L.tkey[c];
-            if (tt != 0xFFFF) { ++cnt; ft = tt < ft ? tt : ft; rk += tt < t; }
-          }
-        }
-        ftv[k] = ft; rkv[k] = rk;
-        const int hv = (t < m && ft == t) ? cnt : 0;   // group size, placed at the group's first time
-        int inc = hv;                                   // inclusive wave scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int y = __shfl_up(inc, o, 64);
-          if (lane >= o) inc += y;
-        }
-        if (t < m) L.sx[t] = (u16)(carry + inc - hv);
-        carry += rl(inc, 63);
-      }
-      Board<N>::wsync();
-#pragma unroll
-      for (int k = 0; k < RR; ++k) {
-        const int t = k * 64 + lane;
-        if (t < m) L.nseq[m - 1 - ((int)L.sx[ftv[k]] + rkv[k])] = L.seq[t];
-      }
+    for (int k = 0; k < RR; ++k) {
+      const int t = k * 64 + lane;
+      kkv[k] = t < m ? (int)L.skey[cur[t]] : 0;
+      if (t < m) L.tkey[kkv[k]] = (u16)t;
     }
     Board<N>::wsync();
-    for (int t = lane; t < m; t += 64) L.seq[t] = L.nseq[t];
-    have = m;
+    // per element: first time / size of its bucket and its rank inside the bucket, from the coords of its residue class; group
+    // sizes are prefix-summed over first times
+    int ftv[RR], rkv[RR];
+    int carry = 0;
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      ftv[k] = 0xFFFF; rkv[k] = 0;
+      if (k * 64 >= m) continue;   // wave-uniform
+      const int t = k * 64 + lane;
+      int ft = 0xFFFF, cnt = 0, rk = 0;
+      const int r0 = kkv[k] % nb;
+      int tts[CNT];
+#pragma unroll
+      for (int j = 0; j < CNT; ++j) { const int c = r0 + j * nb; tts[j] = c < P ? (int)L.tkey[c] : 0xFFFF; }
+#pragma unroll
+      for (int j = 0; j < CNT; ++j) {
+        const int tt = tts[j];
+        if (tt != 0xFFFF) { ++cnt; ft = tt < ft ? tt : ft; rk += tt < t; }
+      }
+      if (!(t < m)) { ft = 0xFFFF; cnt = 0; rk = 0; }
+      ftv[k] = ft; rkv[k] = rk;
+      const int hv = (t < m && ft == t) ? cnt : 0;   // group size, placed at the group's first time
+      const int inc = wave_inclusive_sum(hv);
+      if (t < m) L.sx[t] = (u16)(carry + inc - hv);
+      carry += rl(inc, 63);
+    }
+    Board<N>::wsync();
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      const int t = k * 64 + lane;
+      if (t < m) nxt[m - 1 - ((int)L.sx[ftv[k]] + rkv[k])] = cur[t];
+    }
+  }
+  Board<N>::wsync();
+  u16* const sw = cur; cur = nxt; nxt = sw;          // the new order is the next epoch's sequence: no copy
+  have = m;
+}
+
+template <int N>
+__device__ __forceinline__ void umap_order_wave(ExpandLds<N>& L, int n, int lane) {
+  int have = 0, done = 0;
+  u16* cur = L.seq;
+  u16* nxt = L.nseq;
+  for (int i = lane; i < ExpandLds<N>::PP; i += 64) L.tkey[i] = 0xFFFF;
+  Board<N>::wsync();
+  umap_epoch_wave<N, 0>(L, n, lane, have, done, cur, nxt);
+  umap_epoch_wave<N, 1>(L, n, lane, have, done, cur, nxt);
+  umap_epoch_wave<N, 2>(L, n, lane, have, done, cur, nxt);
+  umap_epoch_wave<N, 3>(L, n, lane, have, done, cur, nxt);
+  umap_epoch_wave<N, 4>(L, n, lane, have, done, cur, nxt);
+  umap_epoch_wave<N, 5>(L, n, lane, have, done, cur, nxt);
+  static_assert(stl_emul::kNumEpochs == 6, "one call per epoch");
+  if (cur != L.seq) {                                  // an odd number of epochs ran: the result sits in nseq
+    for (int t = lane; t < n; t += 64) L.seq[t] = cur[t];
     Board<N>::wsync();
   }
 }

@@ -33,7 +33,7 @@ namespace stl_emul {
 
 // bucket counts of successive rehashes and the element count each can hold before the next one
 constexpr int kNumEpochs = 6;
-STL_HD int epoch_buckets(int e) {
+constexpr STL_HD int epoch_buckets(int e) {
   return e == 0 ? 13 : e == 1 ? 29 : e == 2 ? 59 : e == 3 ? 127 : e == 4 ? 257 : 541;
 }
 
