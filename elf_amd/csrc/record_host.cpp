@@ -709,7 +709,7 @@ int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t
       }
     }
   };
-  const unsigned nt = (unsigned)std::min<int64_t>(std::min<int64_t>(T, num_acts), host_worker_count(16));
+  const unsigned nt = (unsigned)std::min<int64_t>(std::min<int64_t>(T, num_acts), host_worker_count(32));   // one game thread per worker at the trainer's 2048 / 64 = 32
   if (nt < 2 || num_acts < 8) { for (int64_t tt = 0; tt < T; ++tt) acts_of_thread((size_t)tt); }
   else HostWorkers::get().run((size_t)T, nt, acts_of_thread);
   q->next_act += num_acts;
