@@ -1437,6 +1437,19 @@ def main():
             res = gm
         elif rank == 0:
             res["selfplay_games"] = gm
+            # north_star: games/sec "as absolute and as fraction of HBM roofline": the SURVEY 8(d) bytes of one game = moves x rollouts per
+            # move x bytes per rollout (at the headline's measured depth) x games/s, against the HBM peak (x N GPUs)
+            try:
+                bpr = res["roofline"]["algorithmic_bytes_per_rollout"]
+                L_ = (gm.get("game_length") or {}).get("mean_game_length")
+                if bpr and L_ and gm.get("value"):
+                    gbs = gm["value"] * L_ * args.rollouts * max(1, args.mcts_threads) * bpr / 1e9
+                    gm["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
+                                      "traffic": None, "bytes_per_game": L_ * args.rollouts * max(1, args.mcts_threads) * bpr,
+                                      "note": "games/s x (measured game length x rollouts per move x SURVEY 8(d) bytes per rollout at the measured depth); the "
+                                              "step is 99 % convolution (net_roofline), so this fraction is small by construction"}
+            except Exception:
+                pass
     if args.workload == "client" or sub:
         cl = run_client(args, rank, local_rank, world, dist)
         if args.workload == "client":
