@@ -66,8 +66,8 @@ def seeds_for(rank, boards, rep):
 
 PARITY_NOTE = ("bit-exactness of this configuration rests on: mcts_threads = 1; reference fixtures with a stub net whose value head is on the "
                "1/256 grid (tests/golden/mcts_*.npz); the real 20x256 fp32 net against the real reference stack on this GPU "
-               "(tests/test_gpu_mcts.py::test_config3_real_net_against_the_real_reference_stack; profiles/r03a_ and r03m_config3_real_net_parity_*.json: "
-               "138 searches, 135 bit-equal, 3 with one edge off by 1 ulp of its reward sum, no visit count / move differs); hazard H2 (backup order "
+               "(tests/test_gpu_mcts.py::test_config3_real_net_against_the_real_reference_stack; profiles/r03a_, r03m_ and r04w_config3_real_net_parity_*.json: "
+               "208 searches, 204 bit-equal, 4 with one edge off by 1 ulp of its reward sum, no visit count / move differs); hazard H2 (backup order "
                "of a batch: heap-address order in the reference, first occurrence here) measured reference-vs-restatement with an "
                "un-quantised value head on 454 searches: reward sums differ in their last bits, no decision differs "
                "(profiles/r03_h2_divergence_stub_cpu.json); serial-loop equality of the pipelined / graph-replayed / fp16 path "
