@@ -148,3 +148,41 @@ def test_draws_do_not_depend_on_the_host_threads_that_make_them(built):
         finally:
             os.environ.pop("ELF_AMD_HOST_THREADS", None)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_draws_from_two_host_threads_at_once(built):
+    """Two replay buffers drawn from concurrently by two Python threads (ctypes releases the GIL): the shared host worker pool
+    serialises its parallel regions, nothing deadlocks, and each buffer's draws equal what it draws alone."""
+    import threading
+    import numpy as np
+    from elf_amd.train import ReaderQueues
+
+    def make(seed):
+        q = ReaderQueues(num_reader=4, queue_min_size=2, queue_max_size=100, insert_seed=seed, num_threads=8, seed=100 + seed, job_id="")
+        rng = np.random.default_rng(seed)
+        for s in range(80):
+            q.insert(s, int(rng.integers(2, 300)), bool(rng.integers(0, 2)))
+        return q
+
+    def run(q, out, reps):
+        for _ in range(reps):
+            out.append(np.concatenate([np.asarray(x).ravel() for x in q.draw(32, 1)]))
+
+    alone = []
+    for seed in (1, 2):
+        q = make(seed)
+        o = []
+        run(q, o, 3)
+        alone.append(o)
+        q.close()
+    qs = [make(1), make(2)]
+    outs = [[], []]
+    th = [threading.Thread(target=run, args=(qs[i], outs[i], 3)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a draw hung"
+    for i in range(2):
+        assert len(outs[i]) == 3 and all(np.array_equal(a, b) for a, b in zip(outs[i], alone[i]))
+        qs[i].close()
