@@ -419,6 +419,8 @@ typedef struct ElfTrainBatch {      /* device pointers, rows = samples; every po
   int64_t* selfplay_ver;            /* [n]  Record.request.vers.black_ver */
 } ElfTrainBatch;
 
+/* An ElfReplay is not synchronised: call put / draw / extract from one host thread at a time (the reference's reader thread and its
+ * batch consumer are one pipeline here).  Device work is ordered by the streams the caller passes. */
 int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_policies, uint32_t seed, ElfReplay** out);
 int elftrain_destroy(ElfReplay* r);
 int elftrain_capacity(const ElfReplay* r);
