@@ -389,18 +389,14 @@ def gather_per_rank(dist, dev, value, world):
 
 
 def scaling_report(world, value, per_rank, key):
-    """What one `bench.py --gpus N` line says about scaling (BASELINE configs[3]: independent games per GPU): the per-rank values,
-    their sum, and the per-GPU fraction of the N = 1 value on record (profiles/headline_n1.json, written from a 1-GPU run of the same
-    configuration).  The driver computes efficiency itself from its N = 1, 2, 4, 8 runs; this is the same quantity from inside one run."""
-    ref = load_profile_json("headline_n1.json").get(key)
-    return {"n_gpus": world, "per_rank": per_rank, "sum_over_ranks": float(sum(per_rank)) if per_rank else None,
-            "n1_reference": ref, "n1_reference_source": load_profile_json("headline_n1.json").get("source"),
-            "per_gpu_fraction_of_n1": (value / world / ref) if (ref and world) else None,
-            "process_group": dict(DIST_INFO),
-            "measured_curve": "none: no multi-GPU node was available to the builder.  The N > 1 path has run on real kernels with two ranks "
-                              "sharing ONE GPU (ELF_BENCH_SHARE_GPU=1, gloo; profiles/r04*_two_ranks_one_gpu.json: that line exercises the "
-                              "world > 1 code, its per-GPU fraction says nothing about scaling) and in the gloo tests; on a node, run this "
-                              "command with --gpus 2/4/8"}
+    """What one `bench.py --gpus N` line says about scaling (BASELINE configs[3]: independent games per GPU), from THIS run's ranks
+    only: the per-rank values, their sum, and the slowest rank's share of the fastest (balance).  The driver computes efficiency
+    itself from its N = 1, 2, 4, 8 runs; nothing here refers to a stored N = 1 number."""
+    pr = [float(v) for v in (per_rank or [])]
+    return {"n_gpus": world, "metric": key, "per_rank": pr, "sum_over_ranks": float(sum(pr)) if pr else None,
+            "min_over_max": (min(pr) / max(pr)) if pr and max(pr) > 0 else None,
+            "value_over_sum": (value / sum(pr)) if pr and sum(pr) > 0 else None,
+            "process_group": dict(DIST_INFO)}
 
 
 def make_barrier(dist):
@@ -429,8 +425,8 @@ def run_stub(args, rank, local_rank, world, dist, steps, warmup):
         return None
     return {"metric": "stub_units_per_sec", "value": total / dt_max, "unit": "units/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
-            "data": "synthetic", "config": {"workload": "CPU stub (plumbing test of the N-rank path)", "per_rank_units": per_rank, "units": total,
-                                            "scaling_report": scaling_report(world, total / dt_max, [u / dt_max for u in per_rank], "stub_units_per_sec")}}
+            "data": "synthetic", "config": {"workload": "CPU stub (plumbing test of the N-rank path)", "per_rank_units": per_rank, "units": total},
+            "scaling_report": scaling_report(world, total / dt_max, [u / dt_max for u in per_rank], "stub_units_per_sec")}
 
 
 # ------------------------------------------------------------------------------------------------------------------- board step
@@ -567,6 +563,44 @@ def run_feature(args, rank, local_rank, world, dist, steps, warmup):
 
 
 # ------------------------------------------------------------------------------------------------------------------- MCTS
+def mcts_parity_check(dev_index):
+    """The headline's kernels against the REAL reference inside the bench run (checker only, outside every timed region): the searches of
+    the reference fixture tests/golden/mcts_19_r128_fresh.npz (what the reference's self-play stack did with the oracle's stub net) are
+    replayed by this library on the GPU; edge order, visit counts, reward sums (bit patterns) and the move must be equal.
+    -> {"checked": statistics compared, "mismatches": n, "what": ...}"""
+    try:
+        po = _oracle()
+        import elf_amd
+        g = np.load(os.path.join(ROOT, "tests", "golden", "mcts_19_r128_fresh.npz"))
+        cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+        n_s = int(min(4, len(g["n_edges"])))
+        sp = elf_amd.SelfPlay(board_size=19, num_games=1, device=dev_index, mcts_rollout_per_thread=int(cfg["rollouts_per_thread"]),
+                              mcts_rollout_per_batch=int(cfg["rollouts_per_batch"]), mcts_puct=float(np.float32(cfg["c_puct"])),
+                              mcts_virtual_loss=int(cfg["virtual_loss"]), mcts_persistent_tree=bool(cfg["persistent_tree"]),
+                              mcts_epsilon=float(np.float32(cfg["root_epsilon"])), mcts_alpha=float(np.float32(cfg["root_alpha"])),
+                              mcts_unexplored_q_zero=bool(cfg["unexplored_q_zero"]), komi=float(np.float32(cfg["komi"])),
+                              ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
+                              seed=int(cfg["seed"]), log_searches=n_s)
+        while sp.stats()["logged"] < n_s:
+            rows = sp.begin_step()
+            pi, v = po.stub_net(19, sp.s[:rows].cpu().numpy(), int(cfg["net_salt"]), int(cfg["net_tie_levels"]))
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        rec, coord, visits, prior, reward = sp.search_log()
+        sp.close()
+        checked = bad = 0
+        for i in range(n_s):
+            ne = int(g["n_edges"][i])
+            checked += 3 * ne + 1
+            bad += int(np.sum(coord[i, :ne] != g["coord"][i, :ne].astype(np.int32)))
+            bad += int(np.sum(visits[i, :ne] != g["visits"][i, :ne]))
+            bad += int(np.sum(reward[i, :ne].view(np.uint32) != g["reward"][i, :ne].view(np.uint32)))
+            bad += int(rec[i].move_played != int(g["move_played"][i]))
+        return {"checked": checked, "mismatches": bad,
+                "what": "%d searches of the reference fixture mcts_19_r128_fresh replayed on the GPU: edge order, visit counts, reward bits, move" % n_s}
+    except Exception as e:   # the checker is absent (no oracle library on this box): say so, never substitute
+        return {"checked": 0, "mismatches": None, "what": "unavailable: %r" % (e,)}
+
+
 class RandomReplies:
     """Pseudo-random policy/value replies (no conv net): a peaky policy grows deep, narrow trees like a trained net does.  Used
     for --net random and for the untimed tree-growing prologue of the headline.  A pool of replies is drawn once on the GPU and
@@ -615,7 +649,10 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     groups = max(1, args.groups)
     Gg = G // groups
     G = Gg * groups
-    sp = PipelinedSelfPlay(groups=groups, seed=1234, game_idx_base=rank * G, wait_rows=bool(args.wait_rows), net_streams=args.net_streams,
+    # process g of the job is seeded 1234 + 1000 g.  The reference then gives every game thread of a process the
+    # same seed (common/game_base.h:32-38: identical games under a deterministic net); here game i of the rank plays with seed
+    # 1234 + 1000 rank + i (DESIGN.md "Seeds"), so the ranks' games are distinct for up to 1000 games per rank
+    sp = PipelinedSelfPlay(groups=groups, seed=1234 + 1000 * rank, game_idx_base=0, wait_rows=bool(args.wait_rows), net_streams=args.net_streams,
                            board_size=n, num_games=Gg,
                            device=local_rank, mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5,
                            mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5,
@@ -713,7 +750,14 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "value": roll_all / dt_max, "unit": "rollouts/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
+        "config": {"workload_short": "BASELINE configs[%s]: MCTS self-play bs=%d, %d rollouts/move, %s, %d games/GPU in %d group(s), window crosses a move boundary"
+                                     % ("2" if world == 1 else "3, one process per GPU", K, args.rollouts * T,
+                                        ("20x256 %s net on PyTorch-ROCm" % args.net_dtype) if (net is not None and args.net_blocks == 20 and args.net_dim == 256)
+                                        else ("%dx%d %s net" % (args.net_blocks, args.net_dim, args.net_dtype) if net is not None else "no conv net (--net %s)" % args.net),
+                                        G, groups),
+                   "seed_rule": "game i of rank r: 1234 + 1000 r + i (SURVEY 8d config 4 seeds process g with 1234 + 1000 g; %d games per rank instead of "
+                                "the client script's 32: one wave per game wants many games in flight)" % G,
+                   "workload": "BASELINE configs[2]: MCTS self-play bs=%d, %d rollouts/move, puct 1.5, vloss 1, Dirichlet 0.25/0.03, "
                                "persistent tree, %s, %d games per GPU in %d lock-step group(s) pipelined against the net; trees grown for %d "
                                "untimed steps so that the timed window is a search in progress that crosses a move boundary"
                                % (K, args.rollouts * T, net_desc, G, groups, pregrow),
@@ -741,7 +785,6 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                          "180 of recorded games over the measured length of games played to their natural end (no assumed game "
                                          "length; round 3 divided by an assumed 250 moves)",
                    "per_rank_rollouts_per_sec": per_rank,
-                   "scaling_report": scaling_report(world, roll_all / dt_max, per_rank, "mcts_rollouts_per_sec"),
                    "parity_note": PARITY_NOTE,
                    "pregrow_note": "the untimed tree-growing steps answer the leaves with random priors (not the net): the window's mean depth "
                                    "is that of trees shaped by noise priors plus the timed net steps; the search kernels are ~2 %% of the step either way",
@@ -765,6 +808,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                              "with bandwidth -- DESIGN.md section 3" % depth,
                      "mean_depth": depth},
         "selfplay_stats_window": d,
+        "scaling_report": scaling_report(world, roll_all / dt_max, per_rank, "mcts_rollouts_per_sec"),
     }
     if net is not None:
         # the kernel that dominates the timed region is not this library's: PyTorch-ROCm's convolution (north_star leaves the
@@ -804,6 +848,10 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
             res["net_roofline"]["variants_note"] = "eager launches (no HIP graph), same fused epilogue; compare ms_per_2048_rows with avg_call_ms"
         except Exception as e:
             res["net_roofline"]["variants"] = "unavailable: %r" % (e,)
+    if world == 1 and n == 19:
+        res["parity"] = mcts_parity_check(local_rank)
+        if res["parity"]["mismatches"]:
+            raise SystemExit("bench: the search kernels differ from the reference fixture (%r) -- results are invalid" % (res["parity"],))
     if with_cpu:
         base = cpu_baseline_mcts_with_net(n, K, net, dev, dtype) if net is not None else cpu_baseline_mcts_stub(n, K)
         if base.get("value") is None and net is not None:
@@ -958,6 +1006,41 @@ def run_games(args, rank, local_rank, world, dist):
                             "passes, the move limit %d, or resignation" % (Gl * groups, K, 2 * n * n)}
         spl.close()
         gr.clear()
+    # ---- one PLAYED data point at the headline's rollout count: a small cohort plays whole moves from the empty board, end to end (every
+    # search of 8192 rollouts, the move boundaries, Dirichlet draws, tree advance); moves/s = moves counted by the engine / wall time.
+    # It confirms the per-phase moves/s above (derived from rollouts/s of a window) by an end-to-end count.
+    played = None
+    if args.played_moves > 0 and args.played_games > 0:
+        Gp = max(1, args.played_games // groups)
+        spp = PipelinedSelfPlay(groups=groups, seed=555 + 1000 * rank, game_idx_base=0, wait_rows=False, net_streams=args.net_streams, board_size=n,
+                                num_games=Gp, device=local_rank, mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5,
+                                mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5, ply_pass_enabled=0,
+                                policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt, mcts_threads=args.mcts_threads)
+        fn, gr = graphed(spp)
+        spm_p = spp.groups[0].stats()["steps_per_move"]
+        for _ in range(2):
+            spp.step(fn)
+        spp.synchronize()
+        barrier()
+        m0 = spp.stats()["moves"]
+        tpl = time.perf_counter()
+        # the two warm-up steps belong to the first move: run to the end of move `played_moves`
+        for _ in range(args.played_moves * spm_p - 2 + 1):
+            spp.step(fn)
+        spp.synchronize()
+        barrier()
+        dpl = time.perf_counter() - tpl
+        stp = spp.stats()
+        dpl_max, moves_p = reduce_max_sum(dist, dev, dpl, stp["moves"] - m0)
+        played = {"games": Gp * groups * world, "moves_played": moves_p, "seconds": dpl_max, "moves_per_sec": moves_p / dpl_max,
+                  "rollouts_per_move": args.rollouts * T, "rollouts_per_sec": moves_p * args.rollouts * T / dpl_max,
+                  "what": "%d games (%d groups) play %d whole moves each from the empty board at %d rollouts/move with the same net: moves counted by "
+                          "the engine / wall time, move boundaries included" % (Gp * groups, groups, args.played_moves, args.rollouts * T)}
+        p0 = (by_phase.get("0") or {}).get("moves_per_sec")
+        if p0:
+            played["ratio_to_phase0_derived"] = played["moves_per_sec"] / p0
+        spp.close()
+        gr.clear()
     games_from_phases = None
     if by_phase and length and length["mean_game_length"]:
         # seconds per game = sum over the plies of a game of 1 / moves_per_sec(phase of that ply): plies [0,60) at the rate measured at
@@ -969,8 +1052,12 @@ def run_games(args, rank, local_rank, world, dist):
         games_from_phases = 1.0 / sec if sec > 0 else None    # moves/s is the job's aggregate over its games in flight: games/s = 1 / sum over a game's plies of 1 / (moves/s)
     if rank != 0:
         return None
-    return {"metric": "selfplay_games_per_sec", "value": games_from_phases if games_from_phases is not None else games_all / dt_max, "unit": "games/s",
-            "n_gpus": world,
+    derived = games_from_phases is not None
+    return {"metric": "selfplay_games_per_sec (derived: measured moves/s by game phase / measured game length)" if derived
+                      else "selfplay_games_per_sec (played: shortened configuration)",
+            "value": games_from_phases if derived else games_all / dt_max, "unit": "games/s",
+            "n_gpus": world, "derived": bool(derived), "played_moves_per_sec": (played or {}).get("moves_per_sec"),
+            "derived_moves_per_sec_phase0": (by_phase.get("0") or {}).get("moves_per_sec"), "played_point": played,
             "value_note": ("headline configuration (%d rollouts/move): measured moves/s by game phase (moves_per_sec_by_phase) over the MEASURED mean "
                            "game length of this run's games (game_length); no assumed length enters" % (args.rollouts * T)) if games_from_phases is not None
                           else "measured on the shortened configuration (shortened_run); the phase / length legs were switched off",
@@ -1311,6 +1398,172 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     return res
 
 
+# ------------------------------------------------------------------------------------------------------------------- the report
+LINE_LIMIT = 4096   # the driver keeps a bounded tail of stdout: the ONE line it parses must fit well inside it
+
+
+def _clean(x):
+    """strict JSON: NaN / +-inf -> null, numpy scalars -> Python numbers"""
+    if isinstance(x, dict):
+        return {str(k): _clean(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v) for v in x]
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    return x
+
+
+def _num(x, digits=5):
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def _pick(d, keys, digits=5):
+    return {k: _num(d.get(k), digits) for k in keys if isinstance(d, dict) and k in d}
+
+
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_kernel_ms")
+
+
+def _roof(r):
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, ROOF_KEYS)
+    if isinstance(out.get("kernel"), str):
+        out["kernel"] = out["kernel"][:80]
+    if isinstance(out.get("unit"), str):
+        out["unit"] = out["unit"][:40]
+    for k in ("binding_issue_roof", "binding_frac", "lds_bank_conflict_frac"):
+        if r.get(k) is not None:
+            out[k] = _num(r[k], 4)
+    return out
+
+
+def _sub_summary(name, d):
+    """one small object per sub-result: value, unit, roofline fraction, parity -- the notes stay in the full report"""
+    if not isinstance(d, dict):
+        return {"status": str(d)[:60]}
+    if name == "feature_extract":
+        out = {}
+        for key in ("f32", "f16"):
+            if isinstance(d.get(key), dict):
+                r = d[key].get("roofline") or {}
+                out[key] = {"rows_per_sec": _num(d[key].get("rows_per_sec")), "GBps": _num(r.get("achieved")), "frac": _num(r.get("frac"), 4),
+                            "traffic": _num(r.get("traffic")), "avg_kernel_ms": _num(d[key].get("avg_kernel_ms"))}
+        return out
+    out = _pick(d, ("value", "unit", "ms_per_step"))
+    if isinstance(out.get("unit"), str):
+        out["unit"] = out["unit"][:24]
+    r = d.get("roofline")
+    if isinstance(r, dict):
+        out["roofline"] = {k: v for k, v in _roof(r).items() if k in ("bound", "frac", "achieved", "peak", "binding_frac", "lds_bank_conflict_frac", "avg_kernel_ms")}
+    if "parity_checked_boards" in d:
+        out["parity"] = {"checked": d.get("parity_checked_boards"), "mismatches": d.get("parity_mismatches")}
+    cb = d.get("cpu_baseline")
+    if isinstance(cb, dict) and cb.get("value") is not None:
+        out["cpu_baseline"] = _pick(cb, ("value", "cores", "kind"))
+    for k in ("games_per_gpu", "groups", "mean_depth", "select_ms", "expand_backup_ms", "rollouts_per_step", "pinned_host", "device_resident",
+              "moves_per_sec", "played_moves_per_sec", "derived_moves_per_sec_phase0", "derived"):
+        if k in d and not isinstance(d[k], (dict, list, str)):
+            out[k] = _num(d[k])
+    return out
+
+
+SUB_NAMES = ("search_only", "board_step", "board_step_9x9", "feature_extract", "train_loader", "boundary", "selfplay_games", "client_config")
+
+
+def compact_line(res, full_path=None):
+    """The ONE line the driver parses: every key of the bench contract, `roofline` and `cpu_baseline` of the headline, a parity count,
+    and a few numbers per sub-result; < LINE_LIMIT bytes, strict JSON.  Notes, sweeps and per-phase detail are in the full report."""
+    cfg = res.get("config") or {}
+    line = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data"), 7)
+    if isinstance(line.get("metric"), str):
+        line["metric"] = line["metric"][:100]
+    c = _pick(cfg, ("games_per_gpu", "groups", "rollouts_per_step", "mean_depth", "board_size", "mcts_threads", "net_dtype", "net_rows_per_step",
+                    "search_ms_per_step", "select_ms", "expand_backup_ms", "moves_in_window", "move_boundary_ms", "moves_per_sec",
+                    "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB", "seed_rule", "parallelism"))
+    c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:200], **c}
+    if cfg.get("per_rank_rollouts_per_sec") is not None and res.get("n_gpus", 1) > 1:
+        c["per_rank"] = [_num(v) for v in cfg["per_rank_rollouts_per_sec"]]
+    line["config"] = c
+    line["roofline"] = _roof(res.get("roofline"))
+    if isinstance(res.get("roofline"), dict):
+        for k in ("mean_depth", "algorithmic_bytes_per_rollout"):
+            if res["roofline"].get(k) is not None:
+                line["roofline"][k] = _num(res["roofline"][k])
+    nr = res.get("net_roofline")
+    if isinstance(nr, dict):
+        line["net_roofline"] = _pick(nr, ("bound", "achieved", "peak", "unit", "frac", "avg_call_ms", "rows_per_call"))
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample") or "")[:160]
+    else:
+        line["cpu_baseline"] = None
+    par = res.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = _pick(par, ("checked", "mismatches", "what"))
+        if isinstance(line["parity"].get("what"), str):
+            line["parity"]["what"] = line["parity"]["what"][:160]
+    elif "parity_checked_boards" in res:
+        line["parity"] = {"checked": res.get("parity_checked_boards"), "mismatches": res.get("parity_mismatches")}
+    sub = {k: _sub_summary(k, res[k]) for k in SUB_NAMES if k in res}
+    if sub:
+        line["sub"] = sub
+    if isinstance(res.get("scaling_report"), dict) and res.get("n_gpus", 1) > 1:
+        line["scaling_report"] = _pick(res["scaling_report"], ("n_gpus", "sum_over_ranks", "min_over_max"))
+        gm = res.get("selfplay_games")
+        if isinstance(gm, dict):     # the MEASURED games/s of the shortened configuration (all ranks), for the games/sec curve
+            line["scaling_report"]["games_per_sec"] = _num((gm.get("shortened_run") or {}).get("games_per_sec"))
+            line["scaling_report"]["games_per_sec_per_rank"] = [_num(v) for v in (gm.get("per_rank_games_per_sec") or [])]
+    line["full_report"] = full_path
+    line = _clean(line)
+    text = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    # never exceed the limit: drop the sub-results one by one (last first), then the optional blocks
+    drop = [("sub", k) for k in reversed(SUB_NAMES)] + [("net_roofline", None), ("scaling_report", None)]
+    while len(text) >= LINE_LIMIT - 64 and drop:
+        a, b = drop.pop(0)
+        if b is None:
+            line.pop(a, None)
+        elif isinstance(line.get(a), dict):
+            line[a].pop(b, None)
+        line["truncated"] = True
+        text = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    return text
+
+
+def emit(res, args):
+    """Full report -> bench_full.json (next to bench.py, and under gpurun_out/ where that exists); ONE compact line -> stdout."""
+    full = _clean(res)
+    paths = []
+    names = [os.environ.get("ELF_BENCH_FULL") or os.path.join(ROOT, "bench_full.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        names.append(os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+    for p in names:
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1, allow_nan=False)
+            paths.append(os.path.relpath(p, ROOT))
+        except Exception:
+            pass
+    line = compact_line(full, paths[0] if paths else None)
+    assert len(line) < LINE_LIMIT and "\n" not in line
+    json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))   # strict: no NaN / Infinity
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1355,6 +1608,8 @@ def main():
     ap.add_argument("--games-generations", type=int, default=2)
     ap.add_argument("--search-only-games", type=int, default=2048, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
     ap.add_argument("--phase-steps", type=int, default=16, help="timed steps per game phase (plies 0/60/120/180) of the games/s leg; 0 = off")
+    ap.add_argument("--played-games", type=int, default=64, help="cohort of the PLAYED data point at the headline's rollout count; 0 = off")
+    ap.add_argument("--played-moves", type=int, default=2, help="whole moves the cohort plays end to end; 0 = off")
     ap.add_argument("--length-games", type=int, default=32, help="games played to their natural end to measure the game length; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="headline only (no sub-results)")
@@ -1457,8 +1712,7 @@ def main():
         elif rank == 0:
             res["client_config"] = cl
     if rank == 0:
-        print(json.dumps(res))
-        sys.stdout.flush()
+        emit(res, args)
     if dist is not None:
         dist.destroy_process_group()
 

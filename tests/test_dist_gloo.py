@@ -6,6 +6,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -33,56 +35,110 @@ def test_world_size_2_gloo():
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 reports
 
 
-def test_bench_spawns_its_own_ranks():
+def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run with two workers
     (one per GPU on a real node; the CPU stub workload over gloo here) and rank 0 prints one JSON line with n_gpus = 2, the
     slowest rank's time and the sum over ranks."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["ELF_BENCH_BACKEND"] = "gloo"
+    env["ELF_BENCH_FULL"] = str(tmp_path / "full.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "5", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    rep = json.loads(lines[0])
+    rep, full = one_line(r.stdout, env)
     assert rep["n_gpus"] == 2 and rep["steps"] == 5 and rep["scaling"] == "weak"
-    assert rep["config"]["units"] == 5 * (1000 + 1001) and rep["config"]["per_rank_units"] == [5000.0, 5005.0]
+    assert full["config"]["units"] == 5 * (1000 + 1001) and full["config"]["per_rank_units"] == [5000.0, 5005.0]
     assert rep["ms_per_step"] >= 4.0        # rank 1 sleeps 4 ms per step: the report carries the slowest rank
-    # what a multi-GPU line says about scaling (the headline and the measured games/s carry the same block)
-    sr = rep["config"]["scaling_report"]
+    # what a multi-GPU line says about scaling comes from THIS run's ranks only (no stored N = 1 number)
+    sr = full["scaling_report"]
     assert sr["n_gpus"] == 2 and len(sr["per_rank"]) == 2 and abs(sr["sum_over_ranks"] - sum(sr["per_rank"])) < 1e-6
-    assert set(sr) >= {"per_rank", "sum_over_ranks", "n1_reference", "per_gpu_fraction_of_n1", "measured_curve"}
-    assert "no multi-GPU node" in sr["measured_curve"]
+    assert "n1_reference" not in sr and "per_gpu_fraction_of_n1" not in sr and 0 < sr["min_over_max"] <= 1
+    assert rep["scaling_report"]["sum_over_ranks"] == pytest.approx(sr["sum_over_ranks"], rel=1e-4)
+    assert "headline_n1" not in r.stdout
 
 
-import pytest
+def strict_loads(line):
+    def bad(c):
+        raise ValueError("non-finite constant %r in the bench line" % c)
+    return json.loads(line, parse_constant=bad)
+
+
+def one_line(stdout, env):
+    """The driver's view of a bench run: exactly ONE JSON line on stdout, strict JSON, < 4 KB; the full report is a side file."""
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    rep = strict_loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "full_report"):
+        assert k in rep, k
+    assert "workload" in rep["config"]
+    full = strict_loads(open(env["ELF_BENCH_FULL"]).read())
+    return rep, full
+
+
+def test_the_line_of_a_full_default_run_fits_the_driver(tmp_path):
+    """The round-4 driver could not parse a 27 KB line.  compact_line() of a stored FULL default report (every sub-result, all notes)
+    must stay under 4 KB, be strict JSON, and carry the contract keys plus roofline / cpu_baseline / the sub-results' numbers."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04z_bench_n1.json")))
+    assert len(json.dumps(full)) > 20000
+    full["roofline"]["frac"] = float("nan")           # a non-finite number must come out as null, not as NaN
+    line = bench.compact_line(bench._clean(full), "bench_full.json")
+    assert len(line) < 4096
+    rep = strict_loads(line)
+    assert rep["roofline"]["frac"] is None and rep["roofline"]["bound"] == "hbm" and rep["roofline"]["kernel"]
+    assert rep["cpu_baseline"]["kind"] == "reference" and rep["cpu_baseline"]["cores"] > 0 and rep["cpu_baseline"]["value"] > 0
+    assert rep["config"]["games_per_gpu"] == 256 and rep["config"]["rollouts_per_step"] == 4096
+    assert rep["sub"]["board_step"]["parity"] == {"checked": 4096, "mismatches": 0}
+    assert rep["sub"]["feature_extract"]["f32"]["frac"] > 0.5
+    # a report that would not fit loses sub-results, never validity
+    full["config"]["workload_short"] = "x" * 5000
+    for k in list(full):
+        if isinstance(full[k], dict) and k not in ("config", "roofline", "cpu_baseline"):
+            full[k]["metric"] = "y" * 300
+    line = bench.compact_line(bench._clean(full), "bench_full.json")
+    assert len(line) < 4096 and strict_loads(line)["value"] == pytest.approx(full["value"], rel=1e-5)
+
+
+def test_stub_line(tmp_path):
+    env = dict(os.environ, ELF_BENCH_FULL=str(tmp_path / "full.json"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--steps", "3"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep, full = one_line(r.stdout, env)
+    assert rep["n_gpus"] == 1 and rep["steps"] == 3 and full["metric"] == rep["metric"]
 
 
 @pytest.mark.gpu
-def test_two_ranks_share_the_gpu_on_the_real_workloads():
+def test_two_ranks_share_the_gpu_on_the_real_workloads(tmp_path):
     """The world > 1 branches of run_mcts / run_games on real kernels: two ranks on the one GPU of this box (ELF_BENCH_SHARE_GPU=1,
     process group over gloo), a small net and few rollouts.  Each rank plays its own games (game_idx_base = rank x games), the line
     carries the slowest rank's time, the sum of the rollouts and of the finished games, and the per-rank values."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["ELF_BENCH_SHARE_GPU"] = "1"
+    env["ELF_BENCH_FULL"] = str(tmp_path / "full.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "both", "--games", "32", "--groups", "2",
                         "--rollouts", "64", "--steps", "6", "--warmup", "2", "--net-blocks", "2", "--net-dim", "32",
                         "--games-rollouts", "16", "--games-cutoff", "6", "--games-generations", "2"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    rep = json.loads(lines[0])
+    rep, full = one_line(r.stdout, env)
     assert rep["n_gpus"] == 2 and rep["steps"] == 6 and rep["scaling"] == "weak"
     cfg = rep["config"]
-    assert cfg["games_per_gpu"] == 32 and cfg["rollouts_per_step"] == 32 * 16
+    assert cfg["games_per_gpu"] == 32 and cfg["rollouts_per_step"] == 32 * 16 and len(cfg["per_rank"]) == 2
+    assert "1234 + 1000 r" in full["config"]["seed_rule"]
     # value = rollouts of BOTH ranks / the slowest rank's time
-    assert abs(rep["value"] - 2 * 32 * 16 * 6 / (rep["ms_per_step"] * 6 / 1e3)) < 1e-6 * rep["value"]
-    sr = cfg["scaling_report"]
-    assert len(sr["per_rank"]) == 2 and all(v > 0 for v in sr["per_rank"])
+    assert abs(full["value"] - 2 * 32 * 16 * 6 / (full["ms_per_step"] * 6 / 1e3)) < 1e-6 * full["value"]
+    assert rep["roofline"]["frac"] > 0 and rep["roofline"]["bound"] == "hbm"
+    sr = full["scaling_report"]
+    assert len(sr["per_rank"]) == 2 and all(v > 0 for v in sr["per_rank"]) and "n1_reference" not in sr
     assert sr["process_group"]["backend"] == "gloo" and sr["process_group"]["ranks_share_one_gpu"] is True
+    assert rep["scaling_report"]["sum_over_ranks"] == pytest.approx(sum(sr["per_rank"]), rel=1e-4)
+    assert rep["scaling_report"]["games_per_sec"] > 0        # the MEASURED games/s of the shortened configuration rides with an N > 1 line
     assert rep["cpu_baseline"] is None                      # timed on rank 0 at N = 1 only
-    gm = rep["selfplay_games"]
+    gm = full["selfplay_games"]
     assert gm["n_gpus"] == 2 and len(gm["per_rank_games_per_sec"]) == 2
     assert gm["games_finished"] >= 2 * 32                   # both ranks finished at least one generation of their games
 
@@ -90,19 +146,19 @@ def test_two_ranks_share_the_gpu_on_the_real_workloads():
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,extra", [("board", ["--boards", "256", "--steps", "2", "--warmup", "1"]),
                                             ("train", ["--train-batch", "256", "--train-prefetch", "2", "--train-records", "128", "--steps", "3", "--warmup", "1"])])
-def test_two_ranks_share_the_gpu_on_the_board_and_trainer_workloads(workload, extra):
+def test_two_ranks_share_the_gpu_on_the_board_and_trainer_workloads(workload, extra, tmp_path):
     """The world > 1 branches of run_board / run_train (per-rank seeds and records, max-over-ranks time, sum of the units) with two
     ranks on this box's one GPU."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["ELF_BENCH_SHARE_GPU"] = "1"
+    env["ELF_BENCH_FULL"] = str(tmp_path / "full.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload, "--no-cpu-baseline"] + extra,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    rep = json.loads(lines[0])
+    rep, full = one_line(r.stdout, env)
     assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["value"] > 0
     if workload == "board":
-        assert rep["parity_mismatches"] == 0 and rep["config"]["boards_per_gpu"] == 256
+        assert full["parity_mismatches"] == 0 and full["config"]["boards_per_gpu"] == 256
+        assert rep["parity"] == {"checked": 256, "mismatches": 0}
     else:
-        assert rep["config"]["samples_per_launch"] == 512
+        assert full["config"]["samples_per_launch"] == 512
