@@ -26,6 +26,7 @@
 //    the whole legality test is bitboard algebra on them (dilate / funnel shifts on 32-bit halves, DPP for the carries).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 // phase markers for tools/playout_phases.hip (cycle attribution); compiled out of the library
@@ -109,6 +110,22 @@ struct alignas(16) Slot {
 };
 static_assert(sizeof(Slot<19>) == 3840, "19x19 slot is 3.75 KiB");
 static_assert(sizeof(Slot<19>) % 256 == 0 && sizeof(Slot<9>) % 256 == 0, "slot is 256-B granular");
+
+// The board of a search-tree node in HBM: the slot WITHOUT its superko Bloom words (and padding) -- header, labels, liberties, history.
+// A tree node needs no filter of its own: what the filter has to cover is the game's records up to the root (the game board's own
+// Bloom words, one copy per game) plus the positions on the path root -> node, which a descent passes through anyway (k_mcts_select
+// rebuilds the filter in LDS from those before it forwards).  2624 B instead of 3840 B at 19x19.  CBoard is a prefix of Slot.
+template <int N>
+struct alignas(16) CBoard {
+  using G = Geo<N>;
+  Hdr h;
+  u16 pt[G::PP];
+  u16 libs[G::PP];
+  u64 hist[HIST][2][G::R];
+};
+static_assert(sizeof(CBoard<19>) == 2624 && sizeof(CBoard<9>) == 832, "compact node board");
+static_assert(sizeof(CBoard<19>) % 16 == 0 && sizeof(CBoard<9>) % 16 == 0, "compact node board is copied 16 B per lane");
+static_assert(offsetof(Slot<19>, bloom) == sizeof(CBoard<19>) && offsetof(Slot<9>, bloom) == sizeof(CBoard<9>), "CBoard is the slot's prefix");
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -415,6 +432,25 @@ struct Board {
     uint4* d = reinterpret_cast<uint4*>(g);
 #pragma unroll
     for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += 64) d[j] = s[j];
+  }
+  // the same for a tree node's compact board: the Bloom words of the LDS image are left alone (the caller owns them)
+  __device__ __forceinline__ void load(const CBoard<N>* g) {
+    const uint4* s = reinterpret_cast<const uint4*>(g);
+    uint4* d = reinterpret_cast<uint4*>(L);
+#pragma unroll
+    for (int j = lane; j < (int)(sizeof(CBoard<N>) / 16); j += 64) d[j] = s[j];
+    wsync();
+    load_hdr();
+    const int newest = (hist_cnt + HIST - 1) & (HIST - 1);
+    Bw = (lane < R && hist_cnt != 0) ? L->hist[newest][0][lane] : 0ull;
+    Ww = (lane < R && hist_cnt != 0) ? L->hist[newest][1][lane] : 0ull;
+  }
+  __device__ __forceinline__ void store(CBoard<N>* g) {
+    store_hdr();
+    const uint4* s = reinterpret_cast<const uint4*>(L);
+    uint4* d = reinterpret_cast<uint4*>(g);
+#pragma unroll
+    for (int j = lane; j < (int)(sizeof(CBoard<N>) / 16); j += 64) d[j] = s[j];
   }
 
   // base/board.cc:79-107 clearBoard + base/go_state.cc:134-141 reset, straight into LDS

@@ -18,8 +18,18 @@
 // de-duplicated per thread (traj_counts is per batch_rollouts call), evaluation and backup follow in thread order.  That is
 // one of the interleavings the reference's racing threads can produce; T x num_rollouts_per_thread rollouts per move.
 //
-// HBM layout (sized for 288 GB): per game a pool of C fixed-size node records (12 KiB at 19x19):
-//   [64 B header][368 x 16 B edge stats {prior, reward, visits, vloss}][368 x i32 child][368 x u16 coord][368 x u16 orig][board slot 3840 B]
+// HBM layout (sized for 288 GB; round 5: 5.9 KB instead of 12.5 KB per node).  Per game TWO pools of fixed-size node records:
+//   small  [64 B header][compact board 2624 B][NE x f32 prior][NE x u16 coord][NE x u16 orig][16 x 16 B touched-edge stats]   5888 B at 19x19
+//   big    the same with NE = 368 touched-edge entries                                                                        11520 B
+// Per edge a node keeps {prior, coord, orig} (8 B) for every legal move, and {reward, visits, virtual loss, child id} (16 B) only for
+// the edges that have been FOLLOWED at least once ("touched").  Every node but the root hangs on exactly one touched edge, so a tree of n
+// nodes has n - 1 touched edges in all: almost every node has none or a few.  A node is born in the small pool (room for 16 touched
+// edges); when its 17th edge is followed it MOVES to the big pool (k_mcts_select, promote: copy, patch the parent's child id and the
+// 16 children's parent ids).  A big node has >= 16 children that are nodes themselves, so Cb = Cs / 16 + 1 big records can never run
+// out before the small pool does.  Node id < Cs: small record id; else big record id - Cs.
+// The board of a node is the slot without its Bloom words (CBoard, go_board.cuh): the filter a forward needs is rebuilt in LDS from the
+// game board's own Bloom words (one copy per launch) plus the hashes of the positions on the descent's path (the node header carries
+// its position's hash, so the descent collects them on its way down).
 // The edge arrays are kept in SCORING order: first the edges that have been followed at least once, sorted by their index in the
 // reference's unordered_map iteration order (`orig`), then the never-followed ones by descending prior.  A never-followed edge
 // has N = 0, vl = 0, so its PUCT score is a monotone function of its prior: select scores the followed edges and the head of the
@@ -28,8 +38,7 @@
 // Dirichlet eta_i <-> i-th edge, most-visited ties, MCTSPolicy order) goes through `orig`.  An entry moves only when an edge is
 // followed for the first time (it joins the sorted prefix; the entries it passes shift up by one and their child nodes'
 // `parent_edge` follows), so a child's `parent_edge` is always the current position of its edge.
-// The board slot is the same LDS image the board engine uses, so "allocateState" (tree_search.h:174-190)
-// is: 16-B/lane coalesced load of the parent's slot -> Board::forward in LDS -> coalesced store.
+// "allocateState" (tree_search.h:174-190) is: 16-B/lane coalesced load of the parent's compact board -> Board::forward in LDS -> coalesced store.
 #pragma once
 #include "go_board.cuh"
 #include "stl_emul.h"
@@ -55,21 +64,49 @@ struct NodeHdr {          // 64 B
   int flip;               // flipQSign_
   int has_state;          // stateType_ == NODE_STATE_SET
   int n_touched;          // edges followed at least once = length of the orig-sorted prefix of the edge arrays
-  int pad[5];
+  int pad0;
+  u32 hash_lo, hash_hi;   // Zobrist hash of the node's position (words 12, 13): the descent feeds them to the superko filter
+  int pad1[2];
 };
 static_assert(sizeof(NodeHdr) == 64, "NodeHdr must be 64 bytes");
 
-template <int N>
-struct alignas(256) NodeRec {
-  static constexpr int NE = (N * N + 1 + 15) & ~15;
-  NodeHdr h;
-  float4 stat[NE];   // x prior_probability, y reward, z num_visits (int bits), w virtual_loss  (EdgeInfo, tree_search_base.h:102-124)
-  int child[NE];
-  u16 coord[NE];
-  u16 orig[NE];      // index of the edge in the reference's unordered_map iteration order (the arrays themselves are in scoring order)
-  Slot<N> board;
+struct TStat {            // statistics of a FOLLOWED edge (EdgeInfo, tree_search_base.h:102-124, minus the prior)
+  float reward;           // black-positive sum
+  int visits;             // num_visits
+  float vloss;            // virtual_loss
+  int child;              // node id of the child (always >= 0: an edge is touched when its child is created)
 };
-static_assert(sizeof(NodeRec<19>) == 12800, "19x19 node record");
+static_assert(sizeof(TStat) == 16, "TStat is one dwordx4");
+
+// layout of a node record (both classes); a record is addressed as bytes
+template <int N>
+struct NodeL {
+  static constexpr int NE = (N * N + 1 + 15) & ~15;
+  static constexpr int TCS = 16;                                   // touched-edge capacity of a small record
+  static constexpr int OFF_BOARD = 64;
+  static constexpr int OFF_PRIOR = OFF_BOARD + (int)sizeof(CBoard<N>);
+  static constexpr int OFF_COORD = OFF_PRIOR + NE * 4;
+  static constexpr int OFF_ORIG = OFF_COORD + NE * 2;
+  static constexpr int OFF_TST = OFF_ORIG + NE * 2;
+  static constexpr int SMALL = OFF_TST + TCS * 16;
+  static constexpr int BIG = OFF_TST + NE * 16;
+  static_assert(OFF_PRIOR % 16 == 0 && OFF_COORD % 16 == 0 && OFF_ORIG % 16 == 0 && OFF_TST % 16 == 0, "16-B aligned arrays");
+  static_assert(SMALL % 128 == 0 && BIG % 128 == 0, "records are 128-B granular");
+};
+static_assert(NodeL<19>::SMALL == 5888 && NodeL<19>::BIG == 11520, "19x19 node records");
+static_assert(NodeL<9>::SMALL == 1920 && NodeL<9>::BIG == 3200, "9x9 node records");
+
+template <int N>
+struct NodeRef {
+  using L = NodeL<N>;
+  char* p;
+  __device__ __forceinline__ NodeHdr& h() const { return *reinterpret_cast<NodeHdr*>(p); }
+  __device__ __forceinline__ CBoard<N>& board() const { return *reinterpret_cast<CBoard<N>*>(p + L::OFF_BOARD); }
+  __device__ __forceinline__ float* prior() const { return reinterpret_cast<float*>(p + L::OFF_PRIOR); }
+  __device__ __forceinline__ u16* coord() const { return reinterpret_cast<u16*>(p + L::OFF_COORD); }
+  __device__ __forceinline__ u16* orig() const { return reinterpret_cast<u16*>(p + L::OFF_ORIG); }
+  __device__ __forceinline__ TStat* tst() const { return reinterpret_cast<TStat*>(p + L::OFF_TST); }
+};
 
 struct TreeCfg {          // TSOptions / SearchAlgoOptions (tree_search_options.h:23-229) + MCTSActorParams (go/mcts/mcts.h:17-37)
   int rollouts_per_batch;
@@ -88,7 +125,7 @@ struct TreeCfg {          // TSOptions / SearchAlgoOptions (tree_search_options.
 
 struct GameState {        // 64 B per game
   int root;
-  int free_top;           // number of ids on the free stack
+  int free_top;           // number of ids on the small free stack
   int err;
   int rng_pos;            // D4 draws consumed from d4buf this move
   int n_unique;           // leaves of the current batch
@@ -96,7 +133,9 @@ struct GameState {        // 64 B per game
   int row_base;
   int rollouts_done;
   long long node_visits;  // sum over rollouts of the number of visited (selected-at) nodes: mean depth = node_visits / rollouts
-  int pad[6];
+  int free_top_big;       // number of ids on the big free stack
+  int promotions;         // small -> big moves so far (statistics)
+  int pad[4];
 };
 static_assert(sizeof(GameState) == 64, "GameState must be 64 bytes");
 
@@ -115,8 +154,11 @@ struct RowRec { int game, node, d4, pad; };
 
 template <int N>
 struct TreePool {
-  NodeRec<N>* nodes;      // [G][C]
-  int* free_stack;        // [G][C]
+  using L = NodeL<N>;
+  char* small;            // [G][Cs] records of L::SMALL bytes
+  char* big;              // [G][Cb] records of L::BIG bytes
+  int* free_stack;        // [G][Cs] small record ids
+  int* free_big;          // [G][Cb] big record ids (node id - Cs)
   int* parent_of;         // [G][C] dense copy of NodeHdr.parent for the tree sweeps: -2 free slot, -1 root, else parent id
   unsigned char* keep;    // [G][C] scratch of treeAdvance (reachable from the next root)
   GameState* gs;          // [G]
@@ -126,9 +168,26 @@ struct TreePool {
   const unsigned char* mask;   // [G] or nullptr (every game GM_SEARCH): which games the per-game launches act on (GM_*)
   const long long* req_ver;    // [G] or nullptr (TreeCfg.required_version for every game): MCTSActorParams.required_version per game
   int sqrt_n;
-  int C, W, G;
+  int Cs, Cb, C;          // small records, big records, node ids (Cs + Cb) per game
+  int W, G;
   __device__ __forceinline__ int game_mode(int g) const { return mask ? (int)mask[g] : (int)GM_SEARCH; }
-  __device__ __forceinline__ NodeRec<N>* game_nodes(int g) const { return nodes + (size_t)g * C; }
+  __device__ __forceinline__ char* small_of(int g) const { return small + (size_t)g * Cs * L::SMALL; }
+  __device__ __forceinline__ char* big_of(int g) const { return big + (size_t)g * Cb * L::BIG; }
+};
+
+// the records of one game
+template <int N>
+struct GameNodes {
+  using L = NodeL<N>;
+  char* sm;
+  char* bg;
+  int Cs;
+  __device__ __forceinline__ GameNodes(const TreePool<N>& tp, int g) : sm(tp.small_of(g)), bg(tp.big_of(g)), Cs(tp.Cs) {}
+  __device__ __forceinline__ bool is_big(int id) const { return id >= Cs; }
+  __device__ __forceinline__ NodeRef<N> operator[](int id) const {
+    return NodeRef<N>{id < Cs ? sm + (size_t)id * L::SMALL : bg + (size_t)(id - Cs) * L::BIG};
+  }
+  __device__ __forceinline__ int cap(int id) const { return id < Cs ? L::TCS : L::NE; }   // touched-edge capacity
 };
 
 __device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
@@ -157,7 +216,7 @@ struct HdrU {
 template <int N>
 struct TreeSK {
   using G = Geo<N>;
-  const NodeRec<N>* nodes;
+  GameNodes<N> nodes;
   int from;            // node whose state is being forwarded (the new child's parent)
   int move_out;        // the move being played from `from`
   GameSK<N> game;      // records of the game board the root was copied from
@@ -167,23 +226,23 @@ struct TreeSK {
     int a = from, mv = move_out;
     bool hit = false;
     for (;;) {
-      const NodeRec<N>& nd = nodes[a];
+      const NodeRef<N> nd = nodes[a];
       if (mv != M_PASS) {
-        const u64 h = nd.board.h.hash;
+        const u64 h = nd.board().h.hash;
         if (rfl((int)(h == hash))) {
-          const int cnt = nd.board.h.hist_cnt;
+          const int cnt = nd.board().h.hist_cnt;
           const int newest = (cnt + HIST - 1) & (HIST - 1);
           bool same = true;
           if (lane < G::R) {
-            const u64 b = cnt ? nd.board.hist[newest][0][lane] : 0ull, w = cnt ? nd.board.hist[newest][1][lane] : 0ull;
+            const u64 b = cnt ? nd.board().hist[newest][0][lane] : 0ull, w = cnt ? nd.board().hist[newest][1][lane] : 0ull;
             same = b == Bw && w == Ww;
           }
           if (__all(same)) hit = true;
         }
       }
-      const int p = rfl(nd.h.parent);
+      const int p = rfl(nd.h().parent);
       if (p < 0) break;
-      mv = rfl((int)nodes[p].coord[rfl(nd.h.parent_edge)]);
+      mv = rfl((int)nodes[p].coord()[rfl(nd.h().parent_edge)]);
       a = p;
     }
     if (hit) return true;
@@ -196,13 +255,13 @@ struct TreeSK {
 // ------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void node_init(const TreePool<N>& tp, int g, int id, int parent, int parent_edge, float parent_q, int lane) {
-  NodeRec<N>* nd = tp.game_nodes(g) + id;
+  const NodeRef<N> nd = GameNodes<N>(tp, g)[id];
   if (lane < 16) {
     int v = 0;
     if (lane == 0) v = parent;
     else if (lane == 1) v = parent_edge;
     else if (lane == 5 || lane == 6) v = __float_as_int(parent_q);   // NodeT ctor: unsignedMeanQ_ = unsignedParentQ_ (:99-103)
-    reinterpret_cast<int*>(&nd->h)[lane] = v;
+    reinterpret_cast<int*>(&nd.h())[lane] = v;
   }
   if (lane == 0) tp.parent_of[(size_t)g * tp.C + id] = parent;
 }
@@ -248,18 +307,19 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
 // SearchTreeT::clear (:411-416) for game g: every id free, then allocateRoot -> addNode(0.0)
 template <int N>
 __device__ __forceinline__ void tree_clear(const TreePool<N>& tp, int g, int lane) {
-  int* fs = tp.free_stack + (size_t)g * tp.C;
+  int* fs = tp.free_stack + (size_t)g * tp.Cs;
+  int* fb = tp.free_big + (size_t)g * tp.Cb;
   int* po = tp.parent_of + (size_t)g * tp.C;
-  for (int i = lane; i < tp.C; i += 64) {
-    fs[i] = tp.C - 1 - i;   // pops hand out 0, 1, 2, ...
-    po[i] = -2;
-  }
+  for (int i = lane; i < tp.Cs; i += 64) fs[i] = tp.Cs - 1 - i;   // pops hand out 0, 1, 2, ...
+  for (int i = lane; i < tp.Cb; i += 64) fb[i] = tp.Cb - 1 - i;
+  for (int i = lane; i < tp.C; i += 64) po[i] = -2;
   mem_sync();
   node_init(tp, g, 0, -1, -1, 0.0f, lane);
   if (lane == 0) {
     GameState& s = tp.gs[g];
-    s.root = 0; s.free_top = tp.C - 1; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
-    // node_visits is a lifetime counter (statistics): not reset with the tree
+    s.root = 0; s.free_top = tp.Cs - 1; s.free_top_big = tp.Cb; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0;
+    s.rollouts_done = 0;
+    // node_visits / promotions are lifetime counters (statistics): not reset with the tree
   }
 }
 
@@ -275,17 +335,20 @@ template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool, const int32_t* board_ids) {
   const int g = blockIdx.x, lane = threadIdx.x;
   if (rfl(tp.game_mode(g)) == GM_IDLE) return;
-  NodeRec<N>* nodes = tp.game_nodes(g);
+  const GameNodes<N> nodes(tp, g);
   GameState& s = tp.gs[g];
   const int root = rfl(s.root);
   const Slot<N>* src = &pool.slots[board_ids ? board_ids[g] : g];
-  NodeRec<N>& r = nodes[root];
-  if (rfl(r.h.has_state) == 0) {
-    const uint4* sp = reinterpret_cast<const uint4*>(src);
-    uint4* dp = reinterpret_cast<uint4*>(&r.board);
-    for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += 64) dp[j] = sp[j];
-    if (lane == 0) r.h.has_state = 1;
-  } else if (lane == 0 && r.board.h.hash != src->h.hash) {
+  const NodeRef<N> r = nodes[root];
+  if (rfl(r.h().has_state) == 0) {
+    const uint4* sp = reinterpret_cast<const uint4*>(src);          // the slot's prefix is the compact board
+    uint4* dp = reinterpret_cast<uint4*>(&r.board());
+    for (int j = lane; j < (int)(sizeof(CBoard<N>) / 16); j += 64) dp[j] = sp[j];
+    if (lane == 0) {
+      const u64 hh = src->h.hash;
+      r.h().has_state = 1; r.h().hash_lo = (u32)hh; r.h().hash_hi = (u32)(hh >> 32);
+    }
+  } else if (lane == 0 && r.board().h.hash != src->h.hash) {
     s.err |= MCTS_ERR_ROOT_HASH;
   }
   if (lane == 0) { s.rng_pos = 0; s.rollouts_done = 0; }
@@ -325,8 +388,13 @@ __device__ __attribute__((noinline)) double sqrt_beyond_table(int v) { return sq
 
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
-  using NR = NodeRec<N>;
+  using NL = NodeL<N>;
+  using GEO = Geo<N>;
+  constexpr int PATH_MAX = 256;             // levels of a descent whose position hashes are kept for the superko filter
+  constexpr u32 BMASK = GEO::BLOOM * 32 - 1;
   __shared__ Slot<N> lds;
+  __shared__ __attribute__((aligned(16))) u32 gbloom[GEO::BLOOM];   // the game board's own Bloom words: the game's records up to the root
+  __shared__ u32 path_h[2 * PATH_MAX];      // hash (lo, hi) of the node at each level of the current descent
   __shared__ __attribute__((aligned(16))) float uqs[64 + 8];   // unsigned child Qs of one round's visited edges, compacted
   // the unique leaves of this step (unique per search thread), in first-occurrence order: five arrays of KTP entries in the launch's
   // dynamic LDS (KTP = num_threads x rollouts_per_batch rounded up to 64; elfmcts_select passes 20 x KTP bytes)
@@ -347,13 +415,16 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
 #ifdef ELF_PROFILE_SELECT
   unsigned long long sel_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sel_t = __builtin_amdgcn_s_memtime();
 #endif
-  NR* nodes = tp.game_nodes(g);
-  int* fs = tp.free_stack + (size_t)g * tp.C;
+  const GameNodes<N> nodes(tp, g);
+  int* fs = tp.free_stack + (size_t)g * tp.Cs;
+  int* fb = tp.free_big + (size_t)g * tp.Cb;
+  int* po = tp.parent_of + (size_t)g * tp.C;
   GameState& gs = tp.gs[g];
   const int bslot = board_ids ? board_ids[g] : g;
-  const int root = rfl(gs.root);
-  int free_top = rfl(gs.free_top), rng_pos = rfl(gs.rng_pos), err = 0;
-  const int root_sk_len = rfl((int)nodes[root].board.h.sk_len);
+  int root = rfl(gs.root);
+  int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big), rng_pos = rfl(gs.rng_pos), err = 0, promotions = 0;
+  const int root_sk_len = rfl((int)nodes[root].board().h.sk_len);
+  if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(gbloom)[lane] = reinterpret_cast<const uint4*>(pool.slots[bslot].bloom)[lane];
   Board<N> bd;
   bd.init(&lds, pool.zob, nullptr);
 
@@ -376,25 +447,28 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     bool board_in_lds = false;   // LDS holds the state of `node`
     HdrU h;
     // the one memory round trip of a level: the header and the first 64 entries of the scoring order, requested together
-    // (speculatively: a leaf's edge arrays are never used), all coalesced
+    // (speculatively: a leaf's edge arrays are never used), all coalesced.  A small record holds statistics for 16 entries only.
     int hw;
-    float4 st0;
-    int ch0;
+    float pr0;
+    TStat ts0;
     u32 cd0, og0;
     auto request = [&](int nid) {
-      const NR& q = nodes[nid];
-      hw = lane < 16 ? reinterpret_cast<const int*>(&q.h)[lane] : 0;
-      st0 = q.stat[lane];
-      ch0 = q.child[lane];
-      cd0 = q.coord[lane];
-      og0 = q.orig[lane];
+      const NodeRef<N> q = nodes[nid];
+      hw = lane < 16 ? reinterpret_cast<const int*>(q.p)[lane] : 0;
+      pr0 = q.prior()[lane];
+      cd0 = q.coord()[lane];
+      og0 = q.orig()[lane];
+      ts0 = TStat{0.0f, 0, 0.0f, -1};
+      if (nodes.is_big(nid) || lane < NL::TCS) ts0 = q.tst()[lane];
     };
     request(node);
     for (;;) {                   // single_rollout, tree_search.h:264-322
       h.set(hw);
+      // the position hash of every node on the path (header words 12, 13): what the superko filter of a new node has to cover
+      if (depth < PATH_MAX && (lane >> 1) == 6) path_h[2 * depth + lane - 12] = (u32)hw;
       SEL_PHASE(0);   // header + scoring order arrive
       if (h.status != NS_VISITED || h.n_edges == 0 || root_only) break;
-      NR& nd = nodes[node];
+      const NodeRef<N> nd = nodes[node];
       // ---- findMove :205-231 + UCT :361-397 + EdgeInfo::getScore (tree_search_base.h:132-157)
       float umq = h.umq;
       if (cfg.unexplored_q_zero || (cfg.root_unexplored_q_zero && depth == 0)) umq = 0.0f;
@@ -417,10 +491,13 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       // one round of 64 entries of the scoring order; returns whether the next round has to be looked at.  The first round works
       // on the entries that arrived with the header (one instantiation without loads or waits); further rounds (nodes with more
       // than ~60 followed edges, or a long run of equal priors) are read on demand by a second instantiation.
-      auto score_round = [&](const int base, const float4 st, const int ch, const u32 cd, const int e) -> bool {
+      auto score_round = [&](const int base, const float prior, const TStat ts, const u32 cd, const int e) -> bool {
         const bool in = base + lane < ne;
-        const float prior = st.x, reward = st.y, vl = st.w;
-        const int nv = __float_as_int(st.z);
+        // only the followed prefix [0, nt) carries statistics; a never-followed edge has N = 0, vl = 0, reward = 0 and no child
+        const bool tch = base + lane < nt;
+        const float reward = tch ? ts.reward : 0.0f, vl = tch ? ts.vloss : 0.0f;
+        const int nv = tch ? ts.visits : 0;
+        const int ch = tch ? ts.child : -1;
         // one formula for both kinds of edge: with N = 0, vl = 0, reward = 0 it yields nvl = 0, Q = first-play urgency,
         // unsigned_q = umq and prior / 1 = prior
         float r = h.flip ? -reward : reward;
@@ -474,10 +551,12 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         if (nt >= base) unt_key0 = (u32)rl((int)key, nt - base);   // this round holds the head of the prior-sorted run
         return (u32)rl((int)key, 63) == unt_key0;            // false: the run of maximal never-followed scores ends inside this round
       };
-      bool more = score_round(0, st0, ch0, cd0, (int)og0);
+      bool more = score_round(0, pr0, ts0, cd0, (int)og0);
       for (int base = 64; more; base += 64) {
         const int pc = base + lane < ne ? base + lane : 0;
-        more = score_round(base, nd.stat[pc], nd.child[pc], (u32)nd.coord[pc], (int)(u32)nd.orig[pc]);
+        TStat t2{0.0f, 0, 0.0f, -1};
+        if (base + lane < nt) t2 = nd.tst()[base + lane];   // more than 64 followed edges: a big record
+        more = score_round(base, nd.prior()[pc], t2, (u32)nd.coord()[pc], (int)(u32)nd.orig()[pc]);
       }
       SEL_PHASE(1);   // statistics gather, scores, reductions, FPU sum
       if (best_e == 0x7FFFFFFF) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
@@ -485,8 +564,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       // ---- addVirtualLoss :233-251 (an edge followed for the first time gets it together with its move into the prefix below)
       const float new_vl = cfg.virtual_loss > 0 ? __fadd_rn(best_vl, vl_f) : best_vl;
       if (lane == 0) {
-        nd.h.unsigned_mean_q = new_umq;
-        if (cfg.virtual_loss > 0 && best_child >= 0) nd.stat[best_pos].w = new_vl;
+        nd.h().unsigned_mean_q = new_umq;
+        if (cfg.virtual_loss > 0 && best_child >= 0) nd.tst()[best_pos].vloss = new_vl;
       }
       ++depth;
       int child = best_child;
@@ -494,44 +573,89 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       if (child < 0) {
         // ---- followEdge :280-302 -> SearchTreeT::addNode(unsignedMeanQ_) :439-443
         if (free_top <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
+        NodeRef<N> nw = nd;      // the record that receives the new followed edge
+        if (nt >= nodes.cap(node)) {
+          // ---- the 17th followed edge of a small record: the node MOVES to the big pool.  Copy the record, tell the parent (its
+          // child id) and the 16 children (their parent id), return the small record.  Cb = Cs / 16 + 1 big records cannot run out.
+          if (free_top_big <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
+          const int bid = tp.Cs + rfl(fb[free_top_big - 1]);
+          --free_top_big;
+          const NodeRef<N> dst = nodes[bid];
+          {
+            const uint4* sp = reinterpret_cast<const uint4*>(nd.p);
+            uint4* dp = reinterpret_cast<uint4*>(dst.p);
+            for (int q = lane; q < NL::SMALL / 16; q += 64) dp[q] = sp[q];
+          }
+          if (lane < NL::TCS) {
+            const int cch = nd.tst()[lane].child;
+            nodes[cch].h().parent = bid;
+            po[cch] = bid;
+          }
+          if (h.parent >= 0) {
+            if (lane == 0) nodes[h.parent].tst()[h.parent_edge].child = bid;
+          } else {
+            root = bid;
+          }
+          if (lane == 0) { po[bid] = h.parent; po[node] = -2; fs[free_top] = node; }
+          ++free_top;
+          ++promotions;
+          node = bid;
+          nw = dst;
+          mem_sync();            // the copy and the returned id are visible before either is used
+        }
         child = rfl(fs[free_top - 1]);
         --free_top;
         // the edge joins the orig-sorted prefix of the scoring order at position p: entries [p, best_pos) move up by one and
-        // the child nodes of the moved edges learn their new position
+        // the child nodes of the moved FOLLOWED edges learn their new position
         int p = 0;
         for (int b2 = 0; b2 < nt; b2 += 64) {
           const int pos = b2 + lane;
           const bool t = pos < nt;
-          const int v = t ? (int)(b2 == 0 ? og0 : (u32)nd.orig[pos]) : 0;
+          const int v = t ? (int)(b2 == 0 ? og0 : (u32)nw.orig()[pos]) : 0;
           p += __popcll(__ballot(t && v < best_e));
         }
         for (int b2 = best_pos & ~63; b2 >= (p & ~63); b2 -= 64) {   // high rounds first: a round's loads precede its stores
           const int pos = b2 + lane;
           const bool mvd = pos >= p && pos < best_pos;
+          const bool tmv = mvd && pos < nt;
           const int pc = mvd ? pos : 0;
-          const float4 ms = nd.stat[pc];
-          const int mc = nd.child[pc];
-          const u16 md = nd.coord[pc], mo = nd.orig[pc];
-          if (mvd) {
-            nd.stat[pos + 1] = ms; nd.child[pos + 1] = mc; nd.coord[pos + 1] = md; nd.orig[pos + 1] = mo;
-            if (mc >= 0) nodes[mc].h.parent_edge = pos + 1;
-          }
+          const float mp = nw.prior()[pc];
+          const u16 md = nw.coord()[pc], mo = nw.orig()[pc];
+          TStat mt{0.0f, 0, 0.0f, -1};
+          if (tmv) mt = nw.tst()[pos];
+          if (mvd) { nw.prior()[pos + 1] = mp; nw.coord()[pos + 1] = md; nw.orig()[pos + 1] = mo; }
+          if (tmv) { nw.tst()[pos + 1] = mt; nodes[mt.child].h().parent_edge = pos + 1; }
         }
         node_init(tp, g, child, node, p, new_umq, lane);
         if (lane == 0) {
-          nd.stat[p] = make_float4(best_prior_v, 0.0f, __int_as_float(0), new_vl);
-          nd.child[p] = child; nd.coord[p] = (u16)mv; nd.orig[p] = (u16)best_e;
-          nd.h.n_touched = nt + 1;
+          nw.prior()[p] = best_prior_v; nw.coord()[p] = (u16)mv; nw.orig()[p] = (u16)best_e;
+          nw.tst()[p] = TStat{0.0f, 0, new_vl, child};
+          nw.h().n_touched = nt + 1;
         }
         SEL_PHASE(2);   // new node: id, header, scoring-order insertion
         // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
-        bd.load(&nd.board);
-        SEL_PHASE(3);   // parent's board slot to LDS
+        bd.load(&nw.board());
+        // the superko filter of the parent's position: the game's records up to the root (the game board's Bloom words) + the
+        // positions on the path root .. parent (every hash, also those a pass leaves: a filter may hold more, never less)
+        if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(lds.bloom)[lane] = reinterpret_cast<const uint4*>(gbloom)[lane];
+        Board<N>::wsync();
+        if (depth <= PATH_MAX) {
+          for (int l = lane; l < depth; l += 64) {
+            const u32 h1 = path_h[2 * l] & BMASK, h2 = path_h[2 * l + 1] & BMASK;
+            Board<N>::lds_or(&lds.bloom[h1 >> 5], 1u << (h1 & 31));
+            Board<N>::lds_or(&lds.bloom[h2 >> 5], 1u << (h2 & 31));
+          }
+        } else {
+          for (int l = lane; l < GEO::BLOOM; l += 64) lds.bloom[l] = ~0u;   // a path longer than the table: every probe goes to the exact check
+        }
+        Board<N>::wsync();
+        SEL_PHASE(3);   // parent's board to LDS, filter
         TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skr(bslot)}, root_sk_len};
         if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; --depth; break; }
         SEL_PHASE(4);   // Board::forward
-        bd.store(&nodes[child].board);
-        if (lane == 0) nodes[child].h.has_state = 1;
+        const NodeRef<N> cn = nodes[child];
+        bd.store(&cn.board());
+        if (lane == 0) { cn.h().has_state = 1; cn.h().hash_lo = (u32)bd.hash; cn.h().hash_hi = (u32)(bd.hash >> 32); }
         board_in_lds = true;
         node = child;
         h.status = NS_NOT_VISITED; h.n_edges = 0;   // the fresh node is this rollout's leaf: no need to read it back
@@ -556,7 +680,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       int kind = LK_REVISIT, d4 = 0;
       float value = 0.0f;
       if (h.status == NS_NOT_VISITED) {
-        if (!board_in_lds) bd.load(&nodes[node].board);   // only the root can get here without a fresh state
+        if (!board_in_lds) bd.load(&nodes[node].board());   // only the root can get here without a fresh state
         if (bd.terminated()) {                             // MCTSActor::pre_evaluate :185-207
           kind = LK_TERMINAL;
           value = bd.evaluate(cfg.komi) > 0.0f ? 1.0f : -1.0f;
@@ -569,7 +693,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
             ++rng_pos;
           }
         }
-        if (lane == 0) nodes[node].h.status = NS_EVAL_REQUESTED;
+        if (lane == 0) nodes[node].h().status = NS_EVAL_REQUESTED;
       }
       if (lane == 0) {
         lf_node[n_unique] = node; lf_count[n_unique] = 1; lf_meta[n_unique] = kind | (d4 << 8) | (depth << 16);
@@ -594,9 +718,10 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     lr.nn_index = lf_nn[i]; lr.depth = meta >> 16;
   }
   if (lane == 0) {
-    gs.free_top = free_top; gs.rng_pos = rng_pos; gs.n_unique = n_unique; gs.n_nn = n_nn;
+    gs.root = root; gs.free_top = free_top; gs.free_top_big = free_top_big; gs.rng_pos = rng_pos; gs.n_unique = n_unique; gs.n_nn = n_nn;
     gs.rollouts_done += KT;
     gs.node_visits += visited_nodes;
+    if (promotions) gs.promotions += promotions;
     if (err) gs.err |= err;
   }
 }
@@ -649,7 +774,7 @@ __global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, voi
   const LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + u];
   if (rfl(lr.kind) != LK_NN) return;
   const int row = base + rfl(lr.nn_index), node = rfl(lr.node), d4 = rfl(lr.d4);
-  const Slot<N>* sl = &tp.game_nodes(g)[node].board;
+  const CBoard<N>* sl = &GameNodes<N>(tp, g)[node].board();
   const u64* gh = &sl->hist[0][0][0];
   for (int j = lane; j < HIST * 2 * G::R; j += 64) (&hist[0][0][0])[j] = gh[j];
   const int cnt = sl->h.hist_cnt, player = sl->h.next_player;
@@ -664,7 +789,7 @@ __global__ __launch_bounds__(64) void k_mcts_features(TreePool<N> tp, int K, voi
 template <int N>
 struct ExpandLds {
   static constexpr int NA = N * N + 1;
-  static constexpr int NE = NodeRec<N>::NE;
+  static constexpr int NE = NodeL<N>::NE;
   static constexpr int PP = Geo<N>::PP;
   // Three consecutive lifetimes share one region, which is what sets the kernel's occupancy (6.1 KB instead of 11.4 KB per
   // wave at 19x19: 26 instead of 14 resident waves per CU):
@@ -714,7 +839,7 @@ __device__ __forceinline__ int wave_inclusive_sum(int v) {
 template <int N, int EP>
 __device__ __forceinline__ void umap_epoch_wave(ExpandLds<N>& L, int n, int lane, int& have, int& done, u16*& cur, u16*& nxt) {
   constexpr int P = Geo<N>::P;     // coords are < (N+2)^2
-  constexpr int NE = NodeRec<N>::NE;
+  constexpr int NE = NodeL<N>::NE;
   constexpr int nb = stl_emul::epoch_buckets(EP);
   if (done >= n) return;
   const int take = (n < nb ? n : nb) - done;
@@ -974,7 +1099,6 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
                                                      int64_t pi_stride, const float* __restrict__ value, const int64_t* __restrict__ rv,
                                                      int n_rows_host, const int32_t* __restrict__ counts, TreeCfg cfg) {
   using G = Geo<N>;
-  using NR = NodeRec<N>;
   constexpr int NA = N * N + 1, R = (NA + 63) / 64;
   __shared__ ExpandLds<N> L;
   const int row = blockIdx.x, lane = threadIdx.x;
@@ -983,7 +1107,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
   const int n_rows = n_rows_host >= 0 ? n_rows_host : rfl(counts[0]);
   if (row >= n_rows) return;
   const int g = rowmap[row].game, node = rowmap[row].node, d4 = rowmap[row].d4;
-  NR& nd = tp.game_nodes(g)[node];
+  const NodeRef<N> nd = GameNodes<N>(tp, g)[node];
   // MCTSActor::post_nn_result :210-217: the reply's model version must be the requested one (the reference throws)
   const long long need_ver = tp.req_ver ? tp.req_ver[g] : cfg.required_version;
   if (rv != nullptr && need_ver >= 0 && lane == 0 && rv[row] != need_ver) atomicOr(&tp.gs[g].err, MCTS_ERR_VERSION);
@@ -992,7 +1116,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
 #endif
   Board<N> bd;
   bd.init(&L.board, zob, nullptr);
-  bd.load(&nd.board);
+  bd.load(&nd.board());       // the compact board: no forward here, so the Bloom words of the LDS image are never looked at
   EXP_PHASE(0);   // row map + board load
   // ---- post_nn_result :209-230
   bool pass_enabled = bd.ply >= cfg.ply_pass_enabled;
@@ -1149,19 +1273,25 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
   EXP_PHASE(6);   // unordered_map iteration order
   // the edges are stored in scoring order: no edge followed yet, all of them by descending prior = pi2response's sorted order;
   // `orig` carries each edge's index in the map's iteration order
-  for (int jn = lane; jn < n; jn += 64) {
-    const int src = L.seq[jn];
-    nd.stat[src] = make_float4(L.sprob[src], 0.0f, __int_as_float(0), 0.0f);
-    nd.child[src] = -1;
-    nd.coord[src] = L.skey[src];
-    nd.orig[src] = (u16)jn;
+  // (a never-followed edge has no statistics record: 8 B per legal move leave for HBM, not 24)
+  {
+    float* const e_prior = nd.prior();
+    u16* const e_coord = nd.coord();
+    u16* const e_orig = nd.orig();
+    for (int jn = lane; jn < n; jn += 64) {
+      const int src = L.seq[jn];
+      e_prior[src] = L.sprob[src];
+      e_coord[src] = L.skey[src];
+      e_orig[src] = (u16)jn;
+    }
   }
   if (lane == 0) {
-    nd.h.n_touched = 0;
-    nd.h.n_edges = n;
-    nd.h.V = value[row];                                  // resp->value = reply.value :222
-    nd.h.flip = bd.next_player == S_WHITE;                // pre_evaluate :186
-    nd.h.status = NS_VISITED;
+    NodeHdr& nh = nd.h();
+    nh.n_touched = 0;
+    nh.n_edges = n;
+    nh.V = value[row];                                  // resp->value = reply.value :222
+    nh.flip = bd.next_player == S_WHITE;                // pre_evaluate :186
+    nh.status = NS_VISITED;
   }
   EXP_PHASE(7);   // edge records to HBM
 #ifdef ELF_PROFILE_EXPAND
@@ -1181,20 +1311,19 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
 // ------------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg) {
-  using NR = NodeRec<N>;
   const int g = blockIdx.x, lane = threadIdx.x;
-  NR* nodes = tp.game_nodes(g);
+  const GameNodes<N> nodes(tp, g);
   const int nu = rfl(tp.gs[g].n_unique);
   if (nu == 0) return;
   const LeafRec* leaves = tp.leaves + (size_t)g * MCTS_KMAX;
   for (int i = lane; i < nu; i += 64) {      // pre_evaluate result -> setEvaluation with an empty pi
     const LeafRec lr = leaves[i];
     if (lr.kind == LK_TERMINAL) {
-      NR& leaf = nodes[lr.node];
-      leaf.h.V = lr.value;
-      leaf.h.flip = leaf.board.h.next_player == S_WHITE;
-      leaf.h.n_edges = 0;
-      leaf.h.status = NS_VISITED;
+      const NodeRef<N> leaf = nodes[lr.node];
+      leaf.h().V = lr.value;
+      leaf.h().flip = leaf.board().h.next_player == S_WHITE;
+      leaf.h().n_edges = 0;
+      leaf.h().status = NS_VISITED;
     }
   }
   mem_sync();                                // a terminal leaf may be another search thread's revisited leaf in this step
@@ -1207,18 +1336,20 @@ __global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg)
       const LeafRec lr = leaves[c0 + lane];
       c = lr.node; d = lr.depth; count = lr.count;
     }
-    const float reward = have ? nodes[c].h.V : 0.0f;   // MCTSActor::reward (go/mcts/mcts.h:163-165)
+    const float reward = have ? nodes[c].h().V : 0.0f;   // MCTSActor::reward (go/mcts/mcts.h:163-165)
     const float vsub = (float)(cfg.virtual_loss * count);
     const int maxd = (int)wave_max_u32((u32)d);
     for (int lvl = maxd; lvl >= 1; --lvl) {    // updateEdgeStats :253-278 along the trajectories
       const bool act = have && d >= lvl;
       const u64 am = __ballot(act);
-      int p = 0, e = 0;
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      int p = 0;
+      TStat* sp = nullptr;
+      TStat s{0.f, 0, 0.f, -1};
       if (act) {
-        p = nodes[c].h.parent;
-        e = nodes[c].h.parent_edge;
-        s = nodes[p].stat[e];
+        const NodeHdr& ch = nodes[c].h();
+        p = ch.parent;
+        sp = &nodes[p].tst()[ch.parent_edge];
+        s = *sp;
       }
       bool leader = true;
       int zc = 0;
@@ -1230,15 +1361,15 @@ __global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg)
         const float rj = rlf(reward, jl), vj = rlf(vsub, jl);
         if (c == cj) {
           if (jl < lane) leader = false;
-          s.y = __fadd_rn(s.y, rj);
-          s.w = __fsub_rn(s.w, vj);
+          s.reward = __fadd_rn(s.reward, rj);
+          s.vloss = __fsub_rn(s.vloss, vj);
           ++zc;
         }
       }
       if (act && leader) {
-        s.z = __int_as_float(__float_as_int(s.z) + zc);
-        nodes[p].stat[e] = s;
-        atomicAdd(&nodes[p].h.num_visits, zc);
+        s.visits += zc;
+        *sp = s;
+        atomicAdd(&nodes[p].h().num_visits, zc);
       }
       if (act) c = p;
     }
