@@ -729,9 +729,12 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     net_ms = float(np.mean([a.elapsed_time(b) for a, b in sp.t_net])) if sp.t_net else 0.0   # per net call (one group)
     dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
     per_rank = gather_per_rank(dist, dev, my_rollouts / dt, world)
+    npg = int(sp.groups[0].opt.nodes_per_game)
     sp.close()
     if rank != 0:
         return None
+    import elf_amd as _ea
+    tree_gb = G * _ea.tree_bytes_per_game(n, npg) / 1e9
     step_ms = dt_max / steps * 1e3
     depth = d["node_visits"] / max(d["rollouts"], 1)   # measured mean descent depth over the timed window
     bytes_per_step = (d["node_visits"] * ROLLOUT_NODE_BYTES + my_rows * ROLLOUT_EXPAND_BYTES) / steps
@@ -739,7 +742,8 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     achieved = bytes_per_step / search_s / 1e9 if search_s > 0 else None
     # the select kernel alone: per visited node the header + edge statistics + child ids + coords it really loads, per new node
     # the parent's board slot in and the child's out
-    sel_bytes = (d["node_visits"] * (64 + 368 * 22) + my_rows * (2 * 3840 + 64)) / steps if n == 19 else None
+    # (round 5 layout: header + the first 64 entries {prior, coord, orig} + <= 16 touched-edge records; compact boards of 2624 B)
+    sel_bytes = (d["node_visits"] * (64 + 64 * 8 + 256) + my_rows * (2 * 2624 + 64)) / steps if n == 19 else None
     net_desc = ("random-init %d-block/%d-ch net on PyTorch-ROCm (%s, channels_last%s%s; leaf features %s)"
                 % (args.net_blocks, args.net_dim, args.net_dtype, "" if args.no_fold_bn else ", eval BatchNorm folded into the convs",
                    {"eager": "", "fused": ", conv epilogue = one elfnet_bias_act_f16 pass"}[args.net_impl]
@@ -762,7 +766,8 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                "untimed steps so that the timed window is a search in progress that crosses a move boundary"
                                % (K, args.rollouts * T, net_desc, G, groups, pregrow),
                    "search_dtype": "f32 edge statistics (the reference's float), u16 board labels", "net_dtype": args.net_dtype if net is not None else None,
-                   "games_per_gpu": G, "board_size": n, "mcts_threads": T,
+                   "games_per_gpu": G, "board_size": n, "mcts_threads": T, "nodes_per_game": npg,
+                   "node_bytes": _ea.tree_bytes_per_game(n, npg) // npg, "tree_pool_GB": tree_gb,
                    "mcts_threads_note": None if T == 1 else ("mcts_threads = %d: the reference's search threads race on the shared tree (it is nondeterministic "
                                                              "there, SURVEY H8); this engine runs ONE deterministic interleaving of them -- thread t's K descents see "
                                                              "the virtual losses of threads < t -- which is checked against the same interleaving restated in "
@@ -799,9 +804,9 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                      "kernel": "k_mcts_select+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
                      "algorithmic_bytes_per_rollout": bytes_per_step / (G * K * T),
                      "select_kernel": {"achieved_GBps": (sel_bytes / (sel_ms / 1e3) / 1e9) if (sel_bytes and sel_ms > 0) else None,
-                                       "bytes_per_visited_node": 64 + 368 * 22, "bytes_per_new_node": 2 * 3840 + 64,
+                                       "bytes_per_visited_node": 64 + 64 * 8 + 256, "bytes_per_new_node": 2 * 2624 + 64,
                                        "note": "select + leaf-feature launches (HIP events around begin_step); bytes = what the kernel loads "
-                                               "per visited node (header, 368 x 16 B statistics, child ids, coords) and moves per new node"},
+                                               "per visited node (header, 64 x {prior, coord, orig}, <= 16 touched-edge records) and moves per new node (parent's compact board in, child's out)"},
                      "note": "search kernels of this library (HIP events around begin_step / end_step on the groups' launch streams); bytes per "
                              "rollout = measured depth %.2f x (362 x 20 B edge read + 24 B writes) + per expansion 52534 B (SURVEY.md 8d). The "
                              "descent is a dependent pointer chase (one memory round trip per level, one wave per game): latency shares the roof "
@@ -1606,7 +1611,7 @@ def main():
     ap.add_argument("--games-rollouts", type=int, default=32)
     ap.add_argument("--games-cutoff", type=int, default=40)
     ap.add_argument("--games-generations", type=int, default=2)
-    ap.add_argument("--search-only-games", type=int, default=2048, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
+    ap.add_argument("--search-only-games", type=int, default=4096, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
     ap.add_argument("--phase-steps", type=int, default=16, help="timed steps per game phase (plies 0/60/120/180) of the games/s leg; 0 = off")
     ap.add_argument("--played-games", type=int, default=64, help="cohort of the PLAYED data point at the headline's rollout count; 0 = off")
     ap.add_argument("--played-moves", type=int, default=2, help="whole moves the cohort plays end to end; 0 = off")
@@ -1634,22 +1639,28 @@ def main():
         return v if (v is not None and args.workload != "both") else dflt
 
     if sub and args.board_size == 19 and args.search_only_games > 0:
-        # the search kernels without the conv net, with as many games in flight as 288 GB of HBM hold at the headline's pool size
-        # (2048 games x 8192 node records x 12.5 KB = 215 GB): two waves per SIMD in the per-game kernels, two pipelined groups
+        # the search kernels without the conv net, with as many games in flight as the free HBM holds at 8192 node ids per game (up to
+        # --search-only-games): four waves per SIMD in the per-game kernels at 4096 games, two pipelined groups
         try:
             import copy
+            import elf_amd
             a2 = copy.copy(args)
-            a2.net, a2.features, a2.games, a2.groups, a2.nodes_per_game, a2.rollouts, a2.pregrow = "random", "f16", args.search_only_games, 2, 8192, 2048, 0
+            nodes = 8192
+            free, _ = elf_amd.mem_info(local_rank)
+            per_game = elf_amd.tree_bytes_per_game(19, nodes) + 2 * 16 * 18 * 361 + (1 << 16)    # + its feature rows and slack
+            fit = int(0.85 * free // per_game) // 128 * 128
+            so_games = max(128, min(args.search_only_games, fit))
+            a2.net, a2.features, a2.games, a2.groups, a2.nodes_per_game, a2.rollouts, a2.pregrow = "random", "f16", so_games, 2, nodes, 2048, 0
             so = run_mcts(a2, rank, local_rank, world, dist, 32, 88, False)
             if rank == 0:
                 c = so["config"]
                 res["search_only"] = {"metric": "mcts_rollouts_per_sec, search kernels only (random replies instead of the conv net)", "value": so["value"],
                                       "unit": "rollouts/s", "ms_per_step": so["ms_per_step"], "games_per_gpu": c["games_per_gpu"], "groups": c["groups"],
                                       "rollouts_per_step": c["rollouts_per_step"], "mean_depth": c["mean_depth"], "select_ms": c["select_ms"],
-                                      "expand_backup_ms": c["expand_backup_ms"], "roofline": so["roofline"],
-                                      "note": "same kernels, same tree shape (2048 rollouts per move on 8192-node pools, depth ~6.3) as the round-3 search-only "
-                                              "line, with 2048 instead of 1024 games per GPU: the per-game kernels are latency chains, a second resident "
-                                              "wave per SIMD hides them (1024 games, one group: profiles/r04z_bench_search_only.json)"}
+                                      "expand_backup_ms": c["expand_backup_ms"], "roofline": so["roofline"], "nodes_per_game": nodes,
+                                      "tree_pool_GB": so_games * elf_amd.tree_bytes_per_game(19, nodes) / 1e9, "games_that_fit_free_hbm": fit,
+                                      "note": "same kernels, same tree shape (2048 rollouts per move on 8192-node pools, depth ~6.3) as the headline's "
+                                              "search; the per-game kernels are latency chains, more resident waves per SIMD hide them"}
         except Exception as e:   # e.g. not enough free HBM beside another process
             if rank == 0:
                 res["search_only"] = "unavailable: %r" % (e,)

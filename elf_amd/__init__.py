@@ -15,3 +15,18 @@ from .selfplay import SelfPlay, MctsOptions, SpOptions  # noqa: F401,E402
 from . import compat  # noqa: F401,E402
 from .train import ReplayLoader, ReaderQueues, ReplayBuffer, parse_record, sgfstr_to_coords, coords_to_sgfstr  # noqa: F401,E402
 from .client import ClientRecords, parse_request_seq, request_seq_to_json  # noqa: F401,E402
+
+
+def tree_bytes_per_game(board_size, nodes_per_game):
+    """HBM one game's search tree takes at `nodes_per_game` node ids (elfmcts_tree_bytes_per_game, include/elf_amd.h)."""
+    return int(lib().elfmcts_tree_bytes_per_game(int(board_size), int(nodes_per_game)))
+
+
+def mem_info(device=0):
+    """(free, total) HBM bytes of a device (elfgo_mem_info)."""
+    import ctypes as C
+    fr, tot = C.c_size_t(0), C.c_size_t(0)
+    rc = lib().elfgo_mem_info(int(device), C.byref(fr), C.byref(tot))
+    if rc:
+        raise ElfGoError(rc)
+    return int(fr.value), int(tot.value)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "elfmcts_num_games": (_i, [_vp]),
     "elfmcts_edge_stride": (_i, [_vp]),
     "elfmcts_node_bytes": (_sz, [_vp]),
+    "elfmcts_tree_bytes_per_game": (_sz, [_i, _i]),
     "elfmcts_clear": (_i, [_vp, _vp, _i, _vp]),
     "elfmcts_set_root": (_i, [_vp, _vp, _vp]),
     "elfmcts_set_d4": (_i, [_vp, _vp, _vp]),

@@ -311,9 +311,12 @@ struct Board {
   // no s_waitcnt vmcnt(0) behind the fire-and-forget superko stores to HBM.
   __device__ __forceinline__ static void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
-  __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skr) {
+  __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skr) { init(lds, z, skr, threadIdx.x & 63); }
+  // the lane index as an argument: a kernel that wants the per-lane constants set up late (k_mcts_select: after the descent, so that
+  // they are not live across its level loop) passes an opaque copy of its lane index, which keeps the set-up where it is written
+  __device__ __forceinline__ void init(Slot<N>* lds, const u64* z, u64* skr, int lane_) {
     L = lds; zob = z; zob_v = z; zob_lds_on = false; sk_rec = skr;
-    lane = threadIdx.x & 63;
+    lane = lane_;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       int a = k * 64 + lane;
@@ -419,7 +422,10 @@ struct Board {
     const uint4* s = reinterpret_cast<const uint4*>(g);
     uint4* d = reinterpret_cast<uint4*>(L);
 #pragma unroll
-    for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += 64) d[j] = s[j];
+    for (int k = 0; k < ((int)(sizeof(Slot<N>) / 16) + 63) / 64; ++k) {
+      const int j = k * 64 + lane;
+      if (j < (int)(sizeof(Slot<N>) / 16)) d[j] = s[j];
+    }
     wsync();
     load_hdr();
     const int newest = (hist_cnt + HIST - 1) & (HIST - 1);
@@ -431,14 +437,20 @@ struct Board {
     const uint4* s = reinterpret_cast<const uint4*>(L);
     uint4* d = reinterpret_cast<uint4*>(g);
 #pragma unroll
-    for (int j = lane; j < (int)(sizeof(Slot<N>) / 16); j += 64) d[j] = s[j];
+    for (int k = 0; k < ((int)(sizeof(Slot<N>) / 16) + 63) / 64; ++k) {
+      const int j = k * 64 + lane;
+      if (j < (int)(sizeof(Slot<N>) / 16)) d[j] = s[j];
+    }
   }
   // the same for a tree node's compact board: the Bloom words of the LDS image are left alone (the caller owns them)
   __device__ __forceinline__ void load(const CBoard<N>* g) {
     const uint4* s = reinterpret_cast<const uint4*>(g);
     uint4* d = reinterpret_cast<uint4*>(L);
 #pragma unroll
-    for (int j = lane; j < (int)(sizeof(CBoard<N>) / 16); j += 64) d[j] = s[j];
+    for (int k = 0; k < ((int)(sizeof(CBoard<N>) / 16) + 63) / 64; ++k) {
+      const int j = k * 64 + lane;
+      if (j < (int)(sizeof(CBoard<N>) / 16)) d[j] = s[j];
+    }
     wsync();
     load_hdr();
     const int newest = (hist_cnt + HIST - 1) & (HIST - 1);
@@ -450,7 +462,10 @@ struct Board {
     const uint4* s = reinterpret_cast<const uint4*>(L);
     uint4* d = reinterpret_cast<uint4*>(g);
 #pragma unroll
-    for (int j = lane; j < (int)(sizeof(CBoard<N>) / 16); j += 64) d[j] = s[j];
+    for (int k = 0; k < ((int)(sizeof(CBoard<N>) / 16) + 63) / 64; ++k) {
+      const int j = k * 64 + lane;
+      if (j < (int)(sizeof(CBoard<N>) / 16)) d[j] = s[j];
+    }
   }
 
   // base/board.cc:79-107 clearBoard + base/go_state.cc:134-141 reset, straight into LDS

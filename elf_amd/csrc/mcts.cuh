@@ -77,6 +77,11 @@ struct TStat {            // statistics of a FOLLOWED edge (EdgeInfo, tree_searc
   int child;              // node id of the child (always >= 0: an edge is touched when its child is created)
 };
 static_assert(sizeof(TStat) == 16, "TStat is one dwordx4");
+// "no statistics": what a never-followed edge stands for (field by field: a braced constant would be copied from memory through scratch)
+__device__ __forceinline__ TStat tst_none() { TStat t; t.reward = 0.0f; t.visits = 0; t.vloss = 0.0f; t.child = -1; return t; }
+__device__ __forceinline__ TStat tst_make(float reward, int visits, float vloss, int child) {
+  TStat t; t.reward = reward; t.visits = visits; t.vloss = vloss; t.child = child; return t;
+}
 
 // layout of a node record (both classes); a record is addressed as bytes
 template <int N>
@@ -354,6 +359,27 @@ __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool
   if (lane == 0) { s.rng_pos = 0; s.rollouts_done = 0; }
 }
 
+// The move of a node from its small record to a big one (k_mcts_select, the 17th followed edge): copy the record, give the 16
+// children their parent's new id.  Kept out of line: inlined, its temporaries raised the select kernel's register count by 19 (one
+// wave per SIMD less), and it runs once per 17-child node.
+template <int N>
+__device__ __attribute__((noinline)) void promote_record(GameNodes<N> nodes, NodeRef<N> src, NodeRef<N> dst, int* po, int bid) {
+  using NL = NodeL<N>;
+  const int lane = threadIdx.x & 63;
+  const uint4* sp = reinterpret_cast<const uint4*>(src.p);
+  uint4* dp = reinterpret_cast<uint4*>(dst.p);
+  mem_sync();                              // lane 0's store of the node's running mean (this level) precedes the other lanes' reads
+#pragma unroll 1
+  for (int q = lane; q < NL::SMALL / 16; q += 64) dp[q] = sp[q];
+  const int cch = lane < NL::TCS ? src.tst()[lane].child : 0;
+  if (lane < NL::TCS) po[cch] = bid;
+#pragma unroll 1
+  for (int k = 0; k < NL::TCS; ++k) {      // scalar addresses: no per-lane record arithmetic on this rare path
+    const NodeRef<N> cr = nodes[rl(cch, k)];
+    if (lane == 0) cr.h().parent = bid;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // select: num_threads x rollouts_per_batch sequential descents per game (TreeSearchSingleThreadT::batch_rollouts, first
 // half, once per search thread)
@@ -390,11 +416,11 @@ template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
   using NL = NodeL<N>;
   using GEO = Geo<N>;
-  constexpr int PATH_MAX = 256;             // levels of a descent whose position hashes are kept for the superko filter
+  constexpr int PATH_LV = 256;             // levels of a descent whose position hashes are kept for the superko filter
   constexpr u32 BMASK = GEO::BLOOM * 32 - 1;
   __shared__ Slot<N> lds;
   __shared__ __attribute__((aligned(16))) u32 gbloom[GEO::BLOOM];   // the game board's own Bloom words: the game's records up to the root
-  __shared__ u32 path_h[2 * PATH_MAX];      // hash (lo, hi) of the node at each level of the current descent
+  __shared__ u32 path_h[2 * PATH_LV];      // hash (lo, hi) of the node at each level of the current descent
   __shared__ __attribute__((aligned(16))) float uqs[64 + 8];   // unsigned child Qs of one round's visited edges, compacted
   // the unique leaves of this step (unique per search thread), in first-occurrence order: five arrays of KTP entries in the launch's
   // dynamic LDS (KTP = num_threads x rollouts_per_batch rounded up to 64; elfmcts_select passes 20 x KTP bytes)
@@ -425,9 +451,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big), rng_pos = rfl(gs.rng_pos), err = 0, promotions = 0;
   const int root_sk_len = rfl((int)nodes[root].board().h.sk_len);
   if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(gbloom)[lane] = reinterpret_cast<const uint4*>(pool.slots[bslot].bloom)[lane];
-  Board<N> bd;
-  bd.init(&lds, pool.zob, nullptr);
-
   // the D4 codes the coming net leaves draw: one coalesced read per launch (nothing draws besides this wave); beyond 64 draws the
   // kernel falls back to the dependent load
   const int rng_pos0 = rng_pos;
@@ -445,6 +468,14 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     if (jk == 0) thread_start = n_unique;   // traj_counts is per batch_rollouts call, i.e. per search thread
     int node = root, depth = 0;
     bool board_in_lds = false;   // LDS holds the state of `node`
+    // the board engine's per-lane constants (~35 registers) are set up where a board is first needed -- after the descent -- from an
+    // opaque copy of the lane index, so that they are not live (nor hoisted) across the level loop
+    Board<N> bd;
+    auto board_setup = [&]() {
+      int ol = lane;
+      asm volatile("" : "+v"(ol));
+      bd.init(&lds, pool.zob, nullptr, ol);
+    };
     HdrU h;
     // the one memory round trip of a level: the header and the first 64 entries of the scoring order, requested together
     // (speculatively: a leaf's edge arrays are never used), all coalesced.  A small record holds statistics for 16 entries only.
@@ -458,14 +489,14 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       pr0 = q.prior()[lane];
       cd0 = q.coord()[lane];
       og0 = q.orig()[lane];
-      ts0 = TStat{0.0f, 0, 0.0f, -1};
+      ts0 = tst_none();
       if (nodes.is_big(nid) || lane < NL::TCS) ts0 = q.tst()[lane];
     };
     request(node);
     for (;;) {                   // single_rollout, tree_search.h:264-322
       h.set(hw);
       // the position hash of every node on the path (header words 12, 13): what the superko filter of a new node has to cover
-      if (depth < PATH_MAX && (lane >> 1) == 6) path_h[2 * depth + lane - 12] = (u32)hw;
+      if (depth < PATH_LV && (lane >> 1) == 6) path_h[2 * depth + lane - 12] = (u32)hw;
       SEL_PHASE(0);   // header + scoring order arrive
       if (h.status != NS_VISITED || h.n_edges == 0 || root_only) break;
       const NodeRef<N> nd = nodes[node];
@@ -554,7 +585,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       bool more = score_round(0, pr0, ts0, cd0, (int)og0);
       for (int base = 64; more; base += 64) {
         const int pc = base + lane < ne ? base + lane : 0;
-        TStat t2{0.0f, 0, 0.0f, -1};
+        TStat t2 = tst_none();
         if (base + lane < nt) t2 = nd.tst()[base + lane];   // more than 64 followed edges: a big record
         more = score_round(base, nd.prior()[pc], t2, (u32)nd.coord()[pc], (int)(u32)nd.orig()[pc]);
       }
@@ -574,6 +605,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         // ---- followEdge :280-302 -> SearchTreeT::addNode(unsignedMeanQ_) :439-443
         if (free_top <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
         NodeRef<N> nw = nd;      // the record that receives the new followed edge
+#ifndef ELF_X_NOPROMO
         if (nt >= nodes.cap(node)) {
           // ---- the 17th followed edge of a small record: the node MOVES to the big pool.  Copy the record, tell the parent (its
           // child id) and the 16 children (their parent id), return the small record.  Cb = Cs / 16 + 1 big records cannot run out.
@@ -581,16 +613,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           const int bid = tp.Cs + rfl(fb[free_top_big - 1]);
           --free_top_big;
           const NodeRef<N> dst = nodes[bid];
-          {
-            const uint4* sp = reinterpret_cast<const uint4*>(nd.p);
-            uint4* dp = reinterpret_cast<uint4*>(dst.p);
-            for (int q = lane; q < NL::SMALL / 16; q += 64) dp[q] = sp[q];
-          }
-          if (lane < NL::TCS) {
-            const int cch = nd.tst()[lane].child;
-            nodes[cch].h().parent = bid;
-            po[cch] = bid;
-          }
+          promote_record<N>(nodes, nd, dst, po, bid);
           if (h.parent >= 0) {
             if (lane == 0) nodes[h.parent].tst()[h.parent_edge].child = bid;
           } else {
@@ -603,6 +626,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           nw = dst;
           mem_sync();            // the copy and the returned id are visible before either is used
         }
+#endif
         child = rfl(fs[free_top - 1]);
         --free_top;
         // the edge joins the orig-sorted prefix of the scoring order at position p: entries [p, best_pos) move up by one and
@@ -621,7 +645,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           const int pc = mvd ? pos : 0;
           const float mp = nw.prior()[pc];
           const u16 md = nw.coord()[pc], mo = nw.orig()[pc];
-          TStat mt{0.0f, 0, 0.0f, -1};
+          TStat mt = tst_none();
           if (tmv) mt = nw.tst()[pos];
           if (mvd) { nw.prior()[pos + 1] = mp; nw.coord()[pos + 1] = md; nw.orig()[pos + 1] = mo; }
           if (tmv) { nw.tst()[pos + 1] = mt; nodes[mt.child].h().parent_edge = pos + 1; }
@@ -629,17 +653,19 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         node_init(tp, g, child, node, p, new_umq, lane);
         if (lane == 0) {
           nw.prior()[p] = best_prior_v; nw.coord()[p] = (u16)mv; nw.orig()[p] = (u16)best_e;
-          nw.tst()[p] = TStat{0.0f, 0, new_vl, child};
+          nw.tst()[p] = tst_make(0.0f, 0, new_vl, child);
           nw.h().n_touched = nt + 1;
         }
         SEL_PHASE(2);   // new node: id, header, scoring-order insertion
         // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
+        board_setup();
         bd.load(&nw.board());
         // the superko filter of the parent's position: the game's records up to the root (the game board's Bloom words) + the
         // positions on the path root .. parent (every hash, also those a pass leaves: a filter may hold more, never less)
+#ifndef ELF_X_NOBLOOM
         if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(lds.bloom)[lane] = reinterpret_cast<const uint4*>(gbloom)[lane];
         Board<N>::wsync();
-        if (depth <= PATH_MAX) {
+        if (depth <= PATH_LV) {
           for (int l = lane; l < depth; l += 64) {
             const u32 h1 = path_h[2 * l] & BMASK, h2 = path_h[2 * l + 1] & BMASK;
             Board<N>::lds_or(&lds.bloom[h1 >> 5], 1u << (h1 & 31));
@@ -649,6 +675,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           for (int l = lane; l < GEO::BLOOM; l += 64) lds.bloom[l] = ~0u;   // a path longer than the table: every probe goes to the exact check
         }
         Board<N>::wsync();
+#endif
         SEL_PHASE(3);   // parent's board to LDS, filter
         TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skr(bslot)}, root_sk_len};
         if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; --depth; break; }
@@ -680,7 +707,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       int kind = LK_REVISIT, d4 = 0;
       float value = 0.0f;
       if (h.status == NS_NOT_VISITED) {
-        if (!board_in_lds) bd.load(&nodes[node].board());   // only the root can get here without a fresh state
+        if (!board_in_lds) { board_setup(); bd.load(&nodes[node].board()); }   // only the root can get here without a fresh state
         if (bd.terminated()) {                             // MCTSActor::pre_evaluate :185-207
           kind = LK_TERMINAL;
           value = bd.evaluate(cfg.komi) > 0.0f ? 1.0f : -1.0f;
@@ -1344,7 +1371,7 @@ __global__ __launch_bounds__(64) void k_mcts_backup(TreePool<N> tp, TreeCfg cfg)
       const u64 am = __ballot(act);
       int p = 0;
       TStat* sp = nullptr;
-      TStat s{0.f, 0, 0.f, -1};
+      TStat s = tst_none();
       if (act) {
         const NodeHdr& ch = nodes[c].h();
         p = ch.parent;
@@ -1385,26 +1412,29 @@ template <int N>
 __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const float* etas, const float* Z, float epsilon) {
   const int g = blockIdx.x, lane = threadIdx.x;
   if (rfl(tp.game_mode(g)) == GM_IDLE) return;
-  NodeRec<N>& r = tp.game_nodes(g)[rfl(tp.gs[g].root)];
-  const int n = rfl(r.h.n_edges);
-  if (rfl(r.h.status) != NS_VISITED) return;
+  const NodeRef<N> r = GameNodes<N>(tp, g)[rfl(tp.gs[g].root)];
+  const int n = rfl(r.h().n_edges);
+  if (rfl(r.h().status) != NS_VISITED) return;
+  float* const e_prior = r.prior();
+  u16* const e_coord = r.coord();
+  u16* const e_orig = r.orig();
   const float z = Z[g], ome = __fsub_rn(1.0f, epsilon);
   for (int i = lane; i < n; i += 64) {
-    const float p = r.stat[i].x;
-    const int o = r.orig[i];   // eta_o belongs to the o-th edge of the map's iteration order
+    const float p = e_prior[i];
+    const int o = e_orig[i];   // eta_o belongs to the o-th edge of the map's iteration order
     // (1 - epsilon) * p + epsilon * etas[o] / Z, left to right, no contraction
-    r.stat[i].x = __fadd_rn(__fmul_rn(ome, p), __fdiv_rn(__fmul_rn(epsilon, etas[(size_t)g * NodeRec<N>::NE + o]), z));
+    e_prior[i] = __fadd_rn(__fmul_rn(ome, p), __fdiv_rn(__fmul_rn(epsilon, etas[(size_t)g * NodeL<N>::NE + o]), z));
   }
   // the never-followed part of the scoring order follows the NEW priors: descending prior (ties: ascending orig).  Those
   // entries carry no statistics and no child: sort (prior, position) keys, then move prior / coord / orig accordingly.
   mem_sync();
-  const int nt = rfl(r.h.n_touched);
+  const int nt = rfl(r.h().n_touched);
   u64 sx[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int pos = nt + k * 64 + lane;
     sx[k] = ~0ull;
-    if (pos < n) sx[k] = ((u64)(~f2ukey(r.stat[pos].x)) << 32) | ((u32)r.orig[pos] << 16) | (u32)(pos - nt);
+    if (pos < n) sx[k] = ((u64)(~f2ukey(e_prior[pos])) << 32) | ((u32)e_orig[pos] << 16) | (u32)(pos - nt);
   }
   bitonic_sort512(sx, lane);
   float np[8];
@@ -1415,8 +1445,8 @@ __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const flo
     np[k] = 0.0f; nc[k] = 0;
     if (nt + i < n) {
       const int src = nt + (int)(sx[k] & 0xFFFFu);
-      np[k] = r.stat[src].x;
-      nc[k] = r.coord[src];
+      np[k] = e_prior[src];
+      nc[k] = e_coord[src];
     }
   }
   mem_sync();   // every source entry has been read before any destination is written
@@ -1424,9 +1454,9 @@ __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const flo
   for (int k = 0; k < 8; ++k) {
     const int i = k * 64 + lane;
     if (nt + i < n) {
-      r.stat[nt + i] = make_float4(np[k], 0.0f, __int_as_float(0), 0.0f);
-      r.coord[nt + i] = nc[k];
-      r.orig[nt + i] = (u16)((sx[k] >> 16) & 0xFFFFu);
+      e_prior[nt + i] = np[k];
+      e_coord[nt + i] = nc[k];
+      e_orig[nt + i] = (u16)((sx[k] >> 16) & 0xFFFFu);
     }
   }
 }
@@ -1441,14 +1471,14 @@ struct RootInfo {   // 32 B per game
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_root(TreePool<N> tp, RootInfo* info, int32_t* coord, int32_t* visits, float* prior,
                                                    float* reward, int32_t* child) {
-  constexpr int NE = NodeRec<N>::NE;
+  constexpr int NE = NodeL<N>::NE;
   const int g = blockIdx.x, lane = threadIdx.x;
   const GameState& gs = tp.gs[g];
-  const NodeRec<N>& r = tp.game_nodes(g)[rfl(gs.root)];
-  const int n = rfl(r.h.n_edges);
+  const NodeRef<N> r = GameNodes<N>(tp, g)[rfl(gs.root)];
+  const int n = rfl(r.h().n_edges), nt = rfl(r.h().n_touched);
   if (lane == 0) {
     RootInfo ri;
-    ri.n_edges = n; ri.num_visits = r.h.num_visits; ri.status = r.h.status; ri.root = gs.root; ri.V = r.h.V;
+    ri.n_edges = n; ri.num_visits = r.h().num_visits; ri.status = r.h().status; ri.root = gs.root; ri.V = r.h().V;
     ri.rng_pos = gs.rng_pos; ri.err = gs.err; ri.free_top = gs.free_top;
     info[g] = ri;
   }
@@ -1462,69 +1492,76 @@ __global__ __launch_bounds__(64) void k_mcts_root(TreePool<N> tp, RootInfo* info
     if (child) child[o] = -1;
   }
   for (int i = lane; i < n; i += 64) {
-    const size_t o = (size_t)g * NE + r.orig[i];
-    const float4 s = r.stat[i];
-    if (coord) coord[o] = r.coord[i];
-    if (visits) visits[o] = __float_as_int(s.z);
-    if (prior) prior[o] = s.x;
-    if (reward) reward[o] = s.y;
-    if (child) child[o] = r.child[i];
+    const size_t o = (size_t)g * NE + r.orig()[i];
+    TStat t = tst_none();
+    if (i < nt) t = r.tst()[i];
+    if (coord) coord[o] = r.coord()[i];
+    if (visits) visits[o] = t.visits;
+    if (prior) prior[o] = r.prior()[i];
+    if (reward) reward[o] = t.reward;
+    if (child) child[o] = t.child;
   }
 }
 
 // Invariants of the node records (test / debug service, elfmcts_validate): for every live node that has been expanded
-//   entries [0, n_touched): child >= 0, the child's header points back (parent, parent_edge == position), orig ascending
-//   entries [n_touched, n_edges): no child, no statistics, priors descending
+//   entries [0, n_touched): child >= 0, the child's header points back (parent, parent_edge == position), orig ascending;
+//                           n_touched fits the record's class (16 in a small record)
+//   entries [n_touched, n_edges): priors descending
+//   every live node that owns a state carries its position's hash in the header
 // out[0] = number of violations, out[1..4] = code, game, node, position of one of them.
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_validate(TreePool<N> tp, int32_t* out) {
   const int g = blockIdx.x, lane = threadIdx.x;
-  const NodeRec<N>* nodes = tp.game_nodes(g);
+  const GameNodes<N> nodes(tp, g);
   const int* po = tp.parent_of + (size_t)g * tp.C;
   auto fail = [&](int code, int node, int pos) {
     if (atomicAdd(&out[0], 1) == 0) { out[1] = code; out[2] = g; out[3] = node; out[4] = pos; }
   };
   for (int id = blockIdx.y; id < tp.C; id += gridDim.y) {
     if (po[id] == -2) continue;
-    const NodeRec<N>& r = nodes[id];
-    if (r.h.status != NS_VISITED) continue;
-    const int n = r.h.n_edges, nt = r.h.n_touched;
-    if (nt < 0 || nt > n) { if (lane == 0) fail(1, id, nt); continue; }
+    const NodeRef<N> r = nodes[id];
+    const NodeHdr& rh = r.h();
+    if (lane == 0 && rh.parent != po[id]) fail(11, id, po[id]);
+    if (lane == 0 && rh.has_state && (((u64)rh.hash_hi << 32) | rh.hash_lo) != r.board().h.hash) fail(12, id, 0);
+    if (rh.status != NS_VISITED) continue;
+    const int n = rh.n_edges, nt = rh.n_touched;
+    if (nt < 0 || nt > n || nt > nodes.cap(id)) { if (lane == 0) fail(1, id, nt); continue; }
     int visits = 0;
     for (int i = lane; i < n; i += 64) {
-      const float4 s = r.stat[i];
-      const int ch = r.child[i];
-      visits += __float_as_int(s.z);
       if (i < nt) {
+        const TStat t = r.tst()[i];
+        const int ch = t.child;
+        visits += t.visits;
         if (ch < 0 || ch >= tp.C) { fail(2, id, i); continue; }
-        if (nodes[ch].h.parent != id || po[ch] != id) fail(3, id, i);
-        if (nodes[ch].h.parent_edge != i) fail(4, id, i);
-        if (i + 1 < nt && r.orig[i] >= r.orig[i + 1]) fail(5, id, i);
+        if (nodes[ch].h().parent != id || po[ch] != id) fail(3, id, i);
+        if (nodes[ch].h().parent_edge != i) fail(4, id, i);
+        if (i + 1 < nt && r.orig()[i] >= r.orig()[i + 1]) fail(5, id, i);
       } else {
-        if (ch != -1) fail(6, id, i);
-        if (__float_as_int(s.z) != 0 || s.y != 0.0f || s.w != 0.0f) fail(7, id, i);
-        if (i + 1 < n && !(s.x >= r.stat[i + 1].x)) fail(8, id, i);
+        if (i + 1 < n && !(r.prior()[i] >= r.prior()[i + 1])) fail(8, id, i);
       }
-      if (r.orig[i] >= n) fail(9, id, i);
+      if (r.orig()[i] >= n) fail(9, id, i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) visits += __shfl_xor(visits, o, 64);
-    if (lane == 0 && visits != r.h.num_visits) fail(10, id, visits);
+    if (lane == 0 && visits != rh.num_visits) fail(10, id, visits);
   }
 }
 
 // SearchTreeT::treeAdvance :420-436: the child reached by `move` becomes the root, everything else is freed.
-// Two launches over the dense parent array (135 KB per game at 33 792 nodes: L2-resident, coalesced):
+// Two launches over the dense parent array (4 B per node id: L2-resident, coalesced):
 //   k_mcts_advance_mark   G x MB waves: keep[id] = the parent chain of id reaches the next root
-//   k_mcts_advance_sweep  one wave per game: dead ids go back on the free stack in id order (deterministic), re-root.
+//   k_mcts_advance_sweep  one wave per game: dead ids go back on their free stack in id order (deterministic), re-root.
 template <int N>
-__device__ __forceinline__ int advance_next_root(const NodeRec<N>& r, int mv, int lane) {
-  const int n = rfl(r.h.n_edges);
+__device__ __forceinline__ int advance_next_root(const NodeRef<N> r, int mv, int lane) {
+  const int n = rfl(r.h().n_edges), nt = rfl(r.h().n_touched);
   int next_root = -1;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
-    const u64 b = __ballot(i < n && r.coord[i] == mv);
-    if (b) next_root = rfl(r.child[base + (int)__builtin_ctzll(b)]);
+    const u64 b = __ballot(i < n && r.coord()[i] == mv);
+    if (b) {
+      const int pos = base + (int)__builtin_ctzll(b);
+      next_root = pos < nt ? rfl(r.tst()[pos].child) : -1;     // a never-followed edge has no child node
+    }
   }
   return next_root;
 }
@@ -1534,7 +1571,7 @@ __global__ __launch_bounds__(64) void k_mcts_advance_mark(TreePool<N> tp, const 
   const int g = blockIdx.x / MB, part = blockIdx.x % MB, lane = threadIdx.x;
   const int mv = rfl(moves[g]);
   if (mv < 0) return;                        // no move for this game (elfsp_play with a partial move list)
-  const NodeRec<N>* nodes = tp.game_nodes(g);
+  const GameNodes<N> nodes(tp, g);
   const int* po = tp.parent_of + (size_t)g * tp.C;
   unsigned char* keep = tp.keep + (size_t)g * tp.C;
   const int next_root = advance_next_root<N>(nodes[rfl(tp.gs[g].root)], mv, lane);
@@ -1557,26 +1594,29 @@ __global__ __launch_bounds__(64) void k_mcts_advance_mark(TreePool<N> tp, const 
 
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_advance_sweep(TreePool<N> tp, const int32_t* moves) {
-  using NR = NodeRec<N>;
   const int g = blockIdx.x, lane = threadIdx.x;
-  NR* nodes = tp.game_nodes(g);
-  int* fs = tp.free_stack + (size_t)g * tp.C;
+  const GameNodes<N> nodes(tp, g);
+  int* fs = tp.free_stack + (size_t)g * tp.Cs;
+  int* fb = tp.free_big + (size_t)g * tp.Cb;
   int* po = tp.parent_of + (size_t)g * tp.C;
   const unsigned char* keep = tp.keep + (size_t)g * tp.C;
   GameState& gs = tp.gs[g];
   const int mv = rfl(moves[g]);
   if (mv < 0) return;
   int next_root = advance_next_root<N>(nodes[rfl(gs.root)], mv, lane);
-  int free_top = rfl(gs.free_top);
-  for (int base = 0; base < tp.C; base += 64) {
+  int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big);
+  for (int base = 0; base < tp.C; base += 64) {      // Cs is a multiple of 64: a round is all small ids or all big ids
     const int id = base + lane;
     const bool dead = id < tp.C && po[id] != -2 && !keep[id];
     const u64 b = __ballot(dead);
-    if (dead) {
-      po[id] = -2;
-      fs[free_top + __popcll(b & ((1ull << lane) - 1))] = id;
+    const int rank = __popcll(b & ((1ull << lane) - 1));
+    if (base < tp.Cs) {
+      if (dead) { po[id] = -2; fs[free_top + rank] = id; }
+      free_top += __popcll(b);
+    } else {
+      if (dead) { po[id] = -2; fb[free_top_big + rank] = id - tp.Cs; }
+      free_top_big += __popcll(b);
     }
-    free_top += __popcll(b);
   }
   mem_sync();
   if (next_root < 0) {                       // allocateRoot -> addNode(0.0)
@@ -1584,11 +1624,11 @@ __global__ __launch_bounds__(64) void k_mcts_advance_sweep(TreePool<N> tp, const
     --free_top;
     node_init(tp, g, next_root, -1, -1, 0.0f, lane);
   } else if (lane == 0) {
-    nodes[next_root].h.parent = -1;
-    nodes[next_root].h.parent_edge = -1;
+    nodes[next_root].h().parent = -1;
+    nodes[next_root].h().parent_edge = -1;
     po[next_root] = -1;
   }
-  if (lane == 0) { gs.root = next_root; gs.free_top = free_top; }
+  if (lane == 0) { gs.root = next_root; gs.free_top = free_top; gs.free_top_big = free_top_big; }
 }
 
 }  // namespace elfgo

@@ -9,9 +9,12 @@
 
 struct ElfMcts {
   ElfGoEngine* eng = nullptr;
-  int G = 0, C = 0, W = 0, NE = 0;
-  void* nodes = nullptr;
+  int G = 0, C = 0, W = 0, NE = 0;       // C = node ids per game = Cs + Cb
+  int Cs = 0, Cb = 0;                    // small / big node records per game (mcts.cuh)
+  void* small = nullptr;
+  void* big = nullptr;
   int* free_stack = nullptr;
+  int* free_big = nullptr;
   int* parent_of = nullptr;
   unsigned char* keep = nullptr;
   GameState* gs = nullptr;
@@ -24,15 +27,17 @@ struct ElfMcts {
   const unsigned char* mask = nullptr;   // elfmcts_set_game_mask (device bytes, GM_*), nullptr = every game searches
   const long long* req_ver = nullptr;    // elfmcts_set_required_versions (device int64 per game), nullptr = ElfMctsOptions.required_version
   TreeCfg cfg;
-  size_t node_bytes = 0;
+  size_t small_bytes = 0, big_bytes = 0; // bytes of one small / big record
   int feat_fmt = ELFGO_FEAT_F32_NCHW;
 };
 
 template <int N>
 static TreePool<N> tree_of(const ElfMcts* m) {
   TreePool<N> t;
-  t.nodes = reinterpret_cast<NodeRec<N>*>(m->nodes);
+  t.small = reinterpret_cast<char*>(m->small);
+  t.big = reinterpret_cast<char*>(m->big);
   t.free_stack = m->free_stack;
+  t.free_big = m->free_big;
   t.parent_of = m->parent_of;
   t.keep = m->keep;
   t.gs = m->gs;
@@ -42,8 +47,15 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   t.sqrt_n = m->sqrt_n;
   t.mask = m->mask;
   t.req_ver = m->req_ver;
-  t.C = m->C; t.W = m->W; t.G = m->G;
+  t.Cs = m->Cs; t.Cb = m->Cb; t.C = m->C; t.W = m->W; t.G = m->G;
   return t;
+}
+
+// big records per game: a big node has >= 16 children that are nodes themselves (mcts.cuh), so Cs / 16 + 1 cannot run out first
+static int big_records_for(int nodes_per_game) { return nodes_per_game / 16 + 1; }
+static void record_bytes(int n, size_t* small, size_t* big) {
+  *small = n == 19 ? NodeL<19>::SMALL : NodeL<9>::SMALL;
+  *big = n == 19 ? NodeL<19>::BIG : NodeL<9>::BIG;
 }
 
 static int cfg_from(const ElfMctsOptions* o, TreeCfg* c) {
@@ -77,13 +89,16 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
   int rc = cfg_from(opt, &m->cfg);
   if (rc) { delete m; return rc; }
   DevGuard _dg(e->device);
-  m->eng = e; m->G = num_games; m->C = nodes_per_game; m->W = d4_window;
-  m->node_bytes = e->n == 19 ? sizeof(NodeRec<19>) : sizeof(NodeRec<9>);
-  m->NE = e->n == 19 ? NodeRec<19>::NE : NodeRec<9>::NE;
-  const size_t G = num_games, C = nodes_per_game;
+  m->eng = e; m->G = num_games; m->W = d4_window;
+  m->Cs = nodes_per_game; m->Cb = big_records_for(nodes_per_game); m->C = m->Cs + m->Cb;
+  record_bytes(e->n, &m->small_bytes, &m->big_bytes);
+  m->NE = e->n == 19 ? NodeL<19>::NE : NodeL<9>::NE;
+  const size_t G = num_games, C = m->C;
 #define MCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { elfmcts_destroy(m); return (int)_e; } } while (0)
-  MCHK(hipMalloc(&m->nodes, G * C * m->node_bytes));
-  MCHK(hipMalloc((void**)&m->free_stack, G * C * sizeof(int)));
+  MCHK(hipMalloc(&m->small, G * m->Cs * m->small_bytes));
+  MCHK(hipMalloc(&m->big, G * m->Cb * m->big_bytes));
+  MCHK(hipMalloc((void**)&m->free_stack, G * m->Cs * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->free_big, G * m->Cb * sizeof(int)));
   MCHK(hipMalloc((void**)&m->parent_of, G * C * sizeof(int)));
   MCHK(hipMalloc((void**)&m->keep, G * C));
   MCHK(hipMalloc((void**)&m->gs, G * sizeof(GameState)));
@@ -111,8 +126,10 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
 int elfmcts_destroy(ElfMcts* m) {
   if (!m) return ELFGO_E_BADARG;
   DevGuard _dg(m->eng->device);
-  if (m->nodes) (void)hipFree(m->nodes);
+  if (m->small) (void)hipFree(m->small);
+  if (m->big) (void)hipFree(m->big);
   if (m->free_stack) (void)hipFree(m->free_stack);
+  if (m->free_big) (void)hipFree(m->free_big);
   if (m->parent_of) (void)hipFree(m->parent_of);
   if (m->keep) (void)hipFree(m->keep);
   if (m->gs) (void)hipFree(m->gs);
@@ -151,7 +168,18 @@ int elfmcts_set_required_versions(ElfMcts* m, const int64_t* versions) {
 int elfmcts_max_rollouts_per_step(void) { return MCTS_KMAX; }
 int elfmcts_num_games(const ElfMcts* m) { return m ? m->G : ELFGO_E_BADARG; }
 int elfmcts_edge_stride(const ElfMcts* m) { return m ? m->NE : ELFGO_E_BADARG; }
-size_t elfmcts_node_bytes(const ElfMcts* m) { return m ? m->node_bytes : 0; }
+size_t elfmcts_tree_bytes_per_game(int board_size, int nodes_per_game) {
+  if ((board_size != 19 && board_size != 9) || nodes_per_game <= 0) return 0;
+  size_t sm, bg;
+  record_bytes(board_size, &sm, &bg);
+  const size_t Cs = nodes_per_game, Cb = big_records_for(nodes_per_game);
+  // records + free stacks + parent array + keep bytes + the per-game leaf / row tables
+  return Cs * sm + Cb * bg + (Cs + Cb) * (sizeof(int) * 2 + 1) + sizeof(GameState) + MCTS_KMAX * (sizeof(LeafRec) + sizeof(RowRec));
+}
+/* average bytes per node id a game may hold (nodes_per_game of them): small record + its share of the big pool and of the id arrays */
+size_t elfmcts_node_bytes(const ElfMcts* m) {
+  return m ? (elfmcts_tree_bytes_per_game(m->eng->n, m->Cs) + m->Cs - 1) / m->Cs : 0;
+}
 
 int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream) {
   if (!m || n < 0 || n > m->G) return ELFGO_E_BADARG;

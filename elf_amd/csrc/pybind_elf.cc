@@ -606,16 +606,17 @@ class Context {
     const int64_t per_move = (int64_t)ts.num_rollouts_per_thread * ts.num_threads;
     const int64_t npg = go_.nodes_per_game > 0 ? (go_.nodes_per_game + 63) / 64 * 64 : (4 * per_move + 1024 + 63) / 64 * 64;
     const int n = go_.board_size;
-    const int64_t node_bytes = n == 19 ? 12800 : (sp_ ? (int64_t)elfmcts_node_bytes(elfsp_mcts(sp_)) : 0);
+    const int64_t tree_bytes = (int64_t)elfmcts_tree_bytes_per_game(n, (int)npg);
+    const int64_t node_bytes = npg > 0 ? (tree_bytes + npg - 1) / npg : 0;     // small record + its share of the big pool and the id arrays
     std::map<std::string, int64_t> out = {{"max_rollouts_per_step", elfmcts_max_rollouts_per_step()}, {"nodes_per_game", npg},
-                                          {"node_bytes", node_bytes}, {"tree_bytes_per_game_per_ai", npg * node_bytes}};
+                                          {"node_bytes", node_bytes}, {"tree_bytes_per_game_per_ai", tree_bytes}};
     size_t fr = 0, tot = 0;
     int dev = go_.gpu;
     if (dev < 0 && elfgo_get_device(&dev) != 0) dev = 0;
     if (elfgo_mem_info(dev, &fr, &tot) == 0) {
       out["hbm_free_bytes"] = (int64_t)fr;
       out["hbm_total_bytes"] = (int64_t)tot;
-      if (node_bytes > 0) out["max_games_by_free_hbm"] = (int64_t)(fr * 9 / 10) / (npg * node_bytes);
+      if (tree_bytes > 0) out["max_games_by_free_hbm"] = (int64_t)(fr * 9 / 10) / tree_bytes;
     }
     return out;
   }

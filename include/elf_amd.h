@@ -153,7 +153,11 @@ int elfmcts_set_game_mask(ElfMcts* m, const uint8_t* mask);
 int elfmcts_set_required_versions(ElfMcts* m, const int64_t* versions);
 int elfmcts_num_games(const ElfMcts* m);
 int elfmcts_edge_stride(const ElfMcts* m);   /* row length of the per-edge arrays (368 at 19x19, 96 at 9x9) */
-size_t elfmcts_node_bytes(const ElfMcts* m);
+/* HBM one game's tree takes at `nodes_per_game` node ids (records of both classes, id arrays, leaf / row tables): what a caller
+ * sizes num_games x nodes_per_game against elfgo_mem_info.  A node lives in a 5 888-B record (19x19; 1 920 B at 9x9) until its 17th
+ * edge is followed, then in an 11 520-B one; nodes_per_game / 16 + 1 of the latter exist per game and cannot run out first. */
+size_t elfmcts_tree_bytes_per_game(int board_size, int nodes_per_game);
+size_t elfmcts_node_bytes(const ElfMcts* m);   /* elfmcts_tree_bytes_per_game / nodes_per_game, rounded up (6 6xx B at 19x19) */
 /* SearchTreeT::clear (tree_search_node.h:411-416) for games[0..n) (device int32, NULL = all games) */
 int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream);
 /* TreeSearchT::setRootNodeState (tree_search.h:478-493) for every game; board_ids device int32 or NULL (slot g) */
@@ -555,8 +559,8 @@ int elfnet_bias_act_bf16(void* x, const void* bias, const void* res, int64_t row
  * thread's current device unless a device is named */
 int elfgo_set_device(int device);
 int elfgo_get_device(int* device);
-/* free / total HBM of a device in bytes (hipMemGetInfo): what a caller sizes num_games x nodes_per_game against -- a tree node
- * record is elfmcts_node_bytes() (12 800 B at 19x19) and a game keeps nodes_per_game of them per AI */
+/* free / total HBM of a device in bytes (hipMemGetInfo): what a caller sizes num_games x nodes_per_game against --
+ * elfmcts_tree_bytes_per_game() per game and AI */
 int elfgo_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 /* what kind of memory a caller-provided address is: 0 = pageable host (or unknown), 1 = page-locked (pinned) host, 2 = device;
  * *device (may be NULL) <- the owning device for kind 2 */
