@@ -168,13 +168,15 @@ struct TreePool {
   unsigned char* keep;    // [G][C] scratch of treeAdvance (reachable from the next root)
   GameState* gs;          // [G]
   LeafRec* leaves;        // [G][MCTS_KMAX]
-  unsigned char* d4buf;   // [G][W]  pre-drawn rng() % 8 of the actor's mt19937 (go/mcts/mcts.h:175-183)
+  unsigned char* d4buf;   // [G][NT][W / NT]  pre-drawn rng() % 8 of each search thread's MCTSActor mt19937 (go/mcts/mcts.h:175-183)
+  int* rng_pos_t;         // [G][NT] draws each search thread's actor has consumed this move
   const double* sqrt_tab; // [sqrt_n] host libm sqrt((double)k): the reference's std::sqrt(int) (tree_search_base.h:153)
   const unsigned char* mask;   // [G] or nullptr (every game GM_SEARCH): which games the per-game launches act on (GM_*)
   const long long* req_ver;    // [G] or nullptr (TreeCfg.required_version for every game): MCTSActorParams.required_version per game
   int sqrt_n;
   int Cs, Cb, C;          // small records, big records, node ids (Cs + Cb) per game
   int W, G;
+  int NT;                 // search threads the D4 windows were laid out for (TSOptions.num_threads when the pool was created)
   __device__ __forceinline__ int game_mode(int g) const { return mask ? (int)mask[g] : (int)GM_SEARCH; }
   __device__ __forceinline__ char* small_of(int g) const { return small + (size_t)g * Cs * L::SMALL; }
   __device__ __forceinline__ char* big_of(int g) const { return big + (size_t)g * Cb * L::BIG; }
@@ -324,6 +326,7 @@ __device__ __forceinline__ void tree_clear(const TreePool<N>& tp, int g, int lan
     GameState& s = tp.gs[g];
     s.root = 0; s.free_top = tp.Cs - 1; s.free_top_big = tp.Cb; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0;
     s.rollouts_done = 0;
+    for (int t = 0; t < tp.NT; ++t) tp.rng_pos_t[(size_t)g * tp.NT + t] = 0;
     // node_visits / promotions are lifetime counters (statistics): not reset with the tree
   }
 }
@@ -357,6 +360,34 @@ __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool
     s.err |= MCTS_ERR_ROOT_HASH;
   }
   if (lane == 0) { s.rng_pos = 0; s.rollouts_done = 0; }
+  for (int t = lane; t < tp.NT; t += 64) tp.rng_pos_t[(size_t)g * tp.NT + t] = 0;   // a fresh window per search thread and move
+}
+
+// The superko filter of the position a new node is forwarded from (k_mcts_select): the game's records up to the root (the game
+// board's own Bloom words) + the positions on the path root .. parent (every hash, also those a pass leaves: a filter may hold
+// more, never less).  A path longer than the table sends every probe to the exact check.  Out of line for the same reason as
+// promote_record (5 registers).  All three pointers are LDS.
+typedef __attribute__((address_space(3))) u32 lds_u32;
+template <int N, int PATH_LV>
+__device__ __attribute__((noinline)) void rebuild_filter(u32* bloom_g, const u32* gbloom_g, const u32* path_g, int depth) {
+  using GEO = Geo<N>;
+  constexpr u32 BMASK = GEO::BLOOM * 32 - 1;
+  const int lane = threadIdx.x & 63;
+  lds_u32* const bloom = (lds_u32*)bloom_g;
+  const lds_u32* const gbloom = (const lds_u32*)gbloom_g;
+  const lds_u32* const path_h = (const lds_u32*)path_g;
+  if (depth <= PATH_LV) {
+    for (int l = lane; l < GEO::BLOOM; l += 64) bloom[l] = gbloom[l];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int l = lane; l < depth; l += 64) {
+      const u32 h1 = path_h[2 * l] & BMASK, h2 = path_h[2 * l + 1] & BMASK;
+      __hip_atomic_fetch_or(&bloom[h1 >> 5], 1u << (h1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_or(&bloom[h2 >> 5], 1u << (h2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  } else {
+    for (int l = lane; l < GEO::BLOOM; l += 64) bloom[l] = ~0u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
 // The move of a node from its small record to a big one (k_mcts_select, the 17th followed edge): copy the record, give the 16
@@ -417,7 +448,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   using NL = NodeL<N>;
   using GEO = Geo<N>;
   constexpr int PATH_LV = 256;             // levels of a descent whose position hashes are kept for the superko filter
-  constexpr u32 BMASK = GEO::BLOOM * 32 - 1;
   __shared__ Slot<N> lds;
   __shared__ __attribute__((aligned(16))) u32 gbloom[GEO::BLOOM];   // the game board's own Bloom words: the game's records up to the root
   __shared__ u32 path_h[2 * PATH_LV];      // hash (lo, hi) of the node at each level of the current descent
@@ -448,14 +478,29 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   GameState& gs = tp.gs[g];
   const int bslot = board_ids ? board_ids[g] : g;
   int root = rfl(gs.root);
-  int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big), rng_pos = rfl(gs.rng_pos), err = 0, promotions = 0;
+  int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big), err = 0, promotions = 0;
   const int root_sk_len = rfl((int)nodes[root].board().h.sk_len);
   if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(gbloom)[lane] = reinterpret_cast<const uint4*>(pool.slots[bslot].bloom)[lane];
-  // the D4 codes the coming net leaves draw: one coalesced read per launch (nothing draws besides this wave); beyond 64 draws the
-  // kernel falls back to the dependent load
-  const int rng_pos0 = rng_pos;
-  int d4_pre = 0;
-  if (ELF_SEL_D4PRE && cfg.rotation_flip) { const int ix = rng_pos0 + lane; d4_pre = ix < tp.W ? (int)tp.d4buf[(size_t)g * tp.W + ix] : 0; }
+  // Every search thread's MCTSActor owns a generator (all seeded alike, game_selfplay.cc:45-47,77): thread t's net leaves draw their D4
+  // codes from window t of the game, at that thread's own position.  The next 64 codes of the window are read once per thread and
+  // launch, coalesced (nothing draws besides this wave); beyond 64 draws the kernel falls back to the dependent load.
+  const int Wt = tp.W / tp.NT;
+  int rng_pos = 0, rng_pos0 = 0, d4_pre = 0, cur_t = -1;
+  auto thread_enter = [&](int t) {
+    int* const tpos = tp.rng_pos_t + (size_t)g * tp.NT;
+    if (cur_t >= 0 && lane == 0) {
+      tpos[cur_t] = rng_pos;
+      if (cur_t == 0) gs.rng_pos = rng_pos;      // thread 0's actor (also the Dirichlet generator): what RootInfo reports
+    }
+    cur_t = t;
+    rng_pos = rfl(tpos[t]);
+    rng_pos0 = rng_pos;
+    d4_pre = 0;
+    if (ELF_SEL_D4PRE && cfg.rotation_flip) {
+      const int ix = rng_pos0 + lane;
+      d4_pre = ix < Wt ? (int)tp.d4buf[((size_t)g * tp.NT + t) * Wt + ix] : 0;
+    }
+  };
   int n_unique = 0, n_nn = 0, thread_start = 0;
   const float vl_f = (float)cfg.virtual_loss;
   int visited_nodes = 0;
@@ -465,7 +510,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
 
   for (int j = 0, jk = 0; j < KT; ++j, ++jk) {
     if (jk == K) jk = 0;
-    if (jk == 0) thread_start = n_unique;   // traj_counts is per batch_rollouts call, i.e. per search thread
+    if (jk == 0) { thread_start = n_unique; thread_enter(cur_t + 1); }   // traj_counts is per batch_rollouts call, i.e. per search thread
     int node = root, depth = 0;
     bool board_in_lds = false;   // LDS holds the state of `node`
     // the board engine's per-lane constants (~35 registers) are set up where a board is first needed -- after the descent -- from an
@@ -605,7 +650,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         // ---- followEdge :280-302 -> SearchTreeT::addNode(unsignedMeanQ_) :439-443
         if (free_top <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
         NodeRef<N> nw = nd;      // the record that receives the new followed edge
-#ifndef ELF_X_NOPROMO
         if (nt >= nodes.cap(node)) {
           // ---- the 17th followed edge of a small record: the node MOVES to the big pool.  Copy the record, tell the parent (its
           // child id) and the 16 children (their parent id), return the small record.  Cb = Cs / 16 + 1 big records cannot run out.
@@ -626,7 +670,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           nw = dst;
           mem_sync();            // the copy and the returned id are visible before either is used
         }
-#endif
         child = rfl(fs[free_top - 1]);
         --free_top;
         // the edge joins the orig-sorted prefix of the scoring order at position p: entries [p, best_pos) move up by one and
@@ -662,20 +705,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         bd.load(&nw.board());
         // the superko filter of the parent's position: the game's records up to the root (the game board's Bloom words) + the
         // positions on the path root .. parent (every hash, also those a pass leaves: a filter may hold more, never less)
-#ifndef ELF_X_NOBLOOM
-        if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(lds.bloom)[lane] = reinterpret_cast<const uint4*>(gbloom)[lane];
-        Board<N>::wsync();
-        if (depth <= PATH_LV) {
-          for (int l = lane; l < depth; l += 64) {
-            const u32 h1 = path_h[2 * l] & BMASK, h2 = path_h[2 * l + 1] & BMASK;
-            Board<N>::lds_or(&lds.bloom[h1 >> 5], 1u << (h1 & 31));
-            Board<N>::lds_or(&lds.bloom[h2 >> 5], 1u << (h2 & 31));
-          }
-        } else {
-          for (int l = lane; l < GEO::BLOOM; l += 64) lds.bloom[l] = ~0u;   // a path longer than the table: every probe goes to the exact check
-        }
-        Board<N>::wsync();
-#endif
+        rebuild_filter<N, PATH_LV>(lds.bloom, gbloom, path_h, depth);
         SEL_PHASE(3);   // parent's board to LDS, filter
         TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skr(bslot)}, root_sk_len};
         if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; --depth; break; }
@@ -714,9 +744,9 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         } else {
           kind = LK_NN;
           if (cfg.rotation_flip) {                         // get_extractor :175-183: rng() % 8, one draw per NN leaf
-            if (rng_pos >= tp.W) err |= MCTS_ERR_RNG;
+            if (rng_pos >= Wt) err |= MCTS_ERR_RNG;
             else if (ELF_SEL_D4PRE && rng_pos - rng_pos0 < 64) d4 = rl(d4_pre, rng_pos - rng_pos0);
-            else d4 = rfl((int)tp.d4buf[(size_t)g * tp.W + rng_pos]);
+            else d4 = rfl((int)tp.d4buf[((size_t)g * tp.NT + cur_t) * Wt + rng_pos]);
             ++rng_pos;
           }
         }
@@ -745,7 +775,9 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     lr.nn_index = lf_nn[i]; lr.depth = meta >> 16;
   }
   if (lane == 0) {
-    gs.root = root; gs.free_top = free_top; gs.free_top_big = free_top_big; gs.rng_pos = rng_pos; gs.n_unique = n_unique; gs.n_nn = n_nn;
+    if (cur_t >= 0) tp.rng_pos_t[(size_t)g * tp.NT + cur_t] = rng_pos;
+    if (cur_t == 0) gs.rng_pos = rng_pos;
+    gs.root = root; gs.free_top = free_top; gs.free_top_big = free_top_big; gs.n_unique = n_unique; gs.n_nn = n_nn;
     gs.rollouts_done += KT;
     gs.node_visits += visited_nodes;
     if (promotions) gs.promotions += promotions;

@@ -20,6 +20,8 @@ struct ElfMcts {
   GameState* gs = nullptr;
   LeafRec* leaves = nullptr;
   unsigned char* d4buf = nullptr;
+  int* rng_pos_t = nullptr;              // [G][NT]
+  int NT = 1;                            // search threads the D4 windows are laid out for
   double* sqrt_tab = nullptr;
   int sqrt_n = 0;
   RowRec* rowmap = nullptr;
@@ -43,6 +45,8 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   t.gs = m->gs;
   t.leaves = m->leaves;
   t.d4buf = m->d4buf;
+  t.rng_pos_t = m->rng_pos_t;
+  t.NT = m->NT;
   t.sqrt_tab = m->sqrt_tab;
   t.sqrt_n = m->sqrt_n;
   t.mask = m->mask;
@@ -84,12 +88,14 @@ extern "C" {
 int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_window, const ElfMctsOptions* opt, ElfMcts** out) {
   if (!e || !out || num_games <= 0 || num_games > e->capacity || nodes_per_game < 64 || (nodes_per_game & 63) || d4_window <= 0)
     return ELFGO_E_BADARG;
+  // one window per search thread: d4_window = num_threads x (draws one thread can make per move)
+  if (!opt || opt->num_threads <= 0 || d4_window % opt->num_threads) return ELFGO_E_BADARG;
   ElfMcts* m = new (std::nothrow) ElfMcts();
   if (!m) return ELFGO_E_NOMEM;
   int rc = cfg_from(opt, &m->cfg);
   if (rc) { delete m; return rc; }
   DevGuard _dg(e->device);
-  m->eng = e; m->G = num_games; m->W = d4_window;
+  m->eng = e; m->G = num_games; m->W = d4_window; m->NT = opt->num_threads;
   m->Cs = nodes_per_game; m->Cb = big_records_for(nodes_per_game); m->C = m->Cs + m->Cb;
   record_bytes(e->n, &m->small_bytes, &m->big_bytes);
   m->NE = e->n == 19 ? NodeL<19>::NE : NodeL<9>::NE;
@@ -106,6 +112,8 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
   MCHK(hipMalloc((void**)&m->leaves, G * MCTS_KMAX * sizeof(LeafRec)));
   MCHK(hipMalloc((void**)&m->d4buf, G * (size_t)d4_window));
   MCHK(hipMemset(m->d4buf, 0, G * (size_t)d4_window));
+  MCHK(hipMalloc((void**)&m->rng_pos_t, G * (size_t)m->NT * sizeof(int)));
+  MCHK(hipMemset(m->rng_pos_t, 0, G * (size_t)m->NT * sizeof(int)));
   MCHK(hipMalloc((void**)&m->rowmap, G * MCTS_KMAX * sizeof(RowRec)));
   // std::sqrt(int) of the reference (tree_search_base.h:153) tabulated with the host libm
   m->sqrt_n = 1 << 17;
@@ -135,6 +143,7 @@ int elfmcts_destroy(ElfMcts* m) {
   if (m->gs) (void)hipFree(m->gs);
   if (m->leaves) (void)hipFree(m->leaves);
   if (m->d4buf) (void)hipFree(m->d4buf);
+  if (m->rng_pos_t) (void)hipFree(m->rng_pos_t);
   if (m->sqrt_tab) (void)hipFree(m->sqrt_tab);
   if (m->rowmap) (void)hipFree(m->rowmap);
   delete m;
@@ -142,8 +151,16 @@ int elfmcts_destroy(ElfMcts* m) {
 }
 
 int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt) {
-  if (!m) return ELFGO_E_BADARG;
+  if (!m || !opt) return ELFGO_E_BADARG;
+  if (opt->num_threads != m->NT) return ELFGO_E_BADARG;   // the D4 windows are laid out per search thread at creation
   return cfg_from(opt, &m->cfg);
+}
+int elfmcts_num_threads(const ElfMcts* m) { return m ? m->NT : ELFGO_E_BADARG; }
+int elfmcts_thread_draws(ElfMcts* m, int32_t* out_host, void* stream) {
+  if (!m || !out_host) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
+  HIPCHK(hipMemcpyAsync(out_host, m->rng_pos_t, sizeof(int32_t) * (size_t)m->G * m->NT, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
 }
 int elfmcts_set_feature_format(ElfMcts* m, int fmt) {
   if (!m || (fmt != ELFGO_FEAT_F32_NCHW && fmt != ELFGO_FEAT_F16_NHWC)) return ELFGO_E_BADARG;

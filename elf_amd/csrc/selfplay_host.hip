@@ -67,6 +67,9 @@ struct SpRequest {          // MsgRequest (common/record.h:119-149): ModelPair +
 struct SpGame {
   std::mt19937 rng;            // GoGameBase::_rng (game_base.h:32-38)
   std::mt19937 actor_rng[2];   // MCTSActor::rng_ (go/mcts/mcts.h:52) of "actor_black" / "actor_white", seeded with _rng() (game_selfplay.cc:47)
+  // the generators of search threads 1 .. T-1 of each AI: TreeSearchT makes one MCTSActor per thread (tree_search.h:339-343), every one
+  // from the same MCTSActorParams, i.e. the same seed (game_selfplay.cc:45-47,77); thread 0's is actor_rng (also the Dirichlet source)
+  std::vector<std::mt19937> thread_rng[2];
   int64_t actor_ver[2] = {-1, -1};   // MCTSActorParams.required_version of the two AIs (-1: any)
   int pool_of_colour[2] = {0, 0};    // [0] Black's AI, [1] White's AI (curr_ai, game_selfplay.cc:364-366, after player_swap :181-185)
   SpRequest req;               // GoStateExt::curr_request_
@@ -105,6 +108,7 @@ struct SpPool {              // one MCTSGoAI role: its tree pool and options
   std::vector<uint8_t> h_start, h_active, up_active;   // up_active: what d_active holds
   std::vector<int64_t> h_ver, up_ver;
   std::vector<uint8_t> h_d4;
+  std::vector<int32_t> h_tdraws;         // [G][T] D4 draws per search thread of the move that just ended (elfmcts_thread_draws)
   int n_active = 0;
   bool selected = false;                 // a select of this step is waiting for its expand
 };
@@ -313,6 +317,7 @@ static int sp_pool_create(ElfSelfPlay* sp, int a) {
   p.h_start.assign(G, 0); p.h_active.assign(G, 0); p.up_active.assign(G, 0xFF);
   p.h_ver.assign(G, -1); p.up_ver.assign(G, -2);
   p.h_d4.assign((size_t)G * p.W, 0);
+  p.h_tdraws.assign((size_t)G * p.T, 0);
   return 0;
 }
 
@@ -328,9 +333,11 @@ static int sp_restart_games(ElfSelfPlay* sp, const std::vector<int32_t>& ids) {
     SpGame& gm = sp->games[g];
     const bool two = gm.req.white_ver >= 0;
     gm.actor_rng[0].seed(gm.rng());
+    gm.thread_rng[0].assign(sp->pool[0].T > 1 ? sp->pool[0].T - 1 : 0, gm.actor_rng[0]);   // every thread's actor: the same seed
     gm.actor_ver[0] = gm.req.async ? -1 : gm.req.black_ver;
     if (two) {
       gm.actor_rng[1].seed(gm.rng());
+      gm.thread_rng[1].assign(sp->pool[1].T > 1 ? sp->pool[1].T - 1 : 0, gm.actor_rng[1]);
       gm.actor_ver[1] = gm.req.async ? -1 : gm.req.white_ver;
     }
     gm.pool_of_colour[0] = 0;
@@ -522,11 +529,16 @@ static int sp_begin_searches(ElfSelfPlay* sp) {
       if (mixed) HIPCHK(hipStreamSynchronize(sp->stream));   // m2 is a temporary
     }
     // BoardFeature::RandomShuffle draws of this move (go/mcts/mcts.h:175-183), from a copy of the actor stream
+    // one window per search thread: thread t's actor draws from its own generator
     sp_for_games(starting[a], [&](int g) {
-      std::mt19937 c = sp->games[g].actor_rng[a];
-      uint8_t* d = &p.h_d4[(size_t)g * p.W];
-      const int w = sp->games[g].policy_only ? 1 : p.W;
-      for (int i = 0; i < w; ++i) d[i] = (uint8_t)(c() % 8);
+      const int wt = p.W / p.T;
+      for (int t = 0; t < p.T; ++t) {
+        if (t > 0 && sp->games[g].policy_only) break;      // runPolicyOnly evaluates with actors_[0] (tree_search.h:396-399)
+        std::mt19937 c = t == 0 ? sp->games[g].actor_rng[a] : sp->games[g].thread_rng[a][t - 1];
+        uint8_t* d = &p.h_d4[(size_t)g * p.W + (size_t)t * wt];
+        const int w = sp->games[g].policy_only ? 1 : wt;
+        for (int i = 0; i < w; ++i) d[i] = (uint8_t)(c() % 8);
+      }
     });
     SPCHK(elfmcts_set_d4(p.mcts, p.h_d4.data(), sp->stream));
   }
@@ -575,6 +587,7 @@ static int sp_finish_moves(ElfSelfPlay* sp, const std::vector<int32_t> (&done)[2
     HIPCHK(hipMemcpyAsync(sp->h_visits.data(), sp->d_visits, sizeof(int32_t) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
     HIPCHK(hipMemcpyAsync(sp->h_prior.data(), sp->d_prior, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
     HIPCHK(hipMemcpyAsync(sp->h_reward.data(), sp->d_reward, sizeof(float) * (size_t)G * NE, hipMemcpyDeviceToHost, sp->stream));
+    if (p.T > 1) SPCHK(elfmcts_thread_draws(p.mcts, p.h_tdraws.data(), sp->stream));
     HIPCHK(hipStreamSynchronize(sp->stream));
     if (first_wait) { sp->t_after_drain = std::chrono::steady_clock::now(); first_wait = false; }
     // online mode, following_pass (mcts_update_info :104-111): Tromp-Taylor score and last move of the game boards
@@ -594,7 +607,9 @@ static int sp_finish_moves(ElfSelfPlay* sp, const std::vector<int32_t> (&done)[2
       SpGame& gm = sp->games[g];
       const int32_t* info = &sp->h_info[g * ELFMCTS_ROOT_WORDS];
       if (info[6]) return ELFGO_E_MCTS_BASE - info[6];
-      gm.actor_rng[a].discard((unsigned long long)info[5]);   // D4 draws the search consumed
+      gm.actor_rng[a].discard((unsigned long long)info[5]);   // D4 draws the search consumed (thread 0's actor)
+      for (int t = 1; t < p.T && t - 1 < (int)gm.thread_rng[a].size(); ++t)
+        gm.thread_rng[a][t - 1].discard((unsigned long long)p.h_tdraws[(size_t)g * p.T + t]);
       p.h_active[g] = GMASK_IDLE;
       const int n = info[0];
       const int32_t* coord = &sp->h_coord[(size_t)g * NE];

@@ -133,10 +133,17 @@ typedef struct ElfMctsOptions {
  * 5 d4 draws consumed this move 6 error bits 7 free node ids */
 
 /* `num_games` trees over boards of engine `e` (game g searches from board slot board_ids[g]);
- * nodes_per_game (multiple of 64) fixed-size node records each; d4_window = max D4 draws per move. */
+ * nodes_per_game (multiple of 64) node ids each; d4_window = opt->num_threads x (max D4 draws ONE search thread makes per move):
+ * every search thread's MCTSActor owns a generator (TreeSearchT's actor_gen, tree_search.h:339-343; all seeded alike,
+ * game_selfplay.cc:45-47,77), so the draws are laid out as one window per thread. */
 int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_window, const ElfMctsOptions* opt, ElfMcts** out);
 int elfmcts_destroy(ElfMcts* m);
+/* new options for the following steps; num_threads must be the value the trees were created with (ELFGO_E_BADARG otherwise) */
 int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt);
+int elfmcts_num_threads(const ElfMcts* m);
+/* D4 draws each search thread's actor has consumed this move: host int32 [num_games][num_threads], copied on `stream`
+ * (synchronise before reading).  Thread 0's count is also RootInfo word 5. */
+int elfmcts_thread_draws(ElfMcts* m, int32_t* out_host, void* stream);
 /* row format elfmcts_select / elfsp_begin_step write into s_dst (ELFGO_FEAT_*; default fp32 NCHW). With
  * ELFGO_FEAT_F16_NHWC s_dst points to halfs and the stride argument counts halfs. */
 int elfmcts_set_feature_format(ElfMcts* m, int fmt);
@@ -162,7 +169,8 @@ size_t elfmcts_node_bytes(const ElfMcts* m);   /* elfmcts_tree_bytes_per_game / 
 int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream);
 /* TreeSearchT::setRootNodeState (tree_search.h:478-493) for every game; board_ids device int32 or NULL (slot g) */
 int elfmcts_set_root(ElfMcts* m, const int32_t* board_ids, void* stream);
-/* rng() % 8 draws of the actor's mt19937 (BoardFeature::RandomShuffle, board_feature.h:74-78), host uint8 [num_games][d4_window] */
+/* rng() % 8 draws of the search threads' actors (BoardFeature::RandomShuffle, board_feature.h:74-78), host uint8
+ * [num_games][num_threads][d4_window / num_threads]: window t = the coming draws of thread t's mt19937 */
 int elfmcts_set_d4(ElfMcts* m, const uint8_t* d4_host, void* stream);
 /* NodeT::enhanceExploration (tree_search_node.h:132-155): etas device f32 [num_games][edge_stride] in edge
  * iteration order, Z device f32 [num_games] (= 1e-10 + sum of etas, accumulated in fp32 on the host) */

@@ -64,12 +64,29 @@ CASES = {
     # case runs in a process of its own because the generator is seeded once per process
     "mcts_9_pick_uniform": (9, dict(rollouts_per_thread=48, max_searches=40, net_salt=63, policy_distri_cutoff=6, num_games=1,
                                     pick_method=2, move_cutoff=25, fixed_time=1234567)),
+    # round 5: mcts_threads > 1 on the REAL reference.  Its search threads race (tree_search.h:345-368), so these cases run the
+    # turnstile build (oracle/Makefile: libelfsp*_ts.so = the same sources + four elf_ts_hook() calls inserted into a build-time copy
+    # of batch_rollouts; oracle/ref_selfplay.cc): per round the threads descend in thread order, evaluate, set their evaluations and
+    # back up in thread order.  Every thread's MCTSActor draws its D4 codes from its own generator (all seeded alike).
+    "mcts_9_T2_r128": (9, dict(turnstile=1, mcts_threads=2, rollouts_per_thread=64, rollouts_per_batch=8, batchsize=8, max_searches=60,
+                               net_salt=71, policy_distri_cutoff=6)),                                  # plays to the end of a game
+    "mcts_9_T4_r256": (9, dict(turnstile=1, mcts_threads=4, rollouts_per_thread=64, rollouts_per_batch=16, batchsize=16, max_searches=30,
+                               net_salt=72, policy_distri_cutoff=4, net_tie_levels=4)),
+    "mcts_19_T2_r512": (19, dict(turnstile=1, mcts_threads=2, rollouts_per_thread=256, rollouts_per_batch=16, batchsize=16, max_searches=6,
+                                 net_salt=73)),
+    # the canonical client configuration (start_client.sh:11-30): 8 search threads x 1 rollout per batch, virtual loss 5, puct 0.85
+    "mcts_19_T8_client": (19, dict(turnstile=1, mcts_threads=8, rollouts_per_thread=25, rollouts_per_batch=1, batchsize=8, virtual_loss=5,
+                                   c_puct=0.85, max_searches=10, ply_pass_enabled=3, policy_distri_cutoff=30, net_salt=74)),
+    "mcts_9_T3_eval_two_ai": (9, dict(turnstile=1, mcts_threads=3, rollouts_per_thread=32, rollouts_per_batch=4, batchsize=8, max_searches=40,
+                                      black_ver=5, white_ver=6, net_salt=75, white_net_salt=76, white_puct=0.9, policy_distri_cutoff=6,
+                                      move_cutoff=30)),
 }
 
 
 def run_case(name, path):
     n, kw = CASES[name]
-    R = RefSelfPlay(n)
+    kw = dict(kw)
+    R = RefSelfPlay(n, turnstile=bool(kw.pop("turnstile", 0)))
     cfg = dict(MCTS_DEFAULTS)
     cfg.update(kw)
     fixed_time = cfg.pop("fixed_time", None)

@@ -227,6 +227,9 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
   float c_puct = 0;
   int rollouts_per_batch = 0, rollouts_per_thread = 0;
   size_t next_move_number = 0;   // MCTSAI_T::nextMoveNumber_
+  // the generators of the search threads 1 .. T-1's own MCTSActors (TreeSearchT's actor_gen makes one actor per thread, every one
+  // seeded with the SAME params.seed: game_selfplay.cc:45-47,77); thread 0's is actor->rng, which also feeds the Dirichlet draws
+  std::vector<std::mt19937> thread_rng;
 
   // EdgeInfo::getScore (tree_search_base.h:132-157) + NodeT::UCT :361-397 + BestAction :321-358 + findMove :205-231
   bool find_move(Node* nd, int depth, Coord* action) {
@@ -292,8 +295,10 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
   // mcts_threads = T > 1 (TreeSearchT's thread pool, tree_search.h:345-368) is restated as ONE of the interleavings the
   // reference's racing threads can produce: the T batch_rollouts calls of a round run their descents back to back (thread t
   // sees the virtual losses of threads < t; a leaf another thread has already requested is not requested again, :142-153),
-  // then every thread evaluates its own locked leaves (all threads draw from the one actor stream here: the reference's
-  // actors are seeded alike, game_selfplay.cc:45-47,77), then every thread backs up its own trajectories (waitEvaluation :250).
+  // then every thread evaluates its own locked leaves with ITS OWN actor (own mt19937 for the D4 draws, all seeded alike:
+  // game_selfplay.cc:45-47,77), then every thread sets its evaluations and backs up its own trajectories (waitEvaluation :250).
+  // Round 5: this is exactly the schedule the turnstile build of the real reference runs (oracle/Makefile, libelfsp*_ts.so;
+  // ref_selfplay.cc elf_ts_hook): the fixtures mcts_*_T2 / _T4 are that reference's output.
   struct Batch {
     std::vector<Traj> trajs;
     std::vector<Node*> locked;
@@ -341,7 +346,11 @@ struct Search {   // elf/ai/tree_search/tree_search.h TreeSearchSingleThreadT + 
     const int T = cfg->mcts_threads > 1 ? cfg->mcts_threads : 1;
     std::vector<Batch> bs(T);
     for (int t = 0; t < T; ++t) descend(bs[t]);
-    for (int t = 0; t < T; ++t) evaluate(bs[t]);
+    for (int t = 0; t < T; ++t) {
+      if (t > 0) std::swap(actor->rng, thread_rng[t - 1]);   // thread t's MCTSActor draws from its own generator
+      evaluate(bs[t]);
+      if (t > 0) std::swap(actor->rng, thread_rng[t - 1]);
+    }
     for (int t = 0; t < T; ++t) backup(bs[t]);
   }
 
@@ -440,6 +449,7 @@ int orcsp_run(const SpConfig* cfg_in, net_fn net, void* user, SpSearch* out_sear
     actor.rng.seed(game_rng());                  // params.seed = _rng() :47, MCTSActor::rng_(params.seed) mcts.h:52
     Search& se = searches[a];
     se.cfg = cfg; se.actor = &actor;
+    se.thread_rng.assign(cfg->mcts_threads > 1 ? cfg->mcts_threads - 1 : 0, actor.rng);   // the same params.seed for every thread's actor
     se.c_puct = cfg->c_puct; se.rollouts_per_batch = cfg->rollouts_per_batch; se.rollouts_per_thread = cfg->rollouts_per_thread;
     if (a == 1) {
       if (cfg->white_puct > 0.0f) se.c_puct = cfg->white_puct;

@@ -249,18 +249,24 @@ class RefSelfPlay:
     """The reference's own Context + GoGameSelfPlay + MCTSGoAI, net = stub (or a Python callback)."""
 
     @staticmethod
-    def path(n):
-        return os.path.join(HERE, "_ref", "libelfsp%d.so" % n)
+    def path(n, turnstile=False):
+        return os.path.join(HERE, "_ref", "libelfsp%d%s.so" % (n, "_ts" if turnstile else ""))
 
     @classmethod
-    def available(cls, n):
-        return os.path.exists(cls.path(n))
+    def available(cls, n, turnstile=False):
+        return os.path.exists(cls.path(n, turnstile))
 
-    def __init__(self, n):
+    def __init__(self, n, turnstile=False):
+        """turnstile=True: the build whose copy of tree_search.h carries the four elf_ts_hook() calls (oracle/Makefile), with the
+        turnstile switched on: the search threads of a game take turns in thread order (mcts_threads > 1 becomes deterministic)"""
         self.n = n
         self.na = n * n + 1
-        self.L = C.CDLL(self.path(n))
+        self.L = C.CDLL(self.path(n, turnstile))
         self.L.refsp_run.restype = C.c_int
+        self.turnstile = bool(turnstile)
+        if turnstile:
+            assert self.L.refsp_has_turnstile() == 1
+            self.L.refsp_set_turnstile(C.c_int(1))
 
     def run(self, net=None, human_script=None, **kw):
         """-> dict(search=list[RefSpSearch], coord, visits, prior, reward [k, NA], stats); online=1 with human_script = the answers

@@ -181,6 +181,27 @@ struct GameCapture : public GameNotifierBase {
   void OnGameEnd(const GoStateExt& s) override { cap->OnGameEnd(s); }
 };
 
+// ---- the search threads' turnstile (libelfsp*_ts.so only: see oracle/Makefile, target ts_patched) --------------------------------
+// The reference's T search threads race on the shared tree (tree_search.h:345-368), so a T > 1 search has no single answer.  The
+// build `libelfsp{19,9}_ts.so` compiles a COPY of elf/ai/tree_search/tree_search.h (made at build time inside oracle/_ref/, never
+// committed) in which four calls of elf_ts_hook() have been inserted into TreeSearchSingleThreadT::batch_rollouts -- no other line
+// differs, no arithmetic and no data structure is touched.  With the turnstile on, the hooks make the threads of one TreeSearchT
+// take turns in ONE fixed order per round of batch_rollouts calls:
+//     D_0 .. D_{T-1}   thread t runs its K single_rollouts + requestEvaluation loop (:205-233) after thread t-1 has finished its own
+//     (evaluate)       every thread blocks in actor.evaluate on the batcher as always (:236-237); replies arrive in any order
+//     B_0 .. B_{T-1}   thread t runs setEvaluation + its backups (:239-259) after thread t-1 has finished its own
+// and the next round's D_0 starts after B_{T-1}.  Every such run is one of the interleavings the unpatched reference can produce;
+// it is the one elf_amd's engine implements (elf_amd/csrc/mcts.cuh).  With the turnstile off (the default, and always for T = 1)
+// the hooks return at once.
+struct TsTurn {
+  std::mutex m;
+  std::condition_variable cv;
+  int slot = 0;            // 0..T-1: D_t may run; T..2T-1: B_{slot-T} may run
+};
+std::mutex g_ts_m;
+std::map<const void*, std::unique_ptr<TsTurn>> g_ts;   // one per TreeSearchT (keyed by the address of its TSOptions member)
+std::atomic<int> g_ts_on{0};
+
 std::string g_preload_sgf;     // GameOptions.preload_sgf for the next refsp_run ("" = none)
 int g_preload_move_to = -1;
 std::string g_last_records;   // JSON array text of the records of the last refsp_run
@@ -202,6 +223,38 @@ struct Buffers {
 extern "C" {
 
 int refsp_board_size() { return BOARD_SIZE; }
+
+// 1 = this library was built from the turnstile copy of tree_search.h (libelfsp*_ts.so)
+int refsp_has_turnstile() {
+#ifdef ELF_TS_TURNSTILE
+  return 1;
+#else
+  return 0;
+#endif
+}
+// switch the turnstile on / off for the following refsp_run calls (no effect in the stock build, which has no hooks)
+void refsp_set_turnstile(int on) { g_ts_on.store(on ? 1 : 0); }
+
+// called from the four hook lines of the patched batch_rollouts: where = 0 before the descents, 1 before actor.evaluate,
+// 2 after actor.evaluate, 3 at the end of the backups; key = the address of the thread's TSOptions (one per TreeSearchT)
+void elf_ts_hook(int where, int thread_id, const void* key, int num_threads) {
+  if (!g_ts_on.load() || num_threads <= 1) return;
+  TsTurn* t;
+  {
+    std::lock_guard<std::mutex> l(g_ts_m);
+    auto& p = g_ts[key];
+    if (!p) p.reset(new TsTurn());
+    t = p.get();
+  }
+  const int T = num_threads;
+  std::unique_lock<std::mutex> l(t->m);
+  switch (where) {
+    case 0: t->cv.wait(l, [&] { return t->slot == thread_id || !g_ts_on.load(); }); break;
+    case 1: t->slot = thread_id + 1; t->cv.notify_all(); break;
+    case 2: t->cv.wait(l, [&] { return t->slot == T + thread_id || !g_ts_on.load(); }); break;
+    default: t->slot = (T + thread_id + 1) % (2 * T); t->cv.notify_all(); break;
+  }
+}
 
 // Runs reference self-play until cfg->max_searches searches have been captured.
 // out arrays sized [max_searches] / [max_searches][BOARD_NUM_ACTION]. Returns the number captured

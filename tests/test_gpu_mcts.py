@@ -92,6 +92,19 @@ def test_more_than_64_rollouts_per_batch(elf, name):
     run_case(elf, name)
 
 
+@pytest.mark.parametrize("name", ["mcts_9_T2_r128", "mcts_9_T4_r256", "mcts_19_T2_r512", "mcts_19_T8_client", "mcts_9_T3_eval_two_ai"])
+def test_search_threads_match_the_turnstile_reference(elf, name):
+    """TSOptions.num_threads = 2, 3, 4, 8 against the REAL reference.  The reference's search threads race on the shared tree
+    (tree_search.h:345-368), so these fixtures come from its turnstile build (oracle/Makefile, libelfsp*_ts.so: four elf_ts_hook()
+    calls inserted into a build-time copy of TreeSearchSingleThreadT::batch_rollouts, nothing else changed), which makes the threads of
+    a search take turns in one fixed order per round: descents of thread 0 .. T-1, evaluation, setEvaluation + backup of thread
+    0 .. T-1 -- the interleaving k_mcts_select / k_mcts_expand / k_mcts_backup implement.  Every thread's MCTSActor draws its D4 codes
+    from its own generator (all seeded alike, game_selfplay.cc:45-47,77): one D4 window per thread on the device.  Covers a whole
+    9x9 game (terminal leaves, passes), the client configuration (8 threads x 1 rollout per batch, virtual loss 5: revisits of leaves
+    another thread has requested in the same round) and an evaluation game with two 3-thread AIs."""
+    run_case(elf, name)
+
+
 def test_config3_8192_rollouts(elf):
     """BASELINE config 3 search settings: bs 16, 8192 rollouts/move, puct 1.5, vloss 1, eps 0.25 / alpha 0.03."""
     run_case(elf, "mcts_19_r8192")

@@ -17,6 +17,11 @@ CASES_R3 = ["mcts_9_eval_two_ai", "mcts_19_eval_swap", "mcts_9_pick_prior", "mct
             "mcts_9_r256_bs128", "mcts_19_r512_bs256", "mcts_9_pick_uniform", "mcts_9_r1024_bs512"]
 
 
+# round 5: mcts_threads > 1, fixtures from the turnstile build of the REAL reference (oracle/Makefile: libelfsp*_ts.so; four
+# elf_ts_hook() calls inserted into a build-time copy of batch_rollouts force one thread order per round)
+CASES_T = ["mcts_9_T2_r128", "mcts_9_T4_r256", "mcts_19_T2_r512", "mcts_19_T8_client", "mcts_9_T3_eval_two_ai"]
+
+
 @pytest.mark.parametrize("n", [19, 9])
 def test_stub_net_is_a_quantised_distribution(built, n):
     rng = np.random.default_rng(0)
@@ -30,7 +35,7 @@ def test_stub_net_is_a_quantised_distribution(built, n):
     assert len(np.unique(pit[0])) <= 3   # forced equal priors
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + CASES_T)
 def test_fixture_invariants(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
@@ -45,7 +50,7 @@ def test_fixture_invariants(name):
         assert g["best_action"][i] == c[int(np.argmax(g["visits"][i, :ne]))]
         if cfg["persistent_tree"] == 0:   # a fresh tree: the all-at-root first batch adds no visit
             per_batch = int(cfg["rollouts_per_batch"])
-            assert g["total_visits"][i] <= cfg["rollouts_per_thread"] - per_batch
+            assert g["total_visits"][i] <= (cfg["rollouts_per_thread"] - per_batch) * max(1, int(cfg["mcts_threads"]))
         assert ne <= n * n + 1
 
 
@@ -65,12 +70,34 @@ def test_reference_reproduces_fixture(name):
     assert [s.move_played for s in r["search"]] == g["move_played"].tolist()
 
 
+@pytest.mark.parametrize("name", ["mcts_9_T2_r128", "mcts_19_T8_client"])
+def test_turnstile_reference_reproduces_fixture_and_the_stock_build_has_no_hooks(name):
+    """The turnstile build of the reference is deterministic at mcts_threads > 1 and reproduces the committed fixture; the stock
+    build (what every other fixture comes from) carries no hook."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = int(g["board_size"])
+    if not RefSelfPlay.available(n, turnstile=True):
+        pytest.skip("oracle/_ref/libelfsp*_ts.so not built (no /root/reference here)")
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    kw = {k: (float(np.float32(v)) if isinstance(MCTS_DEFAULTS[k], float) else int(v)) for k, v in cfg.items()}
+    kw["max_searches"] = min(int(kw["max_searches"]), 12)
+    m = kw["max_searches"]
+    R = RefSelfPlay(n, turnstile=True)
+    assert R.L.refsp_has_turnstile() == 1 and RefSelfPlay(n).L.refsp_has_turnstile() == 0
+    r = R.run(**kw)
+    assert np.array_equal(r["coord"].astype(np.int16), g["coord"][:m])
+    assert np.array_equal(r["visits"], g["visits"][:m])
+    assert np.array_equal(r["prior"].view(np.uint32), g["prior"][:m].view(np.uint32))
+    assert np.array_equal(r["reward"].view(np.uint32), g["reward"][:m].view(np.uint32))
+    assert [s.move_played for s in r["search"]] == g["move_played"][:m].tolist()
+
+
 RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
                "records_19_cutoff", "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart", "records_9_req2_async",
                "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval", "records_9_sgf", "records_9_sgf_policy_only"]
 
 
-@pytest.mark.parametrize("name", CASES + CASES_R3 + RECORD_RUNS)
+@pytest.mark.parametrize("name", CASES + CASES_R3 + CASES_T + RECORD_RUNS)
 def test_restatement_matches_reference_fixture(built, name):
     """oracle/mcts_oracle.cc (the CPU restatement of MCTSActor, the tree search and the self-play loop over go_oracle.c) replays
     the fixture's configuration and must give what the REAL reference gave: every search's root edges in iteration order,
