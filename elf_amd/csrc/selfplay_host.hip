@@ -70,6 +70,7 @@ struct SpGame {
   // the generators of search threads 1 .. T-1 of each AI: TreeSearchT makes one MCTSActor per thread (tree_search.h:339-343), every one
   // from the same MCTSActorParams, i.e. the same seed (game_selfplay.cc:45-47,77); thread 0's is actor_rng (also the Dirichlet source)
   std::vector<std::mt19937> thread_rng[2];
+  std::mt19937 actor_rng0[2];  // the freshly seeded state of the AI's actors (what a search thread's generator starts from)
   int64_t actor_ver[2] = {-1, -1};   // MCTSActorParams.required_version of the two AIs (-1: any)
   int pool_of_colour[2] = {0, 0};    // [0] Black's AI, [1] White's AI (curr_ai, game_selfplay.cc:364-366, after player_swap :181-185)
   SpRequest req;               // GoStateExt::curr_request_
@@ -333,11 +334,13 @@ static int sp_restart_games(ElfSelfPlay* sp, const std::vector<int32_t>& ids) {
     SpGame& gm = sp->games[g];
     const bool two = gm.req.white_ver >= 0;
     gm.actor_rng[0].seed(gm.rng());
-    gm.thread_rng[0].assign(sp->pool[0].T > 1 ? sp->pool[0].T - 1 : 0, gm.actor_rng[0]);   // every thread's actor: the same seed
+    gm.actor_rng0[0] = gm.actor_rng[0];      // every search thread's actor starts from this state (the same params.seed)
+    gm.thread_rng[0].clear();                // sized at the AI's first search (the pools may be rebuilt for the request's threads first)
     gm.actor_ver[0] = gm.req.async ? -1 : gm.req.black_ver;
     if (two) {
       gm.actor_rng[1].seed(gm.rng());
-      gm.thread_rng[1].assign(sp->pool[1].T > 1 ? sp->pool[1].T - 1 : 0, gm.actor_rng[1]);
+      gm.actor_rng0[1] = gm.actor_rng[1];
+      gm.thread_rng[1].clear();
       gm.actor_ver[1] = gm.req.async ? -1 : gm.req.white_ver;
     }
     gm.pool_of_colour[0] = 0;
@@ -532,6 +535,8 @@ static int sp_begin_searches(ElfSelfPlay* sp) {
     // one window per search thread: thread t's actor draws from its own generator
     sp_for_games(starting[a], [&](int g) {
       const int wt = p.W / p.T;
+      std::vector<std::mt19937>& tr = sp->games[g].thread_rng[a];
+      if ((int)tr.size() != p.T - 1) tr.assign(p.T > 1 ? p.T - 1 : 0, sp->games[g].actor_rng0[a]);   // a new AI: untouched generators
       for (int t = 0; t < p.T; ++t) {
         if (t > 0 && sp->games[g].policy_only) break;      // runPolicyOnly evaluates with actors_[0] (tree_search.h:396-399)
         std::mt19937 c = t == 0 ? sp->games[g].actor_rng[a] : sp->games[g].thread_rng[a][t - 1];

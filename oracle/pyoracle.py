@@ -249,21 +249,25 @@ class RefSelfPlay:
     """The reference's own Context + GoGameSelfPlay + MCTSGoAI, net = stub (or a Python callback)."""
 
     @staticmethod
-    def path(n, turnstile=False):
-        return os.path.join(HERE, "_ref", "libelfsp%d%s.so" % (n, "_ts" if turnstile else ""))
+    def path(n, turnstile=False, canonical_backup=False):
+        return os.path.join(HERE, "_ref", "libelfsp%d%s.so" % (n, "_ts" if turnstile else "_h2" if canonical_backup else ""))
 
     @classmethod
-    def available(cls, n, turnstile=False):
-        return os.path.exists(cls.path(n, turnstile))
+    def available(cls, n, turnstile=False, canonical_backup=False):
+        return os.path.exists(cls.path(n, turnstile, canonical_backup))
 
-    def __init__(self, n, turnstile=False):
+    def __init__(self, n, turnstile=False, canonical_backup=False):
         """turnstile=True: the build whose copy of tree_search.h carries the four elf_ts_hook() calls (oracle/Makefile), with the
         turnstile switched on: the search threads of a game take turns in thread order (mcts_threads > 1 becomes deterministic)"""
         self.n = n
         self.na = n * n + 1
-        self.L = C.CDLL(self.path(n, turnstile))
+        assert not (turnstile and canonical_backup)
+        self.L = C.CDLL(self.path(n, turnstile, canonical_backup))
         self.L.refsp_run.restype = C.c_int
         self.turnstile = bool(turnstile)
+        # canonical_backup=True: the build whose batch_rollouts backs the unique leaves of a batch up in first-occurrence order
+        # instead of heap-address order (SURVEY.md H2; oracle/Makefile, libelfsp*_h2.so)
+        assert self.L.refsp_has_canonical_backup() == (1 if canonical_backup else 0)
         if turnstile:
             assert self.L.refsp_has_turnstile() == 1
             self.L.refsp_set_turnstile(C.c_int(1))

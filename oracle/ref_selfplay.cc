@@ -232,6 +232,15 @@ int refsp_has_turnstile() {
   return 0;
 #endif
 }
+// 1 = this library was built from the copy of tree_search.h whose batch_rollouts backs the leaves up in first-occurrence order
+// (libelfsp*_h2.so, oracle/Makefile: SURVEY.md hazard H2)
+int refsp_has_canonical_backup() {
+#ifdef ELF_H2_CANONICAL
+  return 1;
+#else
+  return 0;
+#endif
+}
 // switch the turnstile on / off for the following refsp_run calls (no effect in the stock build, which has no hooks)
 void refsp_set_turnstile(int on) { g_ts_on.store(on ? 1 : 0); }
 
