@@ -647,6 +647,25 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     net, dtype = build_net(args, n, dev)
     feat_fmt = "f16_nhwc" if (args.features == "f16" or (args.features == "auto" and net is not None and dtype == torch.float16)) else "f32_nchw"
     groups = max(1, args.groups)
+    import elf_amd as _ea0
+    npg_arg = args.nodes_per_game
+    if npg_arg is None and args.rollouts * max(1, args.mcts_threads) >= 4096:
+        # node ids per game: the library's default is 4 x rollouts + 1024 (trees of peaky nets keep large subtrees across moves: 2.2 x
+        # rollouts live nodes were measured with the pregrow's random peaky replies, profiles/r05c_node_usage_random_replies.json).  With
+        # the benchmark's random-init net the tree of a move is almost all new (peak 8089 live nodes at 8192 rollouts over the first
+        # moves, profiles/r05c_node_usage_resnet.json; the pregrow stays inside the first move): 1.5 x rollouts leaves 50 % head room and
+        # lets 2048 games per GPU (two waves per SIMD in the per-game kernels) fit in 167 GB.  A pool that runs out is an error, not a
+        # silent truncation (ELFMCTS_E_POOL).
+        npg_arg = (3 * args.rollouts * max(1, args.mcts_threads) // 2 + 63) // 64 * 64
+    if torch.cuda.is_available():
+        # never ask for more games than the free HBM holds (trees + feature rows + ~25 % head room for the net's activations)
+        free_b, _tot = _ea0.mem_info(local_rank)
+        npg_fit = npg_arg if npg_arg is not None else (4 * args.rollouts * max(1, args.mcts_threads) + 1024)
+        per_game = _ea0.tree_bytes_per_game(n, npg_fit) + 2 * K * max(1, args.mcts_threads) * 18 * n * n * 4
+        fit = int((0.75 if net is not None else 0.92) * free_b // per_game) // (64 * groups) * (64 * groups)
+        if fit < G and fit > 0:
+            sys.stderr.write("bench: %d games per GPU do not fit the free HBM (%.0f GB): running %d\n" % (G, free_b / 1e9, fit))
+            G = fit
     Gg = G // groups
     G = Gg * groups
     # process g of the job is seeded 1234 + 1000 g.  The reference then gives every game thread of a process the
@@ -656,7 +675,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                            board_size=n, num_games=Gg,
                            device=local_rank, mcts_rollout_per_thread=args.rollouts, mcts_rollout_per_batch=K, mcts_puct=1.5,
                            mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5,
-                           ply_pass_enabled=0, policy_distri_cutoff=30, nodes_per_game=args.nodes_per_game, feature_format=feat_fmt,
+                           ply_pass_enabled=0, policy_distri_cutoff=30, nodes_per_game=npg_arg, feature_format=feat_fmt,
                            mcts_threads=args.mcts_threads)
     na = n * n + 1
     rows_max = sp.groups[0].max_rows
@@ -1497,8 +1516,8 @@ def compact_line(res, full_path=None):
         line["metric"] = line["metric"][:100]
     c = _pick(cfg, ("games_per_gpu", "groups", "rollouts_per_step", "mean_depth", "board_size", "mcts_threads", "net_dtype", "net_rows_per_step",
                     "search_ms_per_step", "select_ms", "expand_backup_ms", "moves_in_window", "move_boundary_ms", "moves_per_sec",
-                    "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB", "seed_rule", "parallelism"))
-    c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:200], **c}
+                    "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB"))
+    c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:180], **c}
     if cfg.get("per_rank_rollouts_per_sec") is not None and res.get("n_gpus", 1) > 1:
         c["per_rank"] = [_num(v) for v in cfg["per_rank_rollouts_per_sec"]]
     line["config"] = c
@@ -1587,7 +1606,10 @@ def main():
     ap.add_argument("--board-size", type=int, default=19)
     ap.add_argument("--feature-rows", type=int, default=16384)
     ap.add_argument("--feature-formats", default="f32,f16", help="row formats the feature workload times (one per PMC pass: both use the same kernel)")
-    ap.add_argument("--games", type=int, default=256, help="games per GPU (split over --groups)")
+    ap.add_argument("--games", type=int, default=2048, help="games per GPU of the headline (split over --groups): one wave per game in the "
+                    "search kernels, so 2048 games = two waves per SIMD per launch of a 1024-game group")
+    ap.add_argument("--sub-games", type=int, default=256, help="games per GPU of the sub-results that search with the conv net (game phases, "
+                    "client configuration): they measure moves/s, which does not depend on the games in flight")
     ap.add_argument("--groups", type=int, default=2, help="lock-step game groups pipelined against the net (1 = serial)")
     ap.add_argument("--net-streams", type=int, default=1, help="net streams of the pipeline (1 = the groups' net calls queue on one stream; "
                     "= --groups: every group's call on its own stream)")
@@ -1633,6 +1655,15 @@ def main():
         steps = args.steps if args.steps is not None else 40
         warmup = args.warmup if args.warmup is not None else 8
         res = run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu)
+
+    if torch.cuda.is_available():
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()     # the headline's net graphs / activations go back to the device before the next leg sizes itself
+    import copy as _copy
+    sargs = _copy.copy(args)       # the sub-results that search with the conv net
+    if args.workload == "both":
+        sargs.games = max(args.groups, min(args.games, args.sub_games))
 
     def own(name, dflt):      # --steps/--warmup belong to the headline unless a single sub-workload was asked for
         v = getattr(args, name)
@@ -1698,7 +1729,7 @@ def main():
     if args.workload == "games" or sub or (args.workload == "both" and world > 1 and not args.no_sub):
         # N > 1: the measured games/s of the shortened configuration rides with the headline, so that one `bench.py --gpus N` line
         # per N yields the games/sec scaling curve BASELINE.json names (measured, not the 250-moves-per-game estimate)
-        gm = run_games(args, rank, local_rank, world, dist)
+        gm = run_games(sargs, rank, local_rank, world, dist)
         if args.workload == "games":
             res = gm
         elif rank == 0:
@@ -1717,7 +1748,7 @@ def main():
             except Exception:
                 pass
     if args.workload == "client" or sub:
-        cl = run_client(args, rank, local_rank, world, dist)
+        cl = run_client(sargs, rank, local_rank, world, dist)
         if args.workload == "client":
             res = cl
         elif rank == 0:

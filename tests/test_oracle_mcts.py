@@ -92,6 +92,23 @@ def test_turnstile_reference_reproduces_fixture_and_the_stock_build_has_no_hooks
     assert [s.move_played for s in r["search"]] == g["move_played"][:m].tolist()
 
 
+@pytest.mark.parametrize("name", ["mcts_19_r128_fresh", "mcts_9_r64_ties"])
+def test_canonical_backup_build_reproduces_the_stock_fixtures(name):
+    """The H2 build of the reference (first-occurrence backup order, oracle/Makefile) gives what the stock build gave wherever the
+    order cannot matter: the stub net's values are multiples of 1/256, so the fp32 reward sums are exact in any order."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = int(g["board_size"])
+    if not RefSelfPlay.available(n, canonical_backup=True):
+        pytest.skip("oracle/_ref/libelfsp*_h2.so not built (no /root/reference here)")
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    kw = {k: (float(np.float32(v)) if isinstance(MCTS_DEFAULTS[k], float) else int(v)) for k, v in cfg.items()}
+    R = RefSelfPlay(n, canonical_backup=True)
+    assert R.L.refsp_has_canonical_backup() == 1 and RefSelfPlay(n).L.refsp_has_canonical_backup() == 0
+    r = R.run(**kw)
+    assert np.array_equal(r["visits"], g["visits"]) and np.array_equal(r["reward"].view(np.uint32), g["reward"].view(np.uint32))
+    assert [s.move_played for s in r["search"]] == g["move_played"].tolist()
+
+
 RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
                "records_19_cutoff", "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart", "records_9_req2_async",
                "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval", "records_9_sgf", "records_9_sgf_policy_only"]
