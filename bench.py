@@ -40,6 +40,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+
+def chunked_forward(net, s, chunk_rows=2048):
+    from elf_amd.net import chunked_forward as cf
+    return cf(net, s, chunk_rows)
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz max clock
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s = 1228.8
@@ -92,7 +97,7 @@ def pmc_source_match(name):
 
 
 def load_traffic(kernel):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/gpu_round.sh), committed under profiles/; None when the
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_all.sh), committed under profiles/; None when the
     kernels have changed since the passes were run."""
     if not pmc_source_match("pmc_traffic.json"):
         return None
@@ -114,7 +119,7 @@ def issue_roof(kernel, units_per_launch, kernel_s):
         return {"bound": "issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
                 "traffic": None, "kernel": kernel, "avg_kernel_ms": kernel_s * 1e3, "pmc_source_match": False,
                 "note": "profiles/pmc_issue.json was measured on other kernel sources than the tree holds (kernel_source_hash differs): "
-                        "no issue-roof fraction is derived from stale instruction counts; re-run tools/gpu_r3_pmc.sh + tools/update_issue.py"}
+                        "no issue-roof fraction is derived from stale instruction counts; re-run tools/profile_all.sh + tools/update_issue.py"}
     ach = units_per_launch * valu / kernel_s / 1e9
     salu = per.get("salu_per_unit")
     salu_ach = units_per_launch * salu / kernel_s / 1e9 if salu else None
@@ -685,7 +690,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     if net is not None:
         # initialisation, not a step: the first call of each convolution shape runs MIOpen's find (tens of seconds on a fresh box).
         with torch.no_grad():
-            net({"s": sp.groups[0].s})
+            chunked_forward(net, sp.groups[0].s)
         torch.cuda.synchronize()
     graphs = {}
     if net is not None and args.net_graph:
@@ -708,7 +713,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                 out = gn()
                 return out["pi"], out["V"]
             with torch.no_grad():
-                out = net({"s": s})   # fixed shape [Gg*K, 18, N, N]: rows beyond the count are stale and ignored
+                out = chunked_forward(net, s)   # fixed shape [Gg*K, 18, N, N]: rows beyond the count are stale and ignored
             return out["pi"], out["V"]
         if args.net == "random":
             return rnd()
@@ -820,7 +825,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                      "pmc_source_match": pmc_source_match("pmc_traffic.json"),
                      "traffic_note": "PMC HBM bytes per rollout of the four search kernels (profiles/pmc_traffic.json, search-only run at depth 6.3) x "
                                      "rollouts per step; withheld (null) when the kernel sources have changed since the PMC passes",
-                     "kernel": "k_mcts_select+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
+                     "kernel": "k_mcts_select+k_mcts_leafstate+k_mcts_leafindex+k_mcts_features+k_mcts_expand+k_mcts_backup", "avg_kernel_ms": sel_ms + exp_ms,
                      "algorithmic_bytes_per_rollout": bytes_per_step / (G * K * T),
                      "select_kernel": {"achieved_GBps": (sel_bytes / (sel_ms / 1e3) / 1e9) if (sel_bytes and sel_ms > 0) else None,
                                        "bytes_per_visited_node": 64 + 64 * 8 + 256, "bytes_per_new_node": 2 * 2624 + 64,
@@ -853,7 +858,8 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
             a2 = copy.copy(args)
             a2.net_dtype = "bf16"
             net_b, dt_b = build_net(a2, n, dev)
-            for name, nn_, dt_, rows in (("bf16_2048_rows", net_b, dt_b, rows_call), ("fp16_4096_rows", net, dtype, 2 * rows_call)):
+            rows_v = min(rows_call, 2048)      # the conv shape every net call of this bench has (chunked_forward)
+            for name, nn_, dt_, rows in (("bf16_2048_rows", net_b, dt_b, rows_v), ("fp16_4096_rows", net, dtype, 2 * rows_v)):
                 x = torch.zeros((rows, n, n, 18), dtype=dt_, device=dev).permute(0, 3, 1, 2)   # channels_last [rows,18,N,N]
                 with torch.no_grad():
                     for _ in range(2):
@@ -866,7 +872,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                     e1.record()
                     torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 5
-                var[name] = {"avg_call_ms": ms, "TFLOP/s": flops_pos * rows / (ms / 1e3) / 1e12, "ms_per_2048_rows": ms * rows_call / rows}
+                var[name] = {"avg_call_ms": ms, "TFLOP/s": flops_pos * rows / (ms / 1e3) / 1e12, "ms_per_2048_rows": ms * 2048 / rows}
             del net_b
             res["net_roofline"]["variants"] = var
             res["net_roofline"]["variants_note"] = "eager launches (no HIP graph), same fused epilogue; compare ms_per_2048_rows with avg_call_ms"
@@ -908,7 +914,7 @@ def run_games(args, rank, local_rank, world, dist):
     graphs = {}
     if net is not None:
         with torch.no_grad():
-            net({"s": sp.groups[0].s})
+            chunked_forward(net, sp.groups[0].s)
         from elf_amd.net import GraphedNet
         try:
             for g in sp.groups:
@@ -924,7 +930,7 @@ def run_games(args, rank, local_rank, world, dist):
             o = gn()
         else:
             with torch.no_grad():
-                o = net({"s": s})
+                o = chunked_forward(net, s)
         return o["pi"], o["V"]
 
     barrier = make_barrier(dist)
@@ -964,7 +970,7 @@ def run_games(args, rank, local_rank, world, dist):
                 o = gn()
             else:
                 with torch.no_grad():
-                    o = net({"s": s})
+                    o = chunked_forward(net, s)
             return o["pi"], o["V"]
         return fn, gr
 
@@ -1120,7 +1126,7 @@ def run_client(args, rank, local_rank, world, dist):
     graphs = {}
     if net is not None:
         with torch.no_grad():
-            net({"s": sp.groups[0].s})
+            chunked_forward(net, sp.groups[0].s)
         from elf_amd.net import GraphedNet
         try:
             for g in sp.groups:
@@ -1136,7 +1142,7 @@ def run_client(args, rank, local_rank, world, dist):
             o = gn()
         else:
             with torch.no_grad():
-                o = net({"s": s})
+                o = chunked_forward(net, s)
         return o["pi"], o["V"]
 
     barrier = make_barrier(dist)
@@ -1646,6 +1652,12 @@ def main():
         self_spawn(args.gpus)      # does not return
 
     rank, local_rank, world, dist = init_dist(args)
+    legs, t_leg = {}, [time.time()]
+
+    def leg(name):     # wall seconds per leg of the run (full report): what a default run spends where
+        now = time.time()
+        legs[name] = round(now - t_leg[0], 2)
+        t_leg[0] = now
     with_cpu = (not args.no_cpu_baseline) and world == 1
     sub = args.workload == "both" and world == 1 and not args.no_sub
     res = None
@@ -1655,6 +1667,7 @@ def main():
         steps = args.steps if args.steps is not None else 40
         warmup = args.warmup if args.warmup is not None else 8
         res = run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu)
+        leg("headline")
 
     if torch.cuda.is_available():
         import gc
@@ -1698,34 +1711,40 @@ def main():
             import gc
             gc.collect()                     # a half-built context frees its node pools in its finaliser
             torch.cuda.empty_cache()
+    leg("search_only")
     if args.workload == "board" or sub:
         b = run_board(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3), with_cpu)
         if args.workload == "board":
             res = b
         elif rank == 0:
             res["board_step"] = b
+    leg("board_step")
     if sub and args.board_size == 19:
         b9 = run_board(args, rank, local_rank, world, dist, 8, 2, with_cpu, n=9, boards=args.boards9)
         if rank == 0:
             res["board_step_9x9"] = b9
+    leg("board_step_9x9")
     if args.workload == "feature" or sub:
         f = run_feature(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3))
         if args.workload == "feature":
             res = f
         elif rank == 0:
             res["feature_extract"] = f
+    leg("feature_extract")
     if args.workload == "train" or sub:
         t = run_train(args, rank, local_rank, world, dist, own("steps", 20), own("warmup", 3), with_cpu)
         if args.workload == "train":
             res = t
         elif rank == 0:
             res["train_loader"] = t
+    leg("train_loader")
     if args.workload == "boundary" or sub:
         bd = run_boundary(args, rank, local_rank, world, dist, own("steps", 10), own("warmup", 3))
         if args.workload == "boundary":
             res = bd
         elif rank == 0:
             res["boundary"] = bd
+    leg("boundary")
     if args.workload == "games" or sub or (args.workload == "both" and world > 1 and not args.no_sub):
         # N > 1: the measured games/s of the shortened configuration rides with the headline, so that one `bench.py --gpus N` line
         # per N yields the games/sec scaling curve BASELINE.json names (measured, not the 250-moves-per-game estimate)
@@ -1747,13 +1766,17 @@ def main():
                                               "step is 99 % convolution (net_roofline), so this fraction is small by construction"}
             except Exception:
                 pass
+    leg("selfplay_games")
     if args.workload == "client" or sub:
         cl = run_client(sargs, rank, local_rank, world, dist)
         if args.workload == "client":
             res = cl
         elif rank == 0:
             res["client_config"] = cl
+    leg("client_config")
     if rank == 0:
+        if isinstance(res, dict):
+            res["leg_seconds"] = legs
         emit(res, args)
     if dist is not None:
         dist.destroy_process_group()

@@ -5,7 +5,10 @@
 #include <stdlib.h>
 #include <unistd.h>
 
+#include <pthread.h>
+
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -13,32 +16,49 @@
 
 class HostWorkers {
  public:
-  static HostWorkers& get() { static HostWorkers w; return w; }
-  // fn(i) for i in [0, n), strided over `nt` participants (the caller is participant 0); returns when all of them are done
+  // One pool per PROCESS, never destroyed: the object is leaked on purpose (no join at exit -- a forked child that leaves through
+  // exit() would otherwise join handles that name the parent's threads), and a child process gets a fresh object from the atfork
+  // handler (the parent's mutexes may have been held by threads that do not exist in the child).
+  static HostWorkers& get() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      slot() = new HostWorkers();
+      pthread_atfork(nullptr, nullptr, [] { slot() = new HostWorkers(); });   // child: abandon the inherited object, threads and locks
+    });
+    return *slot();
+  }
+  // fn(i) for i in [0, n), strided over `nt` participants (the caller is participant 0); returns when all of them are done.  An
+  // exception thrown by fn on a worker is carried to the caller and rethrown here once the region has drained.
   void run(size_t n, unsigned nt, const std::function<void(size_t)>& fn) {
     std::unique_lock<std::mutex> call(call_mu_);          // one parallel region at a time (contexts on several host threads)
-    if (owner_ != getpid()) {                              // a forked child inherits the object but not the threads: start over
-      (void)new std::vector<std::thread>(std::move(th_));   // abandoned, never destroyed: the handles name threads of the parent
-      th_.clear();
-      owner_ = getpid();
-    }
     ensure(nt - 1);
     {
       std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn; n_ = n; nt_ = nt; pending_ = nt - 1; ++epoch_;
+      fn_ = &fn; n_ = n; nt_ = nt; pending_ = nt - 1; ++epoch_; failed_ = nullptr;
     }
     cv_.notify_all();
-    for (size_t i = 0; i < n; i += nt) fn(i);
-    std::unique_lock<std::mutex> lk(mu_);
-    done_.wait(lk, [&] { return pending_ == 0; });
-    fn_ = nullptr;
-  }
-  ~HostWorkers() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
+    std::exception_ptr mine;
+    try {
+      for (size_t i = 0; i < n; i += nt) fn(i);
+    } catch (...) {
+      mine = std::current_exception();
+    }
+    std::exception_ptr theirs;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_.wait(lk, [&] { return pending_ == 0; });
+      fn_ = nullptr;
+      theirs = failed_;
+      failed_ = nullptr;
+    }
+    call.unlock();
+    if (mine) std::rethrow_exception(mine);
+    if (theirs) std::rethrow_exception(theirs);
   }
  private:
+  HostWorkers() = default;
+  ~HostWorkers() = delete;                                 // leaked by design (see get())
+  static HostWorkers*& slot() { static HostWorkers* p = nullptr; return p; }
   void ensure(unsigned k) {
     while (th_.size() < k) {
       const unsigned id = (unsigned)th_.size() + 1;        // participant index of this worker
@@ -50,20 +70,25 @@ class HostWorkers {
           const std::function<void(size_t)>* fn; size_t n; unsigned nt;
           {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-            if (stop_) return;
+            cv_.wait(lk, [&] { return epoch_ != seen; });
             seen = epoch_; fn = fn_; n = n_; nt = nt_;
           }
           if (id < nt) {
-            for (size_t i = id; i < n; i += nt) (*fn)(i);
+            std::exception_ptr ex;
+            try {
+              for (size_t i = id; i < n; i += nt) (*fn)(i);
+            } catch (...) {
+              ex = std::current_exception();
+            }
             std::lock_guard<std::mutex> lk(mu_);
+            if (ex && !failed_) failed_ = ex;
             if (--pending_ == 0) done_.notify_one();
           }
         }
       });
+      th_.back().detach();                                 // never joined: the pool lives as long as the process
     }
   }
-  pid_t owner_ = getpid();
   std::mutex call_mu_, mu_;
   std::condition_variable cv_, done_;
   std::vector<std::thread> th_;
@@ -71,7 +96,7 @@ class HostWorkers {
   size_t n_ = 0;
   unsigned nt_ = 0, pending_ = 0;
   uint64_t epoch_ = 0;
-  bool stop_ = false;
+  std::exception_ptr failed_;
 };
 
 

@@ -46,7 +46,7 @@
 namespace elfgo {
 
 enum { NS_NOT_VISITED = 0, NS_EVAL_REQUESTED = 1, NS_VISITED = 2 };   // NodeT::VisitType
-enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2 };
+enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2, LK_STATE_PENDING = 3 };   // PENDING: between k_mcts_select and k_mcts_leafstate
 enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8, MCTS_ERR_VERSION = 16 };
 constexpr int MCTS_KMAX = 1024;  // max rollouts per step = num_threads x rollouts_per_batch: the stride of the per-game leaf / row tables in HBM.
                                  // The leaf table of a step in LDS (k_mcts_select) is sized by the launch: 20 B per rollout of the step
@@ -152,8 +152,9 @@ struct LeafRec {          // 32 B
   float value;
   int nn_index;
   int depth;              // edges between the root and this leaf (length of the trajectory)
-  int pad;
+  int thread;             // the search thread (TSOptions.num_threads) whose batch_rollouts found the leaf first
 };
+constexpr int MCTS_PATH_LV = 64;   // levels of a descent whose position hashes select hands to k_mcts_leafstate (deeper: exact checks only)
 
 struct RowRec { int game, node, d4, pad; };
 
@@ -170,6 +171,8 @@ struct TreePool {
   LeafRec* leaves;        // [G][MCTS_KMAX]
   unsigned char* d4buf;   // [G][NT][W / NT]  pre-drawn rng() % 8 of each search thread's MCTSActor mt19937 (go/mcts/mcts.h:175-183)
   int* rng_pos_t;         // [G][NT] draws each search thread's actor has consumed this move
+  u32* pathbuf;           // [G][KTA][MCTS_PATH_LV][2] hash (lo, hi) of the nodes on each unique leaf's path, root first (k_mcts_select -> k_mcts_leafstate)
+  int KTA;                // leaves per game and step the path buffer was laid out for (num_threads x rollouts_per_batch at creation)
   const double* sqrt_tab; // [sqrt_n] host libm sqrt((double)k): the reference's std::sqrt(int) (tree_search_base.h:153)
   const unsigned char* mask;   // [G] or nullptr (every game GM_SEARCH): which games the per-game launches act on (GM_*)
   const long long* req_ver;    // [G] or nullptr (TreeCfg.required_version for every game): MCTSActorParams.required_version per game
@@ -363,33 +366,6 @@ __global__ __launch_bounds__(64) void k_mcts_set_root(TreePool<N> tp, PoolT pool
   for (int t = lane; t < tp.NT; t += 64) tp.rng_pos_t[(size_t)g * tp.NT + t] = 0;   // a fresh window per search thread and move
 }
 
-// The superko filter of the position a new node is forwarded from (k_mcts_select): the game's records up to the root (the game
-// board's own Bloom words) + the positions on the path root .. parent (every hash, also those a pass leaves: a filter may hold
-// more, never less).  A path longer than the table sends every probe to the exact check.  Out of line for the same reason as
-// promote_record (5 registers).  All three pointers are LDS.
-typedef __attribute__((address_space(3))) u32 lds_u32;
-template <int N, int PATH_LV>
-__device__ __attribute__((noinline)) void rebuild_filter(u32* bloom_g, const u32* gbloom_g, const u32* path_g, int depth) {
-  using GEO = Geo<N>;
-  constexpr u32 BMASK = GEO::BLOOM * 32 - 1;
-  const int lane = threadIdx.x & 63;
-  lds_u32* const bloom = (lds_u32*)bloom_g;
-  const lds_u32* const gbloom = (const lds_u32*)gbloom_g;
-  const lds_u32* const path_h = (const lds_u32*)path_g;
-  if (depth <= PATH_LV) {
-    for (int l = lane; l < GEO::BLOOM; l += 64) bloom[l] = gbloom[l];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (int l = lane; l < depth; l += 64) {
-      const u32 h1 = path_h[2 * l] & BMASK, h2 = path_h[2 * l + 1] & BMASK;
-      __hip_atomic_fetch_or(&bloom[h1 >> 5], 1u << (h1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_or(&bloom[h2 >> 5], 1u << (h2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  } else {
-    for (int l = lane; l < GEO::BLOOM; l += 64) bloom[l] = ~0u;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-}
-
 // The move of a node from its small record to a big one (k_mcts_select, the 17th followed edge): copy the record, give the 16
 // children their parent's new id.  Kept out of line: inlined, its temporaries raised the select kernel's register count by 19 (one
 // wave per SIMD less), and it runs once per 17-child node.
@@ -446,11 +422,6 @@ __device__ __attribute__((noinline)) double sqrt_beyond_table(int v) { return sq
 template <int N, class PoolT>
 __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, const int32_t* board_ids, TreeCfg cfg) {
   using NL = NodeL<N>;
-  using GEO = Geo<N>;
-  constexpr int PATH_LV = 256;             // levels of a descent whose position hashes are kept for the superko filter
-  __shared__ Slot<N> lds;
-  __shared__ __attribute__((aligned(16))) u32 gbloom[GEO::BLOOM];   // the game board's own Bloom words: the game's records up to the root
-  __shared__ u32 path_h[2 * PATH_LV];      // hash (lo, hi) of the node at each level of the current descent
   __shared__ __attribute__((aligned(16))) float uqs[64 + 8];   // unsigned child Qs of one round's visited edges, compacted
   // the unique leaves of this step (unique per search thread), in first-occurrence order: five arrays of KTP entries in the launch's
   // dynamic LDS (KTP = num_threads x rollouts_per_batch rounded up to 64; elfmcts_select passes 20 x KTP bytes)
@@ -476,32 +447,15 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   int* fb = tp.free_big + (size_t)g * tp.Cb;
   int* po = tp.parent_of + (size_t)g * tp.C;
   GameState& gs = tp.gs[g];
-  const int bslot = board_ids ? board_ids[g] : g;
   int root = rfl(gs.root);
   int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big), err = 0, promotions = 0;
-  const int root_sk_len = rfl((int)nodes[root].board().h.sk_len);
-  if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(gbloom)[lane] = reinterpret_cast<const uint4*>(pool.slots[bslot].bloom)[lane];
-  // Every search thread's MCTSActor owns a generator (all seeded alike, game_selfplay.cc:45-47,77): thread t's net leaves draw their D4
-  // codes from window t of the game, at that thread's own position.  The next 64 codes of the window are read once per thread and
-  // launch, coalesced (nothing draws besides this wave); beyond 64 draws the kernel falls back to the dependent load.
-  const int Wt = tp.W / tp.NT;
-  int rng_pos = 0, rng_pos0 = 0, d4_pre = 0, cur_t = -1;
-  auto thread_enter = [&](int t) {
-    int* const tpos = tp.rng_pos_t + (size_t)g * tp.NT;
-    if (cur_t >= 0 && lane == 0) {
-      tpos[cur_t] = rng_pos;
-      if (cur_t == 0) gs.rng_pos = rng_pos;      // thread 0's actor (also the Dirichlet generator): what RootInfo reports
-    }
-    cur_t = t;
-    rng_pos = rfl(tpos[t]);
-    rng_pos0 = rng_pos;
-    d4_pre = 0;
-    if (ELF_SEL_D4PRE && cfg.rotation_flip) {
-      const int ix = rng_pos0 + lane;
-      d4_pre = ix < Wt ? (int)tp.d4buf[((size_t)g * tp.NT + t) * Wt + ix] : 0;
-    }
-  };
-  int n_unique = 0, n_nn = 0, thread_start = 0;
+  // The descent creates nodes (id, header, edge bookkeeping) but not their STATES: "allocateState" (tree_search.h:174-190: copy of the
+  // parent's state + forward) of every new leaf, the terminal test and the D4 draws happen after this kernel, one wave per leaf
+  // (k_mcts_leafstate, k_mcts_leafindex) -- a new leaf has no edges, so nothing in this step descends through it or needs its board.
+  // What the state kernel needs from the descent is the path's position hashes (the superko filter): they arrive with every node
+  // header (words 12, 13) and go to the leaf's row of the path buffer on the way down.
+  u32* const pathrow0 = tp.pathbuf + (size_t)g * tp.KTA * (2 * MCTS_PATH_LV);
+  int n_unique = 0, thread_start = 0, cur_t = -1;
   const float vl_f = (float)cfg.virtual_loss;
   int visited_nodes = 0;
   // GM_POLICY_ONLY = TreeSearchT::runPolicyOnly (tree_search.h:385-407): the root is evaluated if it has not been yet, nothing else
@@ -510,17 +464,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
 
   for (int j = 0, jk = 0; j < KT; ++j, ++jk) {
     if (jk == K) jk = 0;
-    if (jk == 0) { thread_start = n_unique; thread_enter(cur_t + 1); }   // traj_counts is per batch_rollouts call, i.e. per search thread
+    if (jk == 0) { thread_start = n_unique; ++cur_t; }   // traj_counts is per batch_rollouts call, i.e. per search thread
     int node = root, depth = 0;
-    bool board_in_lds = false;   // LDS holds the state of `node`
-    // the board engine's per-lane constants (~35 registers) are set up where a board is first needed -- after the descent -- from an
-    // opaque copy of the lane index, so that they are not live (nor hoisted) across the level loop
-    Board<N> bd;
-    auto board_setup = [&]() {
-      int ol = lane;
-      asm volatile("" : "+v"(ol));
-      bd.init(&lds, pool.zob, nullptr, ol);
-    };
     HdrU h;
     // the one memory round trip of a level: the header and the first 64 entries of the scoring order, requested together
     // (speculatively: a leaf's edge arrays are never used), all coalesced.  A small record holds statistics for 16 entries only.
@@ -540,8 +485,9 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     request(node);
     for (;;) {                   // single_rollout, tree_search.h:264-322
       h.set(hw);
-      // the position hash of every node on the path (header words 12, 13): what the superko filter of a new node has to cover
-      if (depth < PATH_LV && (lane >> 1) == 6) path_h[2 * depth + lane - 12] = (u32)hw;
+      // the position hash of every node on the path (header words 12, 13) -> the path row of the leaf this descent will end in (slot
+      // n_unique: a descent that ends in a duplicate leaf leaves its row to the next one)
+      if (depth < MCTS_PATH_LV && (lane >> 1) == 6) pathrow0[(size_t)n_unique * (2 * MCTS_PATH_LV) + 2 * depth + lane - 12] = (u32)hw;
       SEL_PHASE(0);   // header + scoring order arrive
       if (h.status != NS_VISITED || h.n_edges == 0 || root_only) break;
       const NodeRef<N> nd = nodes[node];
@@ -700,20 +646,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           nw.h().n_touched = nt + 1;
         }
         SEL_PHASE(2);   // new node: id, header, scoring-order insertion
-        // ---- allocateState, tree_search.h:174-190: new State(parent) + actor.forward(state, action)
-        board_setup();
-        bd.load(&nw.board());
-        // the superko filter of the parent's position: the game's records up to the root (the game board's Bloom words) + the
-        // positions on the path root .. parent (every hash, also those a pass leaves: a filter may hold more, never less)
-        rebuild_filter<N, PATH_LV>(lds.bloom, gbloom, path_h, depth);
-        SEL_PHASE(3);   // parent's board to LDS, filter
-        TreeSK<N> sk{nodes, node, mv, GameSK<N>{pool.skr(bslot)}, root_sk_len};
-        if (!bd.forward(mv, sk)) { err |= MCTS_ERR_FORWARD; --depth; break; }
-        SEL_PHASE(4);   // Board::forward
-        const NodeRef<N> cn = nodes[child];
-        bd.store(&cn.board());
-        if (lane == 0) { cn.h().has_state = 1; cn.h().hash_lo = (u32)bd.hash; cn.h().hash_hi = (u32)(bd.hash >> 32); }
-        board_in_lds = true;
         node = child;
         h.status = NS_NOT_VISITED; h.n_edges = 0;   // the fresh node is this rollout's leaf: no need to read it back
         break;
@@ -734,30 +666,18 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     if (dup_idx >= 0) {
       if (lane == 0) ++lf_count[dup_idx];
     } else {
-      int kind = LK_REVISIT, d4 = 0;
-      float value = 0.0f;
+      // a leaf nobody has requested yet (a node this descent created, or the root of a fresh tree): its state, the terminal test
+      // (MCTSActor::pre_evaluate) and the D4 draw follow in k_mcts_leafstate / k_mcts_leafindex
+      int kind = LK_REVISIT;
       if (h.status == NS_NOT_VISITED) {
-        if (!board_in_lds) { board_setup(); bd.load(&nodes[node].board()); }   // only the root can get here without a fresh state
-        if (bd.terminated()) {                             // MCTSActor::pre_evaluate :185-207
-          kind = LK_TERMINAL;
-          value = bd.evaluate(cfg.komi) > 0.0f ? 1.0f : -1.0f;
-        } else {
-          kind = LK_NN;
-          if (cfg.rotation_flip) {                         // get_extractor :175-183: rng() % 8, one draw per NN leaf
-            if (rng_pos >= Wt) err |= MCTS_ERR_RNG;
-            else if (ELF_SEL_D4PRE && rng_pos - rng_pos0 < 64) d4 = rl(d4_pre, rng_pos - rng_pos0);
-            else d4 = rfl((int)tp.d4buf[((size_t)g * tp.NT + cur_t) * Wt + rng_pos]);
-            ++rng_pos;
-          }
-        }
+        kind = LK_STATE_PENDING;
         if (lane == 0) nodes[node].h().status = NS_EVAL_REQUESTED;
       }
       if (lane == 0) {
-        lf_node[n_unique] = node; lf_count[n_unique] = 1; lf_meta[n_unique] = kind | (d4 << 8) | (depth << 16);
-        lf_value[n_unique] = value; lf_nn[n_unique] = n_nn;
+        lf_node[n_unique] = node; lf_count[n_unique] = 1; lf_meta[n_unique] = kind | (cur_t << 8) | (depth << 20);
+        lf_value[n_unique] = 0.0f; lf_nn[n_unique] = 0;
       }
       ++n_unique;
-      if (kind == LK_NN) ++n_nn;
     }
     SEL_PHASE(6);   // leaf bookkeeping (terminal test, D4 draw)
     mem_sync();
@@ -771,18 +691,133 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   for (int i = lane; i < n_unique; i += 64) {
     LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + i];
     const int meta = lf_meta[i];
-    lr.node = lf_node[i]; lr.count = lf_count[i]; lr.kind = meta & 0xFF; lr.d4 = (meta >> 8) & 0xFF; lr.value = lf_value[i];
-    lr.nn_index = lf_nn[i]; lr.depth = meta >> 16;
+    lr.node = lf_node[i]; lr.count = lf_count[i]; lr.kind = meta & 0xFF; lr.d4 = 0; lr.value = 0.0f;
+    lr.nn_index = 0; lr.depth = meta >> 20; lr.thread = (meta >> 8) & 0xFFF;
   }
   if (lane == 0) {
-    if (cur_t >= 0) tp.rng_pos_t[(size_t)g * tp.NT + cur_t] = rng_pos;
-    if (cur_t == 0) gs.rng_pos = rng_pos;
-    gs.root = root; gs.free_top = free_top; gs.free_top_big = free_top_big; gs.n_unique = n_unique; gs.n_nn = n_nn;
+    gs.root = root; gs.free_top = free_top; gs.free_top_big = free_top_big; gs.n_unique = n_unique; gs.n_nn = 0;
     gs.rollouts_done += KT;
     gs.node_visits += visited_nodes;
     if (promotions) gs.promotions += promotions;
     if (err) gs.err |= err;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// leaf states: one wave per (game, unique leaf) that nobody had requested before this step.
+//   a node the descent created:  allocateState, tree_search.h:174-190 -- new State(parent) + actor.forward(state, action): coalesced
+//                                load of the parent's compact board -> Board::forward in LDS -> coalesced store; the superko filter of the
+//                                parent's position is the game board's own Bloom words (the game's records up to the root) + the hashes
+//                                the descent wrote into the leaf's path row (root .. parent; a filter may hold more, never less)
+//   the root of a fresh tree:    its state is there (k_mcts_set_root)
+// then MCTSActor::pre_evaluate (go/mcts/mcts.h:185-207): a terminated position is its own evaluation (+-1 by Tromp-Taylor), anything
+// else needs the net.  The serial part of a step (k_mcts_select: one wave per game, 16 dependent descents) is free of all this.
+// ------------------------------------------------------------------------------------------------
+template <int N, class PoolT>
+__global__ __launch_bounds__(64) void k_mcts_leafstate(TreePool<N> tp, PoolT pool, const int32_t* board_ids, int KT, TreeCfg cfg) {
+  using GEO = Geo<N>;
+  constexpr u32 BMASK = GEO::BLOOM * 32 - 1;
+  __shared__ Slot<N> lds;
+  const int g = blockIdx.x / KT, u = blockIdx.x % KT, lane = threadIdx.x;
+  GameState& gs = tp.gs[g];
+  if (u >= rfl(gs.n_unique)) return;
+  LeafRec& lr = tp.leaves[(size_t)g * MCTS_KMAX + u];
+  if (rfl(lr.kind) != LK_STATE_PENDING) return;
+  const GameNodes<N> nodes(tp, g);
+  const int node = rfl(lr.node), depth = rfl(lr.depth);
+  const NodeRef<N> nd = nodes[node];
+  Board<N> bd;
+  bd.init(&lds, pool.zob, nullptr);
+  if (rfl(nd.h().has_state) == 0) {
+    const int bslot = board_ids ? board_ids[g] : g;
+    const int parent = rfl(nd.h().parent);
+    const NodeRef<N> pn = nodes[parent];
+    const int mv = rfl((int)pn.coord()[rfl(nd.h().parent_edge)]);
+    // the three inputs are requested together: the parent's board, the game's Bloom words, the path's hashes
+    const u32* prow = tp.pathbuf + ((size_t)g * tp.KTA + u) * (2 * MCTS_PATH_LV);
+    uint4 gb = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < GEO::BLOOM / 4) gb = reinterpret_cast<const uint4*>(pool.slots[bslot].bloom)[lane];
+    u32 ph1 = 0, ph2 = 0;
+    const bool on_path = depth <= MCTS_PATH_LV && lane < depth;
+    if (on_path) { ph1 = prow[2 * lane]; ph2 = prow[2 * lane + 1]; }
+    const int root_sk_len = rfl((int)nodes[rfl(gs.root)].board().h.sk_len);
+    bd.load(&pn.board());
+    if (depth <= MCTS_PATH_LV) {
+      if (lane < GEO::BLOOM / 4) reinterpret_cast<uint4*>(lds.bloom)[lane] = gb;
+      Board<N>::wsync();
+      if (on_path) {
+        ph1 &= BMASK; ph2 &= BMASK;
+        Board<N>::lds_or(&lds.bloom[ph1 >> 5], 1u << (ph1 & 31));
+        Board<N>::lds_or(&lds.bloom[ph2 >> 5], 1u << (ph2 & 31));
+      }
+    } else {
+      for (int l = lane; l < GEO::BLOOM; l += 64) lds.bloom[l] = ~0u;   // a path longer than the row: every probe goes to the exact check
+    }
+    Board<N>::wsync();
+    TreeSK<N> sk{nodes, parent, mv, GameSK<N>{pool.skr(bslot)}, root_sk_len};
+    if (!bd.forward(mv, sk)) {
+      if (lane == 0) atomicOr(&gs.err, MCTS_ERR_FORWARD);
+      return;
+    }
+    bd.store(&nd.board());
+    if (lane == 0) { nd.h().has_state = 1; nd.h().hash_lo = (u32)bd.hash; nd.h().hash_hi = (u32)(bd.hash >> 32); }
+  } else {
+    bd.load(&nd.board());
+  }
+  int kind = LK_NN;
+  float value = 0.0f;
+  if (bd.terminated()) {                                 // MCTSActor::pre_evaluate :185-207
+    kind = LK_TERMINAL;
+    value = bd.evaluate(cfg.komi) > 0.0f ? 1.0f : -1.0f;
+  }
+  if (lane == 0) { lr.kind = kind; lr.value = value; }
+}
+
+// One wave per game, after the states: which leaves need the net (in leaf order: the row order of the batch) and their D4 codes.
+// get_extractor (go/mcts/mcts.h:175-183) draws rng() % 8 once per net leaf, in the order the search thread's actor.evaluate walks its
+// locked leaves -- the leaf order of that thread's batch; every search thread's MCTSActor owns a generator (all seeded alike,
+// game_selfplay.cc:45-47,77): thread t's net leaves take the next codes of window t.
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_leafindex(TreePool<N> tp, TreeCfg cfg) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  GameState& gs = tp.gs[g];
+  const int nu = rfl(gs.n_unique);
+  if (nu == 0) { if (lane == 0) gs.n_nn = 0; return; }
+  LeafRec* leaves = tp.leaves + (size_t)g * MCTS_KMAX;
+  const int Wt = tp.W / tp.NT;
+  int* const tpos = tp.rng_pos_t + (size_t)g * tp.NT;
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  int n_nn = 0, err = 0;
+  for (int c0 = 0; c0 < nu; c0 += 64) {
+    const int i = c0 + lane;
+    const bool have = i < nu;
+    int kind = LK_REVISIT, th = 0;
+    if (have) { kind = leaves[i].kind; th = leaves[i].thread; }
+    const bool nn = have && kind == LK_NN;
+    u64 todo = __ballot(nn);
+    const u64 all_nn = todo;
+    int d4 = 0;
+    while (todo) {                                       // the search threads present in this chunk, in leaf (= thread) order
+      const int t = rl(th, (int)__builtin_ctzll(todo));
+      const u64 mine = __ballot(nn && th == t);
+      todo &= ~mine;
+      if (cfg.rotation_flip) {
+        const int pos = rfl(tpos[t]);
+        const int k = pos + __popcll(mine & lt_mask);
+        if (nn && th == t) {
+          if (k < Wt) d4 = (int)tp.d4buf[((size_t)g * tp.NT + t) * Wt + k];
+          else err |= MCTS_ERR_RNG;
+        }
+        const int np = pos + __popcll(mine);
+        if (lane == 0) { tpos[t] = np; if (t == 0) gs.rng_pos = np; }   // thread 0's actor is also the Dirichlet generator: RootInfo reports it
+        mem_sync();                                      // the next chunk of the same thread reads the position back
+      }
+    }
+    if (nn) { leaves[i].nn_index = n_nn + __popcll(all_nn & lt_mask); leaves[i].d4 = d4; }
+    n_nn += __popcll(all_nn);
+  }
+  const bool bad = __ballot(err != 0) != 0;
+  if (lane == 0) { gs.n_nn = n_nn; if (bad) gs.err |= MCTS_ERR_RNG; }
 }
 
 // rows of the net batch: game-major, leaf order within a game; row_base = exclusive prefix of n_nn over games.  One block scans

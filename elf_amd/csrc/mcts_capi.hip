@@ -21,6 +21,8 @@ struct ElfMcts {
   LeafRec* leaves = nullptr;
   unsigned char* d4buf = nullptr;
   int* rng_pos_t = nullptr;              // [G][NT]
+  uint32_t* pathbuf = nullptr;           // [G][KTA][MCTS_PATH_LV][2]
+  int KTA = 0;                           // leaves per game and step the path buffer is laid out for
   int NT = 1;                            // search threads the D4 windows are laid out for
   double* sqrt_tab = nullptr;
   int sqrt_n = 0;
@@ -46,6 +48,8 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   t.leaves = m->leaves;
   t.d4buf = m->d4buf;
   t.rng_pos_t = m->rng_pos_t;
+  t.pathbuf = m->pathbuf;
+  t.KTA = m->KTA;
   t.NT = m->NT;
   t.sqrt_tab = m->sqrt_tab;
   t.sqrt_n = m->sqrt_n;
@@ -112,6 +116,8 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
   MCHK(hipMalloc((void**)&m->leaves, G * MCTS_KMAX * sizeof(LeafRec)));
   MCHK(hipMalloc((void**)&m->d4buf, G * (size_t)d4_window));
   MCHK(hipMemset(m->d4buf, 0, G * (size_t)d4_window));
+  m->KTA = opt->num_threads * opt->num_rollouts_per_batch;
+  MCHK(hipMalloc((void**)&m->pathbuf, G * (size_t)m->KTA * MCTS_PATH_LV * 2 * sizeof(uint32_t)));
   MCHK(hipMalloc((void**)&m->rng_pos_t, G * (size_t)m->NT * sizeof(int)));
   MCHK(hipMemset(m->rng_pos_t, 0, G * (size_t)m->NT * sizeof(int)));
   MCHK(hipMalloc((void**)&m->rowmap, G * MCTS_KMAX * sizeof(RowRec)));
@@ -144,6 +150,7 @@ int elfmcts_destroy(ElfMcts* m) {
   if (m->leaves) (void)hipFree(m->leaves);
   if (m->d4buf) (void)hipFree(m->d4buf);
   if (m->rng_pos_t) (void)hipFree(m->rng_pos_t);
+  if (m->pathbuf) (void)hipFree(m->pathbuf);
   if (m->sqrt_tab) (void)hipFree(m->sqrt_tab);
   if (m->rowmap) (void)hipFree(m->rowmap);
   delete m;
@@ -153,6 +160,7 @@ int elfmcts_destroy(ElfMcts* m) {
 int elfmcts_set_options(ElfMcts* m, const ElfMctsOptions* opt) {
   if (!m || !opt) return ELFGO_E_BADARG;
   if (opt->num_threads != m->NT) return ELFGO_E_BADARG;   // the D4 windows are laid out per search thread at creation
+  if ((int64_t)opt->num_threads * opt->num_rollouts_per_batch > m->KTA) return ELFGO_E_BADARG;   // ... and the path rows per leaf of a step
   return cfg_from(opt, &m->cfg);
 }
 int elfmcts_num_threads(const ElfMcts* m) { return m ? m->NT : ELFGO_E_BADARG; }
@@ -191,7 +199,8 @@ size_t elfmcts_tree_bytes_per_game(int board_size, int nodes_per_game) {
   record_bytes(board_size, &sm, &bg);
   const size_t Cs = nodes_per_game, Cb = big_records_for(nodes_per_game);
   // records + free stacks + parent array + keep bytes + the per-game leaf / row tables
-  return Cs * sm + Cb * bg + (Cs + Cb) * (sizeof(int) * 2 + 1) + sizeof(GameState) + MCTS_KMAX * (sizeof(LeafRec) + sizeof(RowRec));
+  return Cs * sm + Cb * bg + (Cs + Cb) * (sizeof(int) * 2 + 1) + sizeof(GameState) + MCTS_KMAX * (sizeof(LeafRec) + sizeof(RowRec)) +
+         (size_t)16 * MCTS_PATH_LV * 2 * sizeof(uint32_t);   // + the path rows of a 16-leaf step
 }
 /* average bytes per node id a game may hold (nodes_per_game of them): small record + its share of the big pool and of the id arrays */
 size_t elfmcts_node_bytes(const ElfMcts* m) {
@@ -241,6 +250,9 @@ int elfmcts_select(ElfMcts* m, const int32_t* board_ids, void* s_dst, int64_t st
   DISPATCH(m->eng, {
     hipLaunchKernelGGL((k_mcts_select<N, Pool<N>>), dim3(m->G), dim3(64), (size_t)20 * ((KT + 63) & ~63), (hipStream_t)stream, tree_of<N>(m),
                        pool_of<N>(m->eng), board_ids, m->cfg);
+    hipLaunchKernelGGL((k_mcts_leafstate<N, Pool<N>>), dim3(m->G * KT), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), pool_of<N>(m->eng),
+                       board_ids, KT, m->cfg);
+    hipLaunchKernelGGL(k_mcts_leafindex<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), m->cfg);
     hipLaunchKernelGGL(k_mcts_rowbase<N>, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree_of<N>(m), counts);
     hipLaunchKernelGGL(k_mcts_features<N>, dim3(m->G * KT), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), KT, s_dst, stride_elems,
                        m->feat_fmt, m->rowmap);

@@ -7,6 +7,7 @@
 #include "record_host.h"
 #include "host_workers.h"
 
+#include <atomic>
 #include <math.h>
 #include <string.h>
 
@@ -675,20 +676,28 @@ int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t
     for (const auto& b : q->qs) if (b.size() < q->queue_min_size) return ELFGO_E_BADARG;
     q->min_size_satisfied = true;
   }
-  bool any = false;
-  for (const auto& b : q->qs) for (const auto& r : b) any = any || r.num_moves > num_future_actions - 1;
+  bool any = false;   // a record long enough, in a queue the sampler accepts (Sampler::sample refuses queues below queue_min_size)
+  for (const auto& b : q->qs)
+    if (b.size() >= q->queue_min_size)
+      for (const auto& r : b) any = any || r.num_moves > num_future_actions - 1;
   if (!any) return ELFGO_E_BADARG;
   const float kSafeMargin = 0.45;
   const int kNumState = 64;
   // The acts go round the game threads; every thread draws from its own generator and only READS the queues, so the acts of
   // different threads are independent of each other: thread tt's acts (in their order) are one unit of work for the host pool.
   const int64_t T = (int64_t)q->thread_rng.size(), first = q->next_act;
+  std::atomic<bool> stuck{false};
   auto acts_of_thread = [&](size_t tt) {
     std::mt19937& rng = q->thread_rng[tt];
     for (int64_t a = (((int64_t)tt - first) % T + T) % T; a < num_acts; a += T) {
       for (int i = 0; i < kNumState; ++i) {
         const size_t o = (size_t)a * kNumState + i;
+        // The reference's game thread retries for ever (it waits for data); a synchronous call must come back: the eligibility of
+        // some record was checked above, so a draw that has not found one after 2^20 tries means the queues changed under it
+        // (or an eligible record sits in a queue that fell below queue_min_size): the call fails instead of hanging the host pool.
+        int tries = 0;
         while (true) {
+          if (++tries > (1 << 20)) { stuck.store(true); slot[o] = 0; move_to[o] = 0; break; }
           const int even = q->parity_sizes[0], odd = q->parity_sizes[1];
           float even_ratio = static_cast<float>(even) / (even + odd + 1e-6);
           even_ratio = std::max(even_ratio, kSafeMargin);
@@ -713,7 +722,7 @@ int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t
   if (nt < 2 || num_acts < 8) { for (int64_t tt = 0; tt < T; ++tt) acts_of_thread((size_t)tt); }
   else HostWorkers::get().run((size_t)T, nt, acts_of_thread);
   q->next_act += num_acts;
-  return 0;
+  return stuck.load() ? ELFGO_E_BADARG : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

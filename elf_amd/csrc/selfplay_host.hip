@@ -115,6 +115,7 @@ struct SpPool {              // one MCTSGoAI role: its tree pool and options
 };
 
 struct ElfSelfPlay {
+  int64_t ts_deferred = 0;               // requests whose TSOptions could not be applied because other games were still playing (sp_poll_requests)
   ElfSpOptions opt;
   ElfGoEngine* eng = nullptr;
   SpPool pool[2];
@@ -436,7 +437,16 @@ static int sp_poll_requests(ElfSelfPlay* sp) {
       // in the middle of play under the old options -- then every playing game is idle at the barrier and holds no tree.
       bool playing_on = false;
       for (const SpGame& gm : sp->games) playing_on = playing_on || gm.phase == PH_PLAY;
-      if (sp->cur_n_restart > 0 && !playing_on && !sp_ts_pool_equal(sp->cur.ts, sp_ts_of(sp->opt))) SPCHK(sp_apply_ts(sp, sp->cur.ts));
+      const bool ts_differ = !sp_ts_pool_equal(sp->cur.ts, sp_ts_of(sp->opt));
+      if (sp->cur_n_restart > 0 && !playing_on && ts_differ) SPCHK(sp_apply_ts(sp, sp->cur.ts));
+      else if (sp->cur_n_restart > 0 && playing_on && ts_differ) {
+        // some games restarted under a request whose search options differ from the pools', while others play on under the old
+        // ones: the pools belong to the whole context, so the restarted games search with the OLD options (the reference would build
+        // their AIs from the request's).  Not silent: counted (elfsp_ts_requests_deferred) and reported once per context.
+        if (sp->ts_deferred++ == 0)
+          fprintf(stderr, "elf_amd: a request's search options differ from the context's while games are still playing: the %d restarted "
+                          "game(s) keep the context's options until a request restarts every game\n", sp->cur_n_restart);
+      }
     }
     for (SpGame& gm : sp->games) if (gm.phase == PH_BARRIER) gm.phase = PH_PLAY;
     sp->cur_done = true;
@@ -877,6 +887,7 @@ int elfsp_destroy(ElfSelfPlay* sp) {
 }
 
 ElfGoEngine* elfsp_engine(ElfSelfPlay* sp) { return sp ? sp->eng : nullptr; }
+int64_t elfsp_ts_requests_deferred(const ElfSelfPlay* sp) { return sp ? sp->ts_deferred : ELFGO_E_BADARG; }
 ElfMcts* elfsp_mcts(ElfSelfPlay* sp) { return sp ? sp->pool[0].mcts : nullptr; }
 ElfMcts* elfsp_mcts_actor(ElfSelfPlay* sp, int actor) { return (sp && actor >= 0 && actor < 2) ? sp->pool[actor].mcts : nullptr; }
 int elfsp_max_rows(const ElfSelfPlay* sp) { return sp ? sp->G * sp->pool[0].KT : ELFGO_E_BADARG; }

@@ -26,6 +26,17 @@ struct ElfReplay {
   int keep_states = 1;                  // elftrain_set_keep_states
 };
 
+static bool host_is_pinned(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc memory: unknown to the runtime
+  return at.type == hipMemoryTypeHost;
+}
+
+__global__ void k_replay_put_scalars(ReplayStore st, int slot, int32_t nm, int32_t np, int32_t nv, float w, long long black_ver) {
+  st.num_moves[slot] = nm; st.num_pol[slot] = np; st.num_values[slot] = nv; st.winner[slot] = w; st.black_ver[slot] = black_ver;
+}
+
 extern "C" {
 
 int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_policies, uint32_t seed, ElfReplay** out) {
@@ -45,9 +56,8 @@ int elftrain_create(ElfGoEngine* e, int capacity, int max_moves, int with_polici
   A(st.values, cm * sizeof(float)); A(st.num_values, sizeof(int32_t) * capacity);
   if (with_policies) A(st.pol, cm * (size_t)r->P);
   st.nck = max_moves / CK_INTERVAL;
-  const size_t skw = e->n == 19 ? Geo<19>::SKW : Geo<9>::SKW;
-  if (st.nck > 0) A(st.ckpt, (size_t)capacity * st.nck * e->slot_bytes);
-  A(st.skrec, (size_t)capacity * (max_moves + 2) * skw * sizeof(u64));
+  // the checkpoint slots and the games' superko records (~160 KB per 19x19 record) belong to the checkpointed mode
+  // (elftrain_set_keep_states(0)): they are allocated when that mode is first switched on, not for callers that never use it
   A(r->d_dirty, sizeof(int32_t) * capacity);
 #undef A
   r->is_dirty.assign(capacity, 0);
@@ -73,7 +83,7 @@ int elftrain_max_moves(const ElfReplay* r) { return r ? r->st.max_moves : ELFGO_
 int elftrain_num_records(const ElfReplay* r) { return r ? (int)r->filled.size() : ELFGO_E_BADARG; }
 
 // Stream-ordered: the copies are queued on `stream` (host buffers may be reused on return: pageable memory is staged by the
-// runtime before the call returns), so a put that reuses the slot of an evicted record cannot overtake an extraction queued on
+// runtime before the call returns, and for page-locked buffers the call waits for its copies), so a put that reuses the slot of an evicted record cannot overtake an extraction queued on
 // the same stream that still reads it.
 int elftrain_put_async(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
                        const uint8_t* policies_host, int num_policies, const float* values_host, int num_values, void* stream) {
@@ -89,12 +99,13 @@ int elftrain_put_async(ElfReplay* r, int slot, const uint16_t* moves_host, int n
   if (num_policies) HIPCHK(hipMemcpyAsync(st.pol + base * r->P, policies_host, (size_t)num_policies * r->P, hipMemcpyHostToDevice, s));
   if (num_values) HIPCHK(hipMemcpyAsync(st.values + base, values_host, sizeof(float) * num_values, hipMemcpyHostToDevice, s));
   const float w = reward > 0 ? 1.0f : -1.0f;   // fromRecord, go_state_ext.h:250
-  const int32_t nm = num_moves, np = num_policies, nv = num_values;
-  HIPCHK(hipMemcpyAsync(st.num_moves + slot, &nm, 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(st.num_pol + slot, &np, 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(st.num_values + slot, &nv, 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(st.winner + slot, &w, 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(st.black_ver + slot, &black_ver, 8, hipMemcpyHostToDevice, s));
+  // the record's scalars travel as kernel arguments (copied at launch), not as asynchronous copies from this function's stack
+  hipLaunchKernelGGL(k_replay_put_scalars, dim3(1), dim3(1), 0, s, st, slot, (int32_t)num_moves, (int32_t)num_policies, (int32_t)num_values, w,
+                     (long long)black_ver);
+  HIPCHK(hipGetLastError());
+  // "host buffers may be reused on return" holds for pageable memory (staged by the runtime before the copy call returns); a
+  // page-locked or registered buffer is read by the DMA engine later, so the call waits for its copies then
+  if (host_is_pinned(moves_host) || host_is_pinned(policies_host) || host_is_pinned(values_host)) HIPCHK(hipStreamSynchronize(s));
   r->h_num_moves[slot] = num_moves;
   if (!r->is_filled[slot]) { r->is_filled[slot] = 1; r->filled.push_back(slot); }
   if (!r->is_dirty[slot]) { r->is_dirty[slot] = 1; r->dirty.push_back(slot); }   // checkpoints: at the head of the next extraction
@@ -112,6 +123,23 @@ int elftrain_put(ElfReplay* r, int slot, const uint16_t* moves_host, int num_mov
 
 int elftrain_set_keep_states(ElfReplay* r, int on) {
   if (!r) return ELFGO_E_BADARG;
+  if (!on && !r->st.skrec) {
+    // first use of the checkpointed mode: the stores are allocated now; every record put so far is still on the dirty list (the
+    // checkpoint launch is skipped while keep_states is on), so the next extraction writes their checkpoints
+    DevGuard _dg(r->eng->device);
+    ReplayStore& st = r->st;
+    const size_t skw = r->eng->n == 19 ? Geo<19>::SKW : Geo<9>::SKW;
+    const size_t ck_bytes = (size_t)st.capacity * st.nck * r->eng->slot_bytes;
+    const size_t sk_bytes = (size_t)st.capacity * (st.max_moves + 2) * skw * sizeof(u64);
+    if (st.nck > 0) {
+      hipError_t e = hipMalloc((void**)&st.ckpt, ck_bytes);
+      if (e != hipSuccess) { st.ckpt = nullptr; return (int)e; }
+      HIPCHK(hipMemset(st.ckpt, 0, ck_bytes));
+    }
+    hipError_t e = hipMalloc((void**)&st.skrec, sk_bytes);
+    if (e != hipSuccess) { st.skrec = nullptr; if (st.ckpt) { (void)hipFree(st.ckpt); st.ckpt = nullptr; } return (int)e; }
+    HIPCHK(hipMemset(st.skrec, 0, sk_bytes));
+  }
   r->keep_states = on != 0;
   return 0;
 }
@@ -155,8 +183,9 @@ int elftrain_extract(ElfReplay* r, const int32_t* rec, const int32_t* move_to, c
   o.winner = b->winner; o.mcts_scores = b->mcts_scores; o.predicted_value = b->predicted_value;
   o.move_idx = b->move_idx; o.num_move = b->num_move; o.aug_code = b->aug_code; o.selfplay_ver = b->selfplay_ver;
   hipStream_t s = (hipStream_t)stream;
-  if (!r->dirty.empty()) {
+  if (!r->dirty.empty() && !r->keep_states) {
     // the records put since the last extraction get their checkpoints and superko records now, ahead of the samples that use them
+    // (with keep_states on nothing reads them: the slots stay on the dirty list for a later switch of the mode)
     const int nd = (int)r->dirty.size();
     HIPCHK(hipMemcpyAsync(r->d_dirty, r->dirty.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
     DISPATCH(r->eng, hipLaunchKernelGGL((k_replay_checkpoint<N, Pool<N>>), dim3((nd + REPLAY_WAVES_CK - 1) / REPLAY_WAVES_CK), dim3(64 * REPLAY_WAVES_CK), 0, s,

@@ -268,6 +268,11 @@ int elfsp_create(const ElfSpOptions* opt, int device, const uint64_t* zobrist_ho
 int elfsp_destroy(ElfSelfPlay* sp);
 ElfGoEngine* elfsp_engine(ElfSelfPlay* sp);
 ElfMcts* elfsp_mcts(ElfSelfPlay* sp);
+/* requests that restarted SOME games with search options (TSOptions) other than the context's while other games were still playing
+ * under the old ones: the tree pools belong to the whole context and are rebuilt only when no game is mid-play, so those restarted
+ * games kept the context's options (the reference would build their AIs from the request's, game_selfplay.cc:166-180).  0 in every
+ * flow where requests reach all games at a boundary (the reference's own server sends a request to all games of a client). */
+int64_t elfsp_ts_requests_deferred(const ElfSelfPlay* sp);
 int elfsp_max_rows(const ElfSelfPlay* sp);   /* num_games * num_threads * num_rollouts_per_batch */
 /* the same bound for one of the two AIs (the "actor_white" AI may have its own batch override) */
 int elfsp_max_rows_actor(const ElfSelfPlay* sp, int actor);

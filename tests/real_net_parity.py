@@ -3,7 +3,7 @@ elf::Context batcher + GoGameSelfPlay + MCTSGoAI + tree_search/*.h compiled in p
 net -- Model_PolicyValue 20 blocks x 256 channels, torch.manual_seed(0) default init, eval mode, fp32 -- on the same GPU, and
 root statistics are compared search by search: edge order, priors, visit counts, rewards, move played.
 
-TEST INFRASTRUCTURE (used by tests/test_gpu_mcts.py, bench.py's parity note and tools/gpu_r3_parity.sh); the product path does
+TEST INFRASTRUCTURE (used by tests/test_gpu_mcts.py, bench.py's parity note and tools/profile_all.sh); the product path does
 not import it.
 
 "The same net" is made a pure function of the feature row: rows are evaluated in fixed batches of 16 (one convolution

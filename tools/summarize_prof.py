@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Condense rocprofv3 CSVs of one tools/gpu_round.sh visit into a text summary (goes into profiles/)."""
+"""Condense rocprofv3 CSVs of one tools/profile_all.sh visit into a text summary (goes into profiles/)."""
 import csv
 import glob
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Refresh profiles/pmc_issue.json (instructions per unit of work of the LDS-resident kernels) from the PMC summaries of one
-tools/gpu_r4_pmc.sh visit.  usage: python tools/update_issue.py gpurun_out/<tag> <tag>
+tools/profile_all.sh visit.  usage: python tools/update_issue.py gpurun_out/<tag> <tag>
 Units per launch come from the bench line that ran under the same rocprofv3 pass (stats_<workload>.log)."""
 import json, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -49,7 +49,7 @@ for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>
                 "wave_wait_frac": (c["SQ_WAIT_ANY"][0] / c["SQ_WAVE_CYCLES"][0]) if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c else None,
                 "profile": "profiles/%s_%s_rocprofv3.txt" % (tag, profile),
                 "note": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS, mean over %d launches of the bench.py --workload %s run "
-                        "of tools/gpu_r4_pmc.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
+                        "of tools/profile_all.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
 sys.path.insert(0, root)
 from elf_amd._lib import KERNEL_SOURCES, kernel_source_hash   # noqa: E402
 res["_source"] = {"kernel_source_hash": kernel_source_hash(), "files": ["elf_amd/csrc/" + f for f in KERNEL_SOURCES], "visit": tag,

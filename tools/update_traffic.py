@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Refresh profiles/pmc_traffic.json from the PMC summaries of one tools/gpu_r4_pmc.sh visit.
+"""Refresh profiles/pmc_traffic.json from the PMC summaries of one `tools/profile_all.sh <tag> pmc stats` visit.
 usage: python tools/update_traffic.py gpurun_out/<tag> <tag>   (FETCH_SIZE doubled: MI355X_MICROARCH.md, gfx950 counts 128-B requests as 64 B)"""
 import json, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -24,14 +24,15 @@ for k, c in b.items():
 m = counters(os.path.join(out, "summary_mcts.txt"))
 per, n = {}, 0
 for k, c in m.items():
-    for name in ("k_mcts_select", "k_mcts_features", "k_mcts_expand", "k_mcts_backup"):
+    for name in ("k_mcts_select", "k_mcts_leafstate", "k_mcts_leafindex", "k_mcts_features", "k_mcts_expand", "k_mcts_backup"):
         if name in k:
             per[name] = hbm(c); n = c["FETCH_SIZE"][1]
 if per:
-    roll = 16384
+    # profile_all.sh profiles the search-only run at 4096 games in two groups: one launch of a per-game kernel covers 2048 games x 16
+    roll = int(os.environ.get("ELF_PMC_ROLLOUTS_PER_LAUNCH", "32768"))
     res["k_mcts_search<19>"] = {"hbm_bytes_per_rollout": sum(per.values()) / roll, "per_kernel_bytes_per_launch": per, "rollouts_per_launch": roll,
-                                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d steps of bench.py --workload mcts --net random --games 1024 "
-                                        "--rollouts 2048 (16384 rollouts per step); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_mcts_search_only_rocprofv3.txt" % (n, tag)}
+                                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over %d launches of bench.py --workload mcts --net random --games 4096 --groups 2 "
+                                        "--rollouts 2048 (32768 rollouts per launch of a 2048-game group); FETCH_SIZE doubled per MI355X_MICROARCH.md; source profiles/%s_mcts_search_only_rocprofv3.txt" % (n, tag)}
 t = os.path.join(out, "summary_train.txt")
 if os.path.exists(t):
     for k, c in counters(t).items():
