@@ -246,7 +246,7 @@ def cpu_baseline_mcts_stub(n, rollouts_per_batch):
                       "excluded), %.1f s" % (len(r["search"]), rollouts, rollouts_per_batch, cores, cores, dt)}
 
 
-def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=24.0):
+def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=18.0):
     """SURVEY.md 8d / BASELINE.md: the reference stack (its TreeSearchT + batcher, oracle/_ref/libelfsp) driving the SAME
     PyTorch-ROCm net through its batch interface (`refsp_net_fn` plays GCWrapper's part: pinned-host rows -> GPU -> net -> host),
     mcts_threads = 2, batchsize = 16 as in start_selfplay.sh, game threads sized to the host cores.  Bounded sample."""
