@@ -1522,7 +1522,8 @@ def compact_line(res, full_path=None):
         line["metric"] = line["metric"][:100]
     c = _pick(cfg, ("games_per_gpu", "groups", "rollouts_per_step", "mean_depth", "board_size", "mcts_threads", "net_dtype", "net_rows_per_step",
                     "search_ms_per_step", "select_ms", "expand_backup_ms", "moves_in_window", "move_boundary_ms", "moves_per_sec",
-                    "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB"))
+                    "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB", "mean_forwarded_plies",
+                    "mean_replayed_plies", "samples_per_launch", "batch"))
     c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:180], **c}
     if cfg.get("per_rank_rollouts_per_sec") is not None and res.get("n_gpus", 1) > 1:
         c["per_rank"] = [_num(v) for v in cfg["per_rank_rollouts_per_sec"]]

@@ -20,7 +20,7 @@ from .selfplay import SelfPlay
 
 
 class PipelinedSelfPlay:
-    def __init__(self, groups=2, seed=0, game_idx_base=0, wait_rows=False, net_streams=1, **kw):
+    def __init__(self, groups=2, seed=0, game_idx_base=0, wait_rows=False, net_streams=1, search_priority=None, **kw):
         # the first group tells how many games a group holds (SelfPlay's own default when the caller does not say)
         self.groups = [SelfPlay(seed=seed, game_idx_base=game_idx_base, **kw)]
         ng = self.groups[0].num_games
@@ -28,7 +28,17 @@ class PipelinedSelfPlay:
         dev = self.groups[0].device
         self.device = dev
         self.wait_rows = bool(wait_rows)
-        self.search_streams = [torch.cuda.Stream(device=dev) for _ in range(groups)]
+        # search_priority: HIP stream priority of the groups' search streams (negative = higher).  The search kernels are short and
+        # latency-bound and share the GPU with the net's convolutions: at high priority their waves are dispatched ahead of the
+        # convolution's next workgroups instead of waiting for slots (ELF_SEARCH_STREAM_PRIORITY overrides; default: the runtime's)
+        import os
+        if search_priority is None and os.environ.get("ELF_SEARCH_STREAM_PRIORITY", "") != "":
+            search_priority = int(os.environ["ELF_SEARCH_STREAM_PRIORITY"])
+        self.search_priority = search_priority
+        if search_priority is None:
+            self.search_streams = [torch.cuda.Stream(device=dev) for _ in range(groups)]
+        else:
+            self.search_streams = [torch.cuda.Stream(device=dev, priority=int(search_priority)) for _ in range(groups)]
         # net_streams = 1: the groups' net calls queue on one stream, one after the other.  net_streams = groups: every group has its
         # own net stream, so the memory-bound tails of one group's call (conv epilogues, heads) can run beside the other group's
         # convolutions

@@ -15,7 +15,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = {"elf_amd.hip": ["k_playout", "k_extract_agz", "k_forward", "k_legal_mask"], "mcts_capi.hip": ["k_mcts_select", "k_mcts_expand", "k_mcts_backup", "k_mcts_features"],
+SRC = {"elf_amd.hip": ["k_playout", "k_extract_agz", "k_forward", "k_legal_mask"], "mcts_capi.hip": ["k_mcts_select", "k_mcts_leafstate", "k_mcts_expand", "k_mcts_backup", "k_mcts_features"],
        "train_capi.hip": ["k_replay_extract", "k_replay_checkpoint"]}
 PLAIN_CYC, SLOW_CYC = 4.0 / 1.82, 4.0      # SIMD cycles per wave64 instruction (4 SIMDs per CU): measured at 8 waves per SIMD
 
@@ -47,8 +47,22 @@ def main():
             asm = [f for f in os.listdir(td) if f.endswith("gfx950.s")][0]
             text = open(os.path.join(td, asm)).read()
             os.remove(os.path.join(td, asm))
-            for m in re.finditer(r"^(_Z[\w]+):\s*; @.*?\n(.*?)\n\s*\.amdhsa_kernel \1", text, re.S | re.M):
-                name, body = m.group(1), m.group(2)
+            # function bodies by label (a line scan: the text also holds out-of-line device functions, which have no kernel descriptor)
+            kernel_names = set(re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M))
+            bodies, cur = {}, None
+            for line in text.splitlines():
+                m = re.match(r"^(_Z\w+):", line)
+                if m:
+                    cur = m.group(1)
+                    bodies[cur] = []
+                    continue
+                if line.startswith(".Lfunc_end"):
+                    cur = None
+                    continue
+                if cur is not None:
+                    bodies[cur].append(line)
+            for name in sorted(kernel_names & set(bodies)):
+                body = "\n".join(bodies[name])
                 dem = subprocess.run(["c++filt", name], stdout=subprocess.PIPE, text=True).stdout.strip()
                 short = re.sub(r"^void (elfgo::)?", "", dem).split("(")[0]
                 if not any(short.startswith(k) for k in kernels):
