@@ -1617,7 +1617,9 @@ def main():
                     "search kernels, so 2048 games = two waves per SIMD per launch of a 1024-game group")
     ap.add_argument("--sub-games", type=int, default=256, help="games per GPU of the sub-results that search with the conv net (game phases, "
                     "client configuration): they measure moves/s, which does not depend on the games in flight")
-    ap.add_argument("--groups", type=int, default=2, help="lock-step game groups pipelined against the net (1 = serial)")
+    ap.add_argument("--groups", type=int, default=1, help="lock-step game groups pipelined against the net (1 = serial: select -> net -> expand; the "
+                    "net is 99 %% of a step, so pipelining buys < 0.5 %% of throughput, and with one group the HIP-event durations of the "
+                    "search kernels are kernel durations, not times shared with the convolutions of another group)")
     ap.add_argument("--net-streams", type=int, default=1, help="net streams of the pipeline (1 = the groups' net calls queue on one stream; "
                     "= --groups: every group's call on its own stream)")
     ap.add_argument("--rollouts", type=int, default=8192, help="TSOptions.num_rollouts_per_thread")
@@ -1697,12 +1699,21 @@ def main():
             so_games = max(128, min(args.search_only_games, fit))
             a2.net, a2.features, a2.games, a2.groups, a2.nodes_per_game, a2.rollouts, a2.pregrow = "random", "f16", so_games, 2, nodes, 2048, 0
             so = run_mcts(a2, rank, local_rank, world, dist, 32, 88, False)
+            # the same games as ONE group: no launch of another group shares the GPU, so the HIP-event durations are the kernels' own
+            # (the roofline of the kernels); the two-group run above is the throughput figure (its phases overlap)
+            a1 = copy.copy(a2)
+            a1.groups = 1
+            so1 = run_mcts(a1, rank, local_rank, world, dist, 32, 88, False)
             if rank == 0:
                 c = so["config"]
+                so["roofline_pipelined"] = so["roofline"]
+                so["roofline"] = dict(so1["roofline"], measured_on="the same games as one group (kernel durations without another group's "
+                                      "launches beside them): %.1f M rollouts/s, select %.3f ms + expand/backup %.3f ms per %d rollouts"
+                                      % (so1["value"] / 1e6, so1["config"]["select_ms"], so1["config"]["expand_backup_ms"], so1["config"]["rollouts_per_step"]))
                 res["search_only"] = {"metric": "mcts_rollouts_per_sec, search kernels only (random replies instead of the conv net)", "value": so["value"],
                                       "unit": "rollouts/s", "ms_per_step": so["ms_per_step"], "games_per_gpu": c["games_per_gpu"], "groups": c["groups"],
                                       "rollouts_per_step": c["rollouts_per_step"], "mean_depth": c["mean_depth"], "select_ms": c["select_ms"],
-                                      "expand_backup_ms": c["expand_backup_ms"], "roofline": so["roofline"], "nodes_per_game": nodes,
+                                      "expand_backup_ms": c["expand_backup_ms"], "roofline": so["roofline"], "roofline_pipelined": so["roofline_pipelined"], "nodes_per_game": nodes,
                                       "tree_pool_GB": so_games * elf_amd.tree_bytes_per_game(19, nodes) / 1e9, "games_that_fit_free_hbm": fit,
                                       "note": "same kernels, same tree shape (2048 rollouts per move on 8192-node pools, depth ~6.3) as the headline's "
                                               "search; the per-game kernels are latency chains, more resident waves per SIMD hide them"}
