@@ -749,7 +749,13 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     d = {k: st1[k] - st0[k] for k in ("moves", "games", "rollouts", "rows", "steps", "node_visits", "boundary_ns", "boundaries", "boundary_wait_ns")}
     my_rows = d["rows"]
     sel_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_select])) / steps
-    exp_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_expand])) / steps
+    # expand + backup: the HIP events bracket end_step, which at a MOVE BOUNDARY also holds the boundary's host work and kernels
+    # (reported on their own as move_boundary_ms): those steps are left out of the kernels' average launch duration
+    exp_all = np.array([a.elapsed_time(b) for a, b in sp.t_expand], np.float64)
+    exp_med = float(np.median(exp_all)) if len(exp_all) else 0.0
+    exp_plain = exp_all[exp_all <= 3.0 * exp_med] if len(exp_all) else exp_all
+    exp_ms = float(exp_plain.mean()) * (len(exp_all) / max(steps, 1)) if len(exp_plain) else 0.0
+    exp_ms_with_boundaries = float(exp_all.sum()) / steps if len(exp_all) else 0.0
     net_ms = float(np.mean([a.elapsed_time(b) for a, b in sp.t_net])) if sp.t_net else 0.0   # per net call (one group)
     dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
     per_rank = gather_per_rank(dist, dev, my_rollouts / dt, world)
@@ -798,6 +804,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                                              "oracle/mcts_oracle.cc, not against the reference" % T),
                    "rollouts_per_step": G * K * T, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
+                   "expand_backup_ms_incl_move_boundaries": exp_ms_with_boundaries, "end_step_events_with_a_boundary": int(len(exp_all) - len(exp_plain)),
                    "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups, "pregrow_steps": pregrow,
                    "host_wait_per_step": bool(args.wait_rows),
                    "mean_depth": depth, "moves_in_window": d["moves"], "games_finished_in_window": d["games"],
@@ -1520,8 +1527,8 @@ def compact_line(res, full_path=None):
                        "dtype", "data"), 7)
     if isinstance(line.get("metric"), str):
         line["metric"] = line["metric"][:100]
-    c = _pick(cfg, ("games_per_gpu", "groups", "rollouts_per_step", "mean_depth", "board_size", "mcts_threads", "net_dtype", "net_rows_per_step",
-                    "search_ms_per_step", "select_ms", "expand_backup_ms", "moves_in_window", "move_boundary_ms", "moves_per_sec",
+    c = _pick(cfg, ("games_per_gpu", "groups", "rollouts_per_step", "mean_depth", "board_size", "mcts_threads", "net_dtype",
+                    "select_ms", "expand_backup_ms", "moves_in_window", "move_boundary_ms",
                     "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB", "mean_forwarded_plies",
                     "mean_replayed_plies", "samples_per_launch", "batch"))
     c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:180], **c}
@@ -1539,14 +1546,14 @@ def compact_line(res, full_path=None):
     cb = res.get("cpu_baseline")
     if isinstance(cb, dict):
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
-        line["cpu_baseline"]["sample"] = str(cb.get("sample") or "")[:160]
+        line["cpu_baseline"]["sample"] = str(cb.get("sample") or "")[:110]
     else:
         line["cpu_baseline"] = None
     par = res.get("parity")
     if isinstance(par, dict):
         line["parity"] = _pick(par, ("checked", "mismatches", "what"))
         if isinstance(line["parity"].get("what"), str):
-            line["parity"]["what"] = line["parity"]["what"][:160]
+            line["parity"]["what"] = line["parity"]["what"][:90]
     elif "parity_checked_boards" in res:
         line["parity"] = {"checked": res.get("parity_checked_boards"), "mismatches": res.get("parity_mismatches")}
     sub = {k: _sub_summary(k, res[k]) for k in SUB_NAMES if k in res}
