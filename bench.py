@@ -5,17 +5,24 @@
 
 --gpus N > 1 without a launcher environment: the script re-executes itself under `python -m torch.distributed.run --nnodes=1
 --nproc-per-node N --master-addr 127.0.0.1`, one process per GPU (under the driver's own torchrun launch RANK / WORLD_SIZE are
-already set and are used as they are).  Rank 0 prints ONE JSON line.
+already set and are used as they are).
+
+OUTPUT: rank 0 prints ONE compact strict-JSON line (< 4 KB, the last line of stdout): the contract keys, `roofline` and
+`cpu_baseline` of the headline, a parity count, a few numbers per sub-result (compact_line()).  The FULL report -- every sub-result
+with its notes, sweeps and per-phase detail -- is written to bench_full.json next to this file (and under gpurun_out/ where that
+exists; ELF_BENCH_FULL names another path); the line's "full_report" says where.
 
 Default workload = BASELINE.json configs[2], the configuration the headline metric is quoted on: MCTS self-play, 16 rollouts per
 batch per game, 8192 rollouts per move, puct 1.5, virtual loss 1, Dirichlet 0.25/0.03, random-init 20-block/256-channel
-policy/value net on PyTorch-ROCm (fp16, channels_last), G games per GPU in lock-step groups pipelined against the net.  One
-"step" = one batch of the reference's batch interface for every game: G*16 rollouts (select -> leaf features -> net -> expand ->
-backup).  value = rollouts/s summed over ranks.  The trees are grown in an UNTIMED prologue (cheap pseudo-random replies instead
-of the conv net) to the point where the timed steps run at the depth of a search in progress and CROSS A MOVE BOUNDARY (root
-statistics down, move choice, forward, treeAdvance, Dirichlet draws, next search).
+policy/value net on PyTorch-ROCm (fp16, channels_last, called in 2048-row slices), 2048 games per GPU stepped together as one
+group (node pools of 1.5 x rollouts ids per game = 167 GB; --groups 2 pipelines two half-size groups against the net).  One
+"step" = one batch of the reference's batch interface for every game: G*16 rollouts (select -> leaf states -> leaf features -> net
+-> expand -> backup).  value = rollouts/s summed over ranks.  The trees are grown in an UNTIMED prologue (cheap pseudo-random replies
+instead of the conv net) to the point where the timed steps run at the depth of a search in progress and CROSS A MOVE BOUNDARY
+(root statistics down, move choice, forward, treeAdvance, Dirichlet draws, next search).
 
-At N = 1 the same JSON line carries sub-results measured in the same run (each with its own roofline):
+At N = 1 the full report carries sub-results measured in the same run (each with its own roofline; the line has their numbers):
+  search_only     the search kernels without the conv net, as many games as the free HBM holds at 8192 ids per game (4096)
   board_step      configs[1]: 4096 boards 19x19 played to the end by the config-2 policy in one k_playout launch, EVERY final
                   (hash, ply, steps) compared with the reference (parity_checked_boards)
   board_step_9x9  configs[4]: 65 536 boards 9x9, same protocol, same check
@@ -23,8 +30,9 @@ At N = 1 the same JSON line carries sub-results measured in the same run (each w
   train_loader    SURVEY.md 8f-1 trainer input pipeline
   boundary        the pybind11 drop-in boundary (_elf / _elfgames_go): rollouts/s with the batch tensors in pinned host memory
                   (the reference's Allocator) and device-resident, serial wait()/step() loop
-  selfplay_games  whole self-play games per second on a SHORTENED configuration (few rollouts per move, move cutoff): the full
-                  game loop (moves, restarts, records) measured rather than estimated
+  selfplay_games  games/s of the headline configuration, DERIVED (measured moves/s by game phase / measured game length), beside a
+                  PLAYED data point at the headline's rollout count and the shortened configuration played end to end
+  client_config   the reference's start_client.sh search settings (8 search threads x 200 rollouts)
 Weak scaling: every rank owns independent games/boards, no data-path collective.
 """
 import argparse

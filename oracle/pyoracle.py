@@ -250,7 +250,8 @@ class RefSelfPlay:
 
     @staticmethod
     def path(n, turnstile=False, canonical_backup=False):
-        return os.path.join(HERE, "_ref", "libelfsp%d%s.so" % (n, "_ts" if turnstile else "_h2" if canonical_backup else ""))
+        sfx = "_tsh2" if (turnstile and canonical_backup) else "_ts" if turnstile else "_h2" if canonical_backup else ""
+        return os.path.join(HERE, "_ref", "libelfsp%d%s.so" % (n, sfx))
 
     @classmethod
     def available(cls, n, turnstile=False, canonical_backup=False):
@@ -261,7 +262,6 @@ class RefSelfPlay:
         turnstile switched on: the search threads of a game take turns in thread order (mcts_threads > 1 becomes deterministic)"""
         self.n = n
         self.na = n * n + 1
-        assert not (turnstile and canonical_backup)
         self.L = C.CDLL(self.path(n, turnstile, canonical_backup))
         self.L.refsp_run.restype = C.c_int
         self.turnstile = bool(turnstile)

@@ -84,14 +84,14 @@ def search_cfg(**over):
     return cfg
 
 
-def run_reference(memo, n, cfg, games, moves, canonical_backup=False):
+def run_reference(memo, n, cfg, games, moves, canonical_backup=False, turnstile=False):
     """the reference stack, one run per game (game g seeded seed + g, the rule of include/elf_amd.h) -> {g: [search tuples]}.
     canonical_backup=True: the build whose batch_rollouts backs the unique leaves of a batch up in first-occurrence order instead of
     heap-address order (oracle/Makefile, libelfsp*_h2.so: three lines of a build-time copy of tree_search.h) -- the order SURVEY.md H2
     asks the oracle to pin; the engine must equal THAT build in every bit."""
     from pyoracle import RefSelfPlay
     out = {}
-    R = RefSelfPlay(n, canonical_backup=canonical_backup)
+    R = RefSelfPlay(n, canonical_backup=canonical_backup, turnstile=turnstile)   # turnstile: mcts_threads > 1 under the forced schedule
     for g in range(games):
         c = dict(cfg)
         c.update(num_games=1, seed=cfg["seed"] + g, max_searches=moves)
@@ -178,16 +178,17 @@ def compare(ref, got, games, moves):
                 decision_diverged=diverged, max_reward_ulps=max_ulps, first_difference_per_game=per_game)
 
 
-def measure(n=19, games=8, moves=8, rollouts=512, num_block=20, dim=256, seed=1234, memo=None, canonical_backup=False):
+def measure(n=19, games=8, moves=8, rollouts=512, num_block=20, dim=256, seed=1234, memo=None, canonical_backup=False, threads=1):
     from pyoracle import RefSelfPlay
-    if not RefSelfPlay.available(n, canonical_backup=canonical_backup):
+    if not RefSelfPlay.available(n, canonical_backup=canonical_backup, turnstile=threads > 1):
         raise RuntimeError("oracle/_ref/libelfsp%d*.so is not built (make -C oracle ref, needs /root/reference)" % n)
     memo = memo or make_memo_net(n, num_block, dim)
-    cfg = search_cfg(rollouts_per_thread=rollouts, seed=seed)
-    ref = run_reference(memo, n, cfg, games, moves, canonical_backup=canonical_backup)
+    cfg = search_cfg(rollouts_per_thread=rollouts, seed=seed, mcts_threads=threads)
+    ref = run_reference(memo, n, cfg, games, moves, canonical_backup=canonical_backup, turnstile=threads > 1)
     got, engine_misses = run_engine(memo, n, cfg, games, moves)
     res = compare(ref, got, games, moves)
-    res.update(reference_build="canonical backup order (libelfsp*_h2.so)" if canonical_backup else "stock (heap-address backup order)", rollouts=rollouts, net="PolicyValueNet %dx%d fp32 torch.manual_seed(0) eval" % (num_block, dim), seed=seed,
+    res.update(reference_build=("canonical backup order" if canonical_backup else "stock (heap-address backup order)") +
+               (", turnstile schedule of %d search threads" % threads if threads > 1 else ""), mcts_threads=threads, rollouts=rollouts, net="PolicyValueNet %dx%d fp32 torch.manual_seed(0) eval" % (num_block, dim), seed=seed,
                net_rows=memo.rows, net_distinct_positions=len(memo.cache), engine_rows_the_reference_never_asked=engine_misses)
     return res
 
@@ -204,9 +205,10 @@ if __name__ == "__main__":
     ap.add_argument("--board", type=int, default=19)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--out", default="")
+    ap.add_argument("--threads", type=int, default=1, help="mcts_threads (> 1: against the turnstile build of the reference)")
     ap.add_argument("--canonical", type=int, default=0, help="1: against the canonical-backup-order build of the reference (0 ulps expected)")
     a = ap.parse_args()
-    r = measure(a.board, a.games, a.moves, a.rollouts, a.blocks, a.dim, a.seed, canonical_backup=bool(a.canonical))
+    r = measure(a.board, a.games, a.moves, a.rollouts, a.blocks, a.dim, a.seed, canonical_backup=bool(a.canonical), threads=a.threads)
     txt = json.dumps(r, default=lambda o: o.item() if hasattr(o, "item") else str(o))
     print(txt)
     if a.out:
