@@ -415,6 +415,25 @@ def test_config3_real_net_against_the_real_reference_stack(elf):
             assert ref[0][0]["total_visits"] == 8176
 
 
+def test_search_threads_with_the_real_net_against_the_turnstile_reference(elf):
+    """mcts_threads = 2 with the benchmark's own 20 x 256 fp32 net: the real reference under the turnstile schedule AND the canonical
+    backup order (oracle/Makefile, libelfsp19_tsh2.so: both build-time patches) against the engine -- every statistic of 4 searches at
+    2 x 128 rollouts bit for bit, reward sums included (un-quantised values: the order of every fp32 sum matters here).
+    Measured on more searches: profiles/r05x_config3_real_net_parity_canon_T2.json / _T4.json (24 + 8 searches, all bit-equal)."""
+    import real_net_parity as rp
+    from pyoracle import RefSelfPlay
+    if not RefSelfPlay.available(19, turnstile=True, canonical_backup=True):
+        pytest.skip("oracle/_ref/libelfsp19_tsh2.so is not present: make -C oracle ref")
+    memo = rp.make_memo_net(19, 20, 256)
+    moves = 4
+    cfg = rp.search_cfg(rollouts_per_thread=128, seed=99, mcts_threads=2)
+    ref = rp.run_reference(memo, 19, cfg, 1, moves, canonical_backup=True, turnstile=True)
+    got, engine_only_rows = rp.run_engine(memo, 19, cfg, 1, moves)
+    res = rp.compare(ref, got, 1, moves)
+    assert engine_only_rows == 0
+    assert res["searches_compared"] == moves and res["bit_equal"] == moves and res["max_reward_ulps"] == 0, res
+
+
 # ---- round 3: requests, idle games, evaluation games out of step, uniform_random ------------------------------------------------
 def _live_per_game(n, cfg, G, per_game):
     """the reference stack running G game threads (game g seeded seed + g) -> {g: [search tuples]}"""
