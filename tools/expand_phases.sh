@@ -8,12 +8,12 @@ python - <<'PY'
 import ctypes as C, json, subprocess, sys
 sys.path.insert(0, ".")
 sys.argv = ["bench.py", "--workload", "mcts", "--net", "random", "--games", "1024", "--groups", "1", "--nodes-per-game", "8192",
-            "--rollouts", "2048", "--warmup", "24", "--steps", "32", "--no-cpu-baseline"]
+            "--rollouts", "2048", "--warmup", "24", "--steps", "32", "--no-cpu-baseline", "--no-sub", "--pregrow", "0", "--features", "f16"]
 import bench, io, contextlib
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()
-d = json.loads(buf.getvalue().strip().splitlines()[-1])
+d = json.load(open("bench_full.json"))     # the full report beside the compact line (selfplay_stats_window lives there)
 print("search-only (profile build)", d["value"], d["config"]["expand_backup_ms"])
 import elf_amd
 L = C.CDLL(elf_amd._lib.LIB_PATH)
