@@ -1506,6 +1506,8 @@ def _sub_summary(name, d):
                 out[key] = {"rows_per_sec": _num(d[key].get("rows_per_sec")), "GBps": _num(r.get("achieved")), "frac": _num(r.get("frac"), 4),
                             "traffic": _num(r.get("traffic")), "avg_kernel_ms": _num(d[key].get("avg_kernel_ms"))}
         return out
+    if name == "boundary":
+        return {k: _num((d.get(k) or {}).get("rollouts_per_sec")) for k in ("pinned_host", "device_resident") if isinstance(d.get(k), dict)}
     out = _pick(d, ("value", "unit", "ms_per_step"))
     if isinstance(out.get("unit"), str):
         out["unit"] = out["unit"][:24]

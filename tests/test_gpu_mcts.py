@@ -594,6 +594,42 @@ def test_async_request_changes_the_model_without_restarting_the_games(elf):
     sp.close()
 
 
+def test_request_options_that_cannot_be_applied_yet_are_counted_not_dropped_silently(elf):
+    """The tree pools belong to the whole context and are rebuilt for a request's TSOptions only when no game is mid-play.  A request
+    that RESTARTS some games (here: the one that was waiting, num_game_thread_used 1 -> 2) with other search options while another
+    game plays ON (an async request does not restart a playing game, setAsync :150-156) cannot be honoured for the restarted game:
+    it searches with the context's options.  That case is counted (elfsp_ts_requests_deferred) and logged, not silent; the games
+    keep running and the records of the restarted game echo the request."""
+    import torch
+    from elf_amd.client import TsOptions
+    n = 9
+    sp = elf.SelfPlay(board_size=n, num_games=2, mcts_rollout_per_thread=32, mcts_rollout_per_batch=16, seed=5, move_cutoff=10,
+                      keep_records=4, nodes_per_game=1024, model_ver=3)
+    L = elf.lib()
+    assert L.elfsp_ts_requests_deferred(sp._h) == 0
+
+    def step():
+        rows = sp.begin_step()
+        if rows:
+            pi, v = stub_net(n, sp.s[:rows].cpu().numpy(), 9, 0)
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        else:
+            sp.end_step(None, None)
+
+    sp.set_request(3, -1, num_game_thread_used=1)          # both games restart at the barrier; then game 1 waits, game 0 plays
+    while sp.progress()["searches"] < 7 or sp.progress()["waiting"] != 1:
+        step()
+    assert L.elfsp_ts_requests_deferred(sp._h) == 0
+    ts = TsOptions(0, 1, 48, 16, 0, 0, 1, 0, 0, 0.25, 0.03, 1, 1, 0, 0, 1.5, b"")     # 48 rollouts per move instead of 32
+    sp.set_request(4, -1, async_=True, num_game_thread_used=2, mcts_opt=ts)
+    before = sp.progress()["searches"]
+    while sp.progress()["waiting"] != 0 or sp.progress()["searches"] < before + 12:
+        step()
+    assert L.elfsp_ts_requests_deferred(sp._h) == 1          # game 1 restarted under the request while game 0 played on
+    assert sp.stats()["steps_per_move"] == 2                 # the context's options still rule: 32 rollouts = 2 steps of 16
+    sp.close()
+
+
 def test_pipelined_groups_with_requests_and_evaluation_games(elf):
     """PipelinedSelfPlay.step2: game groups pipelined against the net while requests arrive -- self-play, then an evaluation request
     with its own search options (second AI, noise off), then self-play with the next model.  Every group restarts at its own
