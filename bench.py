@@ -864,7 +864,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                                "traffic": None, "kernel": "PyTorch-ROCm net call (MIOpen CK implicit-GEMM 3x3 conv x41 + elfnet_bias_act_f16 epilogues)",
                                "avg_call_ms": net_ms, "rows_per_call": rows_call, "flops_per_position": flops_pos,
                                "note": "not a kernel of this library; dense fp16/bf16 MFMA peak from MI355X_MICROARCH.md"}
-    if net is not None and with_cpu and args.net_dtype == "fp16" and not args.no_sub:
+    if net is not None and with_cpu and args.net_dtype == "fp16" and not args.no_sub and args.net_variants:
         # the levers that stay inside "the net is a PyTorch-ROCm module", measured beside the headline: the same
         # call in bf16 and at twice the rows.  Reports only -- the headline stays fp16 (what the reference times), 2048 rows per call.
         try:
@@ -1646,6 +1646,8 @@ def main():
     ap.add_argument("--pregrow", type=int, default=-1, help="untimed tree-growing steps before the warm-up (-1: so that the move ends mid-window)")
     ap.add_argument("--net", choices=["resnet", "random", "null"], default="resnet")
     ap.add_argument("--no-fold-bn", action="store_true")
+    ap.add_argument("--net-variants", action="store_true", help="also time the net call in bf16 and at 4096 rows (reports only; a second MIOpen "
+                    "find of ~25 s; round 2-4 numbers: DESIGN.md section 3)")
     ap.add_argument("--net-blocks", type=int, default=20)
     ap.add_argument("--net-dim", type=int, default=256)
     ap.add_argument("--net-dtype", choices=["fp16", "bf16", "fp32"], default="fp16")
