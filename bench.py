@@ -756,7 +756,13 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     my_rollouts = G * K * T * steps
     d = {k: st1[k] - st0[k] for k in ("moves", "games", "rollouts", "rows", "steps", "node_visits", "boundary_ns", "boundaries", "boundary_wait_ns")}
     my_rows = d["rows"]
-    sel_ms = float(np.sum([a.elapsed_time(b) for a, b in sp.t_select])) / steps
+    # select chain: the HIP events bracket begin_step, which right after a MOVE BOUNDARY also holds the next search's set-up (root
+    # state, Dirichlet noise, the upload of the D4 draw windows): those steps are left out of the kernels' average as well
+    sel_all = np.array([a.elapsed_time(b) for a, b in sp.t_select], np.float64)
+    sel_med = float(np.median(sel_all)) if len(sel_all) else 0.0
+    sel_plain = sel_all[sel_all <= 3.0 * sel_med] if len(sel_all) else sel_all
+    sel_ms = float(sel_plain.mean()) * (len(sel_all) / max(steps, 1)) if len(sel_plain) else 0.0
+    sel_ms_with_boundaries = float(sel_all.sum()) / steps if len(sel_all) else 0.0
     # expand + backup: the HIP events bracket end_step, which at a MOVE BOUNDARY also holds the boundary's host work and kernels
     # (reported on their own as move_boundary_ms): those steps are left out of the kernels' average launch duration
     exp_all = np.array([a.elapsed_time(b) for a, b in sp.t_expand], np.float64)
@@ -813,6 +819,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "rollouts_per_step": G * K * T, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
                    "expand_backup_ms_incl_move_boundaries": exp_ms_with_boundaries, "end_step_events_with_a_boundary": int(len(exp_all) - len(exp_plain)),
+                   "select_ms_incl_move_boundaries": sel_ms_with_boundaries, "begin_step_events_with_a_boundary": int(len(sel_all) - len(sel_plain)),
                    "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups, "pregrow_steps": pregrow,
                    "host_wait_per_step": bool(args.wait_rows),
                    "mean_depth": depth, "moves_in_window": d["moves"], "games_finished_in_window": d["games"],
