@@ -59,6 +59,23 @@ def test_mcts_bad_arguments_are_status_codes(built):
     assert L.elftrain_put_async(None, 0, None, 0, ctypes.c_float(1.0), 0, None, 0, None, 0, None) == -1
 
 
+def test_tree_memory_accounting_and_the_round_5_entry_points(built):
+    """elfmcts_tree_bytes_per_game is host arithmetic: 5 888-B small records (19x19; 1 920 B at 9x9), nodes / 16 + 1 big records of
+    11 520 B (3 200 B), the id arrays, the leaf / row tables and the path rows -- what a caller sizes num_games against; the
+    per-thread draw accessors refuse null handles with a status code."""
+    import elf_amd
+    L = elf_amd.lib()
+    for n, small, big in ((19, 5888, 11520), (9, 1920, 3200)):
+        for nodes in (64, 8192, 33792):
+            b = elf_amd.tree_bytes_per_game(n, nodes)
+            records = nodes * small + (nodes // 16 + 1) * big
+            assert records < b < records + (nodes + nodes // 16 + 1) * 9 + (1 << 17), (n, nodes, b)
+    assert elf_amd.tree_bytes_per_game(19, 8192) * 4096 < 230e9          # the search-only line: 4096 games fit 288 GB
+    assert elf_amd.tree_bytes_per_game(13, 8192) == 0 and elf_amd.tree_bytes_per_game(19, 0) == 0
+    assert L.elfmcts_num_threads(None) == -1 and L.elfmcts_thread_draws(None, None, None) == -1
+    assert L.elfsp_ts_requests_deferred(None) == -1
+
+
 def test_selfplay_refuses_to_run_without_gpu(built):
     import pytest
     import torch
