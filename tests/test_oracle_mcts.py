@@ -109,6 +109,35 @@ def test_canonical_backup_build_reproduces_the_stock_fixtures(name):
     assert [s.move_played for s in r["search"]] == g["move_played"].tolist()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 14, 16])
+def test_turnstile_reference_equals_restatement_on_random_configurations(built, seed):
+    """Differential check of the mcts_threads > 1 semantics beyond the five committed fixtures: random search settings (threads,
+    rollouts per batch / per thread, virtual loss, puct, Dirichlet on / off, persistent tree, pass rule, prior ties), the REAL
+    reference under the turnstile schedule against the CPU restatement the engine is tested against live on the GPU
+    (tests/test_gpu_mcts.py::test_search_threads_equal_their_restatement)."""
+    n = 9
+    if not RefSelfPlay.available(n, turnstile=True):
+        pytest.skip("oracle/_ref/libelfsp9_ts.so not built (no /root/reference here)")
+    rng = np.random.default_rng(seed)
+    T = int(rng.choice([2, 3, 4, 8]))
+    K = int(rng.choice([1, 2, 4, 8, 16]))
+    kw = dict(MCTS_DEFAULTS)
+    kw.update(num_games=1, mcts_threads=T, rollouts_per_batch=K, batchsize=max(K, 8), rollouts_per_thread=K * int(rng.integers(2, 9)),
+              virtual_loss=int(rng.choice([0, 1, 5])), c_puct=float(np.float32(rng.choice([0.5, 0.85, 1.5]))),
+              root_epsilon=float(np.float32(rng.choice([0.0, 0.25]))), root_alpha=float(np.float32(0.03)),
+              persistent_tree=int(rng.integers(0, 2)), ply_pass_enabled=int(rng.choice([0, 3, 1000])), net_salt=int(rng.integers(1, 1000)),
+              net_tie_levels=int(rng.choice([0, 0, 4])), policy_distri_cutoff=int(rng.choice([0, 6])), seed=int(rng.integers(1, 10000)),
+              max_searches=10)
+    r = RefSelfPlay(n, turnstile=True).run(**kw)
+    p = PortSelfPlay(n).run(**kw)
+    assert len(r["search"]) == len(p["search"]) == 10, kw
+    for k in ("coord", "visits"):
+        assert np.array_equal(r[k], p[k]), (k, kw)
+    for k in ("prior", "reward"):
+        assert np.array_equal(r[k].view(np.uint32), p[k].view(np.uint32)), (k, kw)
+    assert [s.move_played for s in r["search"]] == [s.move_played for s in p["search"]], kw
+
+
 RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
                "records_19_cutoff", "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart", "records_9_req2_async",
                "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval", "records_9_sgf", "records_9_sgf_policy_only"]
