@@ -26,7 +26,6 @@ def mem_info(device=0):
     """(free, total) HBM bytes of a device (elfgo_mem_info)."""
     import ctypes as C
     fr, tot = C.c_size_t(0), C.c_size_t(0)
-    rc = lib().elfgo_mem_info(int(device), C.byref(fr), C.byref(tot))
-    if rc:
-        raise ElfGoError(rc)
+    from ._lib import check
+    check(lib().elfgo_mem_info(int(device), C.byref(fr), C.byref(tot)))
     return int(fr.value), int(tot.value)
