@@ -1668,7 +1668,7 @@ def main():
     ap.add_argument("--games-rollouts", type=int, default=32)
     ap.add_argument("--games-cutoff", type=int, default=40)
     ap.add_argument("--games-generations", type=int, default=2)
-    ap.add_argument("--search-only-games", type=int, default=4096, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
+    ap.add_argument("--search-only-games", type=int, default=4608, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
     ap.add_argument("--phase-steps", type=int, default=16, help="timed steps per game phase (plies 0/60/120/180) of the games/s leg; 0 = off")
     ap.add_argument("--played-games", type=int, default=64, help="cohort of the PLAYED data point at the headline's rollout count; 0 = off")
     ap.add_argument("--played-moves", type=int, default=2, help="whole moves the cohort plays end to end; 0 = off")
