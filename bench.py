@@ -22,7 +22,7 @@ instead of the conv net) to the point where the timed steps run at the depth of 
 (root statistics down, move choice, forward, treeAdvance, Dirichlet draws, next search).
 
 At N = 1 the full report carries sub-results measured in the same run (each with its own roofline; the line has their numbers):
-  search_only     the search kernels without the conv net, as many games as the free HBM holds at 8192 ids per game (4096)
+  search_only     the search kernels without the conv net, 4608 games at 8192 ids per game (250 GB; fewer where less HBM is free)
   board_step      configs[1]: 4096 boards 19x19 played to the end by the config-2 policy in one k_playout launch, EVERY final
                   (hash, ply, steps) compared with the reference (parity_checked_boards)
   board_step_9x9  configs[4]: 65 536 boards 9x9, same protocol, same check
@@ -1713,7 +1713,7 @@ def main():
 
     if sub and args.board_size == 19 and args.search_only_games > 0:
         # the search kernels without the conv net, with as many games in flight as the free HBM holds at 8192 node ids per game (up to
-        # --search-only-games): four waves per SIMD in the per-game kernels at 4096 games, two pipelined groups
+        # --search-only-games): 4.5 waves per SIMD in the per-game kernels at 4608 games, two pipelined groups
         try:
             import copy
             import elf_amd
