@@ -102,6 +102,21 @@ def test_the_line_of_a_full_default_run_fits_the_driver(tmp_path):
     assert len(line) < 4096 and strict_loads(line)["value"] == pytest.approx(full["value"], rel=1e-5)
 
 
+def test_the_line_of_this_rounds_full_report_fits_too():
+    """the same bound on the round-5 full report (more sub-results: search_only with two rooflines, leg timings, played data point)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05t_driver_command_bench_full.json")))
+    line = bench.compact_line(bench._clean(full), "bench_full.json")
+    assert len(line) < 4096
+    rep = strict_loads(line)
+    assert rep["steps"] == 20 and rep["warmup"] == 5 and rep["config"]["games_per_gpu"] == 2048 and rep["config"]["groups"] == 1
+    assert rep["roofline"]["bound"] == "hbm" and 0.2 < rep["roofline"]["frac"] < 1 and rep["roofline"]["traffic"] > 0
+    assert rep["cpu_baseline"]["kind"] == "reference" and rep["parity"]["mismatches"] == 0 and rep["parity"]["checked"] > 4000
+    assert rep["sub"]["search_only"]["value"] > 6e7 and rep["sub"]["boundary"]["pinned_host"] > 3e4
+    assert rep["sub"]["selfplay_games"]["derived"] is True and rep["sub"]["selfplay_games"]["played_moves_per_sec"] > 4
+
+
 def test_stub_line(tmp_path):
     env = dict(os.environ, ELF_BENCH_FULL=str(tmp_path / "full.json"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--steps", "3"], env=env, stdout=subprocess.PIPE,
