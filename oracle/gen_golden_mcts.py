@@ -80,7 +80,43 @@ CASES = {
     "mcts_9_T3_eval_two_ai": (9, dict(turnstile=1, mcts_threads=3, rollouts_per_thread=32, rollouts_per_batch=4, batchsize=8, max_searches=40,
                                       black_ver=5, white_ver=6, net_salt=75, white_net_salt=76, white_puct=0.9, policy_distri_cutoff=6,
                                       move_cutoff=30)),
+    # round 6: searches from DENSE 19x19 positions.  GameOptions.preload_sgf follows a ladder-suite game (game_selfplay.cc:202-219:
+    # the first preload_sgf_move_to moves are forwarded before the first search; :392-405: every searched move is then replaced by the
+    # SGF's next move, so the persistent tree advances along the game).  n_edges 160..300 instead of the 340..361 of every other 19x19
+    # fixture; ply_pass_enabled below the preload ply, so the pass edge, Tromp-Taylor leaves (go/mcts/mcts.h:232-242) and
+    # remove_pass_if_dangerous (:185-207) occur inside a 19x19 tree with dozens of groups, captures and kos.
+    "mcts_19_sgf_p60": (19, dict(preload_sgf=("406844.sgf", 60), rollouts_per_thread=512, max_searches=5, ply_pass_enabled=50, net_salt=81)),
+    "mcts_19_sgf_p120": (19, dict(preload_sgf=("406844.sgf", 120), rollouts_per_thread=512, max_searches=5, ply_pass_enabled=100, net_salt=82)),
+    "mcts_19_sgf_p180": (19, dict(preload_sgf=("406844.sgf", 180), rollouts_per_thread=512, max_searches=5, ply_pass_enabled=100, net_salt=83)),
+    "mcts_19_sgf_p195": (19, dict(preload_sgf=("406844.sgf", 195), rollouts_per_thread=512, max_searches=5, ply_pass_enabled=100, net_salt=84,
+                                  net_tie_levels=5)),
+    "mcts_19_sgf_b_p150": (19, dict(preload_sgf=("@longest", 150), rollouts_per_thread=512, max_searches=6, ply_pass_enabled=20, net_salt=85,
+                                    virtual_loss=5, c_puct=0.85, rollouts_per_batch=8, batchsize=8)),
+    "mcts_19_sgf_c_p100": (19, dict(preload_sgf=("@second", 100), rollouts_per_thread=512, max_searches=6, ply_pass_enabled=60, net_salt=86,
+                                    persistent_tree=0, root_epsilon=0.0)),
+    "mcts_19_sgf_T2_p140": (19, dict(turnstile=1, mcts_threads=2, preload_sgf=("406844.sgf", 140), rollouts_per_thread=256, max_searches=5,
+                                     ply_pass_enabled=100, net_salt=87)),
+    "mcts_19_sgf_r8192_p160": (19, dict(preload_sgf=("406844.sgf", 160), rollouts_per_thread=8192, max_searches=2, ply_pass_enabled=100,
+                                        net_salt=88)),
 }
+
+LADDER = "/root/reference/ladder_suite/ladder"
+
+
+def ladder_game(R, which):
+    """(path, moves) of a ladder-suite game through the reference's own Sgf loader: a file name, or the longest / second-longest
+    game of the suite whose every move is legal"""
+    from pyoracle import Ref
+    ref = Ref(19)
+    if not which.startswith("@"):
+        path = os.path.join(LADDER, which)
+        return path, ref.sgf_moves(path)[0]
+    g = np.load(os.path.join(OUT, "ladder_suite.npz"))
+    lens = np.diff(g["offsets"])
+    order = [i for i in np.argsort(-lens, kind="stable") if str(g["names"][i]) != "406844.sgf"]
+    i = order[0 if which == "@longest" else 1]
+    path = os.path.join(LADDER, str(g["names"][i]))
+    return path, ref.sgf_moves(path)[0]
 
 
 def run_case(name, path):
@@ -90,6 +126,12 @@ def run_case(name, path):
     cfg = dict(MCTS_DEFAULTS)
     cfg.update(kw)
     fixed_time = cfg.pop("fixed_time", None)
+    pre = cfg.pop("preload_sgf", None)
+    extra0 = {}
+    if pre is not None:
+        sgf_path, mv = ladder_game(R, pre[0])
+        R.set_preload(sgf_path, pre[1])
+        extra0 = dict(preload_moves=np.asarray(mv, np.uint16), preload_move_to=np.int32(pre[1]), preload_name=np.array(os.path.basename(sgf_path)))
     if fixed_time is None:
         r = R.run(**cfg)
         r2 = R.run(**cfg)
@@ -99,6 +141,8 @@ def run_case(name, path):
         R.set_time(fixed_time)
         r = R.run(**cfg)
         extra = dict(fixed_time=np.int64(fixed_time))
+    R.set_preload("", -1)
+    extra.update(extra0)
     S = r["search"]
     np.savez_compressed(
         path,

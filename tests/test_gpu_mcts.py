@@ -22,6 +22,8 @@ def run_case(elf_amd, name, max_searches=None):
     sp = sp_from_fixture_cfg(elf_amd, n, cfg, log_searches=m)
     if "fixed_time" in g.files:       # uniform_random: the value time(NULL) gave the reference's pick generator
         sp.set_pick_seed(int(g["fixed_time"]))
+    if "preload_moves" in g.files:    # GameOptions.preload_sgf / preload_sgf_move_to (game_selfplay.cc:202-219,392-405)
+        sp.preload(g["preload_moves"], int(g["preload_move_to"]))
 
     def check_trees(sp, rows_total):
         if sum(rows_total) < 4096:   # the node records' own invariants (scoring order, child back links, visit sums) after every step
@@ -102,6 +104,19 @@ def test_search_threads_match_the_turnstile_reference(elf, name):
     from its own generator (all seeded alike, game_selfplay.cc:45-47,77): one D4 window per thread on the device.  Covers a whole
     9x9 game (terminal leaves, passes), the client configuration (8 threads x 1 rollout per batch, virtual loss 5: revisits of leaves
     another thread has requested in the same round) and an evaluation game with two 3-thread AIs."""
+    run_case(elf, name)
+
+
+@pytest.mark.parametrize("name", ["mcts_19_sgf_p60", "mcts_19_sgf_p120", "mcts_19_sgf_p180", "mcts_19_sgf_p195", "mcts_19_sgf_b_p150",
+                                  "mcts_19_sgf_c_p100", "mcts_19_sgf_T2_p140", "mcts_19_sgf_r8192_p160"])
+def test_search_from_dense_sgf_positions_matches_reference(elf, name):
+    """north_star: "visit counts under a fixed RNG seed ... on the same SGF positions".  The REAL reference stack preloaded with
+    ladder-suite games (GameOptions.preload_sgf, game_selfplay.cc:202-219: 406844.sgf to plies 60 / 120 / 140 / 160 / 180 / 195, and the
+    two longest other games of the suite to plies 150 / 100) searches mid- and late-game 19x19 positions: 183..303 legal moves, dozens of
+    groups, captures and kos inside the tree, ply_pass_enabled below the preload ply so that the pass edge, Tromp-Taylor leaves
+    (go/mcts/mcts.h:232-242) and remove_pass_if_dangerous (:185-207) occur; every searched move is replaced by the SGF's next move
+    (:392-405), so the persistent tree advances along the game.  One case with 2 search threads (turnstile build), one with 8192
+    rollouts per move, one with the client's virtual loss 5 / puct 0.85 / 8 rollouts per batch, one with fresh trees."""
     run_case(elf, name)
 
 

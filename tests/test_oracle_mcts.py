@@ -20,6 +20,10 @@ CASES_R3 = ["mcts_9_eval_two_ai", "mcts_19_eval_swap", "mcts_9_pick_prior", "mct
 # round 5: mcts_threads > 1, fixtures from the turnstile build of the REAL reference (oracle/Makefile: libelfsp*_ts.so; four
 # elf_ts_hook() calls inserted into a build-time copy of batch_rollouts force one thread order per round)
 CASES_T = ["mcts_9_T2_r128", "mcts_9_T4_r256", "mcts_19_T2_r512", "mcts_19_T8_client", "mcts_9_T3_eval_two_ai"]
+# round 6: searches from dense 19x19 positions (GameOptions.preload_sgf follows ladder-suite games to plies 60..195: n_edges 183..303,
+# pass edges, Tromp-Taylor leaves inside the tree; one turnstile T = 2 case, one 8192-rollout case)
+CASES_SGF = ["mcts_19_sgf_p60", "mcts_19_sgf_p120", "mcts_19_sgf_p180", "mcts_19_sgf_p195", "mcts_19_sgf_b_p150", "mcts_19_sgf_c_p100",
+             "mcts_19_sgf_T2_p140", "mcts_19_sgf_r8192_p160"]
 
 
 @pytest.mark.parametrize("n", [19, 9])
@@ -35,7 +39,7 @@ def test_stub_net_is_a_quantised_distribution(built, n):
     assert len(np.unique(pit[0])) <= 3   # forced equal priors
 
 
-@pytest.mark.parametrize("name", CASES + CASES_T)
+@pytest.mark.parametrize("name", CASES + CASES_T + CASES_SGF)
 def test_fixture_invariants(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
@@ -143,7 +147,7 @@ RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "rec
                "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval", "records_9_sgf", "records_9_sgf_policy_only"]
 
 
-@pytest.mark.parametrize("name", CASES + CASES_R3 + CASES_T + RECORD_RUNS)
+@pytest.mark.parametrize("name", CASES + CASES_R3 + CASES_T + CASES_SGF + RECORD_RUNS)
 def test_restatement_matches_reference_fixture(built, name):
     """oracle/mcts_oracle.cc (the CPU restatement of MCTSActor, the tree search and the self-play loop over go_oracle.c) replays
     the fixture's configuration and must give what the REAL reference gave: every search's root edges in iteration order,
@@ -156,7 +160,7 @@ def test_restatement_matches_reference_fixture(built, name):
           "req2_root_epsilon", "req2_root_alpha")
     kw = {k: (float(np.float32(v)) if k in fl else int(v)) for k, v in cfg.items()}
     m = len(g["move_played"])
-    if name == "mcts_19_r8192":
+    if name in ("mcts_19_r8192", "mcts_19_sgf_r8192_p160"):
         m = 1                       # 8192 rollouts per search: one search keeps the CPU suite short
     kw["max_searches"] = m
     P = PortSelfPlay(n)
