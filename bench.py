@@ -279,7 +279,7 @@ def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=
     rollouts = 256
     # "num_games tuned to saturate host cores" -- swept, the best setting reported (one game thread + two search threads
     # per game; start_client.sh:21 runs 32)
-    settings = [g for g in (32, 64, 128) if g == 32 or 3 * g <= 2 * host] or [max(1, min(host // 3, 32))]
+    settings = [g for g in (64, 128, 256) if 3 * g <= 4 * host] or [max(1, min(host // 3, 32))]
     sweep, best = [], None
     for games in settings:
         budget = budget_s / len(settings)
@@ -578,38 +578,46 @@ def run_feature(args, rank, local_rank, world, dist, steps, warmup):
 # ------------------------------------------------------------------------------------------------------------------- MCTS
 def mcts_parity_check(dev_index):
     """The headline's kernels against the REAL reference inside the bench run (checker only, outside every timed region): the searches of
-    the reference fixture tests/golden/mcts_19_r128_fresh.npz (what the reference's self-play stack did with the oracle's stub net) are
-    replayed by this library on the GPU; edge order, visit counts, reward sums (bit patterns) and the move must be equal.
-    -> {"checked": statistics compared, "mismatches": n, "what": ...}"""
+    two reference fixtures (what the reference's self-play stack did with the oracle's stub net) are replayed by this library on the GPU
+    -- tests/golden/mcts_19_r128_fresh.npz (opening positions) and mcts_19_sgf_p180.npz (ladder-suite game 406844.sgf preloaded to ply
+    180: ~200 legal moves, pass edges, Tromp-Taylor leaves inside the tree); edge order, visit counts, reward sums (bit patterns) and
+    the move must be equal.  -> {"checked": statistics compared, "mismatches": n, "what": ...}"""
     try:
         po = _oracle()
         import elf_amd
-        g = np.load(os.path.join(ROOT, "tests", "golden", "mcts_19_r128_fresh.npz"))
-        cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
-        n_s = int(min(4, len(g["n_edges"])))
-        sp = elf_amd.SelfPlay(board_size=19, num_games=1, device=dev_index, mcts_rollout_per_thread=int(cfg["rollouts_per_thread"]),
-                              mcts_rollout_per_batch=int(cfg["rollouts_per_batch"]), mcts_puct=float(np.float32(cfg["c_puct"])),
-                              mcts_virtual_loss=int(cfg["virtual_loss"]), mcts_persistent_tree=bool(cfg["persistent_tree"]),
-                              mcts_epsilon=float(np.float32(cfg["root_epsilon"])), mcts_alpha=float(np.float32(cfg["root_alpha"])),
-                              mcts_unexplored_q_zero=bool(cfg["unexplored_q_zero"]), komi=float(np.float32(cfg["komi"])),
-                              ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
-                              seed=int(cfg["seed"]), log_searches=n_s)
-        while sp.stats()["logged"] < n_s:
-            rows = sp.begin_step()
-            pi, v = po.stub_net(19, sp.s[:rows].cpu().numpy(), int(cfg["net_salt"]), int(cfg["net_tie_levels"]))
-            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
-        rec, coord, visits, prior, reward = sp.search_log()
-        sp.close()
         checked = bad = 0
-        for i in range(n_s):
-            ne = int(g["n_edges"][i])
-            checked += 3 * ne + 1
-            bad += int(np.sum(coord[i, :ne] != g["coord"][i, :ne].astype(np.int32)))
-            bad += int(np.sum(visits[i, :ne] != g["visits"][i, :ne]))
-            bad += int(np.sum(reward[i, :ne].view(np.uint32) != g["reward"][i, :ne].view(np.uint32)))
-            bad += int(rec[i].move_played != int(g["move_played"][i]))
+        what = []
+        for name, n_max in (("mcts_19_r128_fresh", 4), ("mcts_19_sgf_p180", 2)):
+            g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+            cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+            n_s = int(min(n_max, len(g["n_edges"])))
+            sp = elf_amd.SelfPlay(board_size=19, num_games=1, device=dev_index, mcts_rollout_per_thread=int(cfg["rollouts_per_thread"]),
+                                  mcts_rollout_per_batch=int(cfg["rollouts_per_batch"]), mcts_puct=float(np.float32(cfg["c_puct"])),
+                                  mcts_virtual_loss=int(cfg["virtual_loss"]), mcts_persistent_tree=bool(cfg["persistent_tree"]),
+                                  mcts_epsilon=float(np.float32(cfg["root_epsilon"])), mcts_alpha=float(np.float32(cfg["root_alpha"])),
+                                  mcts_unexplored_q_zero=bool(cfg["unexplored_q_zero"]), komi=float(np.float32(cfg["komi"])),
+                                  ply_pass_enabled=int(cfg["ply_pass_enabled"]), policy_distri_cutoff=int(cfg["policy_distri_cutoff"]),
+                                  seed=int(cfg["seed"]), log_searches=n_s)
+            if "preload_moves" in g.files:     # GameOptions.preload_sgf / preload_sgf_move_to (game_selfplay.cc:202-219)
+                sp.preload(g["preload_moves"], int(g["preload_move_to"]))
+            while sp.stats()["logged"] < n_s:
+                rows = sp.begin_step()
+                pi, v = po.stub_net(19, sp.s[:rows].cpu().numpy(), int(cfg["net_salt"]), int(cfg["net_tie_levels"]))
+                sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+            rec, coord, visits, prior, reward = sp.search_log()
+            sp.close()
+            for i in range(n_s):
+                ne = int(g["n_edges"][i])
+                checked += 3 * ne + 1
+                bad += int(rec[i].n_edges != ne)
+                bad += int(np.sum(coord[i, :ne] != g["coord"][i, :ne].astype(np.int32)))
+                bad += int(np.sum(visits[i, :ne] != g["visits"][i, :ne]))
+                bad += int(np.sum(reward[i, :ne].view(np.uint32) != g["reward"][i, :ne].view(np.uint32)))
+                bad += int(rec[i].move_played != int(g["move_played"][i]))
+            what.append("%d of %s" % (n_s, name))
         return {"checked": checked, "mismatches": bad,
-                "what": "%d searches of the reference fixture mcts_19_r128_fresh replayed on the GPU: edge order, visit counts, reward bits, move" % n_s}
+                "what": "searches of reference fixtures replayed on the GPU (%s; the second from a dense ply-180 SGF position): edge order, "
+                        "visit counts, reward bits, move" % ", ".join(what)}
     except Exception as e:   # the checker is absent (no oracle library on this box): say so, never substitute
         return {"checked": 0, "mismatches": None, "what": "unavailable: %r" % (e,)}
 
@@ -814,8 +822,9 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "node_bytes": _ea.tree_bytes_per_game(n, npg) // npg, "tree_pool_GB": tree_gb,
                    "mcts_threads_note": None if T == 1 else ("mcts_threads = %d: the reference's search threads race on the shared tree (it is nondeterministic "
                                                              "there, SURVEY H8); this engine runs ONE deterministic interleaving of them -- thread t's K descents see "
-                                                             "the virtual losses of threads < t -- which is checked against the same interleaving restated in "
-                                                             "oracle/mcts_oracle.cc, not against the reference" % T),
+                                                             "the virtual losses of threads < t -- which is pinned on the REAL reference under that forced "
+                                                             "schedule (its turnstile build, oracle/Makefile libelfsp*_ts.so: fixtures mcts_*_T{2,3,4,8}*, "
+                                                             "mcts_19_sgf_T2_p140)" % T),
                    "rollouts_per_step": G * K * T, "net_rows_per_step": my_rows / steps,
                    "search_ms_per_step": sel_ms + exp_ms, "select_ms": sel_ms, "expand_backup_ms": exp_ms,
                    "expand_backup_ms_incl_move_boundaries": exp_ms_with_boundaries, "end_step_events_with_a_boundary": int(len(exp_all) - len(exp_plain)),

@@ -54,6 +54,9 @@ SIGNATURES = {
     "elfmcts_edge_stride": (_i, [_vp]),
     "elfmcts_node_bytes": (_sz, [_vp]),
     "elfmcts_tree_bytes_per_game": (_sz, [_i, _i]),
+    "elfmcts_tree_bytes_per_game2": (_sz, [_i, _i, _i, _i, _i]),
+    "elfmcts_pool_info": (_i, [_vp, _vp, _i]),
+    "elfmcts_count_live": (_i, [_vp, _vp]),
     "elfmcts_num_threads": (_i, [_vp]),
     "elfmcts_thread_draws": (_i, [_vp, _vp, _vp]),
     "elfmcts_clear": (_i, [_vp, _vp, _i, _vp]),

@@ -18,15 +18,20 @@
 // de-duplicated per thread (traj_counts is per batch_rollouts call), evaluation and backup follow in thread order.  That is
 // one of the interleavings the reference's racing threads can produce; T x num_rollouts_per_thread rollouts per move.
 //
-// HBM layout (sized for 288 GB; round 5: 5.9 KB instead of 12.5 KB per node).  Per game TWO pools of fixed-size node records:
+// HBM layout (sized for 288 GB; round 5: 5.9 KB instead of 12.5 KB per node; round 6: ONE pool per context, shared by its games --
+// the reference allocates nodes from the heap (tree_search_node.h:420-467) and a game whose kept subtree is large simply takes more; G fixed
+// worst-case pools made every game pay for the worst one).  Per context TWO pools of fixed-size node records:
 //   small  [64 B header][compact board 2624 B][NE x f32 prior][NE x u16 coord][NE x u16 orig][16 x 16 B touched-edge stats]   5888 B at 19x19
 //   big    the same with NE = 368 touched-edge entries                                                                        11520 B
 // Per edge a node keeps {prior, coord, orig} (8 B) for every legal move, and {reward, visits, virtual loss, child id} (16 B) only for
 // the edges that have been FOLLOWED at least once ("touched").  Every node but the root hangs on exactly one touched edge, so a tree of n
 // nodes has n - 1 touched edges in all: almost every node has none or a few.  A node is born in the small pool (room for 16 touched
 // edges); when its 17th edge is followed it MOVES to the big pool (k_mcts_select, promote: copy, patch the parent's child id and the
-// 16 children's parent ids).  A big node has >= 16 children that are nodes themselves, so Cb = Cs / 16 + 1 big records can never run
-// out before the small pool does.  Node id < Cs: small record id; else big record id - Cs.
+// 16 children's parent ids).  Promotion fires on the (TCS+1)-th followed edge, so a big node has >= TCS + 1 = 17 children that are nodes
+// themselves: Cb = Cs / TCS + 1 big records can never run out before the small pool does.  Node id < Cs: small record id; else big
+// record id - Cs.  Node ids are CONTEXT-wide: a free stack per class with an atomic top (a wave pops the ids of a whole step with one
+// atomic at the head of k_mcts_select into its game's stash -- off the descents' chain -- and the tree sweep of a move boundary
+// pushes dead ids back); per id a parent (-2 free, -1 root) and the owning game.
 // The board of a node is the slot without its Bloom words (CBoard, go_board.cuh): the filter a forward needs is rebuilt in LDS from the
 // game board's own Bloom words (one copy per launch) plus the hashes of the positions on the descent's path (the node header carries
 // its position's hash, so the descent collects them on its way down).
@@ -130,7 +135,7 @@ struct TreeCfg {          // TSOptions / SearchAlgoOptions (tree_search_options.
 
 struct GameState {        // 64 B per game
   int root;
-  int free_top;           // number of ids on the small free stack
+  int free_top;           // number of small ids in this game's stash (popped from the context's free stack, not yet used)
   int err;
   int rng_pos;            // D4 draws consumed from d4buf this move
   int n_unique;           // leaves of the current batch
@@ -138,9 +143,10 @@ struct GameState {        // 64 B per game
   int row_base;
   int rollouts_done;
   long long node_visits;  // sum over rollouts of the number of visited (selected-at) nodes: mean depth = node_visits / rollouts
-  int free_top_big;       // number of ids on the big free stack
+  int live;               // node ids this game holds (its tree; the stash is not counted)
   int promotions;         // small -> big moves so far (statistics)
-  int pad[4];
+  int live_peak;          // maximum of `live` since the last elfmcts_pool_info(reset) (statistics)
+  int pad[3];
 };
 static_assert(sizeof(GameState) == 64, "GameState must be 64 bytes");
 
@@ -158,15 +164,27 @@ constexpr int MCTS_PATH_LV = 64;   // levels of a descent whose position hashes 
 
 struct RowRec { int game, node, d4, pad; };
 
+struct PoolTops {         // 64 B, one per context
+  int small;              // ids on the context's small free stack (entries [0, small) of gstack)
+  int big;                // ... big free stack
+  int err;                // MCTS_ERR_* raised by the context-wide kernels (sweep)
+  int pad[13];
+};
+
 template <int N>
 struct TreePool {
   using L = NodeL<N>;
-  char* small;            // [G][Cs] records of L::SMALL bytes
-  char* big;              // [G][Cb] records of L::BIG bytes
-  int* free_stack;        // [G][Cs] small record ids
-  int* free_big;          // [G][Cb] big record ids (node id - Cs)
-  int* parent_of;         // [G][C] dense copy of NodeHdr.parent for the tree sweeps: -2 free slot, -1 root, else parent id
-  unsigned char* keep;    // [G][C] scratch of treeAdvance (reachable from the next root)
+  char* small;            // [Cs] records of L::SMALL bytes, shared by the context's games
+  char* big;              // [Cb] records of L::BIG bytes
+  int* gstack;            // [Cs] free small record ids, [0, tops->small) valid
+  int* gstack_big;        // [Cb] free big record ids (node id - Cs)
+  PoolTops* tops;
+  int* free_stack;        // [G][SC] the games' stashes of small ids (GameState.free_top of them valid)
+  int* parent_of;         // [C] dense copy of NodeHdr.parent for the tree sweeps: -2 free slot, -1 root, else parent id
+  int* owner;             // [C] game that holds the id (valid while parent_of != -2)
+  unsigned char* keep;    // [C] scratch of treeAdvance (reachable from the next root)
+  int* adv;               // [G] scratch of treeAdvance / clear: -2 game untouched, -1 free everything + fresh root, else id of the next root
+  int* live_tmp;          // [G] scratch of treeAdvance: nodes kept
   GameState* gs;          // [G]
   LeafRec* leaves;        // [G][MCTS_KMAX]
   unsigned char* d4buf;   // [G][NT][W / NT]  pre-drawn rng() % 8 of each search thread's MCTSActor mt19937 (go/mcts/mcts.h:175-183)
@@ -177,22 +195,21 @@ struct TreePool {
   const unsigned char* mask;   // [G] or nullptr (every game GM_SEARCH): which games the per-game launches act on (GM_*)
   const long long* req_ver;    // [G] or nullptr (TreeCfg.required_version for every game): MCTSActorParams.required_version per game
   int sqrt_n;
-  int Cs, Cb, C;          // small records, big records, node ids (Cs + Cb) per game
+  int Cs, Cb, C;          // small records, big records, node ids (Cs + Cb) of the CONTEXT
+  int SC;                 // stash capacity per game (2 x KTA: a step's ids + the small records its promotions return)
   int W, G;
   int NT;                 // search threads the D4 windows were laid out for (TSOptions.num_threads when the pool was created)
   __device__ __forceinline__ int game_mode(int g) const { return mask ? (int)mask[g] : (int)GM_SEARCH; }
-  __device__ __forceinline__ char* small_of(int g) const { return small + (size_t)g * Cs * L::SMALL; }
-  __device__ __forceinline__ char* big_of(int g) const { return big + (size_t)g * Cb * L::BIG; }
 };
 
-// the records of one game
+// the records of the context (node ids are context-wide; `g` is kept in the signature for the call sites' sake)
 template <int N>
 struct GameNodes {
   using L = NodeL<N>;
   char* sm;
   char* bg;
   int Cs;
-  __device__ __forceinline__ GameNodes(const TreePool<N>& tp, int g) : sm(tp.small_of(g)), bg(tp.big_of(g)), Cs(tp.Cs) {}
+  __device__ __forceinline__ GameNodes(const TreePool<N>& tp, int) : sm(tp.small), bg(tp.big), Cs(tp.Cs) {}
   __device__ __forceinline__ bool is_big(int id) const { return id >= Cs; }
   __device__ __forceinline__ NodeRef<N> operator[](int id) const {
     return NodeRef<N>{id < Cs ? sm + (size_t)id * L::SMALL : bg + (size_t)(id - Cs) * L::BIG};
@@ -273,7 +290,34 @@ __device__ __forceinline__ void node_init(const TreePool<N>& tp, int g, int id, 
     else if (lane == 5 || lane == 6) v = __float_as_int(parent_q);   // NodeT ctor: unsignedMeanQ_ = unsignedParentQ_ (:99-103)
     reinterpret_cast<int*>(&nd.h())[lane] = v;
   }
-  if (lane == 0) tp.parent_of[(size_t)g * tp.C + id] = parent;
+  if (lane == 0) { tp.parent_of[id] = parent; tp.owner[id] = g; }
+}
+
+// Pops up to `want` ids from the context's small free stack into game g's stash (wave-uniform; one atomic).  Only pops run concurrently
+// (pushes happen in the sweep kernels of a move boundary, ordered by the stream), so a pop that overshoots an almost empty stack gives
+// the shortfall back and takes what was there.  Returns the new stash count.
+template <int N>
+__device__ __forceinline__ int stash_refill(const TreePool<N>& tp, int g, int have, int want, int lane) {
+  int* fs = tp.free_stack + (size_t)g * tp.SC;
+  int old = 0;
+  if (lane == 0) old = atomicSub(&tp.tops->small, want);
+  old = rfl(old);
+  const int lo = old - want > 0 ? old - want : 0;
+  const int got = old > lo ? old - lo : 0;
+  if (got < want && lane == 0) atomicAdd(&tp.tops->small, want - got);
+  for (int i = lane; i < got; i += 64) fs[have + i] = tp.gstack[lo + i];
+  return have + got;
+}
+// one big record id (or -1): promotions are rare, the atomic sits on their path only
+template <int N>
+__device__ __forceinline__ int pop_big(const TreePool<N>& tp, int lane) {
+  int id = -1;
+  if (lane == 0) {
+    const int old = atomicSub(&tp.tops->big, 1);
+    if (old > 0) id = tp.Cs + tp.gstack_big[old - 1];
+    else atomicAdd(&tp.tops->big, 1);
+  }
+  return rfl(id);
 }
 
 // wave-wide maximum of a u32 on the DPP network (no LDS crossbar round trips): butterflies inside each 16-lane row
@@ -314,32 +358,31 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
   return ((u64)hi << 32) | lo;
 }
 
-// SearchTreeT::clear (:411-416) for game g: every id free, then allocateRoot -> addNode(0.0)
+// Every id of the context free (creation): the stacks hand out 0, 1, 2, ...
 template <int N>
-__device__ __forceinline__ void tree_clear(const TreePool<N>& tp, int g, int lane) {
-  int* fs = tp.free_stack + (size_t)g * tp.Cs;
-  int* fb = tp.free_big + (size_t)g * tp.Cb;
-  int* po = tp.parent_of + (size_t)g * tp.C;
-  for (int i = lane; i < tp.Cs; i += 64) fs[i] = tp.Cs - 1 - i;   // pops hand out 0, 1, 2, ...
-  for (int i = lane; i < tp.Cb; i += 64) fb[i] = tp.Cb - 1 - i;
-  for (int i = lane; i < tp.C; i += 64) po[i] = -2;
-  mem_sync();
-  node_init(tp, g, 0, -1, -1, 0.0f, lane);
-  if (lane == 0) {
-    GameState& s = tp.gs[g];
-    s.root = 0; s.free_top = tp.Cs - 1; s.free_top_big = tp.Cb; s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0;
-    s.rollouts_done = 0;
-    for (int t = 0; t < tp.NT; ++t) tp.rng_pos_t[(size_t)g * tp.NT + t] = 0;
-    // node_visits / promotions are lifetime counters (statistics): not reset with the tree
-  }
+__global__ __launch_bounds__(256) void k_mcts_pool_init(TreePool<N> tp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < tp.Cs) tp.gstack[i] = tp.Cs - 1 - i;
+  if (i < tp.Cb) tp.gstack_big[i] = tp.Cb - 1 - i;
+  if (i < tp.C) { tp.parent_of[i] = -2; tp.owner[i] = -1; tp.keep[i] = 0; }
+  if (i < tp.G) { tp.adv[i] = -1; tp.live_tmp[i] = 0; }
+  if (i == 0) { tp.tops->small = tp.Cs; tp.tops->big = tp.Cb; tp.tops->err = 0; }
 }
 
-// games == nullptr: game blockIdx.x
+// SearchTreeT::clear (:411-416) for the listed games (games == nullptr: all n = G of them): adv = "free everything, fresh root"; the
+// sweep + re-root launches that follow (elfmcts_clear) do the work.  Search counters are reset here.
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_clear(TreePool<N> tp, const int32_t* games) {
-  tree_clear(tp, games ? games[blockIdx.x] : (int)blockIdx.x, (int)threadIdx.x);
+__global__ __launch_bounds__(256) void k_mcts_clear_mark(TreePool<N> tp, const int32_t* games, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int g = games ? games[i] : i;
+  tp.adv[g] = -1;
+  tp.live_tmp[g] = 0;
+  GameState& s = tp.gs[g];
+  s.err = 0; s.rng_pos = 0; s.n_unique = 0; s.n_nn = 0; s.row_base = 0; s.rollouts_done = 0;
+  for (int t = 0; t < tp.NT; ++t) tp.rng_pos_t[(size_t)g * tp.NT + t] = 0;
+  // node_visits / promotions are lifetime counters (statistics): not reset with the tree
 }
-
 // TreeSearchT::setRootNodeState (tree_search.h:478-493): give the root a copy of the game's state if it
 // has none; otherwise check hash equality (StateTrait::equals, go/mcts/ai.h:40-42).
 template <int N, class PoolT>
@@ -443,12 +486,11 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   unsigned long long sel_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sel_t = __builtin_amdgcn_s_memtime();
 #endif
   const GameNodes<N> nodes(tp, g);
-  int* fs = tp.free_stack + (size_t)g * tp.Cs;
-  int* fb = tp.free_big + (size_t)g * tp.Cb;
-  int* po = tp.parent_of + (size_t)g * tp.C;
+  int* fs = tp.free_stack + (size_t)g * tp.SC;
+  int* po = tp.parent_of;
   GameState& gs = tp.gs[g];
   int root = rfl(gs.root);
-  int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big), err = 0, promotions = 0;
+  int free_top = rfl(gs.free_top), err = 0, promotions = 0, created = 0;
   // The descent creates nodes (id, header, edge bookkeeping) but not their STATES: "allocateState" (tree_search.h:174-190: copy of the
   // parent's state + forward) of every new leaf, the terminal test and the D4 draws happen after this kernel, one wave per leaf
   // (k_mcts_leafstate, k_mcts_leafindex) -- a new leaf has no edges, so nothing in this step descends through it or needs its board.
@@ -461,6 +503,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   // GM_POLICY_ONLY = TreeSearchT::runPolicyOnly (tree_search.h:385-407): the root is evaluated if it has not been yet, nothing else
   const bool root_only = mode == GM_POLICY_ONLY;
   const int K = root_only ? 1 : cfg.rollouts_per_batch, KT = root_only ? 1 : K * cfg.num_threads;
+  // the ids this step can need (one per descent), taken from the context's free stack with ONE atomic, before the descents
+  if (!root_only && free_top < KT) { free_top = stash_refill(tp, g, free_top, KT - free_top, lane); mem_sync(); }
 
   for (int j = 0, jk = 0; j < KT; ++j, ++jk) {
     if (jk == K) jk = 0;
@@ -599,9 +643,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         if (nt >= nodes.cap(node)) {
           // ---- the 17th followed edge of a small record: the node MOVES to the big pool.  Copy the record, tell the parent (its
           // child id) and the 16 children (their parent id), return the small record.  Cb = Cs / 16 + 1 big records cannot run out.
-          if (free_top_big <= 0) { err |= MCTS_ERR_POOL; --depth; break; }
-          const int bid = tp.Cs + rfl(fb[free_top_big - 1]);
-          --free_top_big;
+          const int bid = pop_big(tp, lane);
+          if (bid < 0) { err |= MCTS_ERR_POOL; --depth; break; }
           const NodeRef<N> dst = nodes[bid];
           promote_record<N>(nodes, nd, dst, po, bid);
           if (h.parent >= 0) {
@@ -609,7 +652,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           } else {
             root = bid;
           }
-          if (lane == 0) { po[bid] = h.parent; po[node] = -2; fs[free_top] = node; }
+          if (lane == 0) { po[bid] = h.parent; tp.owner[bid] = g; po[node] = -2; fs[free_top] = node; }
           ++free_top;
           ++promotions;
           node = bid;
@@ -618,6 +661,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         }
         child = rfl(fs[free_top - 1]);
         --free_top;
+        ++created;
         // the edge joins the orig-sorted prefix of the scoring order at position p: entries [p, best_pos) move up by one and
         // the child nodes of the moved FOLLOWED edges learn their new position
         int p = 0;
@@ -695,7 +739,8 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     lr.nn_index = 0; lr.depth = meta >> 20; lr.thread = (meta >> 8) & 0xFFF;
   }
   if (lane == 0) {
-    gs.root = root; gs.free_top = free_top; gs.free_top_big = free_top_big; gs.n_unique = n_unique; gs.n_nn = 0;
+    gs.root = root; gs.free_top = free_top; gs.n_unique = n_unique; gs.n_nn = 0;
+    if (created) { const int lv = gs.live + created; gs.live = lv; if (lv > gs.live_peak) gs.live_peak = lv; }
     gs.rollouts_done += KT;
     gs.node_visits += visited_nodes;
     if (promotions) gs.promotions += promotions;
@@ -769,6 +814,22 @@ __global__ __launch_bounds__(64) void k_mcts_leafstate(TreePool<N> tp, PoolT poo
   if (bd.terminated()) {                                 // MCTSActor::pre_evaluate :185-207
     kind = LK_TERMINAL;
     value = bd.evaluate(cfg.komi) > 0.0f ? 1.0f : -1.0f;
+  } else {
+    // What the expansion of this leaf will need from its BOARD (k_mcts_expand, after the net has answered) is computed here, where the
+    // position sits in LDS anyway: post_nn_result's pass rule (go/mcts/mcts.h:209-242: ply_pass_enabled, remove_pass_if_dangerous =
+    // Tromp-Taylor of this position) and the legal-move mask (s.checkMove x N*N, :308-309).  64 B parked at the head of the node's
+    // prior array (unused until the expansion writes the edges): legal words [0, R), word 7 = pass_enabled | flipQSign << 1.
+    bool pass_enabled = bd.ply >= cfg.ply_pass_enabled;
+    if (cfg.remove_pass_if_dangerous && pass_enabled && bd.lm0 != M_PASS) {   // :232-242
+      const bool black_win = bd.evaluate(cfg.komi) > 0.0f;
+      if ((black_win && bd.next_player == S_WHITE) || (!black_win && bd.next_player == S_BLACK)) pass_enabled = false;
+    }
+    u64 legal, cand;
+    bd.template legal_moves<false>(legal, cand);
+    u64* const park = reinterpret_cast<u64*>(nd.prior());
+    static_assert(GEO::R <= 7, "legal words + one flag word fit 64 B");
+    if (lane < GEO::R) park[lane] = legal;
+    else if (lane == 7) park[7] = (u64)(pass_enabled ? 1 : 0) | ((u64)(bd.next_player == S_WHITE ? 1 : 0) << 1);
   }
   if (lane == 0) { lr.kind = kind; lr.value = value; }
 }
@@ -885,13 +946,11 @@ struct ExpandLds {
   static constexpr int NA = N * N + 1;
   static constexpr int NE = NodeL<N>::NE;
   static constexpr int PP = Geo<N>::PP;
-  // Three consecutive lifetimes share one region, which is what sets the kernel's occupancy (6.1 KB instead of 11.4 KB per
-  // wave at 19x19: 26 instead of 14 resident waves per CU):
-  //   1. board      -- until legal_moves has produced the legal bitboard (registers -> legalw)
-  //   2. prob, key  -- the net's priors and coords in ACTION order: inputs of the register sort and of the exact std::sort replay
-  //   3. seq..sx    -- scratch of umap_order_wave, after the sorted candidates sit in sprob/skey
+  // Two consecutive lifetimes share one region (round 6: the board is not loaded here any more -- the legal mask and the pass rule
+  // arrive with the node, computed by k_mcts_leafstate):
+  //   1. prob, key  -- the net's priors and coords in ACTION order: inputs of the register sort and of the exact std::sort replay
+  //   2. seq..sx    -- scratch of umap_order_wave, after the sorted candidates sit in sprob/skey
   union {
-    Slot<N> board;
     struct {
       float prob[NE];   // candidate priors in action order
       u16 key[NE];      // candidate coords in action order
@@ -908,7 +967,7 @@ struct ExpandLds {
   u16 skey[NE];
   u64 legalw[8];        // legal-move bitboard words (D4-0 action order)
 };
-static_assert(sizeof(ExpandLds<19>) <= 6400, "expand LDS per wave");
+static_assert(sizeof(ExpandLds<19>) <= 5632, "expand LDS per wave");
 
 // inclusive prefix sum over the 64 lanes on the DPP network: Hillis-Steele inside each row of 16 (row_shr 1 / 2 / 4 / 8, zero fill),
 // then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  EXEC must be full.
@@ -1189,7 +1248,7 @@ __device__ unsigned long long g_expand_rowmax[65536];     // per block id: longe
 
 // 6 waves per SIMD: 80 VGPRs instead of 81 (the allocation granule is 8, so 81 meant 5 waves); the LDS region allows 26 per CU
 template <int N>
-__global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64* zob, const RowRec* rowmap, const float* __restrict__ pi,
+__global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const RowRec* rowmap, const float* __restrict__ pi,
                                                      int64_t pi_stride, const float* __restrict__ value, const int64_t* __restrict__ rv,
                                                      int n_rows_host, const int32_t* __restrict__ counts, TreeCfg cfg) {
   using G = Geo<N>;
@@ -1208,24 +1267,20 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
 #ifdef ELF_PROFILE_EXPAND
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
 #endif
-  Board<N> bd;
-  bd.init(&L.board, zob, nullptr);
-  bd.load(&nd.board());       // the compact board: no forward here, so the Bloom words of the LDS image are never looked at
-  EXP_PHASE(0);   // row map + board load
-  // ---- post_nn_result :209-230
-  bool pass_enabled = bd.ply >= cfg.ply_pass_enabled;
-  if (cfg.remove_pass_if_dangerous && pass_enabled && bd.lm0 != M_PASS) {   // :232-242
-    const bool black_win = bd.evaluate(cfg.komi) > 0.0f;
-    if ((black_win && bd.next_player == S_WHITE) || (!black_win && bd.next_player == S_BLACK)) pass_enabled = false;
-  }
-  u64 legal, cand;
-  bd.template legal_moves<false>(legal, cand);
+  // what the expansion needs from the leaf's BOARD was computed by k_mcts_leafstate while the position sat in LDS (the pass rule of
+  // post_nn_result :209-242 and the legal-move mask, s.checkMove :308-309): 64 B at the head of the node's prior array
+  const u64* const park = reinterpret_cast<const u64*>(nd.prior());
+  const u64 pw = lane < 8 ? park[lane] : 0ull;
+  const u32 pflags = (u32)__builtin_amdgcn_readlane((int)(u32)pw, 7);
+  const bool pass_enabled = (pflags & 1u) != 0;
+  const int flip = (int)((pflags >> 1) & 1u);
+  EXP_PHASE(0);   // row map + parked mask
   // ---- pi2response :256-332.  The reference sorts all N*N+1 (coord, prior) pairs by prior (descending) and then keeps
   // the valid ones in that order.  If no two VALID candidates share a prior the result is the unique descending order
   // of the valid ones: a register bitonic sort of 512 slots (8 per lane), invalid candidates keyed last.
-  EXP_PHASE(1);   // pass rule (Tromp-Taylor when enabled) + legal mask
+  EXP_PHASE(1);   // (round 5: pass rule + legal mask; now in k_mcts_leafstate)
   const float* prow = pi + (size_t)row * pi_stride;
-  if (lane < G::R) L.legalw[lane] = legal;
+  if (lane < G::R) L.legalw[lane] = pw;
   Board<N>::wsync();
   constexpr int SK = 8;   // 512 sort slots: element e = k*64 + lane
   u64 sx[SK];
@@ -1384,7 +1439,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const u64
     nh.n_touched = 0;
     nh.n_edges = n;
     nh.V = value[row];                                  // resp->value = reply.value :222
-    nh.flip = bd.next_player == S_WHITE;                // pre_evaluate :186
+    nh.flip = flip;                                     // pre_evaluate :186
     nh.status = NS_VISITED;
   }
   EXP_PHASE(7);   // edge records to HBM
@@ -1531,7 +1586,7 @@ __global__ __launch_bounds__(64) void k_mcts_dirichlet(TreePool<N> tp, const flo
 struct RootInfo {   // 32 B per game
   int n_edges, num_visits, status, root;
   float V;
-  int rng_pos, err, free_top;
+  int rng_pos, err, live;      // live: node ids the game's tree holds
 };
 
 // root edges in iteration order (MCTSResultT::addActions walks exactly this, tree_search_base.h:248-292)
@@ -1546,7 +1601,7 @@ __global__ __launch_bounds__(64) void k_mcts_root(TreePool<N> tp, RootInfo* info
   if (lane == 0) {
     RootInfo ri;
     ri.n_edges = n; ri.num_visits = r.h().num_visits; ri.status = r.h().status; ri.root = gs.root; ri.V = r.h().V;
-    ri.rng_pos = gs.rng_pos; ri.err = gs.err; ri.free_top = gs.free_top;
+    ri.rng_pos = gs.rng_pos; ri.err = gs.err | tp.tops->err; ri.live = gs.live;
     info[g] = ri;
   }
   // the arrays are in scoring order; the caller gets them in the map's iteration order (entry -> slot orig)
@@ -1578,17 +1633,21 @@ __global__ __launch_bounds__(64) void k_mcts_root(TreePool<N> tp, RootInfo* info
 // out[0] = number of violations, out[1..4] = code, game, node, position of one of them.
 template <int N>
 __global__ __launch_bounds__(64) void k_mcts_validate(TreePool<N> tp, int32_t* out) {
-  const int g = blockIdx.x, lane = threadIdx.x;
-  const GameNodes<N> nodes(tp, g);
-  const int* po = tp.parent_of + (size_t)g * tp.C;
-  auto fail = [&](int code, int node, int pos) {
-    if (atomicAdd(&out[0], 1) == 0) { out[1] = code; out[2] = g; out[3] = node; out[4] = pos; }
-  };
-  for (int id = blockIdx.y; id < tp.C; id += gridDim.y) {
+  const int lane = threadIdx.x;
+  const GameNodes<N> nodes(tp, 0);
+  const int* po = tp.parent_of;
+  for (int id = blockIdx.x; id < tp.C; id += gridDim.x) {
     if (po[id] == -2) continue;
+    const int g = tp.owner[id];
+    auto fail = [&](int code, int node, int pos) {
+      if (atomicAdd(&out[0], 1) == 0) { out[1] = code; out[2] = g; out[3] = node; out[4] = pos; }
+    };
+    if (g < 0 || g >= tp.G) { if (lane == 0) fail(13, id, g); continue; }
     const NodeRef<N> r = nodes[id];
     const NodeHdr& rh = r.h();
     if (lane == 0 && rh.parent != po[id]) fail(11, id, po[id]);
+    if (lane == 0 && rh.parent >= 0 && tp.owner[rh.parent] != g) fail(14, id, rh.parent);
+    if (lane == 0 && rh.parent == -1 && tp.gs[g].root != id) fail(15, id, tp.gs[g].root);
     if (lane == 0 && rh.has_state && (((u64)rh.hash_hi << 32) | rh.hash_lo) != r.board().h.hash) fail(12, id, 0);
     if (rh.status != NS_VISITED) continue;
     const int n = rh.n_edges, nt = rh.n_touched;
@@ -1614,10 +1673,21 @@ __global__ __launch_bounds__(64) void k_mcts_validate(TreePool<N> tp, int32_t* o
   }
 }
 
+// per-game node counts by a scan of the owner array (statistics / tests): out[g] = ids whose owner is g
+template <int N>
+__global__ __launch_bounds__(256) void k_mcts_count_live(TreePool<N> tp, int32_t* out) {
+  for (int id = blockIdx.x * 256 + threadIdx.x; id < tp.C; id += gridDim.x * 256)
+    if (tp.parent_of[id] != -2) atomicAdd(&out[tp.owner[id]], 1);
+}
+
 // SearchTreeT::treeAdvance :420-436: the child reached by `move` becomes the root, everything else is freed.
-// Two launches over the dense parent array (4 B per node id: L2-resident, coalesced):
-//   k_mcts_advance_mark   G x MB waves: keep[id] = the parent chain of id reaches the next root
-//   k_mcts_advance_sweep  one wave per game: dead ids go back on their free stack in id order (deterministic), re-root.
+// Four launches over the context's dense id arrays (parent 4 B + owner 4 B per node id: coalesced):
+//   k_mcts_advance_prepare  one wave per game: the id of the next root (or "none" / "this game does not move")
+//   k_mcts_advance_mark     all ids: keep[id] = the parent chain of id reaches its game's next root; kept nodes counted per game
+//   k_mcts_advance_sweep    all ids: dead ids go back on the context's free stacks (one atomic per wave; the ORDER of the ids on
+//                           the stack depends on the waves' timing -- ids are internal, no result depends on them)
+//   k_mcts_advance_reroot   one wave per game: re-root, or a fresh root for a game whose move had no child
+// SearchTreeT::clear is the same sweep with "free everything" for the listed games.
 template <int N>
 __device__ __forceinline__ int advance_next_root(const NodeRef<N> r, int mv, int lane) {
   const int n = rfl(r.h().n_edges), nt = rfl(r.h().n_touched);
@@ -1633,69 +1703,86 @@ __device__ __forceinline__ int advance_next_root(const NodeRef<N> r, int mv, int
   return next_root;
 }
 
+// one wave per game: adv[g] = -2 (no move for this game: elfsp_play with a partial move list), the id of the next root, or -1
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_advance_mark(TreePool<N> tp, const int32_t* moves, int MB) {
-  const int g = blockIdx.x / MB, part = blockIdx.x % MB, lane = threadIdx.x;
+__global__ __launch_bounds__(64) void k_mcts_advance_prepare(TreePool<N> tp, const int32_t* moves) {
+  const int g = blockIdx.x, lane = threadIdx.x;
   const int mv = rfl(moves[g]);
-  if (mv < 0) return;                        // no move for this game (elfsp_play with a partial move list)
-  const GameNodes<N> nodes(tp, g);
-  const int* po = tp.parent_of + (size_t)g * tp.C;
-  unsigned char* keep = tp.keep + (size_t)g * tp.C;
-  const int next_root = advance_next_root<N>(nodes[rfl(tp.gs[g].root)], mv, lane);
-  const int per = ((tp.C + MB - 1) / MB + 63) & ~63;
-  const int lo = part * per, hi = lo + per < tp.C ? lo + per : tp.C;
-  for (int base = lo; base < hi; base += 64) {
-    const int id = base + lane;
-    if (id >= hi) continue;
-    int a = id, k = 0;
-    if (po[id] != -2 && next_root >= 0) {
-      for (;;) {
-        if (a == next_root) { k = 1; break; }
-        a = po[a];
-        if (a < 0) break;
+  int a = -2;
+  if (mv >= 0) a = advance_next_root<N>(GameNodes<N>(tp, g)[rfl(tp.gs[g].root)], mv, lane);
+  if (lane == 0) { tp.adv[g] = a; tp.live_tmp[g] = 0; }
+}
+
+// every id of the context: keep[id] = its game moves and its parent chain reaches the game's next root
+template <int N>
+__global__ __launch_bounds__(256) void k_mcts_advance_mark(TreePool<N> tp) {
+  const int* po = tp.parent_of;
+  for (int id = blockIdx.x * 256 + threadIdx.x; id < tp.C; id += gridDim.x * 256) {
+    int k = 0;
+    if (po[id] != -2) {
+      const int g = tp.owner[id];
+      const int next_root = tp.adv[g];
+      if (next_root >= 0) {
+        int a = id;
+        for (;;) {
+          if (a == next_root) { k = 1; break; }
+          a = po[a];
+          if (a < 0) break;
+        }
+        if (k) atomicAdd(&tp.live_tmp[g], 1);
+      } else if (next_root == -2) {
+        k = 1;                               // the game does not move: nothing of it is freed
       }
     }
-    keep[id] = (unsigned char)k;
+    tp.keep[id] = (unsigned char)k;
   }
 }
 
+// dead ids go back on the context's free stacks: one atomic per wave and class
 template <int N>
-__global__ __launch_bounds__(64) void k_mcts_advance_sweep(TreePool<N> tp, const int32_t* moves) {
-  const int g = blockIdx.x, lane = threadIdx.x;
-  const GameNodes<N> nodes(tp, g);
-  int* fs = tp.free_stack + (size_t)g * tp.Cs;
-  int* fb = tp.free_big + (size_t)g * tp.Cb;
-  int* po = tp.parent_of + (size_t)g * tp.C;
-  const unsigned char* keep = tp.keep + (size_t)g * tp.C;
-  GameState& gs = tp.gs[g];
-  const int mv = rfl(moves[g]);
-  if (mv < 0) return;
-  int next_root = advance_next_root<N>(nodes[rfl(gs.root)], mv, lane);
-  int free_top = rfl(gs.free_top), free_top_big = rfl(gs.free_top_big);
-  for (int base = 0; base < tp.C; base += 64) {      // Cs is a multiple of 64: a round is all small ids or all big ids
-    const int id = base + lane;
-    const bool dead = id < tp.C && po[id] != -2 && !keep[id];
+__global__ __launch_bounds__(256) void k_mcts_advance_sweep(TreePool<N> tp) {
+  const int lane = threadIdx.x & 63;
+  int* po = tp.parent_of;
+  const int rounds = (tp.C + 63) >> 6;       // Cs is a multiple of 64: a round is all small ids or all big ids
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rounds; r += gridDim.x * 4) {
+    const int id = r * 64 + lane;
+    const bool dead = id < tp.C && po[id] != -2 && !tp.keep[id];
     const u64 b = __ballot(dead);
+    if (b == 0) continue;
     const int rank = __popcll(b & ((1ull << lane) - 1));
-    if (base < tp.Cs) {
-      if (dead) { po[id] = -2; fs[free_top + rank] = id; }
-      free_top += __popcll(b);
-    } else {
-      if (dead) { po[id] = -2; fb[free_top_big + rank] = id - tp.Cs; }
-      free_top_big += __popcll(b);
+    const bool sm = r * 64 < tp.Cs;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(sm ? &tp.tops->small : &tp.tops->big, __popcll(b));
+    base = rfl(base);
+    if (dead) {
+      po[id] = -2;
+      if (sm) tp.gstack[base + rank] = id; else tp.gstack_big[base + rank] = id - tp.Cs;
     }
   }
-  mem_sync();
+}
+
+// one wave per game that moved: the child reached by the move becomes the root, or (no such child / clear) a fresh root
+template <int N>
+__global__ __launch_bounds__(64) void k_mcts_advance_reroot(TreePool<N> tp) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  int next_root = rfl(tp.adv[g]);
+  if (next_root == -2) return;
+  const GameNodes<N> nodes(tp, g);
+  GameState& gs = tp.gs[g];
+  int free_top = rfl(gs.free_top), live = rfl(tp.live_tmp[g]);
   if (next_root < 0) {                       // allocateRoot -> addNode(0.0)
-    next_root = rfl(fs[free_top - 1]);
+    if (free_top <= 0) { free_top = stash_refill(tp, g, 0, 1, lane); mem_sync(); }
+    if (free_top <= 0) { if (lane == 0) gs.err |= MCTS_ERR_POOL; return; }
+    next_root = rfl(tp.free_stack[(size_t)g * tp.SC + free_top - 1]);
     --free_top;
     node_init(tp, g, next_root, -1, -1, 0.0f, lane);
+    live = 1;
   } else if (lane == 0) {
     nodes[next_root].h().parent = -1;
     nodes[next_root].h().parent_edge = -1;
-    po[next_root] = -1;
+    tp.parent_of[next_root] = -1;
   }
-  if (lane == 0) { gs.root = next_root; gs.free_top = free_top; gs.free_top_big = free_top_big; }
+  if (lane == 0) { gs.root = next_root; gs.free_top = free_top; gs.live = live; if (live > gs.live_peak) gs.live_peak = live; tp.adv[g] = -2; }
 }
 
 }  // namespace elfgo

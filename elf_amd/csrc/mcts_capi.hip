@@ -1,5 +1,6 @@
 // C ABI of the device-resident MCTS (include/elf_amd.h, elfmcts_*): host side of mcts.cuh.
 #include <math.h>
+#include <stddef.h>
 
 #include <new>
 #include <vector>
@@ -9,14 +10,21 @@
 
 struct ElfMcts {
   ElfGoEngine* eng = nullptr;
-  int G = 0, C = 0, W = 0, NE = 0;       // C = node ids per game = Cs + Cb
-  int Cs = 0, Cb = 0;                    // small / big node records per game (mcts.cuh)
+  int G = 0, C = 0, W = 0, NE = 0;       // C = node ids of the context = Cs + Cb
+  int Cs = 0, Cb = 0;                    // small / big node records of the context, shared by its games (mcts.cuh)
+  int npg = 0;                           // nodes_per_game the context was created with (Cs = G x npg)
+  int SC = 0;                            // stash capacity per game
   void* small = nullptr;
   void* big = nullptr;
+  int* gstack = nullptr;
+  int* gstack_big = nullptr;
+  PoolTops* tops = nullptr;
   int* free_stack = nullptr;
-  int* free_big = nullptr;
   int* parent_of = nullptr;
+  int* owner = nullptr;
   unsigned char* keep = nullptr;
+  int* adv = nullptr;
+  int* live_tmp = nullptr;
   GameState* gs = nullptr;
   LeafRec* leaves = nullptr;
   unsigned char* d4buf = nullptr;
@@ -40,10 +48,16 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   TreePool<N> t;
   t.small = reinterpret_cast<char*>(m->small);
   t.big = reinterpret_cast<char*>(m->big);
+  t.gstack = m->gstack;
+  t.gstack_big = m->gstack_big;
+  t.tops = m->tops;
   t.free_stack = m->free_stack;
-  t.free_big = m->free_big;
   t.parent_of = m->parent_of;
+  t.owner = m->owner;
   t.keep = m->keep;
+  t.adv = m->adv;
+  t.live_tmp = m->live_tmp;
+  t.SC = m->SC;
   t.gs = m->gs;
   t.leaves = m->leaves;
   t.d4buf = m->d4buf;
@@ -59,8 +73,10 @@ static TreePool<N> tree_of(const ElfMcts* m) {
   return t;
 }
 
-// big records per game: a big node has >= 16 children that are nodes themselves (mcts.cuh), so Cs / 16 + 1 cannot run out first
-static int big_records_for(int nodes_per_game) { return nodes_per_game / 16 + 1; }
+// big records per `nodes` small ones: a node moves to a big record when its (TCS+1)-th edge is followed, so a big node has >= TCS + 1
+// children that are nodes themselves (mcts.cuh): nodes / TCS + 1 big records cannot run out before the small ones do
+static_assert(NodeL<19>::TCS == NodeL<9>::TCS, "one touched-edge capacity for both board sizes");
+static int64_t big_records_for(int64_t nodes) { return nodes / NodeL<19>::TCS + 1; }
 static void record_bytes(int n, size_t* small, size_t* big) {
   *small = n == 19 ? NodeL<19>::SMALL : NodeL<9>::SMALL;
   *big = n == 19 ? NodeL<19>::BIG : NodeL<9>::BIG;
@@ -99,24 +115,33 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
   int rc = cfg_from(opt, &m->cfg);
   if (rc) { delete m; return rc; }
   DevGuard _dg(e->device);
-  m->eng = e; m->G = num_games; m->W = d4_window; m->NT = opt->num_threads;
-  m->Cs = nodes_per_game; m->Cb = big_records_for(nodes_per_game); m->C = m->Cs + m->Cb;
+  m->eng = e; m->G = num_games; m->W = d4_window; m->NT = opt->num_threads; m->npg = nodes_per_game;
+  // ONE pool for the context: num_games x nodes_per_game small records (+ their share of big ones), any game may take any of them
+  const int64_t cs = (int64_t)num_games * nodes_per_game, cb = big_records_for(cs);
+  if (cs + cb >= ((int64_t)1 << 31) - 64) { delete m; return ELFGO_E_BADARG; }     // node ids are 32-bit
+  m->Cs = (int)cs; m->Cb = (int)cb; m->C = m->Cs + m->Cb;
+  m->KTA = opt->num_threads * opt->num_rollouts_per_batch;
+  m->SC = 2 * m->KTA;
   record_bytes(e->n, &m->small_bytes, &m->big_bytes);
   m->NE = e->n == 19 ? NodeL<19>::NE : NodeL<9>::NE;
   const size_t G = num_games, C = m->C;
 #define MCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { elfmcts_destroy(m); return (int)_e; } } while (0)
-  MCHK(hipMalloc(&m->small, G * m->Cs * m->small_bytes));
-  MCHK(hipMalloc(&m->big, G * m->Cb * m->big_bytes));
-  MCHK(hipMalloc((void**)&m->free_stack, G * m->Cs * sizeof(int)));
-  MCHK(hipMalloc((void**)&m->free_big, G * m->Cb * sizeof(int)));
-  MCHK(hipMalloc((void**)&m->parent_of, G * C * sizeof(int)));
-  MCHK(hipMalloc((void**)&m->keep, G * C));
+  MCHK(hipMalloc(&m->small, (size_t)m->Cs * m->small_bytes));
+  MCHK(hipMalloc(&m->big, (size_t)m->Cb * m->big_bytes));
+  MCHK(hipMalloc((void**)&m->gstack, (size_t)m->Cs * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->gstack_big, (size_t)m->Cb * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->tops, sizeof(PoolTops)));
+  MCHK(hipMalloc((void**)&m->free_stack, G * m->SC * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->parent_of, C * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->owner, C * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->keep, C));
+  MCHK(hipMalloc((void**)&m->adv, G * sizeof(int)));
+  MCHK(hipMalloc((void**)&m->live_tmp, G * sizeof(int)));
   MCHK(hipMalloc((void**)&m->gs, G * sizeof(GameState)));
   MCHK(hipMemset(m->gs, 0, G * sizeof(GameState)));
   MCHK(hipMalloc((void**)&m->leaves, G * MCTS_KMAX * sizeof(LeafRec)));
   MCHK(hipMalloc((void**)&m->d4buf, G * (size_t)d4_window));
   MCHK(hipMemset(m->d4buf, 0, G * (size_t)d4_window));
-  m->KTA = opt->num_threads * opt->num_rollouts_per_batch;
   MCHK(hipMalloc((void**)&m->pathbuf, G * (size_t)m->KTA * MCTS_PATH_LV * 2 * sizeof(uint32_t)));
   MCHK(hipMalloc((void**)&m->rng_pos_t, G * (size_t)m->NT * sizeof(int)));
   MCHK(hipMemset(m->rng_pos_t, 0, G * (size_t)m->NT * sizeof(int)));
@@ -129,8 +154,14 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
     MCHK(hipMalloc((void**)&m->sqrt_tab, t.size() * sizeof(double)));
     MCHK(hipMemcpy(m->sqrt_tab, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  rc = elfmcts_clear(m, nullptr, num_games, nullptr);
-  if (rc) { elfmcts_destroy(m); return rc; }
+  {
+    size_t most = C > G ? C : G;
+    DISPATCH(e, {
+      hipLaunchKernelGGL(k_mcts_pool_init<N>, dim3((unsigned)((most + 255) / 256)), dim3(256), 0, (hipStream_t)0, tree_of<N>(m));
+      hipLaunchKernelGGL(k_mcts_advance_reroot<N>, dim3(m->G), dim3(64), 0, (hipStream_t)0, tree_of<N>(m));   // adv = -1: a root for every game
+    });
+    MCHK(hipGetLastError());
+  }
   MCHK(hipDeviceSynchronize());
 #undef MCHK
   *out = m;
@@ -142,10 +173,15 @@ int elfmcts_destroy(ElfMcts* m) {
   DevGuard _dg(m->eng->device);
   if (m->small) (void)hipFree(m->small);
   if (m->big) (void)hipFree(m->big);
+  if (m->gstack) (void)hipFree(m->gstack);
+  if (m->gstack_big) (void)hipFree(m->gstack_big);
+  if (m->tops) (void)hipFree(m->tops);
   if (m->free_stack) (void)hipFree(m->free_stack);
-  if (m->free_big) (void)hipFree(m->free_big);
   if (m->parent_of) (void)hipFree(m->parent_of);
+  if (m->owner) (void)hipFree(m->owner);
   if (m->keep) (void)hipFree(m->keep);
+  if (m->adv) (void)hipFree(m->adv);
+  if (m->live_tmp) (void)hipFree(m->live_tmp);
   if (m->gs) (void)hipFree(m->gs);
   if (m->leaves) (void)hipFree(m->leaves);
   if (m->d4buf) (void)hipFree(m->d4buf);
@@ -194,17 +230,80 @@ int elfmcts_max_rollouts_per_step(void) { return MCTS_KMAX; }
 int elfmcts_num_games(const ElfMcts* m) { return m ? m->G : ELFGO_E_BADARG; }
 int elfmcts_edge_stride(const ElfMcts* m) { return m ? m->NE : ELFGO_E_BADARG; }
 size_t elfmcts_tree_bytes_per_game(int board_size, int nodes_per_game) {
-  if ((board_size != 19 && board_size != 9) || nodes_per_game <= 0) return 0;
+  return elfmcts_tree_bytes_per_game2(board_size, nodes_per_game, 1, 16, 1024);
+}
+size_t elfmcts_tree_bytes_per_game2(int board_size, int nodes_per_game, int num_threads, int rollouts_per_batch, int d4_window) {
+  if ((board_size != 19 && board_size != 9) || nodes_per_game <= 0 || num_threads <= 0 || rollouts_per_batch <= 0 || d4_window < 0) return 0;
   size_t sm, bg;
   record_bytes(board_size, &sm, &bg);
-  const size_t Cs = nodes_per_game, Cb = big_records_for(nodes_per_game);
-  // records + free stacks + parent array + keep bytes + the per-game leaf / row tables
-  return Cs * sm + Cb * bg + (Cs + Cb) * (sizeof(int) * 2 + 1) + sizeof(GameState) + MCTS_KMAX * (sizeof(LeafRec) + sizeof(RowRec)) +
-         (size_t)16 * MCTS_PATH_LV * 2 * sizeof(uint32_t);   // + the path rows of a 16-leaf step
+  const size_t Cs = nodes_per_game, kta = (size_t)num_threads * rollouts_per_batch;
+  // a game's share of the context's pool: records (the big class at 1 per TCS small ones), the per-id arrays (free-stack entry, parent,
+  // owner, keep byte), and what IS per game: its stash, leaf / row tables, path rows of a step, D4 windows
+  return Cs * sm + (Cs * bg + NodeL<19>::TCS - 1) / NodeL<19>::TCS + (Cs + Cs / NodeL<19>::TCS + 1) * (sizeof(int) * 3 + 1) +
+         sizeof(GameState) + MCTS_KMAX * (sizeof(LeafRec) + sizeof(RowRec)) + kta * MCTS_PATH_LV * 2 * sizeof(uint32_t) +
+         2 * kta * sizeof(int) + (size_t)d4_window + (size_t)num_threads * sizeof(int) + 2 * sizeof(int);
 }
-/* average bytes per node id a game may hold (nodes_per_game of them): small record + its share of the big pool and of the id arrays */
+/* average bytes per node id of the pool: small record + its share of the big class and of the id arrays */
 size_t elfmcts_node_bytes(const ElfMcts* m) {
-  return m ? (elfmcts_tree_bytes_per_game(m->eng->n, m->Cs) + m->Cs - 1) / m->Cs : 0;
+  return m ? (elfmcts_tree_bytes_per_game2(m->eng->n, m->npg, m->NT, m->KTA / m->NT, m->W) + m->npg - 1) / m->npg : 0;
+}
+
+/* Node ids of the context: out[0] small records in all, [1] of them free (on the context's stack or in a game's stash), [2] big records
+ * in all, [3] free, [4] the largest number of ids one game has held since the last reset, [5] the largest sum over games ... (see header) */
+int elfmcts_pool_info(ElfMcts* m, int64_t* out8_host, int reset_peaks) {
+  if (!m || !out8_host) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
+  HIPCHK(hipDeviceSynchronize());
+  PoolTops t;
+  HIPCHK(hipMemcpy(&t, m->tops, sizeof(t), hipMemcpyDeviceToHost));
+  std::vector<GameState> gs(m->G);
+  HIPCHK(hipMemcpy(gs.data(), m->gs, sizeof(GameState) * m->G, hipMemcpyDeviceToHost));
+  int64_t stash = 0, live = 0, live_max = 0, peak_max = 0, peak_sum = 0;
+  for (auto& g : gs) {
+    stash += g.free_top; live += g.live;
+    if (g.live > live_max) live_max = g.live;
+    if (g.live_peak > peak_max) peak_max = g.live_peak;
+    peak_sum += g.live_peak;
+  }
+  out8_host[0] = m->Cs; out8_host[1] = (int64_t)t.small + stash; out8_host[2] = m->Cb; out8_host[3] = t.big;
+  out8_host[4] = live; out8_host[5] = live_max; out8_host[6] = peak_max; out8_host[7] = peak_sum;
+  if (reset_peaks) {
+    for (auto& g : gs) g.live_peak = g.live;
+    // only the peak field is written back (the games may not be touched concurrently: the device was synchronised above)
+    for (int i = 0; i < m->G; ++i)
+      HIPCHK(hipMemcpy(reinterpret_cast<char*>(m->gs + i) + offsetof(GameState, live_peak), &gs[i].live_peak, sizeof(int), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+/* test / debug service: node ids per game counted by a scan of the owner array (what RootInfo word 7 tracks incrementally) */
+int elfmcts_count_live(ElfMcts* m, int32_t* out_host) {
+  if (!m || !out_host) return ELFGO_E_BADARG;
+  DevGuard _dg(m->eng->device);
+  HIPCHK(hipDeviceSynchronize());
+  int32_t* d = nullptr;
+  HIPCHK(hipMalloc(&d, m->G * sizeof(int32_t)));
+  HIPCHK(hipMemset(d, 0, m->G * sizeof(int32_t)));
+  unsigned blocks = (unsigned)(((size_t)m->C + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_count_live<N>, dim3(blocks), dim3(256), 0, (hipStream_t)0, tree_of<N>(m), d));
+  hipError_t e = hipMemcpy(out_host, d, m->G * sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIPCHK(e);
+  return 0;
+}
+
+static int sweep_launches(ElfMcts* m, hipStream_t st) {
+  // enough waves to fill the chip; each thread covers >= 1 id
+  unsigned blocks = (unsigned)(((size_t)m->C + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  DISPATCH(m->eng, {
+    hipLaunchKernelGGL(k_mcts_advance_mark<N>, dim3(blocks), dim3(256), 0, st, tree_of<N>(m));
+    hipLaunchKernelGGL(k_mcts_advance_sweep<N>, dim3(blocks), dim3(256), 0, st, tree_of<N>(m));
+    hipLaunchKernelGGL(k_mcts_advance_reroot<N>, dim3(m->G), dim3(64), 0, st, tree_of<N>(m));
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream) {
@@ -212,9 +311,9 @@ int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream) {
   if (n == 0) return 0;
   if (!games && n != m->G) return ELFGO_E_BADARG;
   DevGuard _dg(m->eng->device);
-  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_clear<N>, dim3(n), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), games));
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_clear_mark<N>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tree_of<N>(m), games, n));
   HIPCHK(hipGetLastError());
-  return 0;
+  return sweep_launches(m, (hipStream_t)stream);
 }
 
 int elfmcts_set_root(ElfMcts* m, const int32_t* board_ids, void* stream) {
@@ -270,8 +369,7 @@ int elfmcts_expand(ElfMcts* m, const float* pi, int64_t pi_stride_floats, const 
   const int grid = n_rows >= 0 ? n_rows : m->G * m->cfg.rollouts_per_batch * m->cfg.num_threads;
   DISPATCH(m->eng, {
     if (grid > 0)
-      hipLaunchKernelGGL(k_mcts_expand<N>, dim3(grid), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (const u64*)m->eng->zob,
-                         (const RowRec*)m->rowmap, pi, pi_stride_floats, value, rv, n_rows, (const int32_t*)m->last_counts, m->cfg);
+      hipLaunchKernelGGL(k_mcts_expand<N>, dim3(grid), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), (const RowRec*)m->rowmap, pi, pi_stride_floats, value, rv, n_rows, (const int32_t*)m->last_counts, m->cfg);
     hipLaunchKernelGGL(k_mcts_backup<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), m->cfg);
   });
   HIPCHK(hipGetLastError());
@@ -324,10 +422,8 @@ int elfmcts_validate(ElfMcts* m, int32_t* out5_host) {
   int32_t* d = nullptr;
   HIPCHK(hipMalloc(&d, 5 * sizeof(int32_t)));
   HIPCHK(hipMemset(d, 0, 5 * sizeof(int32_t)));
-  int gy = 4096 / m->G;
-  if (gy < 1) gy = 1;
-  if (gy > m->C) gy = m->C;
-  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_validate<N>, dim3(m->G, gy), dim3(64), 0, (hipStream_t)0, tree_of<N>(m), d));
+  int gx = m->C < 8192 ? m->C : 8192;
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_validate<N>, dim3(gx), dim3(64), 0, (hipStream_t)0, tree_of<N>(m), d));
   hipError_t e = hipMemcpy(out5_host, d, 5 * sizeof(int32_t), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   HIPCHK(e);
@@ -348,16 +444,9 @@ int elfmcts_node_visits(ElfMcts* m, int64_t* out_host) {
 int elfmcts_advance(ElfMcts* m, const int32_t* moves, void* stream) {
   if (!m || !moves) return ELFGO_E_BADARG;
   DevGuard _dg(m->eng->device);
-  // enough marking waves to fill the chip whatever the number of games; each covers >= 64 node ids
-  int MB = (2048 + m->G - 1) / m->G;
-  if (MB > m->C / 64) MB = m->C / 64;
-  if (MB < 1) MB = 1;
-  DISPATCH(m->eng, {
-    hipLaunchKernelGGL(k_mcts_advance_mark<N>, dim3(m->G * MB), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), moves, MB);
-    hipLaunchKernelGGL(k_mcts_advance_sweep<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), moves);
-  });
+  DISPATCH(m->eng, hipLaunchKernelGGL(k_mcts_advance_prepare<N>, dim3(m->G), dim3(64), 0, (hipStream_t)stream, tree_of<N>(m), moves));
   HIPCHK(hipGetLastError());
-  return 0;
+  return sweep_launches(m, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -329,6 +329,22 @@ class SelfPlay:
         check(self.L.elfmcts_validate(self.L.elfsp_mcts(self._h), out.ctypes.data))
         return tuple(int(x) for x in out)
 
+    def pool_info(self, actor=0, reset_peaks=False):
+        """elfmcts_pool_info of one AI's trees: the context's shared node pool (synchronises) -> dict(small_total, small_free, big_total,
+        big_free, live, live_max_game, peak_max_game, peak_sum_games); peak_* since the last reset"""
+        out = np.zeros(8, np.int64)
+        m = self.L.elfsp_mcts_actor(self._h, int(actor)) if actor else self.L.elfsp_mcts(self._h)
+        check(self.L.elfmcts_pool_info(m, out.ctypes.data, int(bool(reset_peaks))))
+        k = ("small_total", "small_free", "big_total", "big_free", "live", "live_max_game", "peak_max_game", "peak_sum_games")
+        return dict(zip(k, (int(x) for x in out)))
+
+    def count_live(self, actor=0):
+        """elfmcts_count_live: node ids per game by a scan of the pool (tests)"""
+        out = np.zeros(self.num_games, np.int32)
+        m = self.L.elfsp_mcts_actor(self._h, int(actor)) if actor else self.L.elfsp_mcts(self._h)
+        check(self.L.elfmcts_count_live(m, out.ctypes.data))
+        return out
+
     def finish(self, games, reason):
         """finish_game(reason) + restart for the listed games (FinishReason: 0 resign, 1 two passes, 2 max step, 3 clear, 4 illegal)"""
         g = np.ascontiguousarray(games, dtype=np.int32)

@@ -122,7 +122,7 @@ typedef struct ElfMctsOptions {
   int64_t required_version;         /* MCTSActorParams.required_version: < 0 = replies of any model version are accepted */
 } ElfMctsOptions;
 
-#define ELFMCTS_E_POOL 1      /* node pool of some game exhausted (raise nodes_per_game) */
+#define ELFMCTS_E_POOL 1      /* the context's node pool is exhausted (raise nodes_per_game: the pool holds num_games x nodes_per_game ids) */
 #define ELFMCTS_E_ROOT_HASH 2 /* TreeSearch::Root state is not the same as the input state (tree_search.h:488-492) */
 #define ELFMCTS_E_FORWARD 4   /* a tree edge could not be played */
 #define ELFMCTS_E_RNG 8       /* more D4 draws requested than uploaded with elfmcts_set_d4 */
@@ -130,10 +130,13 @@ typedef struct ElfMctsOptions {
 
 #define ELFMCTS_ROOT_WORDS 8
 /* per-game record of elfmcts_root (int32 words): 0 n_edges 1 num_visits 2 status 3 root id 4 V (float bits)
- * 5 d4 draws consumed this move 6 error bits 7 free node ids */
+ * 5 d4 draws consumed this move 6 error bits 7 node ids the game's tree holds */
 
-/* `num_games` trees over boards of engine `e` (game g searches from board slot board_ids[g]);
- * nodes_per_game (multiple of 64) node ids each; d4_window = opt->num_threads x (max D4 draws ONE search thread makes per move):
+/* `num_games` trees over boards of engine `e` (game g searches from board slot board_ids[g]).
+ * Node memory is ONE pool of num_games x nodes_per_game node ids (nodes_per_game a multiple of 64) shared by the context's games:
+ * the reference takes its nodes from the heap (SearchTreeT::addNode, tree_search_node.h:439-443; recursiveFree :445-467), so a game
+ * whose kept subtree is large simply holds more of them -- size nodes_per_game for the MEAN tree, not for the worst game.  A step's ids
+ * are popped from the pool's free stack with one atomic per game, treeAdvance pushes the freed subtrees back.  d4_window = opt->num_threads x (max D4 draws ONE search thread makes per move):
  * every search thread's MCTSActor owns a generator (TreeSearchT's actor_gen, tree_search.h:339-343; all seeded alike,
  * game_selfplay.cc:45-47,77), so the draws are laid out as one window per thread. */
 int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_window, const ElfMctsOptions* opt, ElfMcts** out);
@@ -160,11 +163,23 @@ int elfmcts_set_game_mask(ElfMcts* m, const uint8_t* mask);
 int elfmcts_set_required_versions(ElfMcts* m, const int64_t* versions);
 int elfmcts_num_games(const ElfMcts* m);
 int elfmcts_edge_stride(const ElfMcts* m);   /* row length of the per-edge arrays (368 at 19x19, 96 at 9x9) */
-/* HBM one game's tree takes at `nodes_per_game` node ids (records of both classes, id arrays, leaf / row tables): what a caller
- * sizes num_games x nodes_per_game against elfgo_mem_info.  A node lives in a 5 888-B record (19x19; 1 920 B at 9x9) until its 17th
- * edge is followed, then in an 11 520-B one; nodes_per_game / 16 + 1 of the latter exist per game and cannot run out first. */
+/* HBM a game adds to a context at `nodes_per_game` node ids (its share of the pool's records of both classes and id arrays, plus
+ * what is per game: stash, leaf / row tables, path rows, D4 windows): what a caller sizes num_games x nodes_per_game against
+ * elfgo_mem_info.  A node lives in a 5 888-B record (19x19; 1 920 B at 9x9) until its 17th edge is followed, then in an 11 520-B one;
+ * one big record per 16 small ones exists and that class cannot run out first (a big node has >= 17 children that are nodes).
+ * The first form assumes 1 search thread, 16 rollouts per batch, a 1024-draw window; the second takes them (path rows are
+ * 512 B per leaf of a step: 512 KB per game at the 1024-leaf maximum). */
 size_t elfmcts_tree_bytes_per_game(int board_size, int nodes_per_game);
-size_t elfmcts_node_bytes(const ElfMcts* m);   /* elfmcts_tree_bytes_per_game / nodes_per_game, rounded up (6 6xx B at 19x19) */
+size_t elfmcts_tree_bytes_per_game2(int board_size, int nodes_per_game, int num_threads, int rollouts_per_batch, int d4_window);
+size_t elfmcts_node_bytes(const ElfMcts* m);   /* elfmcts_tree_bytes_per_game2 / nodes_per_game, rounded up (6 6xx B at 19x19) */
+/* Node ids of the context (synchronises the device).  out8_host: 0 small records in all, 1 of them free (on the pool's stack or in
+ * a game's stash), 2 big records in all, 3 free, 4 ids held by all trees now, 5 by the largest tree now, 6 the most ONE tree has
+ * held since the last reset, 7 the sum over games of those per-tree maxima (what G fixed per-game pools would have to provide:
+ * compare with 4).  reset_peaks != 0 restarts the maxima.  No counterpart in the reference (its nodes live on the heap). */
+int elfmcts_pool_info(ElfMcts* m, int64_t* out8_host, int reset_peaks);
+/* test / debug service: node ids held per game (host int32 [num_games]), counted by a scan of the pool's owner array -- what RootInfo
+ * word 7 tracks incrementally.  Synchronises the device. */
+int elfmcts_count_live(ElfMcts* m, int32_t* out_host);
 /* SearchTreeT::clear (tree_search_node.h:411-416) for games[0..n) (device int32, NULL = all games) */
 int elfmcts_clear(ElfMcts* m, const int32_t* games, int n, void* stream);
 /* TreeSearchT::setRootNodeState (tree_search.h:478-493) for every game; board_ids device int32 or NULL (slot g) */

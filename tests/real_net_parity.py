@@ -84,7 +84,7 @@ def search_cfg(**over):
     return cfg
 
 
-def run_reference(memo, n, cfg, games, moves, canonical_backup=False, turnstile=False):
+def run_reference(memo, n, cfg, games, moves, canonical_backup=False, turnstile=False, preload=None):
     """the reference stack, one run per game (game g seeded seed + g, the rule of include/elf_amd.h) -> {g: [search tuples]}.
     canonical_backup=True: the build whose batch_rollouts backs the unique leaves of a batch up in first-occurrence order instead of
     heap-address order (oracle/Makefile, libelfsp*_h2.so: three lines of a build-time copy of tree_search.h) -- the order SURVEY.md H2
@@ -92,6 +92,22 @@ def run_reference(memo, n, cfg, games, moves, canonical_backup=False, turnstile=
     from pyoracle import RefSelfPlay
     out = {}
     R = RefSelfPlay(n, canonical_backup=canonical_backup, turnstile=turnstile)   # turnstile: mcts_threads > 1 under the forced schedule
+    if preload is not None:   # GameOptions.preload_sgf / preload_sgf_move_to: (Coords of a game, plies forwarded before the first search)
+        import tempfile
+        fd, path = tempfile.mkstemp(suffix=".sgf")
+        with os.fdopen(fd, "w") as fh:
+            fh.write("(;GM[1]FF[4]SZ[%d]KM[7.5]" % n + R.coords2sgfstr(preload[0])[1:])
+        R.set_preload(path, int(preload[1]))
+    try:
+        return _run_reference(R, memo, cfg, games, moves)
+    finally:
+        if preload is not None:
+            R.set_preload("", -1)
+            os.unlink(path)
+
+
+def _run_reference(R, memo, cfg, games, moves):
+    out = {}
     for g in range(games):
         c = dict(cfg)
         c.update(num_games=1, seed=cfg["seed"] + g, max_searches=moves)
@@ -100,7 +116,7 @@ def run_reference(memo, n, cfg, games, moves, canonical_backup=False, turnstile=
     return out
 
 
-def run_engine(memo, n, cfg, games, moves, nodes_per_game=None):
+def run_engine(memo, n, cfg, games, moves, nodes_per_game=None, preload=None):
     import torch
     import elf_amd
     sp = elf_amd.SelfPlay(
@@ -112,6 +128,8 @@ def run_engine(memo, n, cfg, games, moves, nodes_per_game=None):
         policy_distri_cutoff=cfg["policy_distri_cutoff"], move_cutoff=cfg["move_cutoff"], resign_thres=cfg["resign_thres"],
         never_resign_prob=cfg["never_resign_prob"], seed=cfg["seed"], mcts_threads=cfg["mcts_threads"], log_searches=games * moves,
         nodes_per_game=nodes_per_game or (4 * cfg["rollouts_per_thread"] + 1024))
+    if preload is not None:
+        sp.preload(preload[0], int(preload[1]))
     misses0 = memo.misses
     while sp.stats()["logged"] < games * moves:
         rows = sp.begin_step()

@@ -82,7 +82,7 @@ def test_the_line_of_a_full_default_run_fits_the_driver(tmp_path):
     must stay under 4 KB, be strict JSON, and carry the contract keys plus roofline / cpu_baseline / the sub-results' numbers."""
     sys.path.insert(0, ROOT)
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r04z_bench_n1.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "history", "r04z_bench_n1.json")))
     assert len(json.dumps(full)) > 20000
     full["roofline"]["frac"] = float("nan")           # a non-finite number must come out as null, not as NaN
     line = bench.compact_line(bench._clean(full), "bench_full.json")

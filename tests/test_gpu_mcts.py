@@ -141,6 +141,43 @@ def test_exhausted_node_pool_is_a_status_code(elf):
     sp.close()
 
 
+def test_one_game_may_hold_several_times_its_share_of_the_pool(elf):
+    """The node memory of a context is ONE pool of num_games x nodes_per_game ids (the reference takes its nodes from the heap,
+    tree_search_node.h:439-467: a game whose kept subtree is large simply holds more).  Eight games, nodes_per_game = 64 for searches
+    of 256 rollouts per move on a persistent tree -- a fixed per-game pool of 64 ids cannot hold one search -- and only game 0 plays
+    (num_game_thread_used = 1): it must reproduce the reference fixture search for search while its tree holds more than five times
+    the per-game share, and every id is accounted for afterwards."""
+    name = "mcts_19_r256_dir"
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    m = 8
+    cfg["num_games"], cfg["thread_used"] = 8, 1           # DispatcherCallback::OnFirstSend: games 1..7 wait, game 0 is the fixture's game
+    sp = sp_from_fixture_cfg(elf, 19, cfg, log_searches=m, nodes_per_game=64)
+    if "white_ver" not in cfg:                            # a fixture older than the request keys: the helper sent no request
+        sp.set_request(0, -1, float(np.float32(cfg["resign_thres"])), float(np.float32(cfg["never_resign_prob"])), num_game_thread_used=1)
+    p0 = sp.pool_info()
+    assert p0["small_total"] == 8 * 64 and p0["live"] == 8 and p0["small_free"] == p0["small_total"] - 8
+
+    def accounted(sp, rows_total):
+        p, live = sp.pool_info(), sp.count_live()
+        assert live.sum() == p["live"] and live[0] == p["live_max_game"] and (live[1:] == 1).all(), (p, live)
+        assert p["live"] + p["small_free"] + p["big_free"] == p["small_total"] + p["big_total"], p
+    drive_stub(sp, 19, cfg, lambda sp: sp.stats()["logged"] >= m, accounted)
+    rec, coord, visits, prior, reward = sp.search_log()
+    for i in range(m):
+        ne = int(g["n_edges"][i])
+        assert rec[i].game == 0 and rec[i].n_edges == ne
+        assert np.array_equal(coord[i, :ne], g["coord"][i, :ne].astype(np.int32))
+        assert np.array_equal(visits[i, :ne], g["visits"][i, :ne])
+        assert np.array_equal(reward[i, :ne].view(np.uint32), g["reward"][i, :ne].view(np.uint32))
+        assert rec[i].move_played == int(g["move_played"][i])
+    p = sp.pool_info()
+    assert p["peak_max_game"] > 5 * 64, p                       # one tree held more than three per-game shares
+    assert p["live"] + p["small_free"] + p["big_free"] == p["small_total"] + p["big_total"], p     # every id is in a tree or free
+    assert sp.validate_trees()[0] == 0
+    sp.close()
+
+
 LIVE = [
     (9, dict(rollouts_per_thread=96, max_searches=40, seed=4242, net_salt=77, policy_distri_cutoff=9, virtual_loss=2, c_puct=1.1,
              root_epsilon=0.3, root_alpha=0.2, ply_pass_enabled=12, komi=6.5)),
@@ -428,6 +465,31 @@ def test_config3_real_net_against_the_real_reference_stack(elf):
         # 8192 rollouts at bs 16: the all-at-root first batch adds no visit
         if rollouts == 8192:
             assert ref[0][0]["total_visits"] == 8176
+
+
+def test_real_net_from_a_dense_sgf_position_against_the_real_reference_stack(elf):
+    """The same 20 x 256 fp32 net, the search started from a DENSE position: ladder-suite game 406844.sgf preloaded to ply 150
+    (GameOptions.preload_sgf, game_selfplay.cc:202-219; ~220 legal moves, 50+ groups), ply_pass_enabled = 100 so that the pass edge,
+    Tromp-Taylor leaves and remove_pass_if_dangerous (go/mcts/mcts.h:185-207,232-242) occur with un-quantised values; 4 searches at 512
+    rollouts (the played moves are the SGF's, :392-405).  Against the canonical-backup build: 0 ulps on every statistic; against the
+    stock build: the bounded report."""
+    import real_net_parity as rp
+    from pyoracle import RefSelfPlay
+    if not RefSelfPlay.available(19):
+        pytest.skip("oracle/_ref/libelfsp19.so (the reference compiled in place) is not present: make -C oracle ref")
+    memo = rp.make_memo_net(19, 20, 256)
+    pre = (np.load(os.path.join(GOLDEN, "sgf_406844.npz"))["moves"].astype(np.uint16), 150)
+    moves = 4
+    cfg = rp.search_cfg(rollouts_per_thread=512, seed=4321, ply_pass_enabled=100)
+    got, engine_only_rows = rp.run_engine(memo, 19, cfg, 1, moves, preload=pre)
+    assert got[0][0]["n_edges"] < 240
+    if RefSelfPlay.available(19, canonical_backup=True):
+        canon = rp.run_reference(memo, 19, cfg, 1, moves, canonical_backup=True, preload=pre)
+        res = rp.compare(canon, got, 1, moves)
+        assert res["searches_compared"] == moves and res["bit_equal"] == moves and res["max_reward_ulps"] == 0, res
+    ref = rp.run_reference(memo, 19, cfg, 1, moves, preload=pre)
+    res = rp.compare(ref, got, 1, moves)
+    assert res["searches_compared"] == moves and res["decision_diverged"] == 0 and res["max_reward_ulps"] <= 2, res
 
 
 def test_search_threads_with_the_real_net_against_the_turnstile_reference(elf):

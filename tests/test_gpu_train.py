@@ -387,8 +387,11 @@ def test_selfplay_soak_records_replay_on_the_oracle(elf):
     info = torch.zeros((G, 8), dtype=torch.int32, device="cuda")
     assert L.elfmcts_root(L.elfsp_mcts(sp._h), C.c_void_p(info.data_ptr()), None, None, None, None, None, None) == 0
     torch.cuda.synchronize()
-    free = info[:, 7].cpu().numpy()
-    assert (free >= 1024 - 32 * 4 - 64).all(), free.min()
+    live = info[:, 7].cpu().numpy()                       # RootInfo word 7: node ids the game's tree holds
+    assert (live <= 32 * 4 + 64).all() and (live >= 1).all(), (live.min(), live.max())
+    p = sp.pool_info()                                    # the context's shared pool: every id is in a tree or free
+    assert p["live"] == int(live.sum()) == int(sp.count_live().sum()) and p["live"] + p["small_free"] + p["big_free"] == p["small_total"] + p["big_total"], p
+    assert sp.validate_trees()[0] == 0
     sp.close()
 
 
@@ -483,6 +486,9 @@ def test_evaluation_games_soak_with_requests(elf):
         info = torch.zeros((G, 8), dtype=torch.int32, device="cuda")
         assert L.elfmcts_root(L.elfsp_mcts_actor(sp._h, a), C.c_void_p(info.data_ptr()), None, None, None, None, None, None) == 0
         torch.cuda.synchronize()
-        free = info[:, 7].cpu().numpy()
-        assert (free >= 1024 - 48 * 4 - 64).all(), (a, free.min())
+        live = info[:, 7].cpu().numpy()
+        assert (live <= 48 * 4 + 64).all() and (live >= 1).all(), (a, live.min(), live.max())
+        p = sp.pool_info(actor=a)
+        assert p["live"] == int(live.sum()) == int(sp.count_live(actor=a).sum()), (a, p)
+        assert p["live"] + p["small_free"] + p["big_free"] == p["small_total"] + p["big_total"], (a, p)
     sp.close()

@@ -52,7 +52,7 @@ def main():
             if st == spm - 1:      # the tree is largest just before the move is played (treeAdvance frees the siblings' subtrees)
                 L.elfmcts_root(m, C.c_void_p(info.data_ptr()), None, None, None, None, None, None)
                 torch.cuda.synchronize()
-                used = cs - 1 - info[:, 7].cpu().numpy().astype(np.int64) + 1
+                used = info[:, 7].cpu().numpy().astype(np.int64)      # RootInfo word 7: node ids the game's tree holds
                 peak = np.maximum(peak, used)
                 per_move.append({"move": mv + 1, "live_nodes_mean": float(used.mean()), "live_nodes_max": int(used.max())})
             sp.end_step(pi, v)
