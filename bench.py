@@ -627,11 +627,18 @@ class RandomReplies:
     for --net random and for the untimed tree-growing prologue of the headline.  A pool of replies is drawn once on the GPU and
     cycled through, so that a search-only measurement times the search kernels and not torch's random-number kernels."""
 
-    def __init__(self, rows, na, dev, seed, pool=8):
+    def __init__(self, rows, na, dev, seed, pool=8, flat16=False):
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
-        self.pool = [(torch.softmax(4.0 * torch.randn((rows, na), device=dev, generator=gen), dim=1),
-                      torch.tanh(0.5 * torch.randn((rows,), device=dev, generator=gen))) for _ in range(pool)]
+        if flat16:
+            # what the benchmark's random-init fp16 net answers (measured: priors 0.0021 .. 0.0034, ~240 distinct fp16 values among the
+            # 362 of a row): a near-uniform policy on the fp16 grid, i.e. EQUAL priors among the candidates of nearly every row -- the
+            # expansion's exact std::sort replay (go/mcts/mcts.h:292-297) runs for every row, as it does in the headline
+            self.pool = [(torch.softmax(0.08 * torch.randn((rows, na), device=dev, generator=gen), dim=1).half().float(),
+                          0.01 * torch.randn((rows,), device=dev, generator=gen)) for _ in range(pool)]
+        else:
+            self.pool = [(torch.softmax(4.0 * torch.randn((rows, na), device=dev, generator=gen), dim=1),
+                          torch.tanh(0.5 * torch.randn((rows,), device=dev, generator=gen))) for _ in range(pool)]
         self.i = 0
 
     def __call__(self, s=None, rows=None):
@@ -701,6 +708,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     na = n * n + 1
     rows_max = sp.groups[0].max_rows
     rnd = RandomReplies(rows_max, na, dev, 99 + rank)
+    rnd16 = RandomReplies(rows_max, na, dev, 199 + rank, flat16=True) if args.net == "random16" else None
     uni_pi = torch.full((rows_max, na), 1.0 / na, dtype=torch.float32, device=dev)
     zero_v = torch.zeros(rows_max, dtype=torch.float32, device=dev)
     if net is not None:
@@ -733,6 +741,8 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
             return out["pi"], out["V"]
         if args.net == "random":
             return rnd()
+        if args.net == "random16":
+            return rnd16()
         return uni_pi, zero_v
 
     barrier = make_barrier(dist)
@@ -782,11 +792,19 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     dt_max, roll_all = reduce_max_sum(dist, dev, dt, my_rollouts)
     per_rank = gather_per_rank(dist, dev, my_rollouts / dt, world)
     npg = int(sp.groups[0].opt.nodes_per_game)
+    pinfo = [g_.pool_info() for g_ in sp.groups]
     sp.close()
     if rank != 0:
         return None
     import elf_amd as _ea
     tree_gb = G * _ea.tree_bytes_per_game(n, npg) / 1e9
+    # the context's shared node pool after the run (round 6: one pool per game group, any game may hold any id): ids in trees now, the
+    # largest tree, and what G fixed per-game pools would have had to provide (the sum over games of each game's own maximum)
+    pool_stats = {"ids_total": sum(p_["small_total"] for p_ in pinfo), "ids_live_now": sum(p_["live"] for p_ in pinfo),
+                  "largest_tree_now": max(p_["live_max_game"] for p_ in pinfo), "largest_tree_ever": max(p_["peak_max_game"] for p_ in pinfo),
+                  "sum_of_per_game_maxima": sum(p_["peak_sum_games"] for p_ in pinfo),
+                  "note": "ONE pool per game group shared by its games (the reference's nodes live on the heap, tree_search_node.h:439-467): "
+                          "nodes_per_game sizes the pool for the MEAN tree, a game whose kept subtree is large holds more"}
     step_ms = dt_max / steps * 1e3
     depth = d["node_visits"] / max(d["rollouts"], 1)   # measured mean descent depth over the timed window
     bytes_per_step = (d["node_visits"] * ROLLOUT_NODE_BYTES + my_rows * ROLLOUT_EXPAND_BYTES) / steps
@@ -820,6 +838,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "search_dtype": "f32 edge statistics (the reference's float), u16 board labels", "net_dtype": args.net_dtype if net is not None else None,
                    "games_per_gpu": G, "board_size": n, "mcts_threads": T, "nodes_per_game": npg,
                    "node_bytes": _ea.tree_bytes_per_game(n, npg) // npg, "tree_pool_GB": tree_gb,
+                   "node_pool": pool_stats,
                    "mcts_threads_note": None if T == 1 else ("mcts_threads = %d: the reference's search threads race on the shared tree (it is nondeterministic "
                                                              "there, SURVEY H8); this engine runs ONE deterministic interleaving of them -- thread t's K descents see "
                                                              "the virtual losses of threads < t -- which is pinned on the REAL reference under that forced "
@@ -1558,6 +1577,9 @@ def compact_line(res, full_path=None):
                     "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB", "mean_forwarded_plies",
                     "mean_replayed_plies", "samples_per_launch", "batch"))
     c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:180], **c}
+    if isinstance(cfg.get("node_pool"), dict):     # the shared node pool: ids in trees now / the largest tree ever
+        c["live_nodes"] = _num(cfg["node_pool"].get("ids_live_now"))
+        c["largest_tree"] = _num(cfg["node_pool"].get("largest_tree_ever"))
     if cfg.get("per_rank_rollouts_per_sec") is not None and res.get("n_gpus", 1) > 1:
         c["per_rank"] = [_num(v) for v in cfg["per_rank_rollouts_per_sec"]]
     line["config"] = c
@@ -1660,7 +1682,9 @@ def main():
     ap.add_argument("--mcts-threads", type=int, default=1, help="TSOptions.num_threads (search threads per game)")
     ap.add_argument("--nodes-per-game", type=int, default=None)
     ap.add_argument("--pregrow", type=int, default=-1, help="untimed tree-growing steps before the warm-up (-1: so that the move ends mid-window)")
-    ap.add_argument("--net", choices=["resnet", "random", "null"], default="resnet")
+    ap.add_argument("--net", choices=["resnet", "random", "random16", "null"], default="resnet",
+                    help="random: peaky pseudo-random replies (deep trees, no prior ties); random16: near-uniform replies on the fp16 grid like the "
+                         "random-init fp16 net's (prior ties in every row: the expansion's exact std::sort replay); null: uniform")
     ap.add_argument("--no-fold-bn", action="store_true")
     ap.add_argument("--net-variants", action="store_true", help="also time the net call in bf16 and at 4096 rows (reports only; a second MIOpen "
                     "find of ~25 s; round 2-4 numbers: DESIGN.md section 3)")

@@ -55,6 +55,7 @@ enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2, LK_STATE_PENDING = 3 };   // 
 enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8, MCTS_ERR_VERSION = 16 };
 constexpr int MCTS_KMAX = 1024;  // max rollouts per step = num_threads x rollouts_per_batch: the stride of the per-game leaf / row tables in HBM.
                                  // The leaf table of a step in LDS (k_mcts_select) is sized by the launch: 20 B per rollout of the step
+constexpr int MCTS_REFILL = 8;   // steps' worth of node ids a game's stash is topped up to (k_mcts_select); stash capacity = (MCTS_REFILL + 1) x KTA
 enum { GM_IDLE = 0, GM_SEARCH = 1, GM_POLICY_ONLY = 2 };   // per-game mask byte (elfmcts_set_game_mask)
 
 struct NodeHdr {          // 64 B
@@ -196,7 +197,7 @@ struct TreePool {
   const long long* req_ver;    // [G] or nullptr (TreeCfg.required_version for every game): MCTSActorParams.required_version per game
   int sqrt_n;
   int Cs, Cb, C;          // small records, big records, node ids (Cs + Cb) of the CONTEXT
-  int SC;                 // stash capacity per game (2 x KTA: a step's ids + the small records its promotions return)
+  int SC;                 // stash capacity per game ((MCTS_REFILL + 1) x KTA: the top-up + the small records a step's promotions return)
   int W, G;
   int NT;                 // search threads the D4 windows were laid out for (TSOptions.num_threads when the pool was created)
   __device__ __forceinline__ int game_mode(int g) const { return mask ? (int)mask[g] : (int)GM_SEARCH; }
@@ -503,8 +504,15 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   // GM_POLICY_ONLY = TreeSearchT::runPolicyOnly (tree_search.h:385-407): the root is evaluated if it has not been yet, nothing else
   const bool root_only = mode == GM_POLICY_ONLY;
   const int K = root_only ? 1 : cfg.rollouts_per_batch, KT = root_only ? 1 : K * cfg.num_threads;
-  // the ids this step can need (one per descent), taken from the context's free stack with ONE atomic, before the descents
-  if (!root_only && free_top < KT) { free_top = stash_refill(tp, g, free_top, KT - free_top, lane); mem_sync(); }
+  // The ids this step can need (one per descent) come from the game's stash; when it holds fewer, it is topped up from the context's
+  // free stack with ONE atomic, before the descents -- to MCTS_REFILL steps' worth, so that a game pops once in ~MCTS_REFILL steps, and
+  // the games' first pops ask for different amounts so that they do not all come back in the same step (every wave of the launch
+  // starts at once: one same-address atomic per game and step serialised for ~85 us at 4608 games, measured).
+  if (!root_only && free_top < KT) {
+    const int steps_worth = rfl((int)(gs.rollouts_done == 0 && gs.node_visits == 0)) ? 1 + g % MCTS_REFILL : MCTS_REFILL;
+    free_top = stash_refill(tp, g, free_top, steps_worth * KT - free_top, lane);
+    mem_sync();
+  }
 
   for (int j = 0, jk = 0; j < KT; ++j, ++jk) {
     if (jk == K) jk = 0;
@@ -951,11 +959,9 @@ struct ExpandLds {
   //   1. prob, key  -- the net's priors and coords in ACTION order: inputs of the register sort and of the exact std::sort replay
   //   2. seq..sx    -- scratch of umap_order_wave, after the sorted candidates sit in sprob/skey
   union {
-    struct {
-      float prob[NE];   // candidate priors in action order
-      u16 key[NE];      // candidate coords in action order
-      int sort_stack[3 * stl_emul::kSortStack];   // explicit introsort stack of the exact std::sort replay (ties only)
-    };
+    // candidate (prior, coord) pairs in ACTION order, 8 B each {prior bits, coord | scratch << 16}: the input of the exact std::sort
+    // replay (prior ties only), which swaps whole pairs
+    u64 pk[NE];
     struct {
       u16 seq[NE];      // epoch insertion sequence (indices into skey)
       u16 nseq[NE];
@@ -965,9 +971,10 @@ struct ExpandLds {
   };
   float sprob[NE];      // sorted (insertion order of the reference's map)
   u16 skey[NE];
+  u16 scr[NE];          // scratch of the exact std::sort replay (with skey: the stop positions of the partitions)
   u64 legalw[8];        // legal-move bitboard words (D4-0 action order)
 };
-static_assert(sizeof(ExpandLds<19>) <= 5632, "expand LDS per wave");
+static_assert(sizeof(ExpandLds<19>) <= 6400, "expand LDS per wave");
 
 // inclusive prefix sum over the 64 lanes on the DPP network: Hillis-Steele inside each row of 16 (row_shr 1 / 2 / 4 / 8, zero fill),
 // then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  EXEC must be full.
@@ -1158,82 +1165,150 @@ __device__ __forceinline__ void bitonic_sizes_blocked(u64 (&sx)[8], int lane) {
 // ascending; slot e = lane * 8 + k
 __device__ __forceinline__ void bitonic_sort512_blocked(u64 (&sx)[8], int lane) { bitonic_sizes_blocked<2>(sx, lane); }
 
-// The introsort loop of std::sort(pairs, a.second > b.second) over L.key / L.prob [0, n), wave-parallel and exact: the
-// pairing formulation of stl_emul.h (sort_desc_pairing, checked against libstdc++ on the host).  One partition = flags + ranks by
-// ballots over the <= 6 rounds that overlap the range, positions through LDS scratch (the sprob area, not yet in use), parallel
-// swaps.  Leaves the array as __introsort_loop does; the caller finishes with a stable sort (= __final_insertion_sort).
+// The introsort loop of std::sort(pairs, a.second > b.second) (go/mcts/mcts.h:292-297) over the pairs L.pk[0, n), wave-parallel and
+// exact, all segments of one recursion depth partitioned AT ONCE (stl_emul.h (a)-(c): the pairing formulation of __unguarded_partition
+// and its generation-parallel form sort_desc_generations, both checked against std::sort on the host) -- ~9 generations of a few
+// wave-wide passes for 362 pairs instead of ~55 partitions one after the other.  The benchmark's random-init fp16 net answers with a
+// near-uniform policy on the fp16 grid (~240 distinct values among 362 priors), so EVERY row of the headline takes this path.
+// Element e = k * 64 + lane; a lane keeps (first, last) of its elements' segments in registers.  LDS:
+//   pk[e]    the pair at position e; the spare 16 bits of pk[first] carry the segment's cut from the pass that finds it to the pass that
+//            splits the segment (position `first` holds the pivot: no swap of the partition touches it)
+//   pud[x]   (sprob area) exclusive prefix counts of the two stop flags over the whole array: up-stops | down-stops << 16
+//   updp[s]  (skey + scr) slot first + t of a segment: its t-th up-stop (ascending) | its t-th down-stop (descending) << 16
+// Leaves the array as __introsort_loop does; the caller finishes with a stable sort (= __final_insertion_sort).
 template <int N>
-__device__ void introsort_loop_wave(ExpandLds<N>& L, int n, int lane) {
-  constexpr int NE = ExpandLds<N>::NE, RR = (NE + 63) / 64, KS = stl_emul::kSortStack;
-  u16* upos = reinterpret_cast<u16*>(L.sprob);
-  u16* dpos = upos + NE;
-  stl_emul::PairRef<u16> p{L.key, L.prob};
-  int* stk = L.sort_stack;
-  int lg = 0;
-  for (int t = n; t > 1; t >>= 1) ++lg;
-  if (lane == 0) { stk[0] = 0; stk[KS] = n; stk[2 * KS] = 2 * lg; }
-  int sp = 1;
-  Board<N>::wsync();
+__device__ __forceinline__ void introsort_generations_wave(ExpandLds<N>& L, int n, int lane) {
+  constexpr int NE = ExpandLds<N>::NE, RR = (NE + 63) / 64;
+  u32* const pud = reinterpret_cast<u32*>(L.sprob);
+  static_assert(offsetof(ExpandLds<N>, scr) == offsetof(ExpandLds<N>, skey) + NE * 2, "skey and scr are one array of NE u32");
+  u16* const updp16 = L.skey;
+  const u32* const updp = reinterpret_cast<const u32*>(L.skey);
+  u32* const pk32 = reinterpret_cast<u32*>(L.pk);          // pk32[2e] = prior bits, pk32[2e+1] = coord | scratch << 16
+  u16* const pk16 = reinterpret_cast<u16*>(L.pk);          // pk16[4e+3] = scratch
   const u64 lt_mask = (1ull << lane) - 1ull;
-  while (sp > 0) {
-    --sp;
-    int first = rfl(stk[sp]), last = rfl(stk[KS + sp]), depth = rfl(stk[2 * KS + sp]);
-    while (last - first > 16) {
-      if (depth == 0) {                         // __partial_sort fallback: rare, serial
-        if (lane == 0) stl_emul::heap_sort(p, first, last);
-        Board<N>::wsync();
-        break;
-      }
-      --depth;
-      if (lane == 0) stl_emul::median_to_first(p, first, last);
-      Board<N>::wsync();
-      const float P = L.prob[first];
-      int nu = 0, nd = 0;
-      u64 md[RR];
+  int sf[RR], sl[RR];
 #pragma unroll
+  for (int k = 0; k < RR; ++k) { sf[k] = 0; sl[k] = k * 64 + lane < n ? n : 0; }
+  int depth = 0;
+  for (int t = n; t > 1; t >>= 1) depth += 2;             // 2 * floor(lg n)
+  for (;;) {
+    u32 rounds = 0;                                        // rounds that hold an element of a long segment
+#pragma unroll
+    for (int k = 0; k < RR; ++k) rounds |= (__ballot(sl[k] - sf[k] > 16) != 0 ? 1u : 0u) << k;
+    if (rounds == 0) break;
+    if (ELF_RARE(depth == 0)) {
+      // __partial_sort fallback (median-of-3 killers only): serial, one long segment after the other, on unpacked copies
+      float* const hv = L.sprob;
+      u16* const hk = L.skey;
+#pragma unroll 1
       for (int k = 0; k < RR; ++k) {
-        md[k] = 0;
-        if (k * 64 >= last || k * 64 + 63 <= first) continue;        // round outside (first, last): wave-uniform
-        const int e = k * 64 + lane;
-        const bool in = e > first && e < last;
-        const float v = L.prob[in ? e : first];
-        const bool u = in && v <= P, d = in && v >= P;
-        const u64 mu = __ballot(u);
-        md[k] = __ballot(d);
-        if (u) upos[nu + __popcll(mu & lt_mask)] = (u16)e;
-        nu += __popcll(mu);
+        u64 m = __ballot(k * 64 + lane == sf[k] && sl[k] - sf[k] > 16);
+        while (m) {
+          const int l = (int)__builtin_ctzll(m);
+          m &= m - 1;
+          const int first = rl(sf[k], l), last = rl(sl[k], l);
+          for (int i = first + lane; i < last; i += 64) { hv[i] = __uint_as_float(pk32[2 * i]); hk[i] = (u16)pk32[2 * i + 1]; }
+          Board<N>::wsync();
+          if (lane == 0) stl_emul::heap_sort(stl_emul::PairRef<u16>{hk, hv}, first, last);
+          Board<N>::wsync();
+          for (int i = first + lane; i < last; i += 64) { pk32[2 * i] = __float_as_uint(hv[i]); pk32[2 * i + 1] = hk[i]; }
+          Board<N>::wsync();
+        }
       }
-#pragma unroll
-      for (int k = RR - 1; k >= 0; --k) {
-        if (md[k] == 0) continue;
-        const int e = k * 64 + lane;
-        if ((md[k] >> lane) & 1) dpos[nd + __popcll(md[k] & ~lt_mask & ~(1ull << lane))] = (u16)e;
-        nd += __popcll(md[k]);
-      }
-      Board<N>::wsync();
-      const int mn = nu < nd ? nu : nd;
-      int T = 0;                                 // upos ascending, dpos descending: upos[t] < dpos[t] holds exactly for t < T
-      for (int base = 0; base < mn; base += 64) {
-        const int t = base + lane;
-        const bool ok = t < mn && upos[t] < dpos[t];
-        T += __popcll(__ballot(ok));
-      }
-      for (int t = lane; t < T; t += 64) {
-        const int a = upos[t], b = dpos[t];
-        const float va = L.prob[a], vb = L.prob[b];
-        const u16 ka = L.key[a], kb = L.key[b];
-        L.prob[a] = vb; L.prob[b] = va;
-        L.key[a] = kb; L.key[b] = ka;
-      }
-      Board<N>::wsync();
-      const int hi_prev = T > 0 ? rfl((int)dpos[T - 1]) : last;
-      const int ut = T < nu ? rfl((int)upos[T]) : 0x7FFFFFFF;
-      const int cut = ut < hi_prev ? ut : hi_prev;
-      if (lane == 0) { stk[sp] = first; stk[KS + sp] = cut; stk[2 * KS + sp] = depth; }
-      ++sp;
-      first = cut;
-      Board<N>::wsync();
+      break;
     }
+    --depth;
+    // 1. the pivots: __move_median_to_first(first, first + 1, mid, last - 1) of every long segment, by the lane that holds the
+    //    segment's first element: which of the three is the median is a select chain, then one swap of pairs
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      if (!((rounds >> k) & 1)) continue;
+      const bool head = k * 64 + lane == sf[k] && sl[k] - sf[k] > 16;
+      if (__ballot(head) == 0) continue;
+      if (head) {
+        const int first = sf[k], a = first + 1, b = first + ((sl[k] - first) >> 1), c = sl[k] - 1;
+        const float va = __uint_as_float(pk32[2 * a]), vb = __uint_as_float(pk32[2 * b]), vc = __uint_as_float(pk32[2 * c]);
+        const bool ab = va > vb, bc = vb > vc, ac = va > vc;
+        const int m = ab ? (bc ? b : (ac ? c : a)) : (ac ? a : (bc ? c : b));
+        const u64 x = L.pk[first], y = L.pk[m];
+        L.pk[first] = y; L.pk[m] = x;
+      }
+    }
+    Board<N>::wsync();
+    // 2.-4. stop flags and their exclusive prefix counts over the whole array
+    int cu = 0, cd = 0;
+    int pu[RR], pd[RR];
+    u32 mub = 0, mdb = 0;                                  // bit k: this lane's element of round k is an up-stop / down-stop
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      const int e = k * 64 + lane;
+      pu[k] = cu; pd[k] = cd;
+      if ((rounds >> k) & 1) {
+        const bool act = sl[k] - sf[k] > 16, in = act && e > sf[k];
+        const float v = __uint_as_float(pk32[2 * (in ? e : 0)]), P = __uint_as_float(pk32[2 * (act ? sf[k] : 0)]);
+        const bool u = in && v <= P, d = in && v >= P;
+        const u64 mu = __ballot(u), md = __ballot(d);
+        pu[k] = cu + __popcll(mu & lt_mask);
+        pd[k] = cd + __popcll(md & lt_mask);
+        cu += __popcll(mu);
+        cd += __popcll(md);
+        mub |= (u ? 1u : 0u) << k;
+        mdb |= (d ? 1u : 0u) << k;
+      }
+      if (e <= n) pud[e] = (u32)pu[k] | ((u32)pd[k] << 16);
+    }
+    Board<N>::wsync();
+    // 5. the t-th up-stop (ascending) and the t-th down-stop (descending) of a segment meet in slot first + t
+    u32 nund[RR];
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      nund[k] = 0;
+      if (!((rounds >> k) & 1)) continue;
+      const int e = k * 64 + lane;
+      const bool act = sl[k] - sf[k] > 16;
+      const u32 lo = pud[act ? sf[k] + 1 : 0], hi = pud[act ? sl[k] : 0];
+      nund[k] = hi - lo;                                   // up-stops | down-stops << 16 of the segment (no borrow: both halves grow)
+      if ((mub >> k) & 1) updp16[2 * (sf[k] + (pu[k] - (int)(lo & 0xFFFFu)))] = (u16)e;
+      if ((mdb >> k) & 1) updp16[2 * (sf[k] + ((int)(hi >> 16) - pd[k] - 1)) + 1] = (u16)e;
+    }
+    Board<N>::wsync();
+    // 6.-8. slot q of its segment: the pairs that swap are a prefix of the slots; the slot where that ends knows T and the cut
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      if (!((rounds >> k) & 1)) continue;
+      const int q = k * 64 + lane;
+      const bool act = sl[k] - sf[k] > 16;
+      const int first = sf[k], last = sl[k], t = q - first;
+      const int nu = (int)(nund[k] & 0xFFFFu), nd = (int)(nund[k] >> 16);
+      const int mn = nu < nd ? nu : nd;
+      const int qc = act ? q : 0;
+      const u32 s0 = updp[qc], s1 = updp[qc + 1];
+      const int upq = (int)(s0 & 0xFFFFu), dpq = (int)(s0 >> 16), upn = (int)(s1 & 0xFFFFu), dpn = (int)(s1 >> 16);
+      const bool ok = act && t < mn && upq < dpq;
+      const bool okn = act && t + 1 < mn && upn < dpn;
+      if (ok) {
+        const u64 x = L.pk[upq], y = L.pk[dpq];
+        L.pk[upq] = y; L.pk[dpq] = x;
+      }
+      if (ok && !okn) {                                    // T = t + 1
+        const int ut = t + 1 < nu ? upn : 0x7FFFFFFF;
+        pk16[4 * first + 3] = (u16)(ut < dpq ? ut : dpq);
+      } else if (act && t == 0 && !ok) {                   // T = 0
+        const int ut = nu > 0 ? upq : 0x7FFFFFFF;
+        pk16[4 * first + 3] = (u16)(ut < last ? ut : last);
+      }
+    }
+    Board<N>::wsync();
+    // 9. the two parts of every segment
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      if (!((rounds >> k) & 1)) continue;
+      if (sl[k] - sf[k] > 16) {
+        const int cut = pk16[4 * sf[k] + 3];
+        if (k * 64 + lane < cut) sl[k] = cut; else sf[k] = cut;
+      }
+    }
+    Board<N>::wsync();
   }
 }
 
@@ -1295,8 +1370,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
       int a0;
       action_to_coord<N>(i, d4, coord, a0);
       p = prow[i];
-      L.prob[i] = p;            // kept in action order for the exact std::sort replay
-      L.key[i] = (u16)coord;
+      L.pk[i] = (u64)__float_as_uint(p) | ((u64)(u32)coord << 32);   // kept in action order for the exact std::sort replay
       if (coord == M_PASS) valid = pass_enabled;
       else valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;      // s.checkMove(v.first) :308-309
     }
@@ -1356,18 +1430,23 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
       // equal priors among valid candidates: the order is whatever libstdc++'s unstable std::sort makes of ALL N*N+1 pairs
       // (go/mcts/mcts.h:292-297).  Replayed exactly and wave-parallel: the introsort loop on the action-order arrays in LDS, then
       // __final_insertion_sort as what it is, a stable sort by (prior desc, position asc) on the bitonic network, then the filter.
-      introsort_loop_wave<N>(L, NA, lane);
+      EXP_PHASE(4);
+      introsort_generations_wave<N>(L, NA, lane);
+      EXP_PHASE(1);   // the introsort loop of the exact std::sort replay (prior ties only)
+      // slot e = lane * 8 + k (the blocked network); key = (prior desc, position asc), coord as payload
 #pragma unroll
       for (int k = 0; k < SK; ++k) {
-        const int i = k * 64 + lane;
-        sx[k] = i < NA ? (((u64)(~f2ukey(L.prob[i])) << 32) | ((u32)i << 16) | (u32)L.key[i]) : ~0ull;
+        const int i = lane * SK + k;
+        const u64 pr = L.pk[i < NA ? i : 0];
+        sx[k] = i < NA ? (((u64)(~f2ukey(__uint_as_float((u32)pr))) << 32) | ((u32)i << 16) | (u32)((pr >> 32) & 0xFFFFu)) : ~0ull;
       }
       Board<N>::wsync();
-      bitonic_sort512(sx, lane);
-      int w = 0;
+      bitonic_sort512_blocked(sx, lane);
+      // the filter (s.checkMove :308-309): a lane's valid ones go behind those of the lanes below it, in slot order
+      u32 vmask = 0;
 #pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const int e = k * 64 + lane;
+      for (int k = 0; k < SK; ++k) {
+        const int e = lane * SK + k;
         const int coord = (int)(sx[k] & 0xFFFFu);
         bool valid = false;
         if (e < NA) {
@@ -1377,13 +1456,17 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
             valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;
           }
         }
-        const u64 mv = __ballot(valid);
-        if (valid) {
-          const int dst = w + __popcll(mv & ((1ull << lane) - 1ull));
+        vmask |= (valid ? 1u : 0u) << k;
+      }
+      const int cnt = __popc(vmask);
+      int dst = wave_inclusive_sum(cnt) - cnt;
+#pragma unroll
+      for (int k = 0; k < SK; ++k) {
+        if ((vmask >> k) & 1) {
           L.sprob[dst] = ukey2f(~(u32)(sx[k] >> 32));
-          L.skey[dst] = (u16)coord;
+          L.skey[dst] = (u16)(sx[k] & 0xFFFFu);
+          ++dst;
         }
-        w += __popcll(mv);
       }
       Board<N>::wsync();
 #pragma unroll

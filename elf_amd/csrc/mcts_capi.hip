@@ -121,7 +121,7 @@ int elfmcts_create(ElfGoEngine* e, int num_games, int nodes_per_game, int d4_win
   if (cs + cb >= ((int64_t)1 << 31) - 64) { delete m; return ELFGO_E_BADARG; }     // node ids are 32-bit
   m->Cs = (int)cs; m->Cb = (int)cb; m->C = m->Cs + m->Cb;
   m->KTA = opt->num_threads * opt->num_rollouts_per_batch;
-  m->SC = 2 * m->KTA;
+  m->SC = (MCTS_REFILL + 1) * m->KTA;
   record_bytes(e->n, &m->small_bytes, &m->big_bytes);
   m->NE = e->n == 19 ? NodeL<19>::NE : NodeL<9>::NE;
   const size_t G = num_games, C = m->C;
@@ -241,7 +241,7 @@ size_t elfmcts_tree_bytes_per_game2(int board_size, int nodes_per_game, int num_
   // owner, keep byte), and what IS per game: its stash, leaf / row tables, path rows of a step, D4 windows
   return Cs * sm + (Cs * bg + NodeL<19>::TCS - 1) / NodeL<19>::TCS + (Cs + Cs / NodeL<19>::TCS + 1) * (sizeof(int) * 3 + 1) +
          sizeof(GameState) + MCTS_KMAX * (sizeof(LeafRec) + sizeof(RowRec)) + kta * MCTS_PATH_LV * 2 * sizeof(uint32_t) +
-         2 * kta * sizeof(int) + (size_t)d4_window + (size_t)num_threads * sizeof(int) + 2 * sizeof(int);
+         (MCTS_REFILL + 1) * kta * sizeof(int) + (size_t)d4_window + (size_t)num_threads * sizeof(int) + 2 * sizeof(int);
 }
 /* average bytes per node id of the pool: small record + its share of the big class and of the id arrays */
 size_t elfmcts_node_bytes(const ElfMcts* m) {

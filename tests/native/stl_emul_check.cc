@@ -47,6 +47,13 @@ static int check_sort(std::vector<float> vals) {
   stl_emul::sort_desc_pairing(k2.data(), v2.data(), n);
   for (int i = 0; i < n; ++i)
     if (ref[i].first != k2[i] || ref[i].second != v2[i]) return 1;
+  // ... and so must the generation formulation (all segments of one recursion depth partitioned at once: the expand kernel's form)
+  std::vector<Coord> k3(n);
+  std::vector<float> v3(n);
+  for (int i = 0; i < n; ++i) { k3[i] = (Coord)i; v3[i] = vals[i]; }
+  stl_emul::sort_desc_generations(k3.data(), v3.data(), n);
+  for (int i = 0; i < n; ++i)
+    if (ref[i].first != k3[i] || ref[i].second != v3[i]) return 1;
   return 0;
 }
 

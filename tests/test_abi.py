@@ -69,9 +69,16 @@ def test_tree_memory_accounting_and_the_round_5_entry_points(built):
         for nodes in (64, 8192, 33792):
             b = elf_amd.tree_bytes_per_game(n, nodes)
             records = nodes * small + (nodes // 16 + 1) * big
-            assert records < b < records + (nodes + nodes // 16 + 1) * 9 + (1 << 17), (n, nodes, b)
+            assert records - big < b < records + (nodes + nodes // 16 + 1) * 13 + (1 << 17), (n, nodes, b)   # 13 B of id arrays per id
     assert elf_amd.tree_bytes_per_game(19, 8192) * 4096 < 230e9          # the search-only line: 4096 games fit 288 GB
     assert elf_amd.tree_bytes_per_game(13, 8192) == 0 and elf_amd.tree_bytes_per_game(19, 0) == 0
+    # the second form takes what is laid out per leaf of a step and per search thread: 512 B of path row per leaf (1024 leaves = 512 KB)
+    b1 = L.elfmcts_tree_bytes_per_game2(19, 8192, 1, 16, 1024)
+    assert b1 == elf_amd.tree_bytes_per_game(19, 8192)
+    b2 = L.elfmcts_tree_bytes_per_game2(19, 8192, 8, 128, 8 * 1024)
+    assert b2 - b1 == (1024 - 16) * (512 + 9 * 4) + 7 * 1024 + 7 * 4
+    assert L.elfmcts_tree_bytes_per_game2(19, 8192, 0, 16, 1024) == 0
+    assert L.elfmcts_pool_info(None, None, 0) == -1 and L.elfmcts_count_live(None, None) == -1
     assert L.elfmcts_num_threads(None) == -1 and L.elfmcts_thread_draws(None, None, None) == -1
     assert L.elfsp_ts_requests_deferred(None) == -1
 

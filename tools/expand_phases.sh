@@ -5,9 +5,10 @@ set -e
 make -C elf_amd/csrc clean >/dev/null
 make -C elf_amd/csrc HIPCC="/opt/rocm/bin/hipcc -DELF_PROFILE_EXPAND" >/dev/null 2>&1
 python - <<'PY'
-import ctypes as C, json, subprocess, sys
+import ctypes as C, json, os, subprocess, sys
 sys.path.insert(0, ".")
-sys.argv = ["bench.py", "--workload", "mcts", "--net", "random", "--games", "1024", "--groups", "1", "--nodes-per-game", "8192",
+# ELF_NET=random16: near-uniform fp16-grid replies like the headline's random-init net (prior ties in every row)
+sys.argv = ["bench.py", "--workload", "mcts", "--net", os.environ.get("ELF_NET", "random"), "--games", "1024", "--groups", "1", "--nodes-per-game", "8192",
             "--rollouts", "2048", "--warmup", "24", "--steps", "32", "--no-cpu-baseline", "--no-sub", "--pregrow", "0", "--features", "f16"]
 import bench, io, contextlib
 buf = io.StringIO()
@@ -19,8 +20,8 @@ import elf_amd
 L = C.CDLL(elf_amd._lib.LIB_PATH)
 out = (C.c_uint64 * 8)()
 L.elfprof_expand_phases(out)
-names = ["row map + board load", "pass rule + legal mask", "reply read / coords / validity / keys", "bitonic sort (512 slots)",
-         "sorted rows to LDS + tie test", "sequential fp32 normalisation", "unordered_map iteration order", "edge records to HBM"]
+names = ["row map + parked legal mask", "introsort loop of the std::sort replay (ties)", "reply read / coords / validity / keys", "bitonic sort (512 slots)",
+         "sorted rows to LDS + tie test (+ final stable sort and filter on ties)", "sequential fp32 normalisation", "unordered_map iteration order", "edge records to HBM"]
 tot = sum(out)
 rows = d["selfplay_stats_window"]["rows"]
 print("  total %.0f ticks per row (%d rows)" % (tot / rows, rows))

@@ -56,7 +56,10 @@ def main():
                 peak = np.maximum(peak, used)
                 per_move.append({"move": mv + 1, "live_nodes_mean": float(used.mean()), "live_nodes_max": int(used.max())})
             sp.end_step(pi, v)
-    print(json.dumps({"net": a.net, "games": a.games, "rollouts_per_move": a.rollouts, "nodes_per_game": cs, "per_move": per_move,
+    pool = sp.pool_info()
+    print(json.dumps({"net": a.net, "games": a.games, "rollouts_per_move": a.rollouts, "nodes_per_game": cs, "per_move": per_move, "pool": pool,
+                      "pool_GB": a.games * elf_amd.tree_bytes_per_game(19, cs) / 1e9,
+                      "fixed_pools_would_need_ids_per_game": int(peak.max()), "shared_pool_peak_ids_per_game": max(p["live_nodes_mean"] for p in per_move),
                       "peak_live_nodes_over_games": int(peak.max()), "peak_over_rollouts": float(peak.max()) / a.rollouts,
                       "bytes_per_game": elf_amd.tree_bytes_per_game(19, cs)}))
     sp.close()

@@ -11,7 +11,7 @@
 #   pmc       separate --pmc passes (FETCH_SIZE, WRITE_SIZE, LDS, SQ issue) of the same commands   -> pmc_*/ (never combined with a trace)
 #   headline  rocprofv3 --kernel-trace --stats of the headline with a WARM MIOpen user database: the net is run once un-profiled first,
 #             so the summary shows the CK implicit-GEMM convolutions, not MIOpen's find / verification kernels (naive_conv_*)
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift
 STEPS="${*:-tests bench stats pmc headline}"
 OUT=gpurun_out/$TAG
@@ -41,7 +41,7 @@ if has bench; then
   tail -3 $OUT/bench.time; wc -c $OUT/bench_line.json
 fi
 if has stats || has pmc; then
-  for W in board board9 mcts train feat32 feat16; do
+  for W in ${ELF_PROF_W:-board board9 mcts train feat32 feat16}; do     # ELF_PROF_W="mcts": one workload only
     eval CMD=\$PROF_$W
     if has stats; then
       timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_$W -o stats --output-format csv -- $CMD > $OUT/stats_$W.log 2>&1
