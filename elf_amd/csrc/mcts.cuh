@@ -55,6 +55,11 @@ enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2, LK_STATE_PENDING = 3 };   // 
 enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8, MCTS_ERR_VERSION = 16 };
 constexpr int MCTS_KMAX = 1024;  // max rollouts per step = num_threads x rollouts_per_batch: the stride of the per-game leaf / row tables in HBM.
                                  // The leaf table of a step in LDS (k_mcts_select) is sized by the launch: 20 B per rollout of the step
+// k_mcts_expand's std::sort replay: segments up to this length are finished by one lane each instead of by further wave-wide generations.
+// 16 = never (a segment of <= 16 pairs is left to the final insertion sort anyway): measured at 64, the serial lanes' LDS-latency
+// chains (one dependent read per scanned pair) cost MORE than the ~5 generations they replace (end_step 537 -> 595 us per 32 768 rows);
+// the lane-serial path stays as the depth-limit / __partial_sort fallback (median-of-3 killers: tests/adapters.py adversarial_net).
+constexpr int MCTS_SORT_SERIAL_BELOW = 16;
 constexpr int MCTS_REFILL = 8;   // steps' worth of node ids a game's stash is topped up to (k_mcts_select); stash capacity = (MCTS_REFILL + 1) x KTA
 enum { GM_IDLE = 0, GM_SEARCH = 1, GM_POLICY_ONLY = 2 };   // per-game mask byte (elfmcts_set_game_mask)
 
@@ -1193,30 +1198,13 @@ __device__ __forceinline__ void introsort_generations_wave(ExpandLds<N>& L, int 
   for (int t = n; t > 1; t >>= 1) depth += 2;             // 2 * floor(lg n)
   for (;;) {
     u32 rounds = 0;                                        // rounds that hold an element of a long segment
+    bool longer = false;                                   // some segment is longer than a lane finishes well on its own
 #pragma unroll
-    for (int k = 0; k < RR; ++k) rounds |= (__ballot(sl[k] - sf[k] > 16) != 0 ? 1u : 0u) << k;
-    if (rounds == 0) break;
-    if (ELF_RARE(depth == 0)) {
-      // __partial_sort fallback (median-of-3 killers only): serial, one long segment after the other, on unpacked copies
-      float* const hv = L.sprob;
-      u16* const hk = L.skey;
-#pragma unroll 1
-      for (int k = 0; k < RR; ++k) {
-        u64 m = __ballot(k * 64 + lane == sf[k] && sl[k] - sf[k] > 16);
-        while (m) {
-          const int l = (int)__builtin_ctzll(m);
-          m &= m - 1;
-          const int first = rl(sf[k], l), last = rl(sl[k], l);
-          for (int i = first + lane; i < last; i += 64) { hv[i] = __uint_as_float(pk32[2 * i]); hk[i] = (u16)pk32[2 * i + 1]; }
-          Board<N>::wsync();
-          if (lane == 0) stl_emul::heap_sort(stl_emul::PairRef<u16>{hk, hv}, first, last);
-          Board<N>::wsync();
-          for (int i = first + lane; i < last; i += 64) { pk32[2 * i] = __float_as_uint(hv[i]); pk32[2 * i + 1] = hk[i]; }
-          Board<N>::wsync();
-        }
-      }
-      break;
+    for (int k = 0; k < RR; ++k) {
+      rounds |= (__ballot(sl[k] - sf[k] > 16) != 0 ? 1u : 0u) << k;
+      longer = longer || sl[k] - sf[k] > MCTS_SORT_SERIAL_BELOW;
     }
+    if (!__any(longer) || depth == 0) break;
     --depth;
     // 1. the pivots: __move_median_to_first(first, first + 1, mid, last - 1) of every long segment, by the lane that holds the
     //    segment's first element: which of the three is the median is a select chain, then one swap of pairs
@@ -1309,6 +1297,84 @@ __device__ __forceinline__ void introsort_generations_wave(ExpandLds<N>& L, int 
       }
     }
     Board<N>::wsync();
+  }
+  // ---- many short segments are left (each > 16, all <= MCTS_SORT_SERIAL_BELOW unless the depth limit ran out): ONE lane per segment runs
+  // the serial __introsort_loop on it with the depth limit that is left (stl_emul.h (d), sort_desc_hybrid).  A generation costs its
+  // wave-wide passes whatever the segments' lengths; ~20 lanes partitioning ~40 pairs each cost a few hundred instructions once.
+  constexpr int MS = (N * N + 1) / 17 + 1;                 // segments longer than 16 that n pairs can hold
+  u32* const seglist = pud;                                // [0, MS) segments (first | last << 16); [MS, 2 MS) heap-sort to-do list; [2 MS] its length
+  u32* const stk = reinterpret_cast<u32*>(L.skey);         // [slot][16]: first | last << 9 | depth << 18
+  static_assert(NE * 4 >= MS * 16 * 4 && 2 * MS + 1 <= 48 && 48 * 4 + NE * 2 <= NE * 4, "serial introsort scratch fits the sprob / skey + scr areas");
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < RR; ++k) {
+    const bool head = k * 64 + lane == sf[k] && sl[k] - sf[k] > 16;
+    const u64 m = __ballot(head);
+    if (head) seglist[cnt + __popcll(m & lt_mask)] = (u32)sf[k] | ((u32)sl[k] << 16);
+    cnt += __popcll(m);
+  }
+  if (cnt == 0) return;
+  if (lane == 0) seglist[2 * MS] = 0;
+  Board<N>::wsync();
+  if (lane < cnt) {
+    u32* const st = stk + lane * 16;
+    int sp = 1;
+    {
+      const u32 fl = seglist[lane];
+      st[0] = (fl & 0xFFFFu) | ((fl >> 16) << 9) | ((u32)depth << 18);
+    }
+    while (sp > 0) {
+      --sp;
+      const u32 w = st[sp];
+      int first = (int)(w & 0x1FFu), last = (int)((w >> 9) & 0x1FFu), d = (int)(w >> 18);
+      while (last - first > 16) {
+        if (ELF_RARE(d == 0)) {                            // __partial_sort fallback: left to the wave below
+          const u32 slot = atomicAdd(&seglist[2 * MS], 1u);   // the to-do segments are disjoint and longer than 16: at most MS of them
+          seglist[MS + (slot < (u32)MS ? slot : 0u)] = (u32)first | ((u32)last << 16);
+          break;
+        }
+        --d;
+        // __unguarded_partition_pivot: median of (first + 1, mid, last - 1) to first, then the two scans
+        {
+          const int a = first + 1, b = first + ((last - first) >> 1), c = last - 1;
+          const float va = __uint_as_float(pk32[2 * a]), vb = __uint_as_float(pk32[2 * b]), vc = __uint_as_float(pk32[2 * c]);
+          const bool ab = va > vb, bc = vb > vc, ac = va > vc;
+          const int m = ab ? (bc ? b : (ac ? c : a)) : (ac ? a : (bc ? c : b));
+          const u64 x = L.pk[first], y = L.pk[m];
+          L.pk[first] = y; L.pk[m] = x;
+        }
+        const float P = __uint_as_float(pk32[2 * first]);
+        int lo = first + 1, hi = last;
+        for (;;) {
+          while (__uint_as_float(pk32[2 * lo]) > P) ++lo;
+          --hi;
+          while (P > __uint_as_float(pk32[2 * hi])) --hi;
+          if (!(lo < hi)) break;
+          const u64 x = L.pk[lo], y = L.pk[hi];
+          L.pk[lo] = y; L.pk[hi] = x;
+          ++lo;
+        }
+        st[sp++] = (u32)first | ((u32)lo << 9) | ((u32)d << 18);   // the left part waits, the right part goes on (any order: disjoint)
+        first = lo;
+      }
+    }
+  }
+  Board<N>::wsync();
+  const int n_heap = rfl((int)seglist[2 * MS]);
+  if (ELF_RARE(n_heap > 0)) {
+    // median-of-3 killers only: serial heap sorts on unpacked copies, one segment after the other
+    float* const hv = reinterpret_cast<float*>(L.skey);    // the stacks are dead
+    u16* const hk = reinterpret_cast<u16*>(pud + 48);
+    for (int i = 0; i < n_heap && i < MS; ++i) {
+      const u32 fl = seglist[MS + i];
+      const int first = (int)(fl & 0xFFFFu), last = (int)(fl >> 16);
+      for (int q = first + lane; q < last; q += 64) { hv[q] = __uint_as_float(pk32[2 * q]); hk[q] = (u16)pk32[2 * q + 1]; }
+      Board<N>::wsync();
+      if (lane == 0) stl_emul::heap_sort(stl_emul::PairRef<u16>{hk, hv}, first, last);
+      Board<N>::wsync();
+      for (int q = first + lane; q < last; q += 64) { pk32[2 * q] = __float_as_uint(hv[q]); pk32[2 * q + 1] = hk[q]; }
+      Board<N>::wsync();
+    }
   }
 }
 

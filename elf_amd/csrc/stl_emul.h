@@ -358,6 +358,56 @@ static inline void sort_desc_generations(K* keys, float* vals, int n) {
   }
 }
 
+// (d) What the expand kernel runs: generations while some segment is longer than `serial_below` elements (few, long segments: the
+//     wave-wide passes pay), then every remaining long segment is finished by ONE lane with the serial __introsort_loop and the depth
+//     limit that is left (many short segments: a generation would still cost its full wave-wide passes).  Same partitions, other order.
+template <typename K>
+static inline void sort_desc_hybrid(K* keys, float* vals, int n, int serial_below) {
+  if (n <= 0) return;
+  PairRef<K> p{keys, vals};
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  std::vector<int> sf(n, 0), sl(n, n), upos(n + 1), dpos(n + 1);
+  int depth = 2 * lg;
+  for (;;) {
+    bool longer = false;
+    for (int e = 0; e < n; ++e) longer = longer || (sl[e] - sf[e] > serial_below && sl[e] - sf[e] > 16);
+    if (!longer || depth == 0) break;
+    --depth;
+    std::vector<int> cuts(n, -1);
+    for (int e = 0; e < n; ++e)
+      if (e == sf[e] && sl[e] - sf[e] > 16) cuts[e] = partition_pairing(p, sf[e], sl[e], upos.data(), dpos.data());
+    for (int e = 0; e < n; ++e) {
+      if (!(sl[e] - sf[e] > 16)) continue;
+      const int cut = cuts[sf[e]];
+      if (e < cut) sl[e] = cut; else sf[e] = cut;
+    }
+  }
+  for (int e = 0; e < n; ++e) {                          // one lane per remaining long segment
+    if (!(e == sf[e] && sl[e] - sf[e] > 16)) continue;
+    int stk_first[kSortStack], stk_last[kSortStack], stk_depth[kSortStack], sp = 0;
+    stk_first[0] = sf[e]; stk_last[0] = sl[e]; stk_depth[0] = depth; sp = 1;
+    while (sp > 0) {
+      --sp;
+      int first = stk_first[sp], last = stk_last[sp], d = stk_depth[sp];
+      while (last - first > 16) {
+        if (d == 0) { heap_sort(p, first, last); break; }
+        --d;
+        const int cut = partition_pivot(p, first, last);
+        stk_first[sp] = first; stk_last[sp] = cut; stk_depth[sp] = d; ++sp;
+        first = cut;
+      }
+    }
+  }
+  std::vector<K> k2(keys, keys + n);                     // stable descending sort = __final_insertion_sort
+  std::vector<float> v2(vals, vals + n);
+  for (int i = 0; i < n; ++i) {
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (v2[j] > v2[i]) || (v2[j] == v2[i] && j < i);
+    keys[r] = k2[i]; vals[r] = v2[i];
+  }
+}
+
 template <typename K>
 static inline void sort_desc(K* keys, float* vals, int n) {   // host convenience (tests)
   int stk[3 * kSortStack];

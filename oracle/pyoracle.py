@@ -466,7 +466,7 @@ class PortSelfPlay:
         mv = np.ascontiguousarray(moves, dtype=np.uint16)
         self.L.orcsp_set_preload(mv.ctypes.data_as(C.c_void_p), C.c_int(mv.size), C.c_int(move_to))
 
-    def run(self, **kw):
+    def run(self, net=None, **kw):
         cfg = dict(MCTS_DEFAULTS)
         cfg.update(kw)
         c = RefSpConfig(**cfg)
@@ -475,7 +475,18 @@ class PortSelfPlay:
         coord = np.full((m, na), -1, np.int32); visits = np.zeros((m, na), np.int32)
         prior = np.zeros((m, na), np.float32); reward = np.zeros((m, na), np.float32)
         stats = (C.c_int64 * 3)()
-        k = self.L.orcsp_run(C.byref(c), None, None, S, coord.ctypes.data_as(C.c_void_p), visits.ctypes.data_as(C.c_void_p),
+        cb = None
+        if net is not None:      # a Python net instead of the stub: net(s [b,18,n,n]) -> (pi [b,na], v [b])
+            NETFN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+            n = self.n
+
+            def _net(sp, b, pip, vp, _u):
+                s = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_float)), shape=(b, 18, n, n))
+                pi, v = net(s)
+                np.ctypeslib.as_array(C.cast(pip, C.POINTER(C.c_float)), shape=(b, na))[:] = pi
+                np.ctypeslib.as_array(C.cast(vp, C.POINTER(C.c_float)), shape=(b,))[:] = v
+            cb = NETFN(_net)
+        k = self.L.orcsp_run(C.byref(c), cb, None, S, coord.ctypes.data_as(C.c_void_p), visits.ctypes.data_as(C.c_void_p),
                              prior.ctypes.data_as(C.c_void_p), reward.ctypes.data_as(C.c_void_p), stats)
         if k < 0:
             raise RuntimeError("orcsp_run failed: %d" % k)

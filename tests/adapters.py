@@ -108,3 +108,52 @@ class HashNet:
         pi = wgt / wgt.sum(1, keepdim=True)
         v = ((h % 513) - 256).to(torch.float32) * (1.0 / 256.0)
         return pi, v
+
+
+def adversarial_net(n):
+    """A deterministic "net" whose policy rows are the inputs std::sort is sensitive to (go/mcts/mcts.h:292-297 sorts all n*n+1
+    (coord, prior) pairs by prior with an UNSTABLE introsort): per row, chosen by a hash of the feature row, one of -- a median-of-3
+    killer (drives __introsort_loop into its depth limit: the __partial_sort fallback), ascending / descending / organ-pipe ramps,
+    2 and 5 distinct values (large groups of equal priors), all equal, and a generic row on a coarse grid.  Values on the 1/256 grid
+    (exact fp32 sums in any backup order).  Returns net(s [b,18,n,n]) -> (pi [b,n*n+1] f32, v [b] f32)."""
+    import numpy as np
+    na = n * n + 1
+
+    def rows_for(kind, h):
+        i = np.arange(na, dtype=np.float64)
+        if kind == 0:      # median-of-3 killer for the descending comparator (tests/native/stl_emul_check.cc), made positive
+            v = np.zeros(na)
+            k = na // 2
+            for j in range(1, k + 1):
+                if j % 2 == 1:
+                    v[j - 1] = -j
+                    v[j] = -(k + j)
+                v[k + j - 1] = -2 * j
+            return 1.0 + v / 1024.0
+        if kind == 1:
+            return 1.0 + i
+        if kind == 2:
+            return 1.0 + (na - i)
+        if kind == 3:
+            return 1.0 + np.minimum(i, na - i)
+        if kind == 4:
+            return 1.0 + ((i * 7 + h) % 2)
+        if kind == 5:
+            return 1.0 + ((i * 11 + h) % 5)
+        if kind == 6:
+            return np.ones(na)
+        return 1.0 + ((i * 2654435761 + h * 40503) % 97)
+
+    def net(s):
+        s = np.asarray(s)
+        b = s.shape[0]
+        pi = np.zeros((b, na), np.float32)
+        v = np.zeros((b,), np.float32)
+        w = (np.arange(s[0].size, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(12345)) & np.uint64(0xFFFFF)
+        for r in range(b):
+            h = int((s[r].reshape(-1).astype(np.uint64) * w).sum() & np.uint64(0x7FFFFFFF))
+            row = rows_for(h % 8, h // 8)
+            pi[r] = (row / row.sum()).astype(np.float32)
+            v[r] = np.float32(((h >> 5) % 257 - 128) / 256.0)
+        return pi, v
+    return net

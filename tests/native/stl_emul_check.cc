@@ -54,6 +54,14 @@ static int check_sort(std::vector<float> vals) {
   stl_emul::sort_desc_generations(k3.data(), v3.data(), n);
   for (int i = 0; i < n; ++i)
     if (ref[i].first != k3[i] || ref[i].second != v3[i]) return 1;
+  for (int below : {16, 40, 64, 100000}) {   // generations, then one lane per remaining long segment (the kernel uses 64)
+    std::vector<Coord> k4(n);
+    std::vector<float> v4(n);
+    for (int i = 0; i < n; ++i) { k4[i] = (Coord)i; v4[i] = vals[i]; }
+    stl_emul::sort_desc_hybrid(k4.data(), v4.data(), n, below);
+    for (int i = 0; i < n; ++i)
+      if (ref[i].first != k4[i] || ref[i].second != v4[i]) return 1;
+  }
   return 0;
 }
 

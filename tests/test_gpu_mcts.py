@@ -231,6 +231,43 @@ def test_live_differential_against_the_reference_stack(elf, case):
     sp.close()
 
 
+@pytest.mark.parametrize("n", [19, 9])
+def test_adversarial_policy_rows_equal_the_reference(elf, n):
+    """k_mcts_expand's exact std::sort replay (generation-parallel introsort, then one lane per short segment, then the stable final
+    sort) on the rows std::sort is sensitive to: median-of-3 killers (the depth limit and __partial_sort fallback), ramps, organ pipes,
+    2 / 5 distinct values, all equal (tests/adapters.py adversarial_net) -- the REAL reference stack (oracle/_ref; its CPU restatement
+    where that is absent) and the engine search with the same net; every root statistic of every search must be equal."""
+    import torch
+    from adapters import adversarial_net
+    from pyoracle import MCTS_DEFAULTS, PortSelfPlay, RefSelfPlay
+    cfg = dict(MCTS_DEFAULTS)
+    cfg.update(rollouts_per_thread=96 if n == 19 else 128, max_searches=6 if n == 19 else 16, seed=515, ply_pass_enabled=2, policy_distri_cutoff=4)
+    net = adversarial_net(n)
+    ref = (RefSelfPlay(n) if RefSelfPlay.available(n) else PortSelfPlay(n)).run(net=net, **cfg)
+    S = ref["search"]
+    m = len(S)
+    assert m == cfg["max_searches"]
+    sp = _sp_from_cfg(elf, n, cfg, log_searches=m)
+    while sp.stats()["logged"] < m:
+        rows = sp.begin_step()
+        if rows:
+            pi, v = net(sp.s[:rows].cpu().numpy())
+            sp.end_step(torch.from_numpy(pi).to(sp.device), torch.from_numpy(v).to(sp.device))
+        else:
+            sp.end_step(None, None)
+    rec, coord, visits, prior, reward = sp.search_log()
+    for i in range(m):
+        ne = S[i].n_edges
+        ctx = "adversarial rows, %dx%d, search %d" % (n, n, i)
+        assert rec[i].n_edges == ne, ctx
+        assert np.array_equal(coord[i, :ne], ref["coord"][i, :ne]), ctx + ": edge order"
+        assert np.array_equal(visits[i, :ne], ref["visits"][i, :ne]), ctx
+        assert np.array_equal(prior[i, :ne].view(np.uint32), ref["prior"][i, :ne].view(np.uint32)), ctx
+        assert np.array_equal(reward[i, :ne].view(np.uint32), ref["reward"][i, :ne].view(np.uint32)), ctx
+        assert rec[i].move_played == S[i].move_played and rec[i].best_action == S[i].best_action, ctx
+    sp.close()
+
+
 # ---- the benchmarked configuration, pinned (VERDICT r1 "next round" item 1) --------------------------------------------------
 def _sp_from_cfg(elf, n, cfg, **over):
     kw = dict(board_size=n, device=0, mcts_rollout_per_thread=cfg["rollouts_per_thread"], mcts_rollout_per_batch=cfg["rollouts_per_batch"],

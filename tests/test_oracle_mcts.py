@@ -184,3 +184,24 @@ def test_restatement_matches_reference_fixture(built, name):
         assert np.array_equal(r["reward"][i, :ne].view(np.uint32), g["reward"][i, :ne].view(np.uint32)), ctx
         assert S.move_played == int(g["move_played"][i]) and S.best_action == int(g["best_action"][i]), ctx
         assert np.float32(S.root_value) == g["root_value"][i], ctx
+
+
+def test_restatement_equals_reference_on_adversarial_policy_rows(built):
+    """std::sort's order of equal priors (go/mcts/mcts.h:292-297) on the inputs it is sensitive to -- median-of-3 killers (the
+    __partial_sort fallback of __introsort_loop), ramps, organ pipes, few distinct values, all equal (tests/adapters.py
+    adversarial_net) -- through the whole search: the REAL reference stack against the CPU restatement, 19x19, 6 searches."""
+    from adapters import adversarial_net
+    n = 19
+    if not RefSelfPlay.available(n):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    kw = dict(MCTS_DEFAULTS)
+    kw.update(rollouts_per_thread=96, max_searches=6, seed=515, ply_pass_enabled=2, policy_distri_cutoff=4)
+    net = adversarial_net(n)
+    r = RefSelfPlay(n).run(net=net, **kw)
+    p = PortSelfPlay(n).run(net=net, **kw)
+    assert len(r["search"]) == len(p["search"]) == 6
+    for k in ("coord", "visits"):
+        assert np.array_equal(r[k], p[k]), k
+    for k in ("prior", "reward"):
+        assert np.array_equal(r[k].view(np.uint32), p[k].view(np.uint32)), k
+    assert [s.move_played for s in r["search"]] == [s.move_played for s in p["search"]]
