@@ -370,8 +370,14 @@ def init_dist(args):
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device)
+        # what differs between the ranks of a node, gathered once (full report: scaling_report.process_group.ranks): the core slice,
+        # the MIOpen user database and the device of every rank -- slices and databases must be disjoint
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, {"rank": rank, "device": device, "cores": [int(c) for c in mine], "miopen_user_db": os.environ["MIOPEN_USER_DB_PATH"]})
         DIST_INFO.update(backend=backend, host_cores_per_rank=len(mine), ranks_share_one_gpu=bool(share),
-                         miopen_user_db="per rank (%s)" % os.path.dirname(mi))
+                         miopen_user_db="per rank (%s)" % os.path.dirname(mi), ranks=ranks_info)
     if torch.cuda.is_available():
         torch.cuda.set_device(device)
     return rank, device, world, dist
@@ -762,12 +768,23 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     barrier()
     st0 = sp.stats()
     sp.timing = True
+    prof = None
+    if os.environ.get("ELF_BENCH_CPROFILE"):      # diagnostic: where the HOST spends the timed loop (python + ctypes calls), to stderr
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
+    t_host = 0.0
     for i in range(steps):
         sp.step(net_fn)   # every group: net -> expand -> backup -> select -> leaf features
+    t_host = time.perf_counter() - t0     # the host has ENQUEUED every step: if this is the wall time, the launches are the bottleneck
     sp.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
     sp.timing = False
     st1 = sp.stats()
     T = max(1, args.mcts_threads)
@@ -849,7 +866,7 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
                    "expand_backup_ms_incl_move_boundaries": exp_ms_with_boundaries, "end_step_events_with_a_boundary": int(len(exp_all) - len(exp_plain)),
                    "select_ms_incl_move_boundaries": sel_ms_with_boundaries, "begin_step_events_with_a_boundary": int(len(sel_all) - len(sel_plain)),
                    "step_minus_search_ms": step_ms - sel_ms - exp_ms, "groups": groups, "pregrow_steps": pregrow,
-                   "host_wait_per_step": bool(args.wait_rows),
+                   "host_wait_per_step": bool(args.wait_rows), "host_enqueue_ms_per_step": t_host / steps * 1e3,
                    "mean_depth": depth, "moves_in_window": d["moves"], "games_finished_in_window": d["games"],
                    "move_boundaries_in_window": d["boundaries"],
                    "move_boundary_ms": (d["boundary_ns"] / 1e6 / d["boundaries"]) if d["boundaries"] else None,
@@ -889,6 +906,55 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "selfplay_stats_window": d,
         "scaling_report": scaling_report(world, roll_all / dt_max, per_rank, "mcts_rollouts_per_sec"),
     }
+    # ---- the roofs that BIND (round 6).  The SURVEY 8(d) byte model above prices the reference's formulation (362 x 20 B per visited
+    # node, 52 KB per expansion); this layout moves a third of that, so `frac` is a speed-up over the model, not a bandwidth fraction.
+    # Beside it: the bandwidth the kernels really draw (PMC bytes), the dependent-load chain of the descents, and the instruction
+    # issue of the expansion -- each as the time it would take ALONE, and which of them is the longest.
+    rf = res["roofline"]
+    avg_ms = sel_ms + exp_ms
+    bind = {}
+    if rf.get("traffic") and avg_ms > 0:
+        rf["frac_pmc"] = rf["traffic"] / (avg_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+        bind["hbm (PMC bytes at 8 TB/s)"] = rf["traffic"] / (HBM_PEAK_GBS * 1e9) * 1e3
+    else:
+        rf["frac_pmc"] = None
+    chase = load_profile_json("chase.json") or {}
+    hop = None
+    for row in chase.get("rows", []):     # the row measured at (or above) this pool's footprint and this many chasing waves
+        if row["footprint_GB"] >= min(tree_gb, 160.0) - 1e-6 and row["waves"] >= min(Gg, 4608) and (hop is None or row["ns_per_hop"] < hop["ns_per_hop"]):
+            hop = row
+    if hop is not None:
+        # one wave per game runs K x T descents of `depth` levels one after the other, every level one dependent load; the waves of a
+        # launch run side by side (85 VGPRs: 5 per SIMD, 5120 on the chip), so the chain of ONE game is the launch's floor
+        waves_resident = 5 * 4 * 256
+        rounds_of_waves = -(-Gg // waves_resident)
+        rf["latency_chain_ms"] = K * T * depth * hop["ns_per_hop"] * 1e-6 * rounds_of_waves
+        rf["latency_chain_note"] = ("%d descents x %.2f levels x %.0f ns per dependent load (tools/chase.hip: %d waves chasing through %.0f GB) per "
+                                    "resident wave; against select_ms %.3f (which also holds the leaf states and the feature rows)"
+                                    % (K * T, depth, hop["ns_per_hop"], hop["waves"], hop["footprint_GB"], sel_ms))
+        bind["latency chain of the descents"] = rf["latency_chain_ms"]
+    else:
+        rf["latency_chain_ms"] = None
+    iss = load_profile_json("pmc_issue.json") or {}
+    if pmc_source_match("pmc_issue.json") and iss.get("k_mcts_expand<%d>" % n):
+        e_ = iss["k_mcts_expand<%d>" % n]
+        roll_step = G * K * T / max(1, groups)       # per launch of one group
+        t_valu = e_["valu_per_unit"] * roll_step / (VALU_PEAK_GINST * 1e9) * 1e3
+        t_salu = e_["salu_per_unit"] * roll_step / (SALU_PEAK_GINST * 1e9) * 1e3
+        rf["expand_issue"] = {"valu_per_rollout": e_["valu_per_unit"], "salu_per_rollout": e_["salu_per_unit"],
+                              "valu_frac": t_valu / exp_ms if exp_ms > 0 else None, "salu_frac": t_salu / exp_ms if exp_ms > 0 else None,
+                              "note": "SQ_INSTS_VALU / SALU per rollout of k_mcts_expand (search-only PMC pass, no prior ties) x rollouts per launch "
+                                      "/ the nominal issue peaks, over expand_backup_ms; with prior ties in every row (the random-init fp16 net) "
+                                      "the kernel issues about twice as many"}
+        bind["instruction issue of k_mcts_expand (VALU)"] = t_valu
+    if bind:
+        b = max(bind, key=bind.get)
+        rf["binding"] = b
+        rf["binding_ms"] = bind[b]
+        rf["binding_frac"] = bind[b] / avg_ms if avg_ms > 0 else None
+        rf["bounds_ms"] = bind
+    else:
+        rf["binding"] = None
     if net is not None:
         # the kernel that dominates the timed region is not this library's: PyTorch-ROCm's convolution (north_star leaves the
         # net on PyTorch).  Reported for transparency: algorithmic flops of the 20x256 net per position / measured call time.
@@ -1152,6 +1218,42 @@ def run_games(args, rank, local_rank, world, dist):
                                    "measured length of games played to their natural end; beside it the shortened configuration played end to end "
                                    "(%d rollouts/move, move_cutoff %d, %d generations)" % (args.phase_steps, roll, cutoff, args.games_generations),
                        "rollouts_per_move": args.rollouts * T, "games_per_gpu": G, "net": "resnet" if net is not None else args.net}}
+
+
+def run_single_game(args, rank, local_rank, world, dist):
+    """Latency of ONE game (what README.rst:147 and the GTP front-end are about: `--mcts_threads 2 --mcts_rollout_per_thread 8192
+    --batchsize 16`): 1 game, bs 16, 8192 rollouts per search thread and move, the 20 x 256 fp16 net.  Three runs of the headline's own
+    loop: T = 1 with the net call replayed as one HIP graph, T = 1 with eager launches (~85 kernels per call), T = 2 (graph; 16 384
+    rollouts per move).  A step is one batch: 16 T descents, the net on 16 T rows, expansion + backup; a move is 512 steps.  moves/s =
+    1 / (512 x ms_per_step); the split says where a step goes: search kernels, net call, and what is left (launches, host, stream waits)."""
+    import copy
+    out = {"metric": "single-game search latency (1 game, bs 16, 8192 rollouts per thread and move, 20x256 fp16 net)", "unit": "moves/s", "runs": {}}
+    for name, T, graph in (("T1_graph", 1, 1), ("T1_eager", 1, 0), ("T2_graph", 2, 1)):
+        a = copy.copy(args)
+        a.games, a.groups, a.rollouts, a.mcts_threads, a.net_graph, a.pregrow, a.nodes_per_game, a.net = 1, 1, 8192, T, graph, 0, None, "resnet"
+        r = run_mcts(a, rank, local_rank, world, dist, 96, 16, False)
+        if rank != 0 or not isinstance(r, dict):
+            continue
+        c = r["config"]
+        spm = 8192 // c["rollouts_per_step"] * T if c.get("rollouts_per_step") else 512
+        spm = 8192 * T // max(1, c["rollouts_per_step"])
+        net_ms = (r.get("net_roofline") or {}).get("avg_call_ms")
+        step = r["ms_per_step"]
+        search = (c.get("select_ms") or 0.0) + (c.get("expand_backup_ms") or 0.0)
+        out["runs"][name] = {"mcts_threads": T, "net_graph": bool(graph), "rollouts_per_move": 8192 * T, "steps_per_move": spm, "ms_per_step": step,
+                             "moves_per_sec": 1e3 / (step * spm), "seconds_per_move": step * spm / 1e3, "rollouts_per_sec": r["value"],
+                             "search_kernels_ms": search, "net_call_ms": net_ms, "launch_host_wait_ms": step - search - (net_ms or 0.0),
+                             "mean_depth": c.get("mean_depth")}
+    if rank != 0:
+        return None
+    g = out["runs"].get("T1_graph") or {}
+    out.update(value=g.get("moves_per_sec"), ms_per_step=g.get("ms_per_step"), moves_per_sec=g.get("moves_per_sec"),
+               moves_per_sec_T2=(out["runs"].get("T2_graph") or {}).get("moves_per_sec"),
+               moves_per_sec_eager=(out["runs"].get("T1_eager") or {}).get("moves_per_sec"),
+               search_kernels_ms=g.get("search_kernels_ms"), net_call_ms=g.get("net_call_ms"), launch_host_wait_ms=g.get("launch_host_wait_ms"),
+               note="one game cannot fill the chip (one wave descends, 16 waves expand): a step is launch / latency bound -- ~12 kernel launches "
+                    "of the search + the net call at 16 rows; the headline's 2048 games amortise exactly this")
+    return out
 
 
 def run_client(args, rank, local_rank, world, dist):
@@ -1523,9 +1625,14 @@ def _roof(r):
         out["kernel"] = out["kernel"][:80]
     if isinstance(out.get("unit"), str):
         out["unit"] = out["unit"][:40]
-    for k in ("binding_issue_roof", "binding_frac", "lds_bank_conflict_frac"):
+    for k in ("binding_issue_roof", "binding_frac", "lds_bank_conflict_frac", "frac_pmc", "latency_chain_ms", "binding_ms"):
         if r.get(k) is not None:
             out[k] = _num(r[k], 4)
+    if isinstance(r.get("binding"), str):      # which roof binds the search kernels: PMC bandwidth, the descents' latency chain, or issue
+        out["binding"] = r["binding"][:48]
+    if isinstance(r.get("expand_issue"), dict):
+        out["expand_valu_frac"] = _num(r["expand_issue"].get("valu_frac"), 4)
+        out["expand_salu_frac"] = _num(r["expand_issue"].get("salu_frac"), 4)
     return out
 
 
@@ -1548,20 +1655,25 @@ def _sub_summary(name, d):
         out["unit"] = out["unit"][:24]
     r = d.get("roofline")
     if isinstance(r, dict):
-        out["roofline"] = {k: v for k, v in _roof(r).items() if k in ("bound", "frac", "achieved", "peak", "binding_frac", "lds_bank_conflict_frac", "avg_kernel_ms")}
+        out["roofline"] = {k: v for k, v in _roof(r).items() if k in ("bound", "frac", "achieved", "peak", "binding_frac", "lds_bank_conflict_frac", "avg_kernel_ms", "frac_pmc")}
     if "parity_checked_boards" in d:
         out["parity"] = {"checked": d.get("parity_checked_boards"), "mismatches": d.get("parity_mismatches")}
     cb = d.get("cpu_baseline")
     if isinstance(cb, dict) and cb.get("value") is not None:
         out["cpu_baseline"] = _pick(cb, ("value", "cores", "kind"))
+    if name == "search_only":
+        out["rollouts_per_move"] = _num(d.get("rollouts_per_move"))     # NOT the headline's 8192: shorter moves on smaller pools
+        out["nodes_per_game"] = _num(d.get("nodes_per_game"))
     for k in ("games_per_gpu", "groups", "mean_depth", "select_ms", "expand_backup_ms", "rollouts_per_step", "pinned_host", "device_resident",
-              "moves_per_sec", "played_moves_per_sec", "derived_moves_per_sec_phase0", "derived"):
+              "moves_per_sec", "played_moves_per_sec", "derived_moves_per_sec_phase0", "derived", "moves_per_sec_T2", "moves_per_sec_eager",
+              "search_kernels_ms", "net_call_ms", "launch_host_wait_ms"):
         if k in d and not isinstance(d[k], (dict, list, str)):
             out[k] = _num(d[k])
     return out
 
 
-SUB_NAMES = ("search_only", "board_step", "board_step_9x9", "feature_extract", "train_loader", "boundary", "selfplay_games", "client_config")
+SUB_NAMES = ("search_only", "board_step", "board_step_9x9", "feature_extract", "train_loader", "boundary", "selfplay_games", "client_config",
+             "single_game")
 
 
 def compact_line(res, full_path=None):
@@ -1615,7 +1727,7 @@ def compact_line(res, full_path=None):
             line["scaling_report"]["games_per_sec_per_rank"] = [_num(v) for v in (gm.get("per_rank_games_per_sec") or [])]
     line["full_report"] = full_path
     line = _clean(line)
-    text = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     # never exceed the limit: drop the sub-results one by one (last first), then the optional blocks
     drop = [("sub", k) for k in reversed(SUB_NAMES)] + [("net_roofline", None), ("scaling_report", None)]
     while len(text) >= LINE_LIMIT - 64 and drop:
@@ -1625,7 +1737,7 @@ def compact_line(res, full_path=None):
         elif isinstance(line.get(a), dict):
             line[a].pop(b, None)
         line["truncated"] = True
-        text = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     return text
 
 
@@ -1655,7 +1767,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["mcts", "board", "train", "feature", "boundary", "games", "client", "both", "stub"], default="both",
+    ap.add_argument("--workload", choices=["mcts", "board", "train", "feature", "boundary", "games", "client", "single", "both", "stub"], default="both",
                     help="both (default) = mcts headline + every sub-result at N = 1")
     ap.add_argument("--train-batch", type=int, default=2048)
     ap.add_argument("--train-prefetch", type=int, default=16, help="train batches drawn + extracted per launch (1 = one batch per launch)")
@@ -1773,6 +1885,7 @@ def main():
                                       "unit": "rollouts/s", "ms_per_step": so["ms_per_step"], "games_per_gpu": c["games_per_gpu"], "groups": c["groups"],
                                       "rollouts_per_step": c["rollouts_per_step"], "mean_depth": c["mean_depth"], "select_ms": c["select_ms"],
                                       "expand_backup_ms": c["expand_backup_ms"], "roofline": so["roofline"], "roofline_pipelined": so["roofline_pipelined"], "nodes_per_game": nodes,
+                                      "rollouts_per_move": a2.rollouts, "node_pool": c.get("node_pool"),
                                       "tree_pool_GB": so_games * elf_amd.tree_bytes_per_game(19, nodes) / 1e9, "games_that_fit_free_hbm": fit,
                                       "note": "same kernels, same tree shape (2048 rollouts per move on 8192-node pools, depth ~6.3) as the headline's "
                                               "search; the per-game kernels are latency chains, more resident waves per SIMD hide them"}
@@ -1845,6 +1958,16 @@ def main():
         elif rank == 0:
             res["client_config"] = cl
     leg("client_config")
+    if args.workload == "single" or (sub and args.board_size == 19 and args.net == "resnet"):
+        try:
+            sg = run_single_game(sargs, rank, local_rank, world, dist)
+        except Exception as e:
+            sg = "unavailable: %r" % (e,)
+        if args.workload == "single":
+            res = sg
+        elif rank == 0:
+            res["single_game"] = sg
+    leg("single_game")
     if rank == 0:
         if isinstance(res, dict):
             res["leg_seconds"] = legs

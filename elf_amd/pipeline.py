@@ -60,18 +60,18 @@ class PipelinedSelfPlay:
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def _begin(self, i):
+        # no torch.cuda.stream() context here: the group launches on its own stream (SelfPlay.stream), events name theirs
         st = self.search_streams[i]
-        with torch.cuda.stream(st):
-            if self.timing:
-                e0, e1 = self._pair()
-                e0.record(st)
-            self._rows[i] = self.groups[i].begin_step(wait_rows=self.wait_rows)   # select + features
-            if self.timing:
-                e1.record(st)
-                self.t_select.append((e0, e1))
-            ev = torch.cuda.Event()
-            ev.record(st)                       # right behind this group's feature kernel
-            self._ev_sel[i] = ev
+        if self.timing:
+            e0, e1 = self._pair()
+            e0.record(st)
+        self._rows[i] = self.groups[i].begin_step(wait_rows=self.wait_rows)   # select + features
+        if self.timing:
+            e1.record(st)
+            self.t_select.append((e0, e1))
+        ev = torch.cuda.Event()
+        ev.record(st)                       # right behind this group's feature kernel
+        self._ev_sel[i] = ev
 
     def step(self, net_fn):
         """One batch for every group. net_fn(s_tensor, rows) -> (pi, V) is enqueued on the net stream; rows is None when the
@@ -79,14 +79,15 @@ class PipelinedSelfPlay:
         n = len(self.groups)
         if not self._primed:
             for i in range(n):
+                self.groups[i].stream = self.search_streams[i]
                 self._begin(i)
             self._primed = True
         total = 0
         for i in range(n):
             g = self.groups[i]
             ns = self.net_streams[i % len(self.net_streams)]
-            with torch.cuda.stream(ns):
-                ns.wait_event(self._ev_sel[i])                       # features of group i are in g.s
+            ns.wait_event(self._ev_sel[i])                           # features of group i are in g.s
+            with torch.cuda.stream(ns):                              # the net is PyTorch code: it runs on torch's current stream
                 if self.timing:
                     n0, n1 = self._pair()
                     n0.record(ns)
@@ -94,21 +95,24 @@ class PipelinedSelfPlay:
                 if self.timing:
                     n1.record(ns)
                     self.t_net.append((n0, n1))
-                ev_net = torch.cuda.Event()
-                ev_net.record(ns)
+            ev_net = torch.cuda.Event()
+            ev_net.record(ns)
             st = self.search_streams[i]
-            with torch.cuda.stream(st):
-                st.wait_event(ev_net)
-                if self.timing:
-                    e0, e1 = self._pair()
-                    e0.record(st)
+            st.wait_event(ev_net)
+            if self.timing:
+                e0, e1 = self._pair()
+                e0.record(st)
+            if pi is not None and (pi.dtype != torch.float32 or not pi.is_contiguous() or v.dtype != torch.float32):
+                with torch.cuda.stream(st):                          # the conversions are PyTorch kernels: on the group's stream
+                    g.end_step(pi, v)
+            else:
                 g.end_step(pi, v)                                    # expand + backup of group i (+ the move boundary)
-                if self.timing:
-                    e1.record(st)
-                    self.t_expand.append((e0, e1))
-                if pi is not None:
-                    pi.record_stream(st)
-                    v.record_stream(st)
+            if self.timing:
+                e1.record(st)
+                self.t_expand.append((e0, e1))
+            if pi is not None:
+                pi.record_stream(st)
+                v.record_stream(st)
             if self._rows[i] is not None:
                 total += self._rows[i]
             self._begin(i)                                           # next step's select, behind the expansion on the same stream

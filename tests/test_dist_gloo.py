@@ -57,6 +57,36 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert "headline_n1" not in r.stdout
 
 
+def _check_eight_ranks(full, rep):
+    """what differs between the ranks of a node: 8 per-rank values, disjoint core slices (when the host has a core per rank), one MIOpen
+    user database per rank, and a line that still fits the driver with 8 per_rank entries"""
+    pg = full["scaling_report"]["process_group"]
+    assert len(pg["ranks"]) == 8 and sorted(r["rank"] for r in pg["ranks"]) == list(range(8))
+    dbs = [r["miopen_user_db"] for r in pg["ranks"]]
+    assert len(set(dbs)) == 8, dbs
+    host = len(os.sched_getaffinity(0))
+    if host >= 8:
+        seen = set()
+        for r in pg["ranks"]:
+            assert r["cores"] and not (seen & set(r["cores"])), pg["ranks"]
+            seen |= set(r["cores"])
+    assert rep["n_gpus"] == 8 and len(full["scaling_report"]["per_rank"]) == 8 and all(v > 0 for v in full["scaling_report"]["per_rank"])
+
+
+def test_bench_spawns_eight_ranks(tmp_path):
+    """BASELINE configs[3] is an 8-GPU run: `python bench.py --gpus 8` spawns 8 workers (ports, rendezvous, per-rank MIOpen databases
+    and core slices, the reductions of the report) -- the CPU stub workload over gloo here; the line stays under 4 KB."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ELF_BENCH_BACKEND"] = "gloo"
+    env["ELF_BENCH_FULL"] = str(tmp_path / "full.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "stub", "--steps", "3", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep, full = one_line(r.stdout, env)
+    _check_eight_ranks(full, rep)
+    assert full["config"]["units"] == 3 * sum(1000 + k for k in range(8))
+
+
 def strict_loads(line):
     def bad(c):
         raise ValueError("non-finite constant %r in the bench line" % c)
@@ -156,6 +186,33 @@ def test_two_ranks_share_the_gpu_on_the_real_workloads(tmp_path):
     gm = full["selfplay_games"]
     assert gm["n_gpus"] == 2 and len(gm["per_rank_games_per_sec"]) == 2
     assert gm["games_finished"] >= 2 * 32                   # both ranks finished at least one generation of their games
+
+
+@pytest.mark.gpu
+def test_eight_ranks_share_the_gpu_on_the_headline_workload(tmp_path):
+    """`bench.py --gpus 8` for real (README.rst:132-134: one client process per GPU): 8 ranks spawned by
+    bench.py itself, all on this box's one GPU (ELF_BENCH_SHARE_GPU=1, gloo), each with its own games (seeds 1234 + 1000 r + i), MIOpen
+    user database and core slice; the headline workload at toy size with a small conv net.  The compact line carries 8 per_rank entries
+    and stays under 4 KB; cold MIOpen databases and all, the run takes well under 10 minutes."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ELF_BENCH_SHARE_GPU"] = "1"
+    env["ELF_BENCH_FULL"] = str(tmp_path / "full.json")
+    env["TMPDIR"] = str(tmp_path)                   # cold per-rank MIOpen user databases
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "mcts", "--games", "16", "--groups", "1",
+                        "--rollouts", "64", "--steps", "6", "--warmup", "2", "--net-blocks", "2", "--net-dim", "32", "--no-sub"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert time.time() - t0 < 600
+    rep, full = one_line(r.stdout, env)
+    _check_eight_ranks(full, rep)
+    cfg = rep["config"]
+    assert cfg["games_per_gpu"] == 16 and len(cfg["per_rank"]) == 8 and rep["scaling"] == "weak"
+    assert abs(full["value"] - 8 * 16 * 16 * 6 / (full["ms_per_step"] * 6 / 1e3)) < 1e-6 * full["value"]
+    assert full["scaling_report"]["process_group"]["ranks_share_one_gpu"] is True
+    for r_ in full["scaling_report"]["process_group"]["ranks"]:
+        assert os.path.isdir(r_["miopen_user_db"])
 
 
 @pytest.mark.gpu

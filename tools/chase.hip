@@ -19,9 +19,12 @@ __global__ void k_chase(const unsigned* next, size_t stride_words, int hops, uns
   if (lane == 0) out[blockIdx.x] = acc + cur;
 }
 int main() {
-  const size_t stride = 12800;                       // bytes between records (a tree node)
-  for (double gb : {0.05, 1.0, 8.0, 32.0, 100.0}) {
-    for (int waves : {128, 1024}) {
+  const size_t stride = 5888;                        // bytes between records (a small tree-node record, mcts.cuh)
+  FILE* js = fopen("gpurun_out/chase.json", "w");    // tools/profile_all.sh copies it to profiles/<tag>_chase.json; bench.py reads it
+  if (js) fprintf(js, "{\"stride_bytes\": %zu, \"what\": \"ns per dependent 256-B load (one level of a descent): every wave chases its own random cycle through records spread over the footprint\", \"rows\": [", stride);
+  bool first_row = true;
+  for (double gb : {0.05, 8.0, 64.0, 160.0}) {
+    for (int waves : {256, 2048, 4608}) {
       const size_t nrec = (size_t)(gb * 1e9 / stride);
       const int rpw = (int)(nrec / waves);
       unsigned* d; unsigned* out;
@@ -47,8 +50,10 @@ int main() {
       hipDeviceSynchronize();
       double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       printf("footprint %6.2f GB, %4d waves, %d hops: %.0f ns per dependent load\n", gb, waves, hops, dt / hops * 1e9);
+      if (js) { fprintf(js, "%s{\"footprint_GB\": %.2f, \"waves\": %d, \"ns_per_hop\": %.1f}", first_row ? "" : ", ", gb, waves, dt / hops * 1e9); first_row = false; }
       hipFree(d); hipFree(out);
     }
   }
+  if (js) { fprintf(js, "]}\n"); fclose(js); }
   return 0;
 }

@@ -9,11 +9,12 @@
 #   bench     the default `python bench.py` (the driver's command)                   -> bench_line.json, bench_full.json
 #   stats     rocprofv3 --kernel-trace --stats of board / board9 / search-only / train / features  -> summary_<w>.txt
 #   pmc       separate --pmc passes (FETCH_SIZE, WRITE_SIZE, LDS, SQ issue) of the same commands   -> pmc_*/ (never combined with a trace)
+#   chase     tools/chase.hip: ns per dependent load by footprint and number of chasing waves     -> chase.txt, chase.json
 #   headline  rocprofv3 --kernel-trace --stats of the headline with a WARM MIOpen user database: the net is run once un-profiled first,
 #             so the summary shows the CK implicit-GEMM convolutions, not MIOpen's find / verification kernels (naive_conv_*)
 TAG=${1:-r06}
 shift
-STEPS="${*:-tests bench stats pmc headline}"
+STEPS="${*:-tests bench stats pmc headline chase}"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -57,6 +58,11 @@ if has stats || has pmc; then
     python tools/summarize_prof.py $OUT $W > $OUT/summary_$W.txt 2>&1
     grep -E "k_playout|k_mcts|k_replay|k_extract" $OUT/summary_$W.txt | head -8
   done
+fi
+if has chase; then
+  # dependent-load latency per level of a descent (tools/chase.hip) -> chase.json (bench.py: roofline.latency_chain_ms)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/chase.hip -o /tmp/chase 2> $OUT/chase_build.log && timeout 600 /tmp/chase > $OUT/chase.txt 2>&1
+  cp gpurun_out/chase.json $OUT/chase.json 2>/dev/null; tail -12 $OUT/chase.txt
 fi
 if has headline; then
   # warm the per-box MIOpen user database first (un-profiled): the find / verification kernels then stay out of the profiled run

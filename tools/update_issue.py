@@ -55,6 +55,23 @@ for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>
                 "profile": "profiles/%s_%s_rocprofv3.txt" % (tag, profile),
                 "note": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_LDS, mean over %d launches of the bench.py --workload %s run "
                         "of tools/profile_all.sh (%.0f units per launch)" % (c["SQ_INSTS_VALU"][1], wl, units)}
+# round 6: the search kernels, per ROLLOUT of the search-only profile run (one launch = the rollouts of one game group)
+s_m, log_m = os.path.join(out, "summary_mcts.txt"), os.path.join(out, "stats_mcts.log")
+if os.path.exists(s_m) and os.path.exists(log_m):
+    d = bench_line(log_m)
+    if d is not None:
+        per_launch = d["config"]["rollouts_per_step"] / max(1, d["config"].get("groups", 1))
+        for kern in ("k_mcts_select", "k_mcts_leafstate", "k_mcts_features", "k_mcts_expand", "k_mcts_backup"):
+            c = counters(s_m, kern)
+            if "SQ_INSTS_VALU" not in c:
+                continue
+            res[kern + "<19>"] = {"valu_per_unit": c["SQ_INSTS_VALU"][0] / per_launch, "salu_per_unit": c["SQ_INSTS_SALU"][0] / per_launch,
+                                  "lds_per_unit": c.get("SQ_INSTS_LDS", (0.0, 0))[0] / per_launch, "unit": "rollout",
+                                  "wave_issue_frac": (c["SQ_ACTIVE_INST_ANY"][0] / c["SQ_WAVE_CYCLES"][0]) if "SQ_ACTIVE_INST_ANY" in c and "SQ_WAVE_CYCLES" in c else None,
+                                  "wave_wait_frac": (c["SQ_WAIT_ANY"][0] / c["SQ_WAVE_CYCLES"][0]) if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c else None,
+                                  "profile": "profiles/%s_mcts_search_only_rocprofv3.txt" % tag,
+                                  "note": "rocprofv3 --pmc SQ_INSTS_*, mean over %d launches of the search-only profile run (%.0f rollouts per launch)"
+                                          % (c["SQ_INSTS_VALU"][1], per_launch)}
 sys.path.insert(0, root)
 from elf_amd._lib import KERNEL_SOURCES, kernel_source_hash   # noqa: E402
 res["_source"] = {"kernel_source_hash": kernel_source_hash(), "files": ["elf_amd/csrc/" + f for f in KERNEL_SOURCES], "visit": tag,
