@@ -74,6 +74,7 @@ SIGNATURES = {
     "elfsp_engine": (_vp, [_vp]),
     "elfsp_mcts": (_vp, [_vp]),
     "elfsp_ts_requests_deferred": (_i64, [_vp]),
+    "elfsp_ts_games_deferred": (_i, [_vp]),
     "elfsp_max_rows": (_i, [_vp]),
     "elfsp_max_rows_actor": (_i, [_vp, _i]),
     "elfsp_mcts_actor": (_vp, [_vp, _i]),

@@ -431,12 +431,13 @@ const char* elfgo_error_string(int status) {
   if (status == ELFGO_E_BADARG) return "elfgo: bad argument";
   if (status == ELFGO_E_BADSIZE) return "elfgo: unsupported board size (19 or 9)";
   if (status == ELFGO_E_NOMEM) return "elfgo: out of host memory";
+  if (status == ELFGO_E_NODATA) return "elfgo: no eligible record found (the draw state was left unchanged)";
   if (status <= ELFGO_E_MCTS_BASE && status > ELFGO_E_MCTS_BASE - 32) {
     // ELFGO_E_MCTS_BASE - (OR of ELFMCTS_E_* bits)
     static thread_local char buf[320];
     const int bits = ELFGO_E_MCTS_BASE - status;
     snprintf(buf, sizeof(buf), "elfmcts:%s%s%s%s%s",
-             (bits & ELFMCTS_E_POOL) ? " node pool of a game exhausted (raise nodes_per_game);" : "",
+             (bits & ELFMCTS_E_POOL) ? " the context's node pool is exhausted (raise nodes_per_game);" : "",
              (bits & ELFMCTS_E_ROOT_HASH) ? " TreeSearch::Root state is not the same as the input state;" : "",
              (bits & ELFMCTS_E_FORWARD) ? " a move could not be applied (illegal move / invalid preload or tree edge);" : "",
              (bits & ELFMCTS_E_RNG) ? " more D4 draws requested than uploaded;" : "",

@@ -687,6 +687,7 @@ int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t
   // different threads are independent of each other: thread tt's acts (in their order) are one unit of work for the host pool.
   const int64_t T = (int64_t)q->thread_rng.size(), first = q->next_act;
   std::atomic<bool> stuck{false};
+  const std::vector<std::mt19937> rng_before(q->thread_rng);   // a failed call leaves the draw state as it found it
   auto acts_of_thread = [&](size_t tt) {
     std::mt19937& rng = q->thread_rng[tt];
     for (int64_t a = (((int64_t)tt - first) % T + T) % T; a < num_acts; a += T) {
@@ -721,8 +722,14 @@ int elfrq_draw(ElfReaderQueues* q, int num_acts, int num_future_actions, int32_t
   const unsigned nt = (unsigned)std::min<int64_t>(std::min<int64_t>(T, num_acts), host_worker_count(32));   // one game thread per worker at the trainer's 2048 / 64 = 32
   if (nt < 2 || num_acts < 8) { for (int64_t tt = 0; tt < T; ++tt) acts_of_thread((size_t)tt); }
   else HostWorkers::get().run((size_t)T, nt, acts_of_thread);
+  if (stuck.load()) {
+    // no eligible record was found within the bound: the generators and the act counter go back to their state before the call, so
+    // that a retry (after the queues have been refilled) draws what a clean call would have drawn; ELFGO_E_NODATA, not BADARG
+    q->thread_rng = rng_before;
+    return ELFGO_E_NODATA;
+  }
   q->next_act += num_acts;
-  return stuck.load() ? ELFGO_E_BADARG : 0;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -180,6 +180,8 @@ static void sp_for_games(const std::vector<int32_t>& ids, F fn) {
   HostWorkers::get().run(n, nt, [&](size_t i) { fn(ids[i]); });
 }
 
+static ElfTsOptions sp_ts_of(const ElfSpOptions& o);
+static bool sp_ts_pool_equal(const ElfTsOptions& a, const ElfTsOptions& b);
 static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {
   // Record.request = curr_request_ (go_state_ext.h:134): the game's own request incl. the mcts_opt it carried
   SpRecordMeta m = elfrec_meta_from_options(sp->opt);
@@ -188,7 +190,18 @@ static SpRecordMeta sp_meta(const ElfSelfPlay* sp, const SpGame& gm) {
   m.num_game_thread_used = gm.req.thread_used;
   m.player_swap = gm.req.player_swap; m.async = gm.req.async;
   m.client_type = gm.req.client_type;
-  elfrec_meta_set_ts(&m, gm.req.ts);           // vers.mcts_opt as the request carried it
+  // vers.mcts_opt as the request carried it -- except where this game searched with OTHER options: a request that restarted only
+  // some games while the rest played on could not rebuild the context's tree pools (sp_poll_requests, "deferred"); those games'
+  // records carry the search options that were actually used, not the ones the request asked for
+  ElfTsOptions used = gm.req.ts;
+  const ElfTsOptions ctx = sp_ts_of(sp->opt);
+  if (!sp_ts_pool_equal(used, ctx)) {
+    used.num_threads = ctx.num_threads; used.num_rollouts_per_thread = ctx.num_rollouts_per_thread; used.num_rollouts_per_batch = ctx.num_rollouts_per_batch;
+    used.persistent_tree = ctx.persistent_tree; used.pick_method = ctx.pick_method; used.root_epsilon = ctx.root_epsilon; used.root_alpha = ctx.root_alpha;
+    used.virtual_loss = ctx.virtual_loss; used.use_prior = ctx.use_prior; used.c_puct = ctx.c_puct; used.unexplored_q_zero = ctx.unexplored_q_zero;
+    used.root_unexplored_q_zero = ctx.root_unexplored_q_zero;
+  }
+  elfrec_meta_set_ts(&m, used);
   return m;
 }
 
@@ -888,6 +901,13 @@ int elfsp_destroy(ElfSelfPlay* sp) {
 
 ElfGoEngine* elfsp_engine(ElfSelfPlay* sp) { return sp ? sp->eng : nullptr; }
 int64_t elfsp_ts_requests_deferred(const ElfSelfPlay* sp) { return sp ? sp->ts_deferred : ELFGO_E_BADARG; }
+int elfsp_ts_games_deferred(const ElfSelfPlay* sp) {
+  if (!sp) return ELFGO_E_BADARG;
+  const ElfTsOptions ctx = sp_ts_of(sp->opt);
+  int k = 0;
+  for (const SpGame& gm : sp->games) k += gm.phase == PH_PLAY && !gm.req.wait() && !sp_ts_pool_equal(gm.req.ts, ctx);
+  return k;
+}
 ElfMcts* elfsp_mcts(ElfSelfPlay* sp) { return sp ? sp->pool[0].mcts : nullptr; }
 ElfMcts* elfsp_mcts_actor(ElfSelfPlay* sp, int actor) { return (sp && actor >= 0 && actor < 2) ? sp->pool[actor].mcts : nullptr; }
 int elfsp_max_rows(const ElfSelfPlay* sp) { return sp ? sp->G * sp->pool[0].KT : ELFGO_E_BADARG; }

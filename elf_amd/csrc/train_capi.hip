@@ -24,6 +24,13 @@ struct ElfReplay {
   std::vector<uint8_t> is_dirty;
   int32_t* d_dirty = nullptr;           // [capacity]
   int keep_states = 1;                  // elftrain_set_keep_states
+  // page-locked inputs of elftrain_put_async are copied into a small ring of the library's own page-locked buffers and the DMA reads
+  // THOSE: the caller's buffer is free when the call returns without a wait for the stream (which may hold extractions queued before)
+  static constexpr int kStage = 8;
+  char* stage[kStage] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_done[kStage] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes = 0;
+  int stage_next = 0;
 };
 
 static bool host_is_pinned(const void* p) {
@@ -74,6 +81,10 @@ int elftrain_destroy(ElfReplay* r) {
   void* ptrs[] = {r->st.moves, r->st.num_moves, r->st.winner, r->st.black_ver, r->st.pol, r->st.num_pol, r->st.values, r->st.num_values,
                   r->st.ckpt, r->st.skrec, r->d_dirty};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < ElfReplay::kStage; ++i) {
+    if (r->stage_done[i]) { (void)hipEventSynchronize(r->stage_done[i]); (void)hipEventDestroy(r->stage_done[i]); }
+    if (r->stage[i]) (void)hipHostFree(r->stage[i]);
+  }
   delete r;
   return 0;
 }
@@ -83,7 +94,7 @@ int elftrain_max_moves(const ElfReplay* r) { return r ? r->st.max_moves : ELFGO_
 int elftrain_num_records(const ElfReplay* r) { return r ? (int)r->filled.size() : ELFGO_E_BADARG; }
 
 // Stream-ordered: the copies are queued on `stream` (host buffers may be reused on return: pageable memory is staged by the
-// runtime before the call returns, and for page-locked buffers the call waits for its copies), so a put that reuses the slot of an evicted record cannot overtake an extraction queued on
+// runtime before the call returns, and page-locked buffers are copied into the library's staging ring first), so a put that reuses the slot of an evicted record cannot overtake an extraction queued on
 // the same stream that still reads it.
 int elftrain_put_async(ElfReplay* r, int slot, const uint16_t* moves_host, int num_moves, float reward, int64_t black_ver,
                        const uint8_t* policies_host, int num_policies, const float* values_host, int num_values, void* stream) {
@@ -95,17 +106,39 @@ int elftrain_put_async(ElfReplay* r, int slot, const uint16_t* moves_host, int n
   ReplayStore& st = r->st;
   hipStream_t s = (hipStream_t)stream;
   const size_t base = (size_t)slot * st.max_moves;
-  if (num_moves) HIPCHK(hipMemcpyAsync(st.moves + base, moves_host, sizeof(u16) * num_moves, hipMemcpyHostToDevice, s));
-  if (num_policies) HIPCHK(hipMemcpyAsync(st.pol + base * r->P, policies_host, (size_t)num_policies * r->P, hipMemcpyHostToDevice, s));
-  if (num_values) HIPCHK(hipMemcpyAsync(st.values + base, values_host, sizeof(float) * num_values, hipMemcpyHostToDevice, s));
+  // "host buffers may be reused on return": pageable memory is staged by the runtime before the copy call returns; a page-locked or
+  // registered buffer would be read by the DMA engine later, so its bytes go through the library's own staging ring first (one
+  // memcpy on the host; an entry is reused after its event, i.e. after kStage later puts -- no wait for the stream's earlier work)
+  const size_t nb_m = sizeof(u16) * (size_t)num_moves, nb_p = (size_t)num_policies * r->P, nb_v = sizeof(float) * (size_t)num_values;
+  const bool pinned = host_is_pinned(moves_host) || host_is_pinned(policies_host) || host_is_pinned(values_host);
+  const void *src_m = moves_host, *src_p = policies_host, *src_v = values_host;
+  int se = -1;
+  if (pinned) {
+    if (!r->stage_bytes) r->stage_bytes = ((size_t)st.max_moves * (sizeof(u16) + (size_t)r->P + sizeof(float)) + 255) & ~(size_t)255;
+    se = r->stage_next;
+    r->stage_next = (r->stage_next + 1) % ElfReplay::kStage;
+    if (!r->stage[se]) {
+      HIPCHK(hipHostMalloc((void**)&r->stage[se], r->stage_bytes, hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&r->stage_done[se], hipEventDisableTiming));
+    } else {
+      HIPCHK(hipEventSynchronize(r->stage_done[se]));      // the copies of the put that used this entry kStage puts ago
+    }
+    char* b = r->stage[se];
+    if (nb_m) { memcpy(b, moves_host, nb_m); src_m = b; }
+    b += (size_t)st.max_moves * sizeof(u16);
+    if (nb_p) { memcpy(b, policies_host, nb_p); src_p = b; }
+    b += (size_t)st.max_moves * r->P;
+    if (nb_v) { memcpy(b, values_host, nb_v); src_v = b; }
+  }
+  if (num_moves) HIPCHK(hipMemcpyAsync(st.moves + base, src_m, nb_m, hipMemcpyHostToDevice, s));
+  if (num_policies) HIPCHK(hipMemcpyAsync(st.pol + base * r->P, src_p, nb_p, hipMemcpyHostToDevice, s));
+  if (num_values) HIPCHK(hipMemcpyAsync(st.values + base, src_v, nb_v, hipMemcpyHostToDevice, s));
+  if (se >= 0) HIPCHK(hipEventRecord(r->stage_done[se], s));
   const float w = reward > 0 ? 1.0f : -1.0f;   // fromRecord, go_state_ext.h:250
   // the record's scalars travel as kernel arguments (copied at launch), not as asynchronous copies from this function's stack
   hipLaunchKernelGGL(k_replay_put_scalars, dim3(1), dim3(1), 0, s, st, slot, (int32_t)num_moves, (int32_t)num_policies, (int32_t)num_values, w,
                      (long long)black_ver);
   HIPCHK(hipGetLastError());
-  // "host buffers may be reused on return" holds for pageable memory (staged by the runtime before the copy call returns); a
-  // page-locked or registered buffer is read by the DMA engine later, so the call waits for its copies then
-  if (host_is_pinned(moves_host) || host_is_pinned(policies_host) || host_is_pinned(values_host)) HIPCHK(hipStreamSynchronize(s));
   r->h_num_moves[slot] = num_moves;
   if (!r->is_filled[slot]) { r->is_filled[slot] = 1; r->filled.push_back(slot); }
   if (!r->is_dirty[slot]) { r->is_dirty[slot] = 1; r->dirty.push_back(slot); }   // checkpoints: at the head of the next extraction

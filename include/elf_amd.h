@@ -37,6 +37,7 @@ typedef struct ElfGoEngine ElfGoEngine;
 #define ELFGO_E_BADARG (-1)
 #define ELFGO_E_BADSIZE (-2)
 #define ELFGO_E_NOMEM (-3)
+#define ELFGO_E_NODATA (-4)   /* a draw found no eligible record (elfrq_draw); the draw state is left as it was before the call */
 
 #define ELFGO_INFO_WORDS 16
 /* per-board info record written by elfgo_info (int32 words):
@@ -288,6 +289,9 @@ ElfMcts* elfsp_mcts(ElfSelfPlay* sp);
  * games kept the context's options (the reference would build their AIs from the request's, game_selfplay.cc:166-180).  0 in every
  * flow where requests reach all games at a boundary (the reference's own server sends a request to all games of a client). */
 int64_t elfsp_ts_requests_deferred(const ElfSelfPlay* sp);
+/* games that play NOW under the context's search options although their request carried others (see above); their Records carry the
+ * options that were used, not the request's */
+int elfsp_ts_games_deferred(const ElfSelfPlay* sp);
 int elfsp_max_rows(const ElfSelfPlay* sp);   /* num_games * num_threads * num_rollouts_per_batch */
 /* the same bound for one of the two AIs (the "actor_white" AI may have its own batch override) */
 int elfsp_max_rows_actor(const ElfSelfPlay* sp, int actor);

@@ -712,8 +712,8 @@ def test_request_options_that_cannot_be_applied_yet_are_counted_not_dropped_sile
     """The tree pools belong to the whole context and are rebuilt for a request's TSOptions only when no game is mid-play.  A request
     that RESTARTS some games (here: the one that was waiting, num_game_thread_used 1 -> 2) with other search options while another
     game plays ON (an async request does not restart a playing game, setAsync :150-156) cannot be honoured for the restarted game:
-    it searches with the context's options.  That case is counted (elfsp_ts_requests_deferred) and logged, not silent; the games
-    keep running and the records of the restarted game echo the request."""
+    it searches with the context's options.  That case is counted (elfsp_ts_requests_deferred, elfsp_ts_games_deferred) and logged, not
+    silent; the games keep running and their records carry the search options that were actually used."""
     import torch
     from elf_amd.client import TsOptions
     n = 9
@@ -741,6 +741,16 @@ def test_request_options_that_cannot_be_applied_yet_are_counted_not_dropped_sile
         step()
     assert L.elfsp_ts_requests_deferred(sp._h) == 1          # game 1 restarted under the request while game 0 played on
     assert sp.stats()["steps_per_move"] == 2                 # the context's options still rule: 32 rollouts = 2 steps of 16
+    assert L.elfsp_ts_games_deferred(sp._h) == 2             # both games now hold a request whose options the pools do not have
+    # the records say what was USED (32 rollouts per thread), not what the request asked for (48)
+    import json
+    late = []
+    for _ in range(400):
+        late += [r for r in map(json.loads, sp.pop_records()) if r["request"]["vers"]["black_ver"] == 4]
+        if late:
+            break
+        step()
+    assert late and all(r["request"]["vers"]["mcts_opt"]["num_rollouts_per_thread"] == 32 for r in late), late[:1]
     sp.close()
 
 
