@@ -53,6 +53,7 @@ def chunked_forward(net, s, chunk_rows=2048):
     from elf_amd.net import chunked_forward as cf
     return cf(net, s, chunk_rows)
 
+CK_INTERVAL = 16       # elf_amd/csrc/train.cuh: a record's state is checkpointed after every 16th move
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz max clock
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0   # G wave-instructions / s = 1228.8
@@ -1502,8 +1503,8 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     out = ld._alloc(B)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     mt_sum = torch.zeros((), dtype=torch.int64, device=dev)
-    fwd_sum = torch.zeros((), dtype=torch.int64, device=dev)     # plies forwarded from the checkpoints (move_idx mod 32)
-    ck_sum = torch.zeros((), dtype=torch.int64, device=dev)      # samples that load a checkpoint (move_idx >= 32)
+    fwd_sum = torch.zeros((), dtype=torch.int64, device=dev)     # plies forwarded from the checkpoints (move_idx mod CK_INTERVAL)
+    ck_sum = torch.zeros((), dtype=torch.int64, device=dev)      # samples that load a checkpoint (move_idx >= CK_INTERVAL)
     barrier = make_barrier(dist)
     d = ld._draw
     for i in range(warmup):
@@ -1520,8 +1521,8 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
             ld.extract(d[0, :B], d[1, :B], d[2, :B], out=out)          # the dominant kernel, on torch's current stream
             ev[i][1].record()
         mt_sum += out["move_idx"].sum()
-        fwd_sum += (out["move_idx"] % 32).sum()
-        ck_sum += (out["move_idx"] >= 32).sum()
+        fwd_sum += (out["move_idx"] % CK_INTERVAL).sum()
+        ck_sum += (out["move_idx"] >= CK_INTERVAL).sum()
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -1533,7 +1534,7 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     per_sample = replayed / (B * steps) * STEP_BYTES[n] + (26728 if n == 19 else 6008) + P + 4 * (n * n + 1) + 40
     kname = "k_replay_extract<%d>" % n
     # what THIS kernel has to move per sample: the record's checkpoint slot in (3840 B at 19x19, none below ply
-    # 32), the <= 31 moves it forwards, the quantised policy row in; the feature row, the normalised policy, offline_a and 36 B of scalars out
+    # 16), the <= 15 moves it forwards, the quantised policy row in; the feature row, the normalised policy, offline_a and 36 B of scalars out
     slot_b = 3840 if n == 19 else 1024
     row_b = 18 * n * n * (2 if ld.f16 else 4)
     fwd_mean = float(fwd_sum.item()) / (B * steps)
@@ -1547,7 +1548,7 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
         "config": {"workload": "SURVEY.md 8f-1 trainer input pipeline: train batches of %d samples, %d batches drawn + extracted per launch (one "
                                "step = one launch: the trainer prefetches), %d records of %d plies (random legal play on the device engine), one "
                                "MCTS policy per ply, num_future_actions %d, s rows %s; every sample starts from its record's checkpoint (the state "
-                               "after every 32nd move, written once per record) and forwards the rest"
+                               "after every 16th move, written once per record) and forwards the rest"
                                % (B1, KB, R, plies, nfa, ld.f16 and "f16_nhwc" or "f32_nchw"),
                    "batch": B1, "batches_per_launch": KB, "samples_per_launch": B, "records": R, "board_size": n,
                    "sampler": ("reference replay buffer: %d ReaderQueues (q_min 10, q_max 1000) filled with InsertWithParity, draws of "
@@ -1569,7 +1570,7 @@ def run_train(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": load_traffic(kname), "kernel": kname, "avg_kernel_ms": kern_ms, "bytes_per_sample": own_bytes,
             "samples_per_sec_kernel_only": B / (kern_ms / 1e3),
-            "note": "with <= 31 forwards per sample the kernel is an HBM stream: per sample %.0f B = checkpoint slot in (%d B x %.2f of the "
+            "note": "with <= 15 forwards per sample the kernel is an HBM stream: per sample %.0f B = checkpoint slot in (%d B x %.2f of the "
                     "samples) + moves + policy row in, feature row (%d B) + normalised policy + offline_a + scalars out; achieved = samples "
                     "per launch x that / the kernel's mean HIP-event time" % (own_bytes, slot_b, ck_share, row_b)}
     issue = issue_roof(kname, fwd_sum.item() / steps, kern_ms / 1e3)   # unit = one forwarded board step

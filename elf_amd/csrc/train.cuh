@@ -6,7 +6,7 @@
 // The result of that replay is a pure function of (record, move_to), so the store keeps, per record, the state after every
 // CK_INTERVAL-th move (written once, by k_replay_checkpoint when the record is put) and the superko records of the whole game;
 // a sample then loads the checkpoint below its move_to and forwards at most CK_INTERVAL - 1 moves -- same state, same rows, a
-// tenth of the board steps.  HBM is 288 GB: 22 checkpoints x 3840 B + 724 x 104 B of superko records = 160 KB per 19x19 record.
+// twentieth of the board steps.  HBM is 288 GB: 45 checkpoints x 3840 B + 724 x 104 B of superko records = 248 KB per 19x19 record.
 //
 // Replaces, for a batch of n samples, what one reference game thread does per sample:
 //   src_cpp/elfgames/go/train/game_train.cc          GoGameTrain::act :23-58
@@ -35,7 +35,7 @@ struct ReplayStore {
   u64* skrec;            // [capacity][max_moves + 2][SKW] superko records of the record's whole game (GoState::_board_hashes)
   int capacity, max_moves, nck;
 };
-constexpr int CK_INTERVAL = 32;
+constexpr int CK_INTERVAL = 16;   // round 6: 32 -> 16 (a sample forwards 7.5 plies on average instead of 15.5; 173 KB of checkpoints per 19x19 record instead of 88 KB)
 #define REPLAY_WAVES_CK 4
 
 // Superko records of a REPLAYED record: every pre-move position of the game is already in the store (k_replay_checkpoint wrote

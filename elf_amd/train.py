@@ -66,8 +66,8 @@ def parse_record(board_size, rec):
 
 class ReplayLoader:
     """HBM-resident replay store + one-launch batch extraction (k_replay_extract).
-    keep_states=False (default, the trainer's mode): a sample replays from its record's checkpoint (the state after every 32nd
-    move, written once per put) -- at most 31 board steps instead of ~160, the same rows.  keep_states=True: the reference's own
+    keep_states=False (default, the trainer's mode): a sample replays from its record's checkpoint (the state after every 16th
+    move, written once per put) -- at most 15 board steps instead of ~160, the same rows.  keep_states=True: the reference's own
     procedure (reset + forward x move_to), and the replayed GoState of sample i stays in board slot i of `self.engine`."""
 
     def __init__(self, board_size=19, capacity=1024, batchsize=2048, device=0, max_moves=None, with_policies=True,

@@ -474,8 +474,8 @@ int elftrain_put_async(ElfReplay* r, int slot, const uint16_t* moves_host, int n
 /* on != 0 (the default): elftrain_extract does what switchBeforeMove does (go_state_ext.h:283-290: reset, forward x move_to) and
  * leaves the replayed GoState of sample i in board slot i of the engine (elfgo_info / elfgo_legal_mask / ... can look at it;
  * n <= elfgo_capacity).  on == 0 (the trainer's mode): a sample starts from the record's checkpoint below move_to -- the state
- * after every 32nd move is written once per put, by the next extraction, together with the game's superko records -- and
- * forwards at most 31 moves; rows are identical, no board slot is written, n is not limited by the engine's capacity. */
+ * after every 16th move is written once per put, by the next extraction, together with the game's superko records -- and
+ * forwards at most 15 moves; rows are identical, no board slot is written, n is not limited by the engine's capacity. */
 int elftrain_set_keep_states(ElfReplay* r, int on);
 /* GoGameTrain::act's draws for n samples with the store's std::mt19937 (seeded at create): record, move_to =
  * rng() % (num_moves - num_future_actions + 1), D4 code = rng() % 8; results into device int32 [n] arrays */
