@@ -351,10 +351,13 @@ def init_dist(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # every rank tunes and caches its convolutions in its own MIOpen user database: N concurrent finds on one sqlite file
         # serialise on its lock (and have been seen to corrupt it)
-        mi = os.path.join(os.environ.get("TMPDIR", "/tmp"), "elf_amd_miopen", "rank%d" % rank)
+        # (a database path inherited from the environment is shared by all ranks of the launch: every rank takes its own sub-directory
+        # of it -- found by the 8-rank test when a profiling script exported one path for the whole job)
+        base = os.environ.get("MIOPEN_USER_DB_PATH") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "elf_amd_miopen")
+        mi = os.path.join(base, "rank%d" % rank)
         os.makedirs(mi, exist_ok=True)
-        os.environ.setdefault("MIOPEN_USER_DB_PATH", mi)
-        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", mi)
+        os.environ["MIOPEN_USER_DB_PATH"] = mi
+        os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = mi
         # the host side of a rank (boundary threads, torch's intra-op pool) gets its own slice of the cores, as one client process
         # per GPU would be pinned on a node (README.rst:132-134)
         cores = sorted(os.sched_getaffinity(0))

@@ -26,6 +26,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
@@ -606,10 +607,16 @@ class Context {
     const int64_t per_move = (int64_t)ts.num_rollouts_per_thread * ts.num_threads;
     const int64_t npg = go_.nodes_per_game > 0 ? (go_.nodes_per_game + 63) / 64 * 64 : (4 * per_move + 1024 + 63) / 64 * 64;
     const int n = go_.board_size;
-    const int64_t tree_bytes = (int64_t)elfmcts_tree_bytes_per_game(n, (int)npg);
+    // what a game adds to the context's SHARED node pool at npg ids, with the per-game tables of THESE search options (path rows per leaf
+    // of a step, one D4 window per search thread: 512 KB + at the 1024-leaf maximum) -- the node pool itself belongs to all games
+    const int rpb = ts.num_rollouts_per_batch > 0 ? ts.num_rollouts_per_batch : 1, nth = ts.num_threads > 0 ? ts.num_threads : 1;
+    const int64_t steps = (ts.num_rollouts_per_thread + rpb - 1) / rpb;
+    const int64_t d4w = steps * rpb * nth;
+    const int64_t tree_bytes = (int64_t)elfmcts_tree_bytes_per_game2(n, (int)npg, nth, rpb, (int)std::min<int64_t>(d4w, (int64_t)1 << 30));
     const int64_t node_bytes = npg > 0 ? (tree_bytes + npg - 1) / npg : 0;     // small record + its share of the big pool and the id arrays
     std::map<std::string, int64_t> out = {{"max_rollouts_per_step", elfmcts_max_rollouts_per_step()}, {"nodes_per_game", npg},
-                                          {"node_bytes", node_bytes}, {"tree_bytes_per_game_per_ai", tree_bytes}};
+                                          {"node_bytes", node_bytes}, {"tree_bytes_per_game_per_ai", tree_bytes},
+                                          {"node_pool_shared_by_games", 1}};
     size_t fr = 0, tot = 0;
     int dev = go_.gpu;
     if (dev < 0 && elfgo_get_device(&dev) != 0) dev = 0;
