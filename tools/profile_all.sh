@@ -69,7 +69,10 @@ if has headline; then
   timeout 600 $HEADLINE > $OUT/headline_warm.json 2> $OUT/headline_warm.err
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_mctsnet -o stats --output-format csv -- $HEADLINE > $OUT/stats_mctsnet.log 2>&1
   python tools/summarize_prof.py $OUT mctsnet > $OUT/summary_mctsnet.txt 2>&1
-  head -14 $OUT/summary_mctsnet.txt
+  # the same trace split into the tree-growing prologue (random replies) and the steps that follow a net call (every row of the
+  # random-init fp16 net's reply carries prior ties: k_mcts_expand runs its exact std::sort replay there)
+  python tools/headline_kernel_durations.py $OUT/stats_mctsnet >> $OUT/summary_mctsnet.txt 2>&1
+  head -14 $OUT/summary_mctsnet.txt; tail -10 $OUT/summary_mctsnet.txt
   grep -c naive_conv $OUT/summary_mctsnet.txt
 fi
 find $OUT -name '*kernel_trace.csv' -delete
