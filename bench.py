@@ -304,7 +304,8 @@ def cpu_baseline_mcts_with_net(n, rollouts_per_batch, net, dev, dtype, budget_s=
     return {"value": best["rollouts_per_sec"], "unit": "rollouts/s", "cores": min(host, best["num_games"] * 3), "kind": "reference",
             "num_games_sweep": sweep,
             "sample": "best of num_games in %s: %d reference game threads, %d searches of %d rollouts (2 search threads x %d, bs %d), the same "
-                      "%s net on the GPU through the reference's batch interface (%d net calls, mean %.1f rows), net time INCLUDED, %.1f s; "
+                      "%s net on the GPU through the reference's batch interface (%d net calls, mean %.1f rows: at batchsize 16 the reference "
+                      "is bound by the latency of its 16-row net calls, more games do not widen them), net time INCLUDED, %.1f s; "
                       "host has %d cores"
                       % ([r_["num_games"] for r_ in sweep], best["num_games"], best["searches"], rollouts, rollouts // 2, rollouts_per_batch,
                          str(dtype).replace("torch.", ""), best["net_calls"], best["mean_rows_per_call"], best["seconds"], host)}
@@ -1626,7 +1627,7 @@ def _roof(r):
         return None
     out = _pick(r, ROOF_KEYS)
     if isinstance(out.get("kernel"), str):
-        out["kernel"] = out["kernel"][:80]
+        out["kernel"] = out["kernel"][:56]
     if isinstance(out.get("unit"), str):
         out["unit"] = out["unit"][:40]
     for k in ("binding_issue_roof", "binding_frac", "lds_bank_conflict_frac", "frac_pmc", "latency_chain_ms", "binding_ms"):
@@ -1692,7 +1693,7 @@ def compact_line(res, full_path=None):
                     "select_ms", "expand_backup_ms", "moves_in_window", "move_boundary_ms",
                     "boards_per_gpu", "board_steps_per_pass", "nodes_per_game", "node_bytes", "tree_pool_GB", "mean_forwarded_plies",
                     "mean_replayed_plies", "samples_per_launch", "batch"))
-    c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:180], **c}
+    c = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:164], **c}
     if isinstance(cfg.get("node_pool"), dict):     # the shared node pool: ids in trees now / the largest tree ever
         c["live_nodes"] = _num(cfg["node_pool"].get("ids_live_now"))
         c["largest_tree"] = _num(cfg["node_pool"].get("largest_tree_ever"))
@@ -1710,14 +1711,14 @@ def compact_line(res, full_path=None):
     cb = res.get("cpu_baseline")
     if isinstance(cb, dict):
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
-        line["cpu_baseline"]["sample"] = str(cb.get("sample") or "")[:110]
+        line["cpu_baseline"]["sample"] = str(cb.get("sample") or "")[:84]
     else:
         line["cpu_baseline"] = None
     par = res.get("parity")
     if isinstance(par, dict):
         line["parity"] = _pick(par, ("checked", "mismatches", "what"))
         if isinstance(line["parity"].get("what"), str):
-            line["parity"]["what"] = line["parity"]["what"][:90]
+            line["parity"]["what"] = line["parity"]["what"][:64]
     elif "parity_checked_boards" in res:
         line["parity"] = {"checked": res.get("parity_checked_boards"), "mismatches": res.get("parity_mismatches")}
     sub = {k: _sub_summary(k, res[k]) for k in SUB_NAMES if k in res}
