@@ -198,6 +198,10 @@ def test_live_differential_against_the_reference_stack(elf, case):
     n, kw = LIVE[case]
     cfg = dict(MCTS_DEFAULTS)
     cfg.update(kw)
+    if not RefSelfPlay.available(n):       # not silent: the report says which checker ran
+        import warnings
+        warnings.warn("oracle/_ref/libelfsp%d.so is absent: this run compares with the CPU restatement (oracle/mcts_oracle.cc), not with the "
+                      "compiled reference" % n)
     ref = (RefSelfPlay(n) if RefSelfPlay.available(n) else PortSelfPlay(n)).run(**cfg)
     S = ref["search"]
     m = len(S)
