@@ -1818,7 +1818,7 @@ def main():
     ap.add_argument("--games-rollouts", type=int, default=32)
     ap.add_argument("--games-cutoff", type=int, default=40)
     ap.add_argument("--games-generations", type=int, default=2)
-    ap.add_argument("--search-only-games", type=int, default=4608, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
+    ap.add_argument("--search-only-games", type=int, default=9216, help="games per GPU of the search-only sub-result (no conv net); 0 = off")
     ap.add_argument("--phase-steps", type=int, default=16, help="timed steps per game phase (plies 0/60/120/180) of the games/s leg; 0 = off")
     ap.add_argument("--played-games", type=int, default=64, help="cohort of the PLAYED data point at the headline's rollout count; 0 = off")
     ap.add_argument("--played-moves", type=int, default=2, help="whole moves the cohort plays end to end; 0 = off")
@@ -1862,18 +1862,19 @@ def main():
         return v if (v is not None and args.workload != "both") else dflt
 
     if sub and args.board_size == 19 and args.search_only_games > 0:
-        # the search kernels without the conv net, with as many games in flight as the free HBM holds at 8192 node ids per game (up to
-        # --search-only-games): 4.5 waves per SIMD in the per-game kernels at 4608 games, two pipelined groups
+        # the search kernels without the conv net, with as many games in flight as the free HBM holds (up to --search-only-games): moves of
+        # 2048 rollouts on a SHARED node pool of 2 x 2048 ids per game -- round 6: the 250 GB that held 4608 fixed 8192-id pools hold 9216
+        # games now (a tree of these moves peaks near 2.5 k nodes) = 9 waves per SIMD in the per-game kernels, three pipelined groups
         try:
             import copy
             import elf_amd
             a2 = copy.copy(args)
-            nodes = 8192
+            nodes = 4096
             free, _ = elf_amd.mem_info(local_rank)
             per_game = elf_amd.tree_bytes_per_game(19, nodes) + 2 * 16 * 18 * 361 + (1 << 16)    # + its feature rows and slack
-            fit = int(0.85 * free // per_game) // 128 * 128
-            so_games = max(128, min(args.search_only_games, fit))
-            a2.net, a2.features, a2.games, a2.groups, a2.nodes_per_game, a2.rollouts, a2.pregrow = "random", "f16", so_games, 2, nodes, 2048, 0
+            fit = int(0.85 * free // per_game) // 192 * 192
+            so_games = max(192, min(args.search_only_games, fit))
+            a2.net, a2.features, a2.games, a2.groups, a2.nodes_per_game, a2.rollouts, a2.pregrow = "random", "f16", so_games, 3, nodes, 2048, 0
             so = run_mcts(a2, rank, local_rank, world, dist, 32, 88, False)
             # the same games as ONE group: no launch of another group shares the GPU, so the HIP-event durations are the kernels' own
             # (the roofline of the kernels); the two-group run above is the throughput figure (its phases overlap)
@@ -1892,8 +1893,9 @@ def main():
                                       "expand_backup_ms": c["expand_backup_ms"], "roofline": so["roofline"], "roofline_pipelined": so["roofline_pipelined"], "nodes_per_game": nodes,
                                       "rollouts_per_move": a2.rollouts, "node_pool": c.get("node_pool"),
                                       "tree_pool_GB": so_games * elf_amd.tree_bytes_per_game(19, nodes) / 1e9, "games_that_fit_free_hbm": fit,
-                                      "note": "same kernels, same tree shape (2048 rollouts per move on 8192-node pools, depth ~6.3) as the headline's "
-                                              "search; the per-game kernels are latency chains, more resident waves per SIMD hide them"}
+                                      "note": "same kernels, same tree shape (2048 rollouts per move, depth ~6.3) as the headline's search, on a shared "
+                                              "node pool of 4096 ids per game; the per-game kernels are latency chains, more resident waves per "
+                                              "SIMD hide them (4608 games on fixed 8192-id pools, the round-5 configuration: 72 M rollouts/s)"}
         except Exception as e:   # e.g. not enough free HBM beside another process
             if rank == 0:
                 res["search_only"] = "unavailable: %r" % (e,)
