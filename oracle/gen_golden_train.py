@@ -94,6 +94,12 @@ RECORD_CASES_R3 = {
     "online_9_not_following": (9, dict(rollouts_per_thread=32, rollouts_per_batch=8, batchsize=8, max_searches=100, net_salt=81, num_games=1,
                                        online=1, following_pass=1, net_value_on=1, net_value=1.0,
                                        human_script=[PASS, SKIP, 33, SKIP, PASS, SKIP, 20, CLEAR, 5])),
+    # round 6: Records of games that start from a DENSE 19x19 position -- ladder-suite game 406844.sgf preloaded to ply 170
+    # (GameOptions.preload_sgf, game_selfplay.cc:202-219), the remaining 30 moves searched (64 rollouts each, pass enabled) and replaced
+    # by the SGF's (:392-405), the game finished when the SGF is exhausted (FR_MAX_STEP :393-395), restarted and preloaded again: two
+    # finished games, 200-move contents, quantised policies of late-game positions (~190 legal moves, pass edges)
+    "records_19_sgf_preload": (19, dict(rollouts_per_thread=64, max_searches=64, policy_distri_cutoff=0, net_salt=91, ply_pass_enabled=100,
+                                        preload_sgf=("406844.sgf", 170))),
 }
 
 
@@ -139,7 +145,14 @@ def dump_case(name, n, kw):
     cfg = dict(MCTS_DEFAULTS)
     kw = dict(kw)
     pre = kw.pop("preload", None)
+    pre_sgf = kw.pop("preload_sgf", None)
     extra = {}
+    if pre_sgf is not None:
+        from pyoracle import Ref
+        path = os.path.join("/root/reference/ladder_suite/ladder", pre_sgf[0])
+        mv = Ref(n).sgf_moves(path)[0]
+        R.set_preload(path, pre_sgf[1])
+        extra = dict(preload_moves=np.array(mv, np.uint16), preload_move_to=np.int32(pre_sgf[1]), preload_name=np.array(pre_sgf[0]))
     if pre is not None:
         port = Port(n)
         st = port.new()

@@ -229,7 +229,7 @@ def test_loader_argument_errors(elf):
     ld.close()
 
 
-@pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff",
+@pytest.mark.parametrize("name", ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff", "records_19_sgf_preload",
                                   "records_9_eval", "records_9_eval_swap_resign",
                                   "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_sgf_policy_only"])
 def test_selfplay_records_equal_reference_dump(elf, name):

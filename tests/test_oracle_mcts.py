@@ -142,7 +142,7 @@ def test_turnstile_reference_equals_restatement_on_random_configurations(built, 
     assert [s.move_played for s in r["search"]] == [s.move_played for s in p["search"]], kw
 
 
-RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign",
+RECORD_RUNS = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_sgf_preload",
                "records_19_cutoff", "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart", "records_9_req2_async",
                "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "records_9_req2_ts", "records_9_req2_eval", "records_9_sgf", "records_9_sgf_policy_only"]
 

@@ -11,7 +11,7 @@ import pytest
 from conftest import GOLDEN
 from pyoracle import RefSelfPlay, sgfstr2coords
 
-CASES = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff",
+CASES = ["records_9_cutoff", "records_9_resign", "records_9_twopass", "records_9_neverresign", "records_9_preload", "records_19_resign", "records_19_cutoff", "records_19_sgf_preload",
          "records_9_eval", "records_9_eval_swap_resign", "records_9_req2_restart",
          "records_9_cheat_selfplay", "records_9_cheat_eval", "records_9_cheat_eval_swap", "online_9_script", "online_9_following_pass"]
 
