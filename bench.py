@@ -380,7 +380,10 @@ def init_dist(args):
         # what differs between the ranks of a node, gathered once (full report: scaling_report.process_group.ranks): the core slice,
         # the MIOpen user database and the device of every rank -- slices and databases must be disjoint
         ranks_info = [None] * world
-        dist.all_gather_object(ranks_info, {"rank": rank, "device": device, "cores": [int(c) for c in mine], "miopen_user_db": os.environ["MIOPEN_USER_DB_PATH"]})
+        try:
+            dist.all_gather_object(ranks_info, {"rank": rank, "device": device, "cores": [int(c) for c in mine], "miopen_user_db": os.environ["MIOPEN_USER_DB_PATH"]})
+        except Exception as e:      # a report detail, never a reason to lose the run
+            ranks_info = "unavailable: %r" % (e,)
         DIST_INFO.update(backend=backend, host_cores_per_rank=len(mine), ranks_share_one_gpu=bool(share),
                          miopen_user_db="per rank (%s)" % os.path.dirname(mi), ranks=ranks_info)
     if torch.cuda.is_available():
