@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--moves", type=int, default=4)
     ap.add_argument("--rollouts", type=int, default=8192)
     ap.add_argument("--nodes-per-game", type=int, default=None)
+    ap.add_argument("--validate", action="store_true", help="after every move: the node records' invariants (elfmcts_validate) and the pool's "
+                    "books (ids in trees by a scan = RootInfo = pool_info; trees + free = total)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     args = argparse.Namespace(net=a.net, net_blocks=20, net_dim=256, net_dtype="fp16", no_fold_bn=False, net_impl="fused", board_size=19)
@@ -56,6 +58,12 @@ def main():
                 peak = np.maximum(peak, used)
                 per_move.append({"move": mv + 1, "live_nodes_mean": float(used.mean()), "live_nodes_max": int(used.max())})
             sp.end_step(pi, v)
+        if a.validate:
+            bad = sp.validate_trees()
+            p_, live = sp.pool_info(), sp.count_live()
+            assert bad[0] == 0, ("node record invariants", bad)
+            assert int(live.sum()) == p_["live"] and p_["live"] + p_["small_free"] + p_["big_free"] == p_["small_total"] + p_["big_total"], p_
+            per_move[-1].update(validated=True, ids_in_trees=p_["live"], big_records_in_use=p_["big_total"] - p_["big_free"])
     pool = sp.pool_info()
     print(json.dumps({"net": a.net, "games": a.games, "rollouts_per_move": a.rollouts, "nodes_per_game": cs, "per_move": per_move, "pool": pool,
                       "pool_GB": a.games * elf_amd.tree_bytes_per_game(19, cs) / 1e9,
