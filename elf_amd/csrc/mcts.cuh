@@ -514,7 +514,12 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
   // the games' first pops ask for different amounts so that they do not all come back in the same step (every wave of the launch
   // starts at once: one same-address atomic per game and step serialised for ~85 us at 4608 games, measured).
   if (!root_only && free_top < KT) {
-    const int steps_worth = rfl((int)(gs.rollouts_done == 0 && gs.node_visits == 0)) ? 1 + g % MCTS_REFILL : MCTS_REFILL;
+    // ... but never more than a quarter of the game's nominal share of the pool: a wide step (num_threads x rollouts per batch up to
+    // 1024) on a small pool must not let the first games' stashes starve the others
+    int most = (tp.Cs / tp.G) / (4 * KT);
+    most = most < 1 ? 1 : most > MCTS_REFILL ? MCTS_REFILL : most;
+    int steps_worth = rfl((int)(gs.rollouts_done == 0 && gs.node_visits == 0)) ? 1 + g % MCTS_REFILL : MCTS_REFILL;
+    steps_worth = steps_worth > most ? most : steps_worth;
     free_top = stash_refill(tp, g, free_top, steps_worth * KT - free_top, lane);
     mem_sync();
   }
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         NodeRef<N> nw = nd;      // the record that receives the new followed edge
         if (nt >= nodes.cap(node)) {
           // ---- the 17th followed edge of a small record: the node MOVES to the big pool.  Copy the record, tell the parent (its
-          // child id) and the 16 children (their parent id), return the small record.  Cb = Cs / 16 + 1 big records cannot run out.
+          // child id) and the 16 children (their parent id), return the small record to the stash.  Cb = Cs / TCS + 1 big records cannot run out.
           const int bid = pop_big(tp, lane);
           if (bid < 0) { err |= MCTS_ERR_POOL; --depth; break; }
           const NodeRef<N> dst = nodes[bid];

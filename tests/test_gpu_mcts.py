@@ -178,6 +178,26 @@ def test_one_game_may_hold_several_times_its_share_of_the_pool(elf):
     sp.close()
 
 
+def test_wide_steps_on_a_small_pool_do_not_starve_each_other(elf):
+    """A game's stash is topped up to several steps' worth of node ids with one atomic -- but never beyond a quarter of its nominal
+    share of the pool: 8 games whose step is 256 rollouts wide (4 search threads x 64 per batch) on 512 ids per game would otherwise
+    let the first two games' stashes (8 x 256 ids each) empty the pool before the others have popped anything."""
+    import torch
+    n, G = 9, 8
+    sp = elf.SelfPlay(board_size=n, num_games=G, mcts_rollout_per_thread=64, mcts_rollout_per_batch=64, mcts_threads=4, nodes_per_game=512,
+                      seed=11, move_cutoff=12, policy_distri_cutoff=4)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(40):                       # 40 moves of every game, across game ends and restarts
+        rows = sp.begin_step()
+        pi = torch.softmax(2.0 * torch.randn((sp.max_rows, n * n + 1), device="cuda", generator=gen), dim=1)
+        v = torch.tanh(torch.randn(sp.max_rows, device="cuda", generator=gen))
+        sp.end_step(pi[:max(rows, 1)], v[:max(rows, 1)]) if rows else sp.end_step(None, None)
+    p = sp.pool_info()
+    assert p["live"] + p["small_free"] + p["big_free"] == p["small_total"] + p["big_total"], p
+    assert sp.validate_trees()[0] == 0
+    sp.close()
+
+
 LIVE = [
     (9, dict(rollouts_per_thread=96, max_searches=40, seed=4242, net_salt=77, policy_distri_cutoff=9, virtual_loss=2, c_puct=1.1,
              root_epsilon=0.3, root_alpha=0.2, ply_pass_enabled=12, komi=6.5)),
