@@ -111,3 +111,27 @@ def test_genmove_reports_a_resignation(elf):
     assert replies[-1] == "resign" and len(replies) == 51 and "resign" not in replies[:-1]
     assert int(eng.boards.info_host(n=1)["ply"][0]) == 1          # finish_game(FR_RESIGN) restarted the board
     eng.close()
+
+
+def test_gtp_genmove_latency_19x19(elf, record_property):
+    """Single-game latency through the GTP front-end (what README.rst:147 is about: one game, bs 16): `genmove` on 19x19 with 1024 and
+    4096 rollouts per move and a net that costs nothing (random replies on the GPU), i.e. the search kernels + the per-step Python
+    callback of this front-end.  A step is 7 kernel launches for ONE game: launch-bound, ~0.3-0.5 ms; the bound below is loose (a
+    regression guard, not a benchmark: `bench.py`'s sub-result `single_game` times the same loop with the real net)."""
+    import time
+    import torch
+    from elf_amd.gtp import GtpEngine
+    n = 19
+    out = {}
+    for rollouts in (1024, 4096):
+        eng = GtpEngine(make_actor(n), board_size=n, mcts_rollout_per_thread=rollouts, nodes_per_game=4 * rollouts + 1024)
+        assert eng.command("genmove b").startswith("= ")        # first move: also pays the one-off set-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = eng.command("genmove w")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert r.startswith("= ") and dt < 0.01 * rollouts / 16 + 2.0, (rollouts, dt)     # < 10 ms per step of 16 rollouts
+        out[rollouts] = dt
+        record_property("genmove_seconds_%d_rollouts" % rollouts, dt)
+    print("genmove latency 19x19 (no net cost): %s" % {k: "%.3f s = %.2f ms per 16-rollout step" % (v, v / (k / 16) * 1e3) for k, v in out.items()})
