@@ -55,11 +55,6 @@ enum { LK_NN = 0, LK_TERMINAL = 1, LK_REVISIT = 2, LK_STATE_PENDING = 3 };   // 
 enum { MCTS_ERR_POOL = 1, MCTS_ERR_ROOT_HASH = 2, MCTS_ERR_FORWARD = 4, MCTS_ERR_RNG = 8, MCTS_ERR_VERSION = 16 };
 constexpr int MCTS_KMAX = 1024;  // max rollouts per step = num_threads x rollouts_per_batch: the stride of the per-game leaf / row tables in HBM.
                                  // The leaf table of a step in LDS (k_mcts_select) is sized by the launch: 20 B per rollout of the step
-// k_mcts_expand's std::sort replay: segments up to this length are finished by one lane each instead of by further wave-wide generations.
-// 16 = never (a segment of <= 16 pairs is left to the final insertion sort anyway): measured at 64, the serial lanes' LDS-latency
-// chains (one dependent read per scanned pair) cost MORE than the ~5 generations they replace (end_step 537 -> 595 us per 32 768 rows);
-// the lane-serial path stays as the depth-limit / __partial_sort fallback (median-of-3 killers: tests/adapters.py adversarial_net).
-constexpr int MCTS_SORT_SERIAL_BELOW = 16;
 constexpr int MCTS_REFILL = 8;   // steps' worth of node ids a game's stash is topped up to (k_mcts_select); stash capacity = (MCTS_REFILL + 1) x KTA
 enum { GM_IDLE = 0, GM_SEARCH = 1, GM_POLICY_ONLY = 2 };   // per-game mask byte (elfmcts_set_game_mask)
 
@@ -152,7 +147,9 @@ struct GameState {        // 64 B per game
   int live;               // node ids this game holds (its tree; the stash is not counted)
   int promotions;         // small -> big moves so far (statistics)
   int live_peak;          // maximum of `live` since the last elfmcts_pool_info(reset) (statistics)
-  int pad[3];
+  int tie_hint;           // k_mcts_expand: the last reply row of this game held equal priors among its valid candidates (a HINT: which of two
+                          // exact paths a row tries first; written without ordering by the rows of a step)
+  int pad[2];
 };
 static_assert(sizeof(GameState) == 64, "GameState must be 64 bytes");
 
@@ -461,6 +458,9 @@ __device__ unsigned long long g_select_phase[4096][8];   // per block id: no ato
 __device__ __attribute__((noinline)) double sqrt_beyond_table(int v) { return sqrt((double)v); }
 
 // A/B switches (tools/gpu_r4_f.sh, gpu_r4_g.sh); measured: profiles/r04f_select_ab.txt, r04g_expand_ab.txt
+#ifndef ELF_EXP_TIE_PROBE
+#define ELF_EXP_TIE_PROBE 1  // k_mcts_expand looks for one pair of equal priors before it sorts, in games whose last row had one
+#endif
 #ifndef ELF_EXP_BLOCKED
 #define ELF_EXP_BLOCKED 1    // k_mcts_expand sorts with the slots blocked 8 per lane (bitonic_sort512_blocked)
 #endif
@@ -969,9 +969,10 @@ struct ExpandLds {
   //   1. prob, key  -- the net's priors and coords in ACTION order: inputs of the register sort and of the exact std::sort replay
   //   2. seq..sx    -- scratch of umap_order_wave, after the sorted candidates sit in sprob/skey
   union {
-    // candidate (prior, coord) pairs in ACTION order, 8 B each {prior bits, coord | scratch << 16}: the input of the exact std::sort
-    // replay (prior ties only), which swaps whole pairs
-    u64 pk[NE];
+    // candidate (prior, coord) pairs in ACTION order, 8 B each {prior bits, coord | valid << 16}: the input of the exact std::sort
+    // replay (prior ties only), which swaps whole pairs; [NA, NE + 16) is padding that compares below every prior (the 16-wide
+    // windows of the final ranks may run past the last pair)
+    u64 pk[NE + 16];
     struct {
       u16 seq[NE];      // epoch insertion sequence (indices into skey)
       u16 nseq[NE];
@@ -981,7 +982,7 @@ struct ExpandLds {
   };
   float sprob[NE];      // sorted (insertion order of the reference's map)
   u16 skey[NE];
-  u16 scr[NE];          // scratch of the exact std::sort replay (with skey: the stop positions of the partitions)
+  u16 scr[NE];          // scratch of the exact std::sort replay (with skey: the rank-indexed stop positions of a partition; the tie probe's table)
   u64 legalw[8];        // legal-move bitboard words (D4-0 action order)
 };
 static_assert(sizeof(ExpandLds<19>) <= 6400, "expand LDS per wave");
@@ -1175,211 +1176,165 @@ __device__ __forceinline__ void bitonic_sizes_blocked(u64 (&sx)[8], int lane) {
 // ascending; slot e = lane * 8 + k
 __device__ __forceinline__ void bitonic_sort512_blocked(u64 (&sx)[8], int lane) { bitonic_sizes_blocked<2>(sx, lane); }
 
-// The introsort loop of std::sort(pairs, a.second > b.second) (go/mcts/mcts.h:292-297) over the pairs L.pk[0, n), wave-parallel and
-// exact, all segments of one recursion depth partitioned AT ONCE (stl_emul.h (a)-(c): the pairing formulation of __unguarded_partition
-// and its generation-parallel form sort_desc_generations, both checked against std::sort on the host) -- ~9 generations of a few
-// wave-wide passes for 362 pairs instead of ~55 partitions one after the other.  The benchmark's random-init fp16 net answers with a
-// near-uniform policy on the fp16 grid (~240 distinct values among 362 priors), so EVERY row of the headline takes this path.
-// Element e = k * 64 + lane; a lane keeps (first, last) of its elements' segments in registers.  LDS:
-//   pk[e]    the pair at position e; the spare 16 bits of pk[first] carry the segment's cut from the pass that finds it to the pass that
-//            splits the segment (position `first` holds the pivot: no swap of the partition touches it)
-//   pud[x]   (sprob area) exclusive prefix counts of the two stop flags over the whole array: up-stops | down-stops << 16
-//   updp[s]  (skey + scr) slot first + t of a segment: its t-th up-stop (ascending) | its t-th down-stop (descending) << 16
-// Leaves the array as __introsort_loop does; the caller finishes with a stable sort (= __final_insertion_sort).
+// lanes below this one whose bit is set in m
+__device__ __forceinline__ int mbcnt64(u64 m) { return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+
+// One __unguarded_partition of the segment [first, last) (wave-uniform bounds, pivot value P already at `first`) by the whole wave:
+// stl_emul.h (e).  Element first + 1 + 64 j + lane in round j; RM = rounds compiled in (1: the segment has <= 65 pairs -- most have).
+//   * up-stop U[nub] at e swaps iff nda(e) > nub(e); down-stop D[nda] at e swaps iff nub(e) > nda(e)   (nub: up-stops strictly before e,
+//     nda: down-stops strictly after e, both from the two ballots of each round and their running totals)
+//   * ud[t] / ud[NE + t]: position of the swapping up-stop / down-stop of rank t; every swapper stores ITS OWN OLD pair at its partner's place
+//   * returns the cut: the lowest position that holds an up-stop which does not swap or a down-stop which does, else `last`
+template <int N, int RM>
+__device__ __forceinline__ int partition_segment_wave(ExpandLds<N>& L, const int first, const int last, const float P, const int lane) {
+  constexpr int NE = ExpandLds<N>::NE;
+  u16* const ud = L.skey;
+  u64 x[RM], mu[RM], md[RM];
+  int cu[RM], cd[RM];
+  int nu = 0, nd = 0;
+#pragma unroll
+  for (int j = 0; j < RM; ++j) {
+    x[j] = 0; mu[j] = 0; md[j] = 0; cu[j] = nu; cd[j] = nd;
+    if (j > 0 && first + 1 + 64 * j >= last) continue;     // wave-uniform
+    const int e = first + 1 + 64 * j + lane;
+    const bool in = e < last;
+    x[j] = L.pk[in ? e : first];
+    const float v = __uint_as_float((u32)x[j]);
+    mu[j] = __ballot(in && v <= P);
+    md[j] = __ballot(in && v >= P);
+    nu += __popcll(mu[j]);
+    nd += __popcll(md[j]);
+  }
+  u64 mF[RM];
+  int tt[RM];                                               // where this lane finds its partner's position (-1: it does not swap)
+#pragma unroll
+  for (int j = 0; j < RM; ++j) {
+    mF[j] = 0; tt[j] = -1;
+    if (j > 0 && first + 1 + 64 * j >= last) continue;
+    const int e = first + 1 + 64 * j + lane;
+    const bool u = (mu[j] >> lane) & 1, d = (md[j] >> lane) & 1;
+    const int nub = cu[j] + mbcnt64(mu[j]);
+    const int nda = nd - cd[j] - mbcnt64(md[j]) - (d ? 1 : 0);
+    const bool su = u && nda > nub, sd = d && nub > nda;
+    if (su || sd) ud[su ? nub : NE + nda] = (u16)e;
+    mF[j] = __ballot((u && !su) || sd);
+    tt[j] = su ? NE + nub : (sd ? nda : -1);
+  }
+  Board<N>::wsync();
+#pragma unroll
+  for (int j = 0; j < RM; ++j) {
+    if (j > 0 && first + 1 + 64 * j >= last) continue;
+    if (tt[j] >= 0) L.pk[ud[tt[j]]] = x[j];
+  }
+  Board<N>::wsync();
+  int cut = last;
+#pragma unroll
+  for (int j = RM - 1; j >= 0; --j)
+    if (mF[j] != 0) cut = first + 1 + 64 * j + (int)__builtin_ctzll(mF[j]);
+  return cut;
+}
+
+// std::sort(pairs, a.second > b.second) (go/mcts/mcts.h:292-297) over the pairs L.pk[0, n), exact, as the wave runs it since round 6b
+// (stl_emul.h (e), checked against std::sort on the host): the partition tree of __introsort_loop is walked ONE SEGMENT AT A TIME by
+// the whole wave -- a row of 362 priors has ~40 partitions, all but a handful of <= 65 pairs (one round of 64 lanes), and with the
+// segment's bounds and pivot in scalar registers a partition is two ballots, two lane counts, one u16 store / load and one pair store
+// per element.  (Rounds 5-6a partitioned all segments of one recursion depth at once: ~10 generations x 6 rounds x 5 passes of
+// per-element segment tables, 54 % of a row's cycles with ties -- profiles/r06_expand_phases_ties.txt.)
+// The benchmark's random-init fp16 net answers with a near-uniform policy on the fp16 grid (~240 distinct values among 362 priors),
+// so EVERY row of the headline takes this path.  Scratch (all dead outside this function):
+//   sprob as u32:  [0, 24) the stack of segments that wait (first | last << 9 | depth << 18); [24, 36) boundary bits of the segments
+//                  the loop leaves, as u64 words; [36] number of heap-sort segments, [37, 37 + MS) the list of them
+//   skey + scr:    ud[0, NE) / ud[NE, 2 NE) the rank-indexed positions of partition_segment_wave
+// Returns with the boundary words in bw[]; the caller finishes with the window ranks (= __final_insertion_sort).
 template <int N>
-__device__ __forceinline__ void introsort_generations_wave(ExpandLds<N>& L, int n, int lane) {
-  constexpr int NE = ExpandLds<N>::NE, RR = (NE + 63) / 64;
-  u32* const pud = reinterpret_cast<u32*>(L.sprob);
-  static_assert(offsetof(ExpandLds<N>, scr) == offsetof(ExpandLds<N>, skey) + NE * 2, "skey and scr are one array of NE u32");
-  u16* const updp16 = L.skey;
-  const u32* const updp = reinterpret_cast<const u32*>(L.skey);
-  u32* const pk32 = reinterpret_cast<u32*>(L.pk);          // pk32[2e] = prior bits, pk32[2e+1] = coord | scratch << 16
-  u16* const pk16 = reinterpret_cast<u16*>(L.pk);          // pk16[4e+3] = scratch
-  const u64 lt_mask = (1ull << lane) - 1ull;
-  int sf[RR], sl[RR];
-#pragma unroll
-  for (int k = 0; k < RR; ++k) { sf[k] = 0; sl[k] = k * 64 + lane < n ? n : 0; }
+struct SortScratch {
+  static constexpr int NE = ExpandLds<N>::NE;
+  static constexpr int RRB = (N * N + 1 + 63) / 64;        // boundary words
+  static constexpr int MS = (N * N + 1) / 17 + 1;          // segments longer than 16 that n pairs can hold
+  static constexpr int STK = 0, BND = 24, TODO = 36, HK = (37 + MS + 3) & ~3;   // u32 offsets into sprob
+  static_assert(2 * RRB <= TODO - BND, "boundary words");
+  static_assert(HK * 4 + NE * 2 <= NE * 4, "heap-sort copy of the coords fits sprob");
+};
+
+template <int N>
+__device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const int n, const int lane, u64 (&bw)[SortScratch<N>::RRB]) {
+  using SS = SortScratch<N>;
+  constexpr int NE = ExpandLds<N>::NE;
+  static_assert(offsetof(ExpandLds<N>, scr) == offsetof(ExpandLds<N>, skey) + NE * 2, "skey and scr are one array of 2 NE u16");
+  static_assert(offsetof(ExpandLds<N>, sprob) % 8 == 0, "u64 words inside sprob");
+  u32* const w32 = reinterpret_cast<u32*>(L.sprob);
+  u32* const stk = w32 + SS::STK;
+  unsigned long long* const bnd = reinterpret_cast<unsigned long long*>(w32 + SS::BND);
+  u32* const todo = w32 + SS::TODO;
+  const u32* const pk32 = reinterpret_cast<const u32*>(L.pk);
+  if (lane < SS::RRB) bnd[lane] = lane == 0 ? 1ull : 0ull;
+  if (lane == 0) todo[0] = 0u;
   int depth = 0;
-  for (int t = n; t > 1; t >>= 1) depth += 2;             // 2 * floor(lg n)
+  for (int t = n; t > 1; t >>= 1) depth += 2;              // 2 * floor(lg n)
+  int first = 0, last = n, sp = 0;
+  Board<N>::wsync();
   for (;;) {
-    u32 rounds = 0;                                        // rounds that hold an element of a long segment
-    bool longer = false;                                   // some segment is longer than a lane finishes well on its own
-#pragma unroll
-    for (int k = 0; k < RR; ++k) {
-      rounds |= (__ballot(sl[k] - sf[k] > 16) != 0 ? 1u : 0u) << k;
-      longer = longer || sl[k] - sf[k] > MCTS_SORT_SERIAL_BELOW;
-    }
-    if (!__any(longer) || depth == 0) break;
-    --depth;
-    // 1. the pivots: __move_median_to_first(first, first + 1, mid, last - 1) of every long segment, by the lane that holds the
-    //    segment's first element: which of the three is the median is a select chain, then one swap of pairs
-#pragma unroll
-    for (int k = 0; k < RR; ++k) {
-      if (!((rounds >> k) & 1)) continue;
-      const bool head = k * 64 + lane == sf[k] && sl[k] - sf[k] > 16;
-      if (__ballot(head) == 0) continue;
-      if (head) {
-        const int first = sf[k], a = first + 1, b = first + ((sl[k] - first) >> 1), c = sl[k] - 1;
-        const float va = __uint_as_float(pk32[2 * a]), vb = __uint_as_float(pk32[2 * b]), vc = __uint_as_float(pk32[2 * c]);
-        const bool ab = va > vb, bc = vb > vc, ac = va > vc;
-        const int m = ab ? (bc ? b : (ac ? c : a)) : (ac ? a : (bc ? c : b));
-        const u64 x = L.pk[first], y = L.pk[m];
-        L.pk[first] = y; L.pk[m] = x;
+    while (last - first > 16) {
+      if (ELF_RARE(depth == 0)) {                           // __partial_sort fallback (median-of-3 killers): after the loop
+        if (lane == 0) { const u32 c = todo[0]; todo[0] = c + 1u; todo[1 + (c < (u32)SS::MS ? c : 0u)] = (u32)first | ((u32)last << 16); }
+        break;
       }
+      --depth;
+      // __move_median_to_first(first, first + 1, mid, last - 1): three reads, a scalar select chain, one swap of pairs
+      const int a = first + 1, b = first + ((last - first) >> 1), c = last - 1;
+      const float pv = __uint_as_float(pk32[2 * (lane == 0 ? a : (lane == 1 ? b : c))]);
+      const float va = rlf(pv, 0), vb = rlf(pv, 1), vc = rlf(pv, 2);
+      const bool ab = va > vb, bc = vb > vc, ac = va > vc;
+      const int m = ab ? (bc ? b : (ac ? c : a)) : (ac ? a : (bc ? c : b));
+      const float P = ab ? (bc ? vb : (ac ? vc : va)) : (ac ? va : (bc ? vc : vb));
+      if (lane < 2) {
+        const u64 xx = L.pk[lane == 0 ? first : m];
+        L.pk[lane == 0 ? m : first] = xx;
+      }
+      Board<N>::wsync();
+      int cut;
+      if (last - first <= 65) cut = partition_segment_wave<N, 1>(L, first, last, P, lane);
+      else if (last - first <= 129) cut = partition_segment_wave<N, 2>(L, first, last, P, lane);
+      else cut = partition_segment_wave<N, (N * N + 63) / 64>(L, first, last, P, lane);
+      if (lane == 0) {
+        atomicOr(&bnd[cut >> 6], 1ull << (cut & 63));
+        if (cut - first > 16) stk[sp] = (u32)first | ((u32)cut << 9) | ((u32)depth << 18);   // the left part waits (any order: disjoint)
+      }
+      if (cut - first > 16) ++sp;
+      first = cut;
     }
+    if (sp == 0) break;
+    --sp;
     Board<N>::wsync();
-    // 2.-4. stop flags and their exclusive prefix counts over the whole array
-    int cu = 0, cd = 0;
-    int pu[RR], pd[RR];
-    u32 mub = 0, mdb = 0;                                  // bit k: this lane's element of round k is an up-stop / down-stop
-#pragma unroll
-    for (int k = 0; k < RR; ++k) {
-      const int e = k * 64 + lane;
-      pu[k] = cu; pd[k] = cd;
-      if ((rounds >> k) & 1) {
-        const bool act = sl[k] - sf[k] > 16, in = act && e > sf[k];
-        const float v = __uint_as_float(pk32[2 * (in ? e : 0)]), P = __uint_as_float(pk32[2 * (act ? sf[k] : 0)]);
-        const bool u = in && v <= P, d = in && v >= P;
-        const u64 mu = __ballot(u), md = __ballot(d);
-        pu[k] = cu + __popcll(mu & lt_mask);
-        pd[k] = cd + __popcll(md & lt_mask);
-        cu += __popcll(mu);
-        cd += __popcll(md);
-        mub |= (u ? 1u : 0u) << k;
-        mdb |= (d ? 1u : 0u) << k;
-      }
-      if (e <= n) pud[e] = (u32)pu[k] | ((u32)pd[k] << 16);
-    }
-    Board<N>::wsync();
-    // 5. the t-th up-stop (ascending) and the t-th down-stop (descending) of a segment meet in slot first + t
-    u32 nund[RR];
-#pragma unroll
-    for (int k = 0; k < RR; ++k) {
-      nund[k] = 0;
-      if (!((rounds >> k) & 1)) continue;
-      const int e = k * 64 + lane;
-      const bool act = sl[k] - sf[k] > 16;
-      const u32 lo = pud[act ? sf[k] + 1 : 0], hi = pud[act ? sl[k] : 0];
-      nund[k] = hi - lo;                                   // up-stops | down-stops << 16 of the segment (no borrow: both halves grow)
-      if ((mub >> k) & 1) updp16[2 * (sf[k] + (pu[k] - (int)(lo & 0xFFFFu)))] = (u16)e;
-      if ((mdb >> k) & 1) updp16[2 * (sf[k] + ((int)(hi >> 16) - pd[k] - 1)) + 1] = (u16)e;
-    }
-    Board<N>::wsync();
-    // 6.-8. slot q of its segment: the pairs that swap are a prefix of the slots; the slot where that ends knows T and the cut
-#pragma unroll
-    for (int k = 0; k < RR; ++k) {
-      if (!((rounds >> k) & 1)) continue;
-      const int q = k * 64 + lane;
-      const bool act = sl[k] - sf[k] > 16;
-      const int first = sf[k], last = sl[k], t = q - first;
-      const int nu = (int)(nund[k] & 0xFFFFu), nd = (int)(nund[k] >> 16);
-      const int mn = nu < nd ? nu : nd;
-      const int qc = act ? q : 0;
-      const u32 s0 = updp[qc], s1 = updp[qc + 1];
-      const int upq = (int)(s0 & 0xFFFFu), dpq = (int)(s0 >> 16), upn = (int)(s1 & 0xFFFFu), dpn = (int)(s1 >> 16);
-      const bool ok = act && t < mn && upq < dpq;
-      const bool okn = act && t + 1 < mn && upn < dpn;
-      if (ok) {
-        const u64 x = L.pk[upq], y = L.pk[dpq];
-        L.pk[upq] = y; L.pk[dpq] = x;
-      }
-      if (ok && !okn) {                                    // T = t + 1
-        const int ut = t + 1 < nu ? upn : 0x7FFFFFFF;
-        pk16[4 * first + 3] = (u16)(ut < dpq ? ut : dpq);
-      } else if (act && t == 0 && !ok) {                   // T = 0
-        const int ut = nu > 0 ? upq : 0x7FFFFFFF;
-        pk16[4 * first + 3] = (u16)(ut < last ? ut : last);
-      }
-    }
-    Board<N>::wsync();
-    // 9. the two parts of every segment
-#pragma unroll
-    for (int k = 0; k < RR; ++k) {
-      if (!((rounds >> k) & 1)) continue;
-      if (sl[k] - sf[k] > 16) {
-        const int cut = pk16[4 * sf[k] + 3];
-        if (k * 64 + lane < cut) sl[k] = cut; else sf[k] = cut;
-      }
-    }
-    Board<N>::wsync();
-  }
-  // ---- many short segments are left (each > 16, all <= MCTS_SORT_SERIAL_BELOW unless the depth limit ran out): ONE lane per segment runs
-  // the serial __introsort_loop on it with the depth limit that is left (stl_emul.h (d), sort_desc_hybrid).  A generation costs its
-  // wave-wide passes whatever the segments' lengths; ~20 lanes partitioning ~40 pairs each cost a few hundred instructions once.
-  constexpr int MS = (N * N + 1) / 17 + 1;                 // segments longer than 16 that n pairs can hold
-  u32* const seglist = pud;                                // [0, MS) segments (first | last << 16); [MS, 2 MS) heap-sort to-do list; [2 MS] its length
-  u32* const stk = reinterpret_cast<u32*>(L.skey);         // [slot][16]: first | last << 9 | depth << 18
-  static_assert(NE * 4 >= MS * 16 * 4 && 2 * MS + 1 <= 48 && 48 * 4 + NE * 2 <= NE * 4, "serial introsort scratch fits the sprob / skey + scr areas");
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < RR; ++k) {
-    const bool head = k * 64 + lane == sf[k] && sl[k] - sf[k] > 16;
-    const u64 m = __ballot(head);
-    if (head) seglist[cnt + __popcll(m & lt_mask)] = (u32)sf[k] | ((u32)sl[k] << 16);
-    cnt += __popcll(m);
-  }
-  if (cnt == 0) return;
-  if (lane == 0) seglist[2 * MS] = 0;
-  Board<N>::wsync();
-  if (lane < cnt) {
-    u32* const st = stk + lane * 16;
-    int sp = 1;
-    {
-      const u32 fl = seglist[lane];
-      st[0] = (fl & 0xFFFFu) | ((fl >> 16) << 9) | ((u32)depth << 18);
-    }
-    while (sp > 0) {
-      --sp;
-      const u32 w = st[sp];
-      int first = (int)(w & 0x1FFu), last = (int)((w >> 9) & 0x1FFu), d = (int)(w >> 18);
-      while (last - first > 16) {
-        if (ELF_RARE(d == 0)) {                            // __partial_sort fallback: left to the wave below
-          const u32 slot = atomicAdd(&seglist[2 * MS], 1u);   // the to-do segments are disjoint and longer than 16: at most MS of them
-          seglist[MS + (slot < (u32)MS ? slot : 0u)] = (u32)first | ((u32)last << 16);
-          break;
-        }
-        --d;
-        // __unguarded_partition_pivot: median of (first + 1, mid, last - 1) to first, then the two scans
-        {
-          const int a = first + 1, b = first + ((last - first) >> 1), c = last - 1;
-          const float va = __uint_as_float(pk32[2 * a]), vb = __uint_as_float(pk32[2 * b]), vc = __uint_as_float(pk32[2 * c]);
-          const bool ab = va > vb, bc = vb > vc, ac = va > vc;
-          const int m = ab ? (bc ? b : (ac ? c : a)) : (ac ? a : (bc ? c : b));
-          const u64 x = L.pk[first], y = L.pk[m];
-          L.pk[first] = y; L.pk[m] = x;
-        }
-        const float P = __uint_as_float(pk32[2 * first]);
-        int lo = first + 1, hi = last;
-        for (;;) {
-          while (__uint_as_float(pk32[2 * lo]) > P) ++lo;
-          --hi;
-          while (P > __uint_as_float(pk32[2 * hi])) --hi;
-          if (!(lo < hi)) break;
-          const u64 x = L.pk[lo], y = L.pk[hi];
-          L.pk[lo] = y; L.pk[hi] = x;
-          ++lo;
-        }
-        st[sp++] = (u32)first | ((u32)lo << 9) | ((u32)d << 18);   // the left part waits, the right part goes on (any order: disjoint)
-        first = lo;
-      }
-    }
+    const u32 w = (u32)rfl((int)stk[sp]);
+    first = (int)(w & 0x1FFu); last = (int)((w >> 9) & 0x1FFu); depth = (int)(w >> 18);
   }
   Board<N>::wsync();
-  const int n_heap = rfl((int)seglist[2 * MS]);
+  const int n_heap = rfl((int)todo[0]);
   if (ELF_RARE(n_heap > 0)) {
-    // median-of-3 killers only: serial heap sorts on unpacked copies, one segment after the other
-    float* const hv = reinterpret_cast<float*>(L.skey);    // the stacks are dead
-    u16* const hk = reinterpret_cast<u16*>(pud + 48);
-    for (int i = 0; i < n_heap && i < MS; ++i) {
-      const u32 fl = seglist[MS + i];
-      const int first = (int)(fl & 0xFFFFu), last = (int)(fl >> 16);
-      for (int q = first + lane; q < last; q += 64) { hv[q] = __uint_as_float(pk32[2 * q]); hk[q] = (u16)pk32[2 * q + 1]; }
+    // median-of-3 killers only: serial heap sorts on unpacked copies, one segment after the other; a heap-sorted segment is in its
+    // final order, so every position of it becomes a boundary
+    float* const hv = reinterpret_cast<float*>(L.skey);    // the rank-indexed positions are dead
+    u16* const hk = reinterpret_cast<u16*>(w32 + SS::HK);
+    u32* const pkw = reinterpret_cast<u32*>(L.pk);
+    for (int i = 0; i < n_heap && i < SS::MS; ++i) {
+      const u32 fl = (u32)rfl((int)todo[1 + i]);
+      const int hf = (int)(fl & 0xFFFFu), hl = (int)(fl >> 16);
+      for (int q = hf + lane; q < hl; q += 64) { hv[q] = __uint_as_float(pkw[2 * q]); hk[q] = (u16)((pkw[2 * q + 1] & 0x7FFFu) | ((pkw[2 * q + 1] >> 1) & 0x8000u)); }
       Board<N>::wsync();
-      if (lane == 0) stl_emul::heap_sort(stl_emul::PairRef<u16>{hk, hv}, first, last);
+      if (lane == 0) stl_emul::heap_sort(stl_emul::PairRef<u16>{hk, hv}, hf, hl);
       Board<N>::wsync();
-      for (int q = first + lane; q < last; q += 64) { pk32[2 * q] = __float_as_uint(hv[q]); pk32[2 * q + 1] = hk[q]; }
+      for (int q = hf + lane; q < hl; q += 64) {
+        pkw[2 * q] = __float_as_uint(hv[q]); pkw[2 * q + 1] = ((u32)hk[q] & 0x7FFFu) | (((u32)hk[q] & 0x8000u) << 1);
+        atomicOr(&bnd[q >> 6], 1ull << (q & 63));
+      }
       Board<N>::wsync();
     }
+  }
+#pragma unroll
+  for (int w = 0; w < SS::RRB; ++w) {
+    const u64 v = bnd[w];
+    bw[w] = ((u64)(u32)rfl((int)(u32)(v >> 32)) << 32) | (u64)(u32)rfl((int)(u32)v);
   }
 }
 
@@ -1431,6 +1386,15 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
   constexpr int SK = 8;   // 512 sort slots: element e = k*64 + lane
   u64 sx[SK];
   int nvalid = 0;
+  // Equal priors among the valid candidates send a row to the exact std::sort replay below, which needs nothing from the register sort.
+  // Whether a row has them is only known after that sort -- unless the game's previous row had them (fp16 nets tie in every row): then
+  // a probe looks for ONE equal pair first (a 512-slot table of action ids keyed by a hash of the prior bits: last writer wins, a reader
+  // that finds another id compares the two priors).  A hit skips the register sort; a miss (no ties, or all of them hidden by
+  // collisions) costs ~100 instructions and falls through to the sort and its exact tie test.  Either way the result is the same.
+  const bool probe = ELF_EXP_TIE_PROBE && rfl(tp.gs[g].tie_hint) != 0;
+  u16* const ptab = L.skey;                                  // skey + scr: 2 NE u16
+  constexpr int PSH = 2 * ExpandLds<N>::NE >= 512 ? 23 : 25; // 512 / 128 slots
+  static_assert((1 << (32 - PSH)) <= 2 * ExpandLds<N>::NE, "the probe's table fits skey + scr");
 #pragma unroll
   for (int k = 0; k < SK; ++k) {
     const int i = ELF_EXP_BLOCKED ? lane * SK + k : k * 64 + lane;   // sort slot <-> action id (any bijection does)
@@ -1441,9 +1405,13 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
       int a0;
       action_to_coord<N>(i, d4, coord, a0);
       p = prow[i];
-      L.pk[i] = (u64)__float_as_uint(p) | ((u64)(u32)coord << 32);   // kept in action order for the exact std::sort replay
       if (coord == M_PASS) valid = pass_enabled;
       else valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;      // s.checkMove(v.first) :308-309
+      // kept in action order for the exact std::sort replay
+      L.pk[i] = (u64)__float_as_uint(p) | ((u64)((u32)coord | (valid ? 0x10000u : 0u)) << 32);
+      if (probe && valid) ptab[(__float_as_uint(p) * 0x9E3779B1u) >> PSH] = (u16)i;
+    } else if (i < ExpandLds<N>::NE + 16) {
+      L.pk[i] = 0xFF800000ull;                               // -inf, invalid
     }
     nvalid += __popcll(__ballot(valid));
     // monotone float -> uint key (ascending with the value), inverted for a descending sort; coord as payload
@@ -1451,6 +1419,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
     const u32 ukey = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
     sx[k] = valid ? (((u64)(~ukey) << 32) | (u32)coord) : ~0ull;
   }
+  static_assert(ExpandLds<N>::NE + 16 <= 64 * SK, "the key loop also writes the padding of pk");
   EXP_PHASE(2);   // reply read, action->coord, validity, sort keys
   int n = 0;   // number of edges
   bool tie = false;
@@ -1463,6 +1432,22 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
     n = 1;
   } else {
     n = nvalid;
+    if (probe) {
+      Board<N>::wsync();
+      const u32* const pk32 = reinterpret_cast<const u32*>(L.pk);
+#pragma unroll
+      for (int k = 0; k < SK; ++k) {
+        const int i = ELF_EXP_BLOCKED ? lane * SK + k : k * 64 + lane;
+        if (sx[k] != ~0ull) {                                 // valid
+          const u32 bits = pk32[2 * i];
+          const int o = ptab[(bits * 0x9E3779B1u) >> PSH];
+          tie |= o != i && pk32[2 * o] == bits;
+        }
+      }
+      tie = __any(tie);
+      Board<N>::wsync();
+    }
+    if (!tie) {
     if (ELF_EXP_BLOCKED) {
       bitonic_sort512_blocked(sx, lane);
       EXP_PHASE(3);   // register bitonic sort of 512 slots
@@ -1497,52 +1482,71 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
       const int e = k * 64 + lane;
       if (e + 1 < n) tie |= (sp[k] == L.sprob[e + 1]);
     }
-    if (__any(tie)) {
+    tie = __any(tie);
+    }
+    if (tie) {
       // equal priors among valid candidates: the order is whatever libstdc++'s unstable std::sort makes of ALL N*N+1 pairs
-      // (go/mcts/mcts.h:292-297).  Replayed exactly and wave-parallel: the introsort loop on the action-order arrays in LDS, then
-      // __final_insertion_sort as what it is, a stable sort by (prior desc, position asc) on the bitonic network, then the filter.
+      // (go/mcts/mcts.h:292-297).  Replayed exactly: the introsort loop on the action-order pairs in LDS, one segment at a time
+      // (introsort_segments_wave); __final_insertion_sort as what it is, the stable sort of every segment the loop leaves -- a
+      // pair's final place is its segment's start plus the pairs of a 16-wide window that go before it; then the filter.
       EXP_PHASE(4);
-      introsort_generations_wave<N>(L, NA, lane);
+      u64 bw[SortScratch<N>::RRB];
+      introsort_segments_wave<N>(L, NA, lane, bw);
       EXP_PHASE(1);   // the introsort loop of the exact std::sort replay (prior ties only)
-      // slot e = lane * 8 + k (the blocked network); key = (prior desc, position asc), coord as payload
+      {
+        const u32* const pk32 = reinterpret_cast<const u32*>(L.pk);
+        const u64 le_mask = ((1ull << lane) - 1ull) | (1ull << lane);
+        u64 xe[R];
+        int fp[R];
 #pragma unroll
-      for (int k = 0; k < SK; ++k) {
-        const int i = lane * SK + k;
-        const u64 pr = L.pk[i < NA ? i : 0];
-        sx[k] = i < NA ? (((u64)(~f2ukey(__uint_as_float((u32)pr))) << 32) | ((u32)i << 16) | (u32)((pr >> 32) & 0xFFFFu)) : ~0ull;
-      }
-      Board<N>::wsync();
-      bitonic_sort512_blocked(sx, lane);
-      // the filter (s.checkMove :308-309): a lane's valid ones go behind those of the lanes below it, in slot order
-      u32 vmask = 0;
+        for (int k = 0; k < R; ++k) {
+          const int e = k * 64 + lane;
+          xe[k] = 0; fp[k] = -1;
+          if (e < NA) {
+            const u64 m = bw[k] & le_mask;
+            int sf;
+            if (k == 0) sf = 63 - (int)__builtin_clzll(m);                   // bit 0 is always set
+            else sf = m != 0 ? k * 64 + 63 - (int)__builtin_clzll(m) : k * 64 - 1 - (int)__builtin_clzll(bw[k - 1]);
+            xe[k] = L.pk[e];
+            const float v = __uint_as_float((u32)xe[k]);
+            const u32* const win = pk32 + 2 * sf;
+            int r = 0;
+            u32 eq = 0;
 #pragma unroll
-      for (int k = 0; k < SK; ++k) {
-        const int e = lane * SK + k;
-        const int coord = (int)(sx[k] & 0xFFFFu);
-        bool valid = false;
-        if (e < NA) {
-          if (coord == M_PASS) valid = pass_enabled;
-          else {
-            const int x = coord % G::S - 1, y = coord / G::S - 1, a0 = x * N + y;
-            valid = (L.legalw[a0 >> 6] >> (a0 & 63)) & 1;
+            for (int t = 0; t < 16; ++t) {
+              const float vj = __uint_as_float(win[2 * t]);
+              r += vj > v ? 1 : 0;
+              eq |= vj == v ? (1u << t) : 0u;
+            }
+            fp[k] = sf + r + __popc(eq & ((1u << (e - sf)) - 1u));
           }
         }
-        vmask |= (valid ? 1u : 0u) << k;
-      }
-      const int cnt = __popc(vmask);
-      int dst = wave_inclusive_sum(cnt) - cnt;
+        Board<N>::wsync();
 #pragma unroll
-      for (int k = 0; k < SK; ++k) {
-        if ((vmask >> k) & 1) {
-          L.sprob[dst] = ukey2f(~(u32)(sx[k] >> 32));
-          L.skey[dst] = (u16)(sx[k] & 0xFFFFu);
-          ++dst;
+        for (int k = 0; k < R; ++k)
+          if (fp[k] >= 0) L.pk[fp[k]] = xe[k];
+        Board<N>::wsync();
+        // the filter (s.checkMove :308-309), in sorted order
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const int e = k * 64 + lane;
+          const u64 y = L.pk[e < NA ? e : 0];
+          const bool valid = e < NA && ((y >> 48) & 1ull) != 0;
+          const u64 mv = __ballot(valid);
+          if (valid) {
+            const int dst = cnt + mbcnt64(mv);
+            L.sprob[dst] = __uint_as_float((u32)y);
+            L.skey[dst] = (u16)((y >> 32) & 0xFFFFu);
+          }
+          cnt += __popcll(mv);
         }
       }
       Board<N>::wsync();
 #pragma unroll
       for (int k = 0; k < R; ++k) { const int e = k * 64 + lane; sp[k] = e < n ? L.sprob[e] : 0.0f; }
     }
+    if (ELF_EXP_TIE_PROBE && lane == 0 && (rfl(tp.gs[g].tie_hint) != 0) != tie) tp.gs[g].tie_hint = tie ? 1 : 0;
     EXP_PHASE(4);   // sorted rows to LDS, tie test (+ exact std::sort replay on ties)
     // normalize :244-254: total = 1e-10 + sequential fp32 sum in sorted order.  The chain of n dependent adds is the cost; every
     // lane runs it redundantly on broadcast 16-B LDS reads of the sorted priors (issued ahead of the adds), which beats a

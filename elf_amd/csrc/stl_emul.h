@@ -408,6 +408,83 @@ static inline void sort_desc_hybrid(K* keys, float* vals, int n, int serial_belo
   }
 }
 
+// (e) What the expand kernel runs since round 6b: the partition tree walked ONE SEGMENT AT A TIME by the whole wave.  A row of 362
+//     priors has only ~40 partitions (at most ~8 long segments exist at any time, most of them <= 65 pairs = one round of 64 lanes), and
+//     with the segment's bounds and pivot wave-uniform every per-element table of form (c) goes away:
+//       * whether an element swaps is a LOCAL question.  With nub(e) = up-stops strictly before e and nda(e) = down-stops strictly
+//         after e (both inside the segment): the up-stop at e is U[nub] and swaps iff D[nub] > e iff nda(e) >= nub(e) + 1; the
+//         down-stop at e is D[nda] and swaps iff U[nda] < e iff nub(e) > nda(e).  (Never both: the two conditions contradict.)
+//       * partners find each other through two rank-indexed position arrays; each swapper then WRITES ITS OWN OLD PAIR to its
+//         partner's position (no read of a pair that another lane may already have replaced).
+//       * cut = min(U[T], D[T-1], last) is the lowest position holding an up-stop that does not swap or a down-stop that does.
+//     __final_insertion_sort: the segments the loop leaves (<= 16 pairs each) are ordered among themselves -- every pair of a segment
+//     compares >= every pair of the next -- so the stable sort of the whole array is the stable sort of each segment: the final place
+//     of the pair at e in segment [sf, sl) is sf + #{j in [sf, sl): v[j] > v[e]} + #{j in [sf, e): v[j] == v[e]}, and because of that
+//     same order a 16-wide window from sf may run past sl without counting anything.  Segments finished by the heap-sort fallback
+//     are sorted already: every one of their positions is marked as a boundary.
+template <typename K>
+static inline void sort_desc_segments(K* keys, float* vals, int n) {
+  if (n <= 0) return;
+  PairRef<K> p{keys, vals};
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  std::vector<char> bnd(n + 1, 0);
+  bnd[0] = 1;
+  std::vector<int> UP(n + 1), DP(n + 1), nub(n), nda(n);
+  std::vector<char> su(n), sd(n), u(n), d(n);
+  int stk_first[kSortStack], stk_last[kSortStack], stk_depth[kSortStack], sp = 0;
+  stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    while (last - first > 16) {
+      if (depth == 0) {
+        heap_sort(p, first, last);
+        for (int e = first; e < last; ++e) bnd[e] = 1;
+        break;
+      }
+      --depth;
+      median_to_first(p, first, last);
+      const float P = p.v[first];
+      int cu = 0, cd = 0;
+      for (int e = first + 1; e < last; ++e) { u[e] = p.v[e] <= P; d[e] = p.v[e] >= P; nub[e] = cu; cu += u[e]; cd += d[e]; }
+      const int ndt = cd;
+      cd = 0;
+      for (int e = first + 1; e < last; ++e) { cd += d[e]; nda[e] = ndt - cd; }   // down-stops strictly after e
+      int cut = last;
+      for (int e = last - 1; e > first; --e) {
+        su[e] = u[e] && nda[e] >= nub[e] + 1;
+        sd[e] = d[e] && nub[e] > nda[e];
+        if (su[e]) UP[nub[e]] = e;
+        if (sd[e]) DP[nda[e]] = e;
+        if ((u[e] && !su[e]) || sd[e]) cut = e;
+      }
+      std::vector<float> v0(vals + first, vals + last);
+      std::vector<K> k0(keys + first, keys + last);
+      for (int e = first + 1; e < last; ++e) {
+        if (su[e]) { const int q = DP[nub[e]]; keys[q] = k0[e - first]; vals[q] = v0[e - first]; }
+        if (sd[e]) { const int q = UP[nda[e]]; keys[q] = k0[e - first]; vals[q] = v0[e - first]; }
+      }
+      bnd[cut] = 1;
+      stk_first[sp] = first; stk_last[sp] = cut; stk_depth[sp] = depth; ++sp;
+      first = cut;
+    }
+  }
+  std::vector<K> k2(keys, keys + n);
+  std::vector<float> v2(vals, vals + n);
+  for (int e = 0; e < n; ++e) {
+    int sf = e;
+    while (!bnd[sf]) --sf;
+    int r = 0;
+    for (int t = 0; t < 16; ++t) {
+      const int j = sf + t;
+      if (j >= n) break;
+      r += (v2[j] > v2[e]) || (j < e && v2[j] == v2[e]);
+    }
+    keys[sf + r] = k2[e]; vals[sf + r] = v2[e];
+  }
+}
+
 template <typename K>
 static inline void sort_desc(K* keys, float* vals, int n) {   // host convenience (tests)
   int stk[3 * kSortStack];

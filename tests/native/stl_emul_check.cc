@@ -54,6 +54,14 @@ static int check_sort(std::vector<float> vals) {
   stl_emul::sort_desc_generations(k3.data(), v3.data(), n);
   for (int i = 0; i < n; ++i)
     if (ref[i].first != k3[i] || ref[i].second != v3[i]) return 1;
+  {   // one segment at a time, local swap rule, window ranks (the expand kernel's form since round 6b)
+    std::vector<Coord> k5(n);
+    std::vector<float> v5(n);
+    for (int i = 0; i < n; ++i) { k5[i] = (Coord)i; v5[i] = vals[i]; }
+    stl_emul::sort_desc_segments(k5.data(), v5.data(), n);
+    for (int i = 0; i < n; ++i)
+      if (ref[i].first != k5[i] || ref[i].second != v5[i]) return 1;
+  }
   for (int below : {16, 40, 64, 100000}) {   // generations, then one lane per remaining long segment (the kernel uses 64)
     std::vector<Coord> k4(n);
     std::vector<float> v4(n);
