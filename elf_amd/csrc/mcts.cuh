@@ -1178,53 +1178,112 @@ __device__ __forceinline__ void bitonic_sort512_blocked(u64 (&sx)[8], int lane) 
 
 // lanes below this one whose bit is set in m
 __device__ __forceinline__ int mbcnt64(u64 m) { return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+// the lane mask of a predicate as it sits in the scalar registers (HIP's __ballot goes through a 0 / 1 vector first)
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// One __unguarded_partition of the segment [first, last) (wave-uniform bounds, pivot value P already at `first`) by the whole wave:
-// stl_emul.h (e).  Element first + 1 + 64 j + lane in round j; RM = rounds compiled in (1: the segment has <= 65 pairs -- most have).
-//   * up-stop U[nub] at e swaps iff nda(e) > nub(e); down-stop D[nda] at e swaps iff nub(e) > nda(e)   (nub: up-stops strictly before e,
-//     nda: down-stops strictly after e, both from the two ballots of each round and their running totals)
-//   * ud[t] / ud[NE + t]: position of the swapping up-stop / down-stop of rank t; every swapper stores ITS OWN OLD pair at its partner's place
-//   * returns the cut: the lowest position that holds an up-stop which does not swap or a down-stop which does, else `last`
+// a lane mask from the scalar registers as a per-lane predicate (no instruction: the mask IS the condition)
+__device__ __forceinline__ bool lane_of(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// __move_median_to_first's choice among (a, b, c) = (first + 1, mid, last - 1) for wave-uniform values: 0 = a, 1 = b, 2 = c.
+// The if-chain of libstdc++ (`a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b))`, ties included) as a table
+// indexed by its three comparisons.
+__device__ __forceinline__ int median3_choice(float va, float vb, float vc) {
+  const int code = (va > vb ? 4 : 0) | (vb > vc ? 2 : 0) | (va > vc ? 1 : 0);
+  return (0x5821 >> (2 * code)) & 3;
+}
+
+// One __unguarded_partition of a segment with wave-uniform bounds by the whole wave -- stl_emul.h (e):
+//   * with nub(e) = up-stops (v <= P) strictly before e and nda(e) = down-stops (v >= P) strictly after e, both inside the segment:
+//     the up-stop at e is U[nub] and swaps iff nda > nub; the down-stop at e is D[nda] and swaps iff nub > nda
+//   * ud[2 t] / ud[2 t + 1]: position of the swapping up-stop / down-stop of rank t (t <= n / 2); every swapper stores ITS OWN OLD pair
+//     at its partner's place
+//   * the cut is the lowest position that holds an up-stop which does not swap or a down-stop which does, else `last`
+// The stop and swap flags exist only as lane masks in scalar registers (a compare each, restricted to the segment by a scalar AND);
+// the cut is a scalar find-first-set.  (The kernel is bound by the NUMBER of instructions it issues, vector and scalar alike --
+// profiles/r06b_expand_pmc.txt -- so what is uniform is computed once, but not at the price of more scalar instructions than the
+// vector ones it saves.)
+//
+// partition_small_wave: a segment of <= 64 pairs, pivot selection included.  Lane i holds pair first + i, so __move_median_to_first
+// reads its three candidates from registers, the pivot swap is two lanes storing their pairs at each other's place plus one register
+// move, and the partition needs no further load.  Most of a row's ~45 partitions are this kind.
+template <int N>
+__device__ __forceinline__ int partition_small_wave(ExpandLds<N>& L, const int first, const int last, const int lane) {
+  char* const udb = reinterpret_cast<char*>(L.skey);
+  u64* const pk = L.pk;
+  const int len = last - first;                             // 17 .. 64
+  u64 x = pk[first + lane];                                 // lanes >= len read pairs beyond the segment: masked below
+  const float v0 = __uint_as_float((u32)x);
+  const int ib = len >> 1, ic = len - 1;
+  const int ch = median3_choice(rlf(v0, 1), rlf(v0, ib), rlf(v0, ic));
+  const int im = ch == 0 ? 1 : (ch == 1 ? ib : ic);
+  const float P = rlf(v0, im);
+  // the pair at `first` and the median change places: in LDS now, and in lane im's register (lane 0 takes no part in the partition)
+  const u64 m_im = 1ull << im;
+  if (lane_of(m_im | 1ull)) pk[first + (lane_of(m_im) ? 0 : im)] = x;
+  {
+    const u32 lo0 = (u32)rl((int)(u32)x, 0), hi0 = (u32)rl((int)(u32)(x >> 32), 0);
+    if (lane_of(m_im)) x = ((u64)hi0 << 32) | lo0;
+  }
+  const float v = __uint_as_float((u32)x);
+  const u64 seg = (~0ull >> (64 - len)) & ~1ull;            // lanes 1 .. len - 1
+  const u64 mu = ballot64(v <= P) & seg, md = ballot64(v >= P) & seg;
+  const int nub = mbcnt64(mu);
+  const int nda = (int)__popcll(md) - mbcnt64(md >> 1);     // down-stops above this lane (bit 0 of md is clear)
+  const u64 msu = ballot64(nda > nub) & mu, msd = ballot64(nub > nda) & md;
+  if (lane_of(msu | msd)) {
+    const int own = (lane_of(msu) ? nub : nda) * 4 + (lane_of(msd) ? 2 : 0);   // byte offset into ud
+    *reinterpret_cast<u16*>(udb + own) = (u16)(first + lane);
+    Board<N>::wsync();
+    pk[*reinterpret_cast<const u16*>(udb + (own ^ 2))] = x;
+  }
+  Board<N>::wsync();
+  const u64 mF = (mu & ~msu) | msd;
+  return mF != 0 ? first + (int)__builtin_ctzll(mF) : last;
+}
+
+// partition_segment_wave: longer segments, pivot value P already at `first`; element first + 1 + 64 j + lane in round j of RM.
 template <int N, int RM>
 __device__ __forceinline__ int partition_segment_wave(ExpandLds<N>& L, const int first, const int last, const float P, const int lane) {
-  constexpr int NE = ExpandLds<N>::NE;
-  u16* const ud = L.skey;
+  char* const udb = reinterpret_cast<char*>(L.skey);
+  u64* const pk = L.pk;
   u64 x[RM], mu[RM], md[RM];
   int cu[RM], cd[RM];
   int nu = 0, nd = 0;
 #pragma unroll
   for (int j = 0; j < RM; ++j) {
     x[j] = 0; mu[j] = 0; md[j] = 0; cu[j] = nu; cd[j] = nd;
-    if (j > 0 && first + 1 + 64 * j >= last) continue;     // wave-uniform
-    const int e = first + 1 + 64 * j + lane;
-    const bool in = e < last;
-    x[j] = L.pk[in ? e : first];
+    const int left = last - (first + 1 + 64 * j);           // elements of this round and the following ones
+    if (j > 0 && left <= 0) continue;                       // wave-uniform
+    x[j] = pk[first + 1 + 64 * j + lane];                   // lanes beyond the segment read pairs that are masked below
     const float v = __uint_as_float((u32)x[j]);
-    mu[j] = __ballot(in && v <= P);
-    md[j] = __ballot(in && v >= P);
+    const u64 seg = left >= 64 ? ~0ull : (~0ull >> (64 - left));
+    mu[j] = ballot64(v <= P) & seg;
+    md[j] = ballot64(v >= P) & seg;
     nu += __popcll(mu[j]);
     nd += __popcll(md[j]);
   }
-  u64 mF[RM];
-  int tt[RM];                                               // where this lane finds its partner's position (-1: it does not swap)
+  u64 mF[RM], msw[RM];
+  int own[RM];                                              // this lane's byte offset into ud; its partner's is own ^ 2
 #pragma unroll
   for (int j = 0; j < RM; ++j) {
-    mF[j] = 0; tt[j] = -1;
+    mF[j] = 0; msw[j] = 0; own[j] = 0;
     if (j > 0 && first + 1 + 64 * j >= last) continue;
-    const int e = first + 1 + 64 * j + lane;
-    const bool u = (mu[j] >> lane) & 1, d = (md[j] >> lane) & 1;
     const int nub = cu[j] + mbcnt64(mu[j]);
-    const int nda = nd - cd[j] - mbcnt64(md[j]) - (d ? 1 : 0);
-    const bool su = u && nda > nub, sd = d && nub > nda;
-    if (su || sd) ud[su ? nub : NE + nda] = (u16)e;
-    mF[j] = __ballot((u && !su) || sd);
-    tt[j] = su ? NE + nub : (sd ? nda : -1);
+    // down-stops strictly after this element: all of them minus those up to and including this lane
+    const int nda = (nd - cd[j] - (int)(md[j] & 1ull)) - mbcnt64(md[j] >> 1);
+    const u64 msu = ballot64(nda > nub) & mu[j], msd = ballot64(nub > nda) & md[j];
+    mF[j] = (mu[j] & ~msu) | msd;
+    msw[j] = msu | msd;
+    if (lane_of(msw[j])) {
+      own[j] = (lane_of(msu) ? nub : nda) * 4 + (lane_of(msd) ? 2 : 0);
+      *reinterpret_cast<u16*>(udb + own[j]) = (u16)(first + 1 + 64 * j + lane);
+    }
   }
   Board<N>::wsync();
 #pragma unroll
   for (int j = 0; j < RM; ++j) {
     if (j > 0 && first + 1 + 64 * j >= last) continue;
-    if (tt[j] >= 0) L.pk[ud[tt[j]]] = x[j];
+    if (lane_of(msw[j])) pk[*reinterpret_cast<const u16*>(udb + (own[j] ^ 2))] = x[j];
   }
   Board<N>::wsync();
   int cut = last;
@@ -1236,43 +1295,40 @@ __device__ __forceinline__ int partition_segment_wave(ExpandLds<N>& L, const int
 
 // std::sort(pairs, a.second > b.second) (go/mcts/mcts.h:292-297) over the pairs L.pk[0, n), exact, as the wave runs it since round 6b
 // (stl_emul.h (e), checked against std::sort on the host): the partition tree of __introsort_loop is walked ONE SEGMENT AT A TIME by
-// the whole wave -- a row of 362 priors has ~40 partitions, all but a handful of <= 65 pairs (one round of 64 lanes), and with the
-// segment's bounds and pivot in scalar registers a partition is two ballots, two lane counts, one u16 store / load and one pair store
-// per element.  (Rounds 5-6a partitioned all segments of one recursion depth at once: ~10 generations x 6 rounds x 5 passes of
-// per-element segment tables, 54 % of a row's cycles with ties -- profiles/r06_expand_phases_ties.txt.)
+// the whole wave -- a row of 362 priors has ~45 partitions, all but ~10 of <= 64 pairs (one round of 64 lanes), and with the
+// segment's bounds and pivot in scalar registers a partition is two compares, four lane counts, one u16 store / load and one pair
+// store per element.  (Rounds 5-6a partitioned all segments of one recursion depth at once: ~10 generations x 6 rounds x 5 passes of
+// per-element segment tables, 9 069 vector instructions per row with ties against ~4 500 now.)
 // The benchmark's random-init fp16 net answers with a near-uniform policy on the fp16 grid (~240 distinct values among 362 priors),
-// so EVERY row of the headline takes this path.  Scratch (all dead outside this function):
-//   sprob as u32:  [0, 24) the stack of segments that wait (first | last << 9 | depth << 18); [24, 36) boundary bits of the segments
-//                  the loop leaves, as u64 words; [36] number of heap-sort segments, [37, 37 + MS) the list of them
-//   skey + scr:    ud[0, NE) / ud[NE, 2 NE) the rank-indexed positions of partition_segment_wave
-// Returns with the boundary words in bw[]; the caller finishes with the window ranks (= __final_insertion_sort).
+// so EVERY row of the headline takes this path.  Scratch (all dead outside this function and the window ranks that follow it):
+//   sprob as u32:  [0, 24) the stack of segments that wait (first | last << 9 | depth << 18); [24] number of heap-sort segments,
+//                  [25, 25 + MS) the list of them; from CUT on, one byte per position: "a segment the loop leaves starts here"
+//   skey + scr:    the rank-indexed positions of the partitions (at most n / 2 swaps: 2 (n / 2 + 1) u16)
 template <int N>
 struct SortScratch {
   static constexpr int NE = ExpandLds<N>::NE;
-  static constexpr int RRB = (N * N + 1 + 63) / 64;        // boundary words
   static constexpr int MS = (N * N + 1) / 17 + 1;          // segments longer than 16 that n pairs can hold
-  static constexpr int STK = 0, BND = 24, TODO = 36, HK = (37 + MS + 3) & ~3;   // u32 offsets into sprob
-  static_assert(2 * RRB <= TODO - BND, "boundary words");
-  static_assert(HK * 4 + NE * 2 <= NE * 4, "heap-sort copy of the coords fits sprob");
+  static constexpr int STK = 0, TODO = 24, CUT = (25 + MS + 3) & ~3;   // u32 offsets into sprob
+  static constexpr int CUTW = (NE + 7) / 8 * 2;            // u32 words of flag bytes (8-byte granular)
+  static_assert((CUT + CUTW) * 4 <= NE * 4, "the cut flags fit sprob");
+  static_assert(CUTW <= 128, "two words per lane clear the cut flags");
 };
 
 template <int N>
-__device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const int n, const int lane, u64 (&bw)[SortScratch<N>::RRB]) {
+__device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const int n, const int lane) {
   using SS = SortScratch<N>;
   constexpr int NE = ExpandLds<N>::NE;
   static_assert(offsetof(ExpandLds<N>, scr) == offsetof(ExpandLds<N>, skey) + NE * 2, "skey and scr are one array of 2 NE u16");
-  static_assert(offsetof(ExpandLds<N>, sprob) % 8 == 0, "u64 words inside sprob");
   u32* const w32 = reinterpret_cast<u32*>(L.sprob);
   u32* const stk = w32 + SS::STK;
-  unsigned long long* const bnd = reinterpret_cast<unsigned long long*>(w32 + SS::BND);
   u32* const todo = w32 + SS::TODO;
-  const u32* const pk32 = reinterpret_cast<const u32*>(L.pk);
-  if (lane < SS::RRB) bnd[lane] = lane == 0 ? 1ull : 0ull;
+  unsigned char* const cutf = reinterpret_cast<unsigned char*>(w32 + SS::CUT);
+  u32* const pk32 = reinterpret_cast<u32*>(L.pk);
   if (lane == 0) todo[0] = 0u;
+  if (2 * lane < SS::CUTW) { w32[SS::CUT + 2 * lane] = lane == 0 ? 1u : 0u; w32[SS::CUT + 2 * lane + 1] = 0u; }   // position 0 starts a segment
   int depth = 0;
   for (int t = n; t > 1; t >>= 1) depth += 2;              // 2 * floor(lg n)
   int first = 0, last = n, sp = 0;
-  Board<N>::wsync();
   for (;;) {
     while (last - first > 16) {
       if (ELF_RARE(depth == 0)) {                           // __partial_sort fallback (median-of-3 killers): after the loop
@@ -1280,28 +1336,32 @@ __device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const i
         break;
       }
       --depth;
-      // __move_median_to_first(first, first + 1, mid, last - 1): three reads, a scalar select chain, one swap of pairs
-      const int a = first + 1, b = first + ((last - first) >> 1), c = last - 1;
-      const float pv = __uint_as_float(pk32[2 * (lane == 0 ? a : (lane == 1 ? b : c))]);
-      const float va = rlf(pv, 0), vb = rlf(pv, 1), vc = rlf(pv, 2);
-      const bool ab = va > vb, bc = vb > vc, ac = va > vc;
-      const int m = ab ? (bc ? b : (ac ? c : a)) : (ac ? a : (bc ? c : b));
-      const float P = ab ? (bc ? vb : (ac ? vc : va)) : (ac ? va : (bc ? vc : vb));
-      if (lane < 2) {
-        const u64 xx = L.pk[lane == 0 ? first : m];
-        L.pk[lane == 0 ? m : first] = xx;
-      }
-      Board<N>::wsync();
       int cut;
-      if (last - first <= 65) cut = partition_segment_wave<N, 1>(L, first, last, P, lane);
-      else if (last - first <= 129) cut = partition_segment_wave<N, 2>(L, first, last, P, lane);
-      else cut = partition_segment_wave<N, (N * N + 63) / 64>(L, first, last, P, lane);
-      if (lane == 0) {
-        atomicOr(&bnd[cut >> 6], 1ull << (cut & 63));
-        if (cut - first > 16) stk[sp] = (u32)first | ((u32)cut << 9) | ((u32)depth << 18);   // the left part waits (any order: disjoint)
+      if (last - first <= 64) {
+        cut = partition_small_wave<N>(L, first, last, lane);
+      } else {
+        // __move_median_to_first(first, first + 1, mid, last - 1): three reads, a scalar select chain, one swap of pairs
+        const int a = first + 1, b = first + ((last - first) >> 1), c = last - 1;
+        const float pv = __uint_as_float(pk32[2 * (lane == 0 ? a : (lane == 1 ? b : c))]);
+        const int ch = median3_choice(rlf(pv, 0), rlf(pv, 1), rlf(pv, 2));
+        const int m = ch == 0 ? a : (ch == 1 ? b : c);
+        const float P = rlf(pv, ch);
+        if (lane < 2) {
+          const u64 xx = L.pk[lane == 0 ? first : m];
+          L.pk[lane == 0 ? m : first] = xx;
+        }
+        Board<N>::wsync();
+        if (last - first <= 129) cut = partition_segment_wave<N, 2>(L, first, last, P, lane);
+        else cut = partition_segment_wave<N, (N * N + 63) / 64>(L, first, last, P, lane);
       }
-      if (cut - first > 16) ++sp;
-      first = cut;
+      // every cut starts a segment; of two parts that are both longer than 16 the left one waits (any order: disjoint)
+      const bool wl = cut - first > 16, wr = last - cut > 16;
+      if (lane == 0) {
+        cutf[cut] = 1;
+        if (wl && wr) stk[sp] = (u32)first | ((u32)cut << 9) | ((u32)depth << 18);
+      }
+      if (wl && wr) ++sp;
+      if (wr) first = cut; else last = cut;
     }
     if (sp == 0) break;
     --sp;
@@ -1312,29 +1372,15 @@ __device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const i
   Board<N>::wsync();
   const int n_heap = rfl((int)todo[0]);
   if (ELF_RARE(n_heap > 0)) {
-    // median-of-3 killers only: serial heap sorts on unpacked copies, one segment after the other; a heap-sorted segment is in its
-    // final order, so every position of it becomes a boundary
-    float* const hv = reinterpret_cast<float*>(L.skey);    // the rank-indexed positions are dead
-    u16* const hk = reinterpret_cast<u16*>(w32 + SS::HK);
-    u32* const pkw = reinterpret_cast<u32*>(L.pk);
+    // median-of-3 killers only: serial heap sorts, one segment after the other; a heap-sorted segment is in its final order, so every
+    // position of it is a segment of its own
     for (int i = 0; i < n_heap && i < SS::MS; ++i) {
       const u32 fl = (u32)rfl((int)todo[1 + i]);
       const int hf = (int)(fl & 0xFFFFu), hl = (int)(fl >> 16);
-      for (int q = hf + lane; q < hl; q += 64) { hv[q] = __uint_as_float(pkw[2 * q]); hk[q] = (u16)((pkw[2 * q + 1] & 0x7FFFu) | ((pkw[2 * q + 1] >> 1) & 0x8000u)); }
-      Board<N>::wsync();
-      if (lane == 0) stl_emul::heap_sort(stl_emul::PairRef<u16>{hk, hv}, hf, hl);
-      Board<N>::wsync();
-      for (int q = hf + lane; q < hl; q += 64) {
-        pkw[2 * q] = __float_as_uint(hv[q]); pkw[2 * q + 1] = ((u32)hk[q] & 0x7FFFu) | (((u32)hk[q] & 0x8000u) << 1);
-        atomicOr(&bnd[q >> 6], 1ull << (q & 63));
-      }
+      if (lane == 0) stl_emul::heap_sort(stl_emul::PairRefInterleaved{{pk32}, {pk32}}, hf, hl);
+      for (int q = hf + lane; q < hl; q += 64) cutf[q] = 1;
       Board<N>::wsync();
     }
-  }
-#pragma unroll
-  for (int w = 0; w < SS::RRB; ++w) {
-    const u64 v = bnd[w];
-    bw[w] = ((u64)(u32)rfl((int)(u32)(v >> 32)) << 32) | (u64)(u32)rfl((int)(u32)v);
   }
 }
 
@@ -1490,12 +1536,16 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
       // (introsort_segments_wave); __final_insertion_sort as what it is, the stable sort of every segment the loop leaves -- a
       // pair's final place is its segment's start plus the pairs of a 16-wide window that go before it; then the filter.
       EXP_PHASE(4);
-      u64 bw[SortScratch<N>::RRB];
-      introsort_segments_wave<N>(L, NA, lane, bw);
+      introsort_segments_wave<N>(L, NA, lane);
       EXP_PHASE(1);   // the introsort loop of the exact std::sort replay (prior ties only)
       {
         const u32* const pk32 = reinterpret_cast<const u32*>(L.pk);
-        const u64 le_mask = ((1ull << lane) - 1ull) | (1ull << lane);
+        const unsigned char* const cutf = reinterpret_cast<const unsigned char*>(reinterpret_cast<const u32*>(L.sprob) + SortScratch<N>::CUT);
+        // segment starts as lane masks: word k = positions 64 k .. 64 k + 63
+        u64 bw[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) bw[k] = ballot64(cutf[k * 64 + lane] != 0);   // bytes past NE: scratch of this block, masked by e < NA below
+        const u64 le_mask = ~0ull >> (63 - lane);            // lanes 0 .. lane
         u64 xe[R];
         int fp[R];
 #pragma unroll
@@ -1503,6 +1553,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
           const int e = k * 64 + lane;
           xe[k] = 0; fp[k] = -1;
           if (e < NA) {
+            // the highest segment start at or below e: in this word, else the highest of the word before (a segment has <= 16 pairs)
             const u64 m = bw[k] & le_mask;
             int sf;
             if (k == 0) sf = 63 - (int)__builtin_clzll(m);                   // bit 0 is always set
@@ -1510,15 +1561,15 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
             xe[k] = L.pk[e];
             const float v = __uint_as_float((u32)xe[k]);
             const u32* const win = pk32 + 2 * sf;
-            int r = 0;
-            u32 eq = 0;
+            // r: pairs of the window that compare above this one; eq: bit 15 - t = the pair at sf + t compares equal
+            u32 r = 0, eq = 0;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
               const float vj = __uint_as_float(win[2 * t]);
-              r += vj > v ? 1 : 0;
-              eq |= vj == v ? (1u << t) : 0u;
+              r += vj > v ? 1u : 0u;
+              eq = eq + eq + (vj == v ? 1u : 0u);
             }
-            fp[k] = sf + r + __popc(eq & ((1u << (e - sf)) - 1u));
+            fp[k] = sf + (int)r + __popc(eq >> (16 - (e - sf)));   // e - sf <= 15; e == sf: eq >> 16 = 0
           }
         }
         Board<N>::wsync();

@@ -25,8 +25,10 @@
 
 #if defined(__HIPCC__)
 #define STL_HD __host__ __device__ __forceinline__
+#define STL_HD_MEMBER __host__ __device__ __forceinline__
 #else
 #define STL_HD static inline
+#define STL_HD_MEMBER inline
 #endif
 
 namespace stl_emul {
@@ -71,8 +73,17 @@ STL_HD void umap_iteration_order(const K* keys, int n, int* order, int* tmp) {
 // Elements are (key, val) pairs held in two parallel arrays; comp(a, b) = val[a] > val[b].
 template <typename K>
 struct PairRef {
+  using key_t = K;
   K* k;
   float* v;
+};
+// the same view over interleaved 8-byte pairs {float value, u32 key}: what the expand kernel keeps in LDS
+struct PairRefInterleaved {
+  using key_t = uint32_t;
+  struct KeyView { uint32_t* w; STL_HD_MEMBER uint32_t& operator[](int i) const { return w[2 * i + 1]; } };
+  struct ValView { uint32_t* w; STL_HD_MEMBER float& operator[](int i) const { return reinterpret_cast<float*>(w)[2 * i]; } };
+  KeyView k;
+  ValView v;
 };
 
 template <typename K>
@@ -109,8 +120,8 @@ STL_HD void insertion_sort(PairRef<K> p, int first, int last) {
   }
 }
 
-template <typename K>
-STL_HD void adjust_heap(PairRef<K> p, int first, int hole, int len, K vk, float vv) {
+template <typename P>
+STL_HD void adjust_heap(P p, int first, int hole, int len, typename P::key_t vk, float vv) {
   const int top = hole;
   int second = hole;
   while (second < (len - 1) / 2) {
@@ -133,8 +144,8 @@ STL_HD void adjust_heap(PairRef<K> p, int first, int hole, int len, K vk, float 
   p.k[first + hole] = vk; p.v[first + hole] = vv;
 }
 
-template <typename K>
-STL_HD void heap_sort(PairRef<K> p, int first, int last) {   // __partial_sort(first, last, last)
+template <typename P>
+STL_HD void heap_sort(P p, int first, int last) {   // __partial_sort(first, last, last)
   const int len = last - first;
   if (len >= 2) {                                             // __make_heap
     int parent = (len - 2) / 2;
@@ -146,7 +157,7 @@ STL_HD void heap_sort(PairRef<K> p, int first, int last) {   // __partial_sort(f
   }
   while (last - first > 1) {                                  // __sort_heap / __pop_heap
     --last;
-    const K vk = p.k[last];
+    const typename P::key_t vk = p.k[last];
     const float vv = p.v[last];
     p.k[last] = p.k[first]; p.v[last] = p.v[first];
     adjust_heap(p, first, 0, last - first, vk, vv);

@@ -73,6 +73,23 @@ static int check_sort(std::vector<float> vals) {
   return 0;
 }
 
+// heap_sort over the interleaved {value, key} pairs of the expand kernel's LDS array against the same over two parallel arrays
+static int check_heap_interleaved(std::mt19937& rng, int n, int levels) {
+  std::vector<unsigned> k(n), w(2 * n);
+  std::vector<float> v(n);
+  for (int i = 0; i < n; ++i) {
+    v[i] = (float)(rng() % (unsigned)levels) / 3.0f; k[i] = (unsigned)i | 0x10000u;
+    w[2 * i + 1] = k[i];
+    reinterpret_cast<float*>(w.data())[2 * i] = v[i];
+  }
+  const int first = n / 5, last = n - n / 7;
+  stl_emul::heap_sort(stl_emul::PairRef<unsigned>{k.data(), v.data()}, first, last);
+  stl_emul::heap_sort(stl_emul::PairRefInterleaved{{w.data()}, {w.data()}}, first, last);
+  for (int i = 0; i < n; ++i)
+    if (w[2 * i + 1] != k[i] || reinterpret_cast<float*>(w.data())[2 * i] != v[i]) return 1;
+  return 0;
+}
+
 int main() {
   std::mt19937 rng(12345);
   int bad = 0, cases = 0;
@@ -114,6 +131,8 @@ int main() {
     for (auto& x : v) x = (float)(rng() % (unsigned)levels) / 7.0f;
     sbad += check_sort(v); ++scases;
   }
+  for (int n : {17, 40, 100, 362})
+    for (int levels : {2, 7, 1000}) { sbad += check_heap_interleaved(rng, n, levels); ++scases; }
   printf("sort cases %d bad %d\n", scases, sbad);
   return (bad || sbad) ? 1 : 0;
 }
