@@ -572,29 +572,12 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
       int best_e = 0x7FFFFFFF, best_pos = 0, best_child = -1, best_mv = 0;
       float best_vl = 0.0f, best_prior_v = 0.0f, tq = 0.0f;
       int tv = 0;
-      // one round of 64 entries of the scoring order; returns whether the next round has to be looked at.  The first round works
-      // on the entries that arrived with the header (one instantiation without loads or waits); further rounds (nodes with more
-      // than ~60 followed edges, or a long run of equal priors) are read on demand by a second instantiation.
-      auto score_round = [&](const int base, const float prior, const TStat ts, const u32 cd, const int e) -> bool {
-        const bool in = base + lane < ne;
-        // only the followed prefix [0, nt) carries statistics; a never-followed edge has N = 0, vl = 0, reward = 0 and no child
-        const bool tch = base + lane < nt;
-        const float reward = tch ? ts.reward : 0.0f, vl = tch ? ts.vloss : 0.0f;
-        const int nv = tch ? ts.visits : 0;
-        const int ch = tch ? ts.child : -1;
-        // one formula for both kinds of edge: with N = 0, vl = 0, reward = 0 it yields nvl = 0, Q = first-play urgency,
-        // unsigned_q = umq and prior / 1 = prior
-        float r = h.flip ? -reward : reward;
-        r = __fsub_rn(r, vl);
-        const int nvl = (int)__fadd_rn((float)nv, vl);                       // int + float -> float -> int
-        const float q = nvl > 0 ? __fdiv_rn(r, (float)nvl) : fpu;
-        const float uq = nv > 0 ? __fdiv_rn(reward, (float)nv) : umq;
-        const float pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);   // float / int, then * double sqrt, stored to float
-        const float score = cfg.use_prior ? __fadd_rn(__fmul_rn(pp, cfg.c_puct), q) : q;
-        // keys compare like the floats do (-0.0 == +0.0: canonicalised by + 0.0f; NaN never wins a '>': key 0)
-        const u32 key = (in && score == score) ? f2ukey(__fadd_rn(score, 0.0f)) : 0u;
-        // BestAction::addAction :333-347: sequential fp32 sum of unsigned_q over edges that are not first visits, in edge order
-        u64 vm = __ballot(in && nvl != 0);
+      float uq_r = 0.0f;
+      u64 vm_r = 0;                                          // the round's unsigned child Qs and which lanes' count
+      // BestAction::addAction :333-347: sequential fp32 sum of unsigned_q over edges that are not first visits, in edge order.  The sum
+      // of a round is taken AFTER the round's arg-max (and, for the last round, after the chosen child's record has been requested):
+      // nothing on the way to the next level waits for it.
+      auto fpu_round = [&](const float uq, u64 vm) {
         const int tvr = __popcll(vm);
         tv += tvr;
         if (tvr <= 6) {
@@ -618,6 +601,29 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
           }
           Board<N>::wsync();
         }
+      };
+      // one round of 64 entries of the scoring order; returns whether the next round has to be looked at.  The first round works
+      // on the entries that arrived with the header (one instantiation without loads or waits); further rounds (nodes with more
+      // than ~60 followed edges, or a long run of equal priors) are read on demand by a second instantiation.
+      auto score_round = [&](const int base, const float prior, const TStat ts, const u32 cd, const int e) -> bool {
+        const bool in = base + lane < ne;
+        // only the followed prefix [0, nt) carries statistics; a never-followed edge has N = 0, vl = 0, reward = 0 and no child
+        const bool tch = base + lane < nt;
+        const float reward = tch ? ts.reward : 0.0f, vl = tch ? ts.vloss : 0.0f;
+        const int nv = tch ? ts.visits : 0;
+        const int ch = tch ? ts.child : -1;
+        // one formula for both kinds of edge: with N = 0, vl = 0, reward = 0 it yields nvl = 0, Q = first-play urgency,
+        // unsigned_q = umq and prior / 1 = prior
+        float r = h.flip ? -reward : reward;
+        r = __fsub_rn(r, vl);
+        const int nvl = (int)__fadd_rn((float)nv, vl);                       // int + float -> float -> int
+        const float q = nvl > 0 ? __fdiv_rn(r, (float)nvl) : fpu;
+        const float uq = nv > 0 ? __fdiv_rn(reward, (float)nv) : umq;
+        const float pp = (float)((double)__fdiv_rn(prior, (float)(1 + nv)) * sq);   // float / int, then * double sqrt, stored to float
+        const float score = cfg.use_prior ? __fadd_rn(__fmul_rn(pp, cfg.c_puct), q) : q;
+        // keys compare like the floats do (-0.0 == +0.0: canonicalised by + 0.0f; NaN never wins a '>': key 0)
+        const u32 key = (in && score == score) ? f2ukey(__fadd_rn(score, 0.0f)) : 0u;
+        uq_r = uq; vm_r = __ballot(in && nvl != 0);
         // strict '>' in iteration order = the lowest edge index among the maxima: one maximum of (score key, ~index)
         const u64 k64 = ((u64)key << 32) | (u32)(0xFFFF - e);
         const u64 kmax64 = wave_max_u64(k64);
@@ -636,14 +642,20 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         return (u32)rl((int)key, 63) == unt_key0;            // false: the run of maximal never-followed scores ends inside this round
       };
       bool more = score_round(0, pr0, ts0, cd0, (int)og0);
+      const u32 og_first = og0;                              // the first round's `orig` entries (the request below reuses the registers)
       for (int base = 64; more; base += 64) {
+        fpu_round(uq_r, vm_r);
         const int pc = base + lane < ne ? base + lane : 0;
         TStat t2 = tst_none();
         if (base + lane < nt) t2 = nd.tst()[base + lane];   // more than 64 followed edges: a big record
         more = score_round(base, nd.prior()[pc], t2, (u32)nd.coord()[pc], (int)(u32)nd.orig()[pc]);
       }
-      SEL_PHASE(1);   // statistics gather, scores, reductions, FPU sum
       if (best_e == 0x7FFFFFFF) { err |= MCTS_ERR_FORWARD; break; }   // every score NaN: cannot happen with finite priors
+      // the next level's round trip starts HERE, as soon as the child is known: the rest of this level (the last round's FPU sum, the
+      // running mean, the virtual loss) runs while the child's header and scoring order are on their way
+      if (best_child >= 0) request(best_child);              // existing children always own a state (created together with the node)
+      fpu_round(uq_r, vm_r);
+      SEL_PHASE(1);   // statistics gather, scores, reductions, FPU sum
       const float new_umq = __fdiv_rn(__fadd_rn(h.upq, tq), (float)(tv + 1));   // :227-228
       // ---- addVirtualLoss :233-251 (an edge followed for the first time gets it together with its move into the prefix below)
       const float new_vl = cfg.virtual_loss > 0 ? __fadd_rn(best_vl, vl_f) : best_vl;
@@ -686,7 +698,7 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         for (int b2 = 0; b2 < nt; b2 += 64) {
           const int pos = b2 + lane;
           const bool t = pos < nt;
-          const int v = t ? (int)(b2 == 0 ? og0 : (u32)nw.orig()[pos]) : 0;
+          const int v = t ? (int)(b2 == 0 ? og_first : (u32)nw.orig()[pos]) : 0;
           p += __popcll(__ballot(t && v < best_e));
         }
         for (int b2 = best_pos & ~63; b2 >= (p & ~63); b2 -= 64) {   // high rounds first: a round's loads precede its stores
@@ -713,7 +725,6 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         break;
       }
       node = child;
-      request(node);             // existing children always own a state (created together with the node)
     }
     visited_nodes += depth;
     SEL_PHASE(5);   // slot store issue, loop exit
