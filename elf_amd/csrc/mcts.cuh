@@ -323,6 +323,13 @@ __device__ __forceinline__ int pop_big(const TreePool<N>& tp, int lane) {
   return rfl(id);
 }
 
+// lanes below this one whose bit is set in m
+__device__ __forceinline__ int mbcnt64(u64 m) { return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+// the lane mask of a predicate as it sits in the scalar registers (HIP's __ballot goes through a 0 / 1 vector first)
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// a lane mask from the scalar registers as a per-lane predicate (no instruction: the mask IS the condition)
+__device__ __forceinline__ bool lane_of(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // wave-wide maximum of a u32 on the DPP network (no LDS crossbar round trips): butterflies inside each 16-lane row
 // (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8), then row_bcast:15 into rows 1/3 and row_bcast:31 into rows 2/3;
 // lane 63 ends up with the maximum over all 64 lanes.  EXEC must be full.
@@ -341,26 +348,6 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 #undef ELF_DPP_MAX
   return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
-// the same butterfly for a 64-bit key (hi word decides, lo word breaks ties)
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-#define ELF_DPP_MAX64(ctrl, rmask)                                                                             \
-  {                                                                                                            \
-    const u32 olo = (u32)__builtin_amdgcn_update_dpp((int)(u32)v, (int)(u32)v, ctrl, rmask, 0xf, false);        \
-    const u32 ohi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(v >> 32), (int)(u32)(v >> 32), ctrl, rmask, 0xf, false); \
-    const u64 o = ((u64)ohi << 32) | olo;                                                                      \
-    v = o > v ? o : v;                                                                                         \
-  }
-  ELF_DPP_MAX64(0xB1, 0xf)
-  ELF_DPP_MAX64(0x4E, 0xf)
-  ELF_DPP_MAX64(0x124, 0xf)
-  ELF_DPP_MAX64(0x128, 0xf)
-  ELF_DPP_MAX64(0x142, 0xa)
-  ELF_DPP_MAX64(0x143, 0xc)
-#undef ELF_DPP_MAX64
-  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63);
-  return ((u64)hi << 32) | lo;
-}
-
 // Every id of the context free (creation): the stacks hand out 0, 1, 2, ...
 template <int N>
 __global__ __launch_bounds__(256) void k_mcts_pool_init(TreePool<N> tp) {
@@ -450,6 +437,7 @@ __device__ __attribute__((noinline)) void promote_record(GameNodes<N> nodes, Nod
 // phase markers for cycle attribution (tools/select_phases.sh builds with -DELF_PROFILE_SELECT; compiled out of the library)
 #ifdef ELF_PROFILE_SELECT
 __device__ unsigned long long g_select_phase[4096][8];   // per block id: no atomics, summed on the host
+__device__ unsigned long long g_select_step[1024][4];    // per step (rollouts_done / KT, mod 1024): sum, max of the waves' ticks, waves, max visited nodes
 #define SEL_PHASE(k) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); sel_acc[k] += _t - sel_t; sel_t = _t; } while (0)
 #else
 #define SEL_PHASE(k)
@@ -624,14 +612,21 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
         // keys compare like the floats do (-0.0 == +0.0: canonicalised by + 0.0f; NaN never wins a '>': key 0)
         const u32 key = (in && score == score) ? f2ukey(__fadd_rn(score, 0.0f)) : 0u;
         uq_r = uq; vm_r = __ballot(in && nvl != 0);
-        // strict '>' in iteration order = the lowest edge index among the maxima: one maximum of (score key, ~index)
-        const u64 k64 = ((u64)key << 32) | (u32)(0xFFFF - e);
-        const u64 kmax64 = wave_max_u64(k64);
-        const u32 kmax = (u32)(kmax64 >> 32);
+        // strict '>' in iteration order = the lowest edge index among the maxima.  One 32-bit maximum of the score keys on the DPP
+        // network (6 dependent steps); only when several entries share it -- equal priors among never-followed edges -- a second one
+        // over their indices.  (Until round 6b: one 64-bit maximum of (key, ~index), 5 instructions per step, on every level.)
+        const u32 kmax = wave_max_u32(key);
         if (kmax != 0 && kmax >= best_key) {
-          const int emin = 0xFFFF - (int)(u32)kmax64;
+          const u64 mm = ballot64(key == kmax);
+          int bl, emin;
+          if (__popcll(mm) == 1) {
+            bl = (int)__builtin_ctzll(mm);
+            emin = rl(e, bl);
+          } else {
+            emin = 0xFFFF - (int)wave_max_u32(lane_of(mm) ? (u32)(0xFFFF - e) : 0u);
+            bl = (int)__builtin_ctzll(ballot64(lane_of(mm) && e == emin));
+          }
           if (kmax > best_key || emin < best_e) {
-            const int bl = (int)__builtin_ctzll(__ballot(k64 == kmax64));
             best_key = kmax; best_e = emin; best_pos = base + bl;
             best_child = rl(ch, bl); best_mv = rl((int)cd, bl); best_vl = rlf(vl, bl); best_prior_v = rlf(prior, bl);
           }
@@ -757,6 +752,15 @@ __global__ __launch_bounds__(64) void k_mcts_select(TreePool<N> tp, PoolT pool, 
     SEL_PHASE(7);   // fence: this rollout's stores are visible to the next descent
   }
 #ifdef ELF_PROFILE_SELECT
+  if (lane == 0) {
+    unsigned long long tot = 0;
+    for (int k = 0; k < 8; ++k) tot += sel_acc[k];
+    const int step = (int)((gs.rollouts_done / (KT > 0 ? KT : 1)) & 1023);
+    atomicAdd(&g_select_step[step][0], tot);
+    atomicMax(&g_select_step[step][1], tot);
+    atomicAdd(&g_select_step[step][2], 1ull);
+    atomicMax(&g_select_step[step][3], (unsigned long long)visited_nodes);
+  }
   if (lane < 8 && g < 4096)
     g_select_phase[g][lane] += lane == 0 ? sel_acc[0] : lane == 1 ? sel_acc[1] : lane == 2 ? sel_acc[2] : lane == 3 ? sel_acc[3]
                              : lane == 4 ? sel_acc[4] : lane == 5 ? sel_acc[5] : lane == 6 ? sel_acc[6] : sel_acc[7];
@@ -1187,13 +1191,7 @@ __device__ __forceinline__ void bitonic_sizes_blocked(u64 (&sx)[8], int lane) {
 // ascending; slot e = lane * 8 + k
 __device__ __forceinline__ void bitonic_sort512_blocked(u64 (&sx)[8], int lane) { bitonic_sizes_blocked<2>(sx, lane); }
 
-// lanes below this one whose bit is set in m
-__device__ __forceinline__ int mbcnt64(u64 m) { return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
-// the lane mask of a predicate as it sits in the scalar registers (HIP's __ballot goes through a 0 / 1 vector first)
-__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// a lane mask from the scalar registers as a per-lane predicate (no instruction: the mask IS the condition)
-__device__ __forceinline__ bool lane_of(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // __move_median_to_first's choice among (a, b, c) = (first + 1, mid, last - 1) for wave-uniform values: 0 = a, 1 = b, 2 = c.
 // The if-chain of libstdc++ (`a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b))`, ties included) as a table
@@ -1366,13 +1364,16 @@ __device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const i
         else cut = partition_segment_wave<N, (N * N + 63) / 64>(L, first, last, P, lane);
       }
       // every cut starts a segment; of two parts that are both longer than 16 the left one waits (any order: disjoint)
-      const bool wl = cut - first > 16, wr = last - cut > 16;
-      if (lane == 0) {
-        cutf[cut] = 1;
-        if (wl && wr) stk[sp] = (u32)first | ((u32)cut << 9) | ((u32)depth << 18);
+      if (lane == 0) cutf[cut] = 1;
+      if (last - cut > 16) {
+        if (cut - first > 16) {
+          if (lane == 0) stk[sp] = (u32)first | ((u32)cut << 9) | ((u32)depth << 18);
+          sp = rfl(sp + 1);
+        }
+        first = cut;
+      } else {
+        last = cut;
       }
-      if (wl && wr) ++sp;
-      if (wr) first = cut; else last = cut;
     }
     if (sp == 0) break;
     --sp;

@@ -388,6 +388,15 @@ extern "C" int elfprof_select_phases(unsigned long long* out8) {
 }
 #endif
 
+#ifdef ELF_PROFILE_SELECT
+// profile builds only: per step {sum, max of the waves' ticks, waves, max visited nodes of a wave}
+extern "C" int elfprof_select_steps(unsigned long long* out4096) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out4096, HIP_SYMBOL(elfgo::g_select_step), 4096 * sizeof(unsigned long long)));
+  return 0;
+}
+#endif
+
 #ifdef ELF_PROFILE_EXPAND
 // profile builds only: accumulated s_memtime ticks per k_mcts_expand phase (see EXP_PHASE in mcts.cuh)
 extern "C" int elfprof_expand_phases(unsigned long long* out8) {

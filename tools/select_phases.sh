@@ -26,6 +26,14 @@ roll = 56 * 1024 * 16
 print("  total %.0f ticks per rollout" % (tot / roll))
 for n, v in zip(names, out):
     print("  %-46s %6.2f %%  %8.0f ticks/rollout" % (n, 100.0 * v / tot, v / roll))
+st = (C.c_uint64 * 4096)()
+L.elfprof_select_steps(st)
+import numpy as np
+a = np.array(st[:], dtype=np.float64).reshape(1024, 4)
+a = a[a[:, 2] > 0]
+mean = a[:, 0] / a[:, 2]
+print("  per step (one launch): mean wave %.0f ticks, slowest wave %.0f ticks (x %.2f); visited nodes per wave: mean %.1f, most %.0f"
+      % (mean[8:].mean(), a[8:, 1].mean(), (a[8:, 1] / mean[8:]).mean(), 16 * d["config"]["mean_depth"], a[8:, 3].mean()))
 PY
 make -C elf_amd/csrc clean >/dev/null
 make -C elf_amd/csrc >/dev/null 2>&1
