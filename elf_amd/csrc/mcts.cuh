@@ -1195,11 +1195,16 @@ __device__ __forceinline__ void bitonic_sort512_blocked(u64 (&sx)[8], int lane) 
 
 // __move_median_to_first's choice among (a, b, c) = (first + 1, mid, last - 1) for wave-uniform values: 0 = a, 1 = b, 2 = c.
 // The if-chain of libstdc++ (`a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b))`, ties included) as a table
-// indexed by its three comparisons.
+// indexed by its three comparisons.  Computed by every lane alike, on the VECTOR unit: a CU has four of those and ONE scalar unit
+// (1.00 scalar instruction per clock and CU against 1.82 vector ones, "Issue roofs" in DESIGN.md), and the replay's control flow
+// keeps the scalar unit busy enough.
 __device__ __forceinline__ int median3_choice(float va, float vb, float vc) {
   const int code = (va > vb ? 4 : 0) | (vb > vc ? 2 : 0) | (va > vc ? 1 : 0);
   return (0x5821 >> (2 * code)) & 3;
 }
+// a wave-uniform value as a vector register (keeps what is computed from it on the vector unit)
+__device__ __forceinline__ float in_vgpr(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int in_vgpr(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // One __unguarded_partition of a segment with wave-uniform bounds by the whole wave -- stl_emul.h (e):
 //   * with nub(e) = up-stops (v <= P) strictly before e and nda(e) = down-stops (v >= P) strictly after e, both inside the segment:
@@ -1207,44 +1212,49 @@ __device__ __forceinline__ int median3_choice(float va, float vb, float vc) {
 //   * ud[2 t] / ud[2 t + 1]: position of the swapping up-stop / down-stop of rank t (t <= n / 2); every swapper stores ITS OWN OLD pair
 //     at its partner's place
 //   * the cut is the lowest position that holds an up-stop which does not swap or a down-stop which does, else `last`
-// The stop and swap flags exist only as lane masks in scalar registers (a compare each, restricted to the segment by a scalar AND);
-// the cut is a scalar find-first-set.  (The kernel is bound by the NUMBER of instructions it issues, vector and scalar alike --
-// profiles/r06b_expand_pmc.txt -- so what is uniform is computed once, but not at the price of more scalar instructions than the
-// vector ones it saves.)
+// The two stop flags and the two swap flags are lane masks that come straight out of a compare each (lanes outside the segment
+// compare a NaN; a lane that is no up-stop compares against INT_MAX); the cut is a scalar find-first-set.  No lane is switched off
+// anywhere: a lane that does not swap stores its position in a slot of its own, reads it back and rewrites its own pair in place.
 //
 // partition_small_wave: a segment of <= 64 pairs, pivot selection included.  Lane i holds pair first + i, so __move_median_to_first
 // reads its three candidates from registers, the pivot swap is two lanes storing their pairs at each other's place plus one register
 // move, and the partition needs no further load.  Most of a row's ~45 partitions are this kind.
 template <int N>
 __device__ __forceinline__ int partition_small_wave(ExpandLds<N>& L, const int first, const int last, const int lane) {
-  char* const udb = reinterpret_cast<char*>(L.skey);
+  constexpr int DUMMY = 2 * ((N * N + 1) / 2 + 1);          // ud slots [DUMMY, DUMMY + 64): one per lane that does not swap
+  static_assert(DUMMY + 64 <= 2 * ExpandLds<N>::NE, "slots of the lanes that do not swap");
+  u16* const ud = L.skey;
   u64* const pk = L.pk;
   const int len = last - first;                             // 17 .. 64
   u64 x = pk[first + lane];                                 // lanes >= len read pairs beyond the segment: masked below
   const float v0 = __uint_as_float((u32)x);
   const int ib = len >> 1, ic = len - 1;
-  const int ch = median3_choice(rlf(v0, 1), rlf(v0, ib), rlf(v0, ic));
-  const int im = ch == 0 ? 1 : (ch == 1 ? ib : ic);
+  const int ch = median3_choice(in_vgpr(rlf(v0, 1)), in_vgpr(rlf(v0, ib)), in_vgpr(rlf(v0, ic)));
+  const int im = rfl(ch == 0 ? 1 : (ch == 1 ? ib : ic));
   const float P = rlf(v0, im);
-  // the pair at `first` and the median change places: in LDS now, and in lane im's register (lane 0 takes no part in the partition)
-  const u64 m_im = 1ull << im;
-  if (lane_of(m_im | 1ull)) pk[first + (lane_of(m_im) ? 0 : im)] = x;
+  // the pair at `first` and the median change places: in LDS now (every other lane rewrites its own pair where it is), and in lane
+  // im's register (lane 0 takes no part in the partition)
+  const bool is_m = lane == im;
+  pk[first + (is_m ? 0 : (lane == 0 ? im : lane))] = x;
   {
     const u32 lo0 = (u32)rl((int)(u32)x, 0), hi0 = (u32)rl((int)(u32)(x >> 32), 0);
-    if (lane_of(m_im)) x = ((u64)hi0 << 32) | lo0;
+    if (is_m) x = ((u64)hi0 << 32) | lo0;
   }
-  const float v = __uint_as_float((u32)x);
-  const u64 seg = (~0ull >> (64 - len)) & ~1ull;            // lanes 1 .. len - 1
-  const u64 mu = ballot64(v <= P) & seg, md = ballot64(v >= P) & seg;
+  const bool in = (u32)(lane - 1) < (u32)(len - 1);         // lanes 1 .. len - 1
+  const float v = in ? __uint_as_float((u32)x) : __uint_as_float(0x7FC00000u);   // NaN: neither stop
+  const bool u = v <= P, d = v >= P;
+  const u64 mu = ballot64(u), md = ballot64(d);
   const int nub = mbcnt64(mu);
-  const int nda = (int)__popcll(md) - mbcnt64(md >> 1);     // down-stops above this lane (bit 0 of md is clear)
-  const u64 msu = ballot64(nda > nub) & mu, msd = ballot64(nub > nda) & md;
-  if (lane_of(msu | msd)) {
-    const int own = (lane_of(msu) ? nub : nda) * 4 + (lane_of(msd) ? 2 : 0);   // byte offset into ud
-    *reinterpret_cast<u16*>(udb + own) = (u16)(first + lane);
-    Board<N>::wsync();
-    pk[*reinterpret_cast<const u16*>(udb + (own ^ 2))] = x;
-  }
+  const int nda = (int)__popcll(md) - mbcnt64(md) - (d ? 1 : 0);      // down-stops above this lane
+  const bool su = nda > (u ? nub : 0x7FFFFFFF), sd = nub > (d ? nda : 0x7FFFFFFF);
+  const u64 msu = ballot64(su), msd = ballot64(sd);
+  const int slot = (su || sd) ? 2 * (su ? nub : nda) + (sd ? 1 : 0) : DUMMY + lane;
+  ud[slot] = (u16)(first + lane);
+  Board<N>::wsync();
+  // (lane 0 still holds the pair that sat at `first` before the pivot moved there: its store goes to the last padding pair, which no
+  // window of the final ranks reaches)
+  const int partner = ud[(su || sd) ? (slot ^ 1) : slot];
+  pk[lane == 0 ? ExpandLds<N>::NE + 15 : partner] = x;
   Board<N>::wsync();
   const u64 mF = (mu & ~msu) | msd;
   return mF != 0 ? first + (int)__builtin_ctzll(mF) : last;
@@ -1253,7 +1263,8 @@ __device__ __forceinline__ int partition_small_wave(ExpandLds<N>& L, const int f
 // partition_segment_wave: longer segments, pivot value P already at `first`; element first + 1 + 64 j + lane in round j of RM.
 template <int N, int RM>
 __device__ __forceinline__ int partition_segment_wave(ExpandLds<N>& L, const int first, const int last, const float P, const int lane) {
-  char* const udb = reinterpret_cast<char*>(L.skey);
+  constexpr int DUMMY = 2 * ((N * N + 1) / 2 + 1);          // ud slots [DUMMY, DUMMY + 64): written by lanes that do not swap, never read
+  u16* const ud = L.skey;
   u64* const pk = L.pk;
   u64 x[RM], mu[RM], md[RM];
   int cu[RM], cd[RM];
@@ -1263,36 +1274,35 @@ __device__ __forceinline__ int partition_segment_wave(ExpandLds<N>& L, const int
     x[j] = 0; mu[j] = 0; md[j] = 0; cu[j] = nu; cd[j] = nd;
     const int left = last - (first + 1 + 64 * j);           // elements of this round and the following ones
     if (j > 0 && left <= 0) continue;                       // wave-uniform
-    x[j] = pk[first + 1 + 64 * j + lane];                   // lanes beyond the segment read pairs that are masked below
-    const float v = __uint_as_float((u32)x[j]);
-    const u64 seg = left >= 64 ? ~0ull : (~0ull >> (64 - left));
-    mu[j] = ballot64(v <= P) & seg;
-    md[j] = ballot64(v >= P) & seg;
+    x[j] = pk[first + 1 + 64 * j + lane];                   // lanes beyond the segment read pairs that compare as NaN below
+    const float v = lane < left ? __uint_as_float((u32)x[j]) : __uint_as_float(0x7FC00000u);
+    mu[j] = ballot64(v <= P);
+    md[j] = ballot64(v >= P);
     nu += __popcll(mu[j]);
     nd += __popcll(md[j]);
   }
   u64 mF[RM], msw[RM];
-  int own[RM];                                              // this lane's byte offset into ud; its partner's is own ^ 2
+  int slot[RM];                                             // this lane's slot in ud; its partner's is slot ^ 1
 #pragma unroll
   for (int j = 0; j < RM; ++j) {
-    mF[j] = 0; msw[j] = 0; own[j] = 0;
+    mF[j] = 0; msw[j] = 0; slot[j] = 0;
     if (j > 0 && first + 1 + 64 * j >= last) continue;
+    const bool u = lane_of(mu[j]), d = lane_of(md[j]);
     const int nub = cu[j] + mbcnt64(mu[j]);
-    // down-stops strictly after this element: all of them minus those up to and including this lane
-    const int nda = (nd - cd[j] - (int)(md[j] & 1ull)) - mbcnt64(md[j] >> 1);
-    const u64 msu = ballot64(nda > nub) & mu[j], msd = ballot64(nub > nda) & md[j];
+    const int nda = (nd - cd[j]) - mbcnt64(md[j]) - (d ? 1 : 0);     // down-stops strictly after this element
+    const bool su = nda > (u ? nub : 0x7FFFFFFF), sd = nub > (d ? nda : 0x7FFFFFFF);
+    const u64 msu = ballot64(su), msd = ballot64(sd);
     mF[j] = (mu[j] & ~msu) | msd;
     msw[j] = msu | msd;
-    if (lane_of(msw[j])) {
-      own[j] = (lane_of(msu) ? nub : nda) * 4 + (lane_of(msd) ? 2 : 0);
-      *reinterpret_cast<u16*>(udb + own[j]) = (u16)(first + 1 + 64 * j + lane);
-    }
+    slot[j] = (su || sd) ? 2 * (su ? nub : nda) + (sd ? 1 : 0) : DUMMY + lane;
+    ud[slot[j]] = (u16)(first + 1 + 64 * j + lane);
   }
   Board<N>::wsync();
 #pragma unroll
   for (int j = 0; j < RM; ++j) {
     if (j > 0 && first + 1 + 64 * j >= last) continue;
-    if (lane_of(msw[j])) pk[*reinterpret_cast<const u16*>(udb + (own[j] ^ 2))] = x[j];
+    const int partner = ud[slot[j] ^ 1];                    // (a lane that does not swap reads a slot nobody cares about)
+    pk[lane_of(msw[j]) ? partner : first + 1 + 64 * j + lane] = x[j];
   }
   Board<N>::wsync();
   int cut = last;
@@ -1352,7 +1362,7 @@ __device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const i
         // __move_median_to_first(first, first + 1, mid, last - 1): three reads, a scalar select chain, one swap of pairs
         const int a = first + 1, b = first + ((last - first) >> 1), c = last - 1;
         const float pv = __uint_as_float(pk32[2 * (lane == 0 ? a : (lane == 1 ? b : c))]);
-        const int ch = median3_choice(rlf(pv, 0), rlf(pv, 1), rlf(pv, 2));
+        const int ch = rfl(median3_choice(in_vgpr(rlf(pv, 0)), in_vgpr(rlf(pv, 1)), in_vgpr(rlf(pv, 2))));
         const int m = ch == 0 ? a : (ch == 1 ? b : c);
         const float P = rlf(pv, ch);
         if (lane < 2) {
