@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
 #pragma unroll
       for (int k = 0; k < R; ++k) { const int e = k * 64 + lane; sp[k] = e < n ? L.sprob[e] : 0.0f; }
     }
-    if (ELF_EXP_TIE_PROBE && lane == 0 && (rfl(tp.gs[g].tie_hint) != 0) != tie) tp.gs[g].tie_hint = tie ? 1 : 0;
+    if (ELF_EXP_TIE_PROBE && lane == 0 && probe != tie) tp.gs[g].tie_hint = tie ? 1 : 0;
     EXP_PHASE(4);   // sorted rows to LDS, tie test (+ exact std::sort replay on ties)
     // normalize :244-254: total = 1e-10 + sequential fp32 sum in sorted order.  The chain of n dependent adds is the cost; every
     // lane runs it redundantly on broadcast 16-B LDS reads of the sorted priors (issued ahead of the adds), which beats a

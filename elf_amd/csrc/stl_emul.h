@@ -229,8 +229,8 @@ STL_HD void sort_desc(K* keys, float* vals, int n, int* stk) {
 //     that received the last swapped-in value <= P.  Flags, ranks and swaps are all data-parallel.
 // (b) __final_insertion_sort only ever moves an element left past strictly smaller ones: its result is the STABLE descending sort
 //     of whatever the introsort loop left behind, i.e. a sort by (value desc, position asc) -- a bitonic network on the device.
-// sort_desc_pairing is this formulation run serially; tests/native/stl_emul_check.cc checks it against std::sort, and the expand
-// kernel (mcts.cuh, sort_desc_wave) follows it step for step.
+// sort_desc_pairing is this formulation run serially; tests/native/stl_emul_check.cc checks it against std::sort.  The expand
+// kernel's form is (e) below; (c) and (d) are what it ran in rounds 5-6a, kept as independent cross-checks of the pairing idea.
 template <typename K>
 STL_HD void median_to_first(PairRef<K> p, int first, int last) {   // __move_median_to_first(first, first+1, mid, last-1)
   const int mid = first + (last - first) / 2;
@@ -299,7 +299,7 @@ static inline void sort_desc_pairing(K* keys, float* vals, int n) {
 //     meet in slot first + t of two position arrays; the pairs that swap are a prefix of the slots (upos ascending, dpos descending),
 //     so the slot where "swap" turns into "no swap" knows T and with it the cut.  ~10 generations for 362 elements instead of ~55
 //     partitions one after the other.  sort_desc_generations is this formulation run serially, array for array what the expand kernel
-//     keeps in LDS (mcts.cuh, introsort_generations_wave); tests/native/stl_emul_check.cc checks it against std::sort.
+//     kept in LDS in rounds 5-6a; tests/native/stl_emul_check.cc checks it against std::sort.
 template <typename K>
 static inline void sort_desc_generations(K* keys, float* vals, int n) {
   if (n <= 0) return;
@@ -369,7 +369,7 @@ static inline void sort_desc_generations(K* keys, float* vals, int n) {
   }
 }
 
-// (d) What the expand kernel runs: generations while some segment is longer than `serial_below` elements (few, long segments: the
+// (d) Rounds 5-6a, measured and not used: generations while some segment is longer than `serial_below` elements (few, long segments: the
 //     wave-wide passes pay), then every remaining long segment is finished by ONE lane with the serial __introsort_loop and the depth
 //     limit that is left (many short segments: a generation would still cost its full wave-wide passes).  Same partitions, other order.
 template <typename K>
@@ -419,7 +419,7 @@ static inline void sort_desc_hybrid(K* keys, float* vals, int n, int serial_belo
   }
 }
 
-// (e) What the expand kernel runs since round 6b: the partition tree walked ONE SEGMENT AT A TIME by the whole wave.  A row of 362
+// (e) What the expand kernel runs since round 6b (mcts.cuh, introsort_segments_wave): the partition tree walked ONE SEGMENT AT A TIME by the whole wave.  A row of 362
 //     priors has only ~40 partitions (at most ~8 long segments exist at any time, most of them <= 65 pairs = one round of 64 lanes), and
 //     with the segment's bounds and pivot wave-uniform every per-element table of form (c) goes away:
 //       * whether an element swaps is a LOCAL question.  With nub(e) = up-stops strictly before e and nda(e) = down-stops strictly
