@@ -693,9 +693,9 @@ def run_mcts(args, rank, local_rank, world, dist, steps, warmup, with_cpu):
     npg_arg = args.nodes_per_game
     if npg_arg is None and args.rollouts * max(1, args.mcts_threads) >= 4096:
         # node ids per game: the library's default is 4 x rollouts + 1024 (trees of peaky nets keep large subtrees across moves: 2.2 x
-        # rollouts live nodes were measured with the pregrow's random peaky replies, profiles/r05c_node_usage_random_replies.json).  With
+        # rollouts live nodes were measured with the pregrow's random peaky replies, profiles/history/r05c_node_usage_random_replies.json).  With
         # the benchmark's random-init net the tree of a move is almost all new (peak 8918 live nodes over 10 moves of 64 games at 8192
-        # rollouts, profiles/r05q_node_usage_resnet_10_moves.json; the pregrow stays inside the first move): 1.5 x rollouts leaves 38 % head room and
+        # rollouts, profiles/history/r05q_node_usage_resnet_10_moves.json; the pregrow stays inside the first move): 1.5 x rollouts leaves 38 % head room and
         # lets 2048 games per GPU (two waves per SIMD in the per-game kernels) fit in 167 GB.  A pool that runs out is an error, not a
         # silent truncation (ELFMCTS_E_POOL).
         npg_arg = (3 * args.rollouts * max(1, args.mcts_threads) // 2 + 63) // 64 * 64

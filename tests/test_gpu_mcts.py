@@ -557,7 +557,7 @@ def test_search_threads_with_the_real_net_against_the_turnstile_reference(elf):
     """mcts_threads = 2 with the benchmark's own 20 x 256 fp32 net: the real reference under the turnstile schedule AND the canonical
     backup order (oracle/Makefile, libelfsp19_tsh2.so: both build-time patches) against the engine -- every statistic of 4 searches at
     2 x 128 rollouts bit for bit, reward sums included (un-quantised values: the order of every fp32 sum matters here).
-    Measured on more searches: profiles/r05x_config3_real_net_parity_canon_T2.json / _T4.json (24 + 8 searches, all bit-equal)."""
+    Measured on more searches: profiles/history/r05x_config3_real_net_parity_canon_T2.json / _T4.json (24 + 8 searches, all bit-equal)."""
     import real_net_parity as rp
     from pyoracle import RefSelfPlay
     if not RefSelfPlay.available(19, turnstile=True, canonical_backup=True):
