@@ -116,3 +116,15 @@ def test_header_is_plain_c_and_links_from_c(built, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "abi_c_check ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_pmc_profiles_were_measured_on_the_kernel_sources_in_the_tree():
+    """bench.py prices `roofline.traffic`, `frac_pmc` and the issue roofs against profiles/pmc_traffic.json / pmc_issue.json / valu_mix.json
+    only while they carry the hash of the kernel sources in the tree (elf_amd._lib.kernel_source_hash); a kernel edit without a new
+    tools/profile_all.sh visit would silently blank those fields in the driver's line."""
+    import json
+    from elf_amd._lib import kernel_source_hash
+    h = kernel_source_hash()
+    for name in ("pmc_traffic.json", "pmc_issue.json", "valu_mix.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d.get("_source", {}).get("kernel_source_hash") == h, name
