@@ -20,7 +20,8 @@ import elf_amd  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--net", default="random")
+    ap.add_argument("--net", default="random", help="random: peaky replies without prior ties; random16: near-uniform replies on the fp16 grid (prior ties in every "
+                    "row: the expansion's exact std::sort replay); resnet: the benchmark's net")
     ap.add_argument("--games", type=int, default=64)
     ap.add_argument("--moves", type=int, default=4)
     ap.add_argument("--rollouts", type=int, default=8192)
@@ -29,7 +30,7 @@ def main():
                     "books (ids in trees by a scan = RootInfo = pool_info; trees + free = total)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    args = argparse.Namespace(net=a.net, net_blocks=20, net_dim=256, net_dtype="fp16", no_fold_bn=False, net_impl="fused", board_size=19)
+    args = argparse.Namespace(net="random" if a.net == "random16" else a.net, net_blocks=20, net_dim=256, net_dtype="fp16", no_fold_bn=False, net_impl="fused", board_size=19)
     net, dtype = bench.build_net(args, 19, dev)
     sp = elf_amd.SelfPlay(board_size=19, num_games=a.games, device=0, mcts_rollout_per_thread=a.rollouts, mcts_rollout_per_batch=16,
                           mcts_puct=1.5, mcts_virtual_loss=1, mcts_persistent_tree=True, mcts_epsilon=0.25, mcts_alpha=0.03, komi=7.5,
@@ -38,7 +39,7 @@ def main():
     L = elf_amd.lib()
     m = L.elfsp_mcts(sp._h)
     info = torch.zeros((a.games, 8), dtype=torch.int32, device=dev)
-    rnd = bench.RandomReplies(sp.max_rows, 362, dev, 7)
+    rnd = bench.RandomReplies(sp.max_rows, 362, dev, 7, flat16=(a.net == "random16"))
     cs = int(sp.opt.nodes_per_game)
     peak, per_move = np.zeros(a.games, np.int64), []
     spm = sp.stats()["steps_per_move"]
