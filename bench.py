@@ -22,7 +22,8 @@ instead of the conv net) to the point where the timed steps run at the depth of 
 (root statistics down, move choice, forward, treeAdvance, Dirichlet draws, next search).
 
 At N = 1 the full report carries sub-results measured in the same run (each with its own roofline; the line has their numbers):
-  search_only     the search kernels without the conv net, 4608 games at 8192 ids per game (250 GB; fewer where less HBM is free)
+  search_only     the search kernels without the conv net: 9216 games in three groups on a shared node pool of 4096 ids per game
+                  (250 GB; fewer where less HBM is free), 2048-rollout moves; kernel durations from the same games as one group
   board_step      configs[1]: 4096 boards 19x19 played to the end by the config-2 policy in one k_playout launch, EVERY final
                   (hash, ply, steps) compared with the reference (parity_checked_boards)
   board_step_9x9  configs[4]: 65 536 boards 9x9, same protocol, same check
