@@ -997,10 +997,29 @@ struct ExpandLds {
   };
   float sprob[NE];      // sorted (insertion order of the reference's map)
   u16 skey[NE];
-  u16 scr[NE];          // scratch of the exact std::sort replay (with skey: the rank-indexed stop positions of a partition; the tie probe's table)
+  // 19x19: the replay's rank-indexed positions and the tie probe's table live in sprob (free while they are needed); 9x9: sprob is too
+  // small for them, they use skey + scr
+  static constexpr bool UD_IN_SPROB = N >= 19;
+  // u16 offset into sprob of the position arrays: behind the replay's stack, heap-sort list and cut flags (SortScratch)
+  static constexpr int UD_OFF = 2 * (((25 + (N * N + 1) / 17 + 1 + 3) & ~3) + (NE + 7) / 8 * 2);
+  static constexpr int UD_LEN = 2 * ((N * N + 1) / 2 + 1) + 64;
+  static_assert(!UD_IN_SPROB || UD_OFF + UD_LEN <= 2 * NE, "the position arrays fit sprob behind the cut flags");
+  static_assert(!UD_IN_SPROB || 512 <= 2 * NE, "the tie probe's table fits sprob");
+  u16 scr[UD_IN_SPROB ? 4 : NE];
   u64 legalw[8];        // legal-move bitboard words (D4-0 action order)
 };
-static_assert(sizeof(ExpandLds<19>) <= 6400, "expand LDS per wave");
+static_assert(sizeof(ExpandLds<19>) <= 5632, "expand LDS per wave: 29 waves per CU by LDS, so the 72 VGPRs decide (7 per SIMD)");
+// the rank-indexed position arrays of the partitions (2 (n / 2 + 1) slots + one per lane that does not swap) / the tie probe's table
+template <int N>
+__device__ __forceinline__ u16* replay_ud(ExpandLds<N>& L) {
+  if constexpr (ExpandLds<N>::UD_IN_SPROB) return reinterpret_cast<u16*>(L.sprob) + ExpandLds<N>::UD_OFF;
+  else return L.skey;
+}
+template <int N>
+__device__ __forceinline__ u16* probe_table(ExpandLds<N>& L) {
+  if constexpr (ExpandLds<N>::UD_IN_SPROB) return reinterpret_cast<u16*>(L.sprob);
+  else return L.skey;
+}
 
 // inclusive prefix sum over the 64 lanes on the DPP network: Hillis-Steele inside each row of 16 (row_shr 1 / 2 / 4 / 8, zero fill),
 // then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  EXEC must be full.
@@ -1218,12 +1237,12 @@ __device__ __forceinline__ int in_vgpr(int v) { asm volatile("" : "+v"(v)); retu
 //
 // partition_small_wave: a segment of <= 64 pairs, pivot selection included.  Lane i holds pair first + i, so __move_median_to_first
 // reads its three candidates from registers, the pivot swap is two lanes storing their pairs at each other's place plus one register
-// move, and the partition needs no further load.  Most of a row's ~45 partitions are this kind.
+// move, and the partition needs no further load.  Most of a row's ~36 partitions are this kind.
 template <int N>
 __device__ __forceinline__ int partition_small_wave(ExpandLds<N>& L, const int first, const int last, const int lane) {
   constexpr int DUMMY = 2 * ((N * N + 1) / 2 + 1);          // ud slots [DUMMY, DUMMY + 64): one per lane that does not swap
-  static_assert(DUMMY + 64 <= 2 * ExpandLds<N>::NE, "slots of the lanes that do not swap");
-  u16* const ud = L.skey;
+  static_assert(DUMMY + 64 <= ExpandLds<N>::UD_LEN, "slots of the lanes that do not swap");
+  u16* const ud = replay_ud<N>(L);
   u64* const pk = L.pk;
   const int len = last - first;                             // 17 .. 64
   u64 x = pk[first + lane];                                 // lanes >= len read pairs beyond the segment: masked below
@@ -1264,7 +1283,7 @@ __device__ __forceinline__ int partition_small_wave(ExpandLds<N>& L, const int f
 template <int N, int RM>
 __device__ __forceinline__ int partition_segment_wave(ExpandLds<N>& L, const int first, const int last, const float P, const int lane) {
   constexpr int DUMMY = 2 * ((N * N + 1) / 2 + 1);          // ud slots [DUMMY, DUMMY + 64): written by lanes that do not swap, never read
-  u16* const ud = L.skey;
+  u16* const ud = replay_ud<N>(L);
   u64* const pk = L.pk;
   u64 x[RM], mu[RM], md[RM];
   int cu[RM], cd[RM];
@@ -1314,15 +1333,16 @@ __device__ __forceinline__ int partition_segment_wave(ExpandLds<N>& L, const int
 
 // std::sort(pairs, a.second > b.second) (go/mcts/mcts.h:292-297) over the pairs L.pk[0, n), exact, as the wave runs it since round 6b
 // (stl_emul.h (e), checked against std::sort on the host): the partition tree of __introsort_loop is walked ONE SEGMENT AT A TIME by
-// the whole wave -- a row of 362 priors has ~45 partitions, all but ~10 of <= 64 pairs (one round of 64 lanes), and with the
+// the whole wave -- a row of 362 priors has ~36 partitions, all but ~9 of <= 64 pairs (one round of 64 lanes), and with the
 // segment's bounds and pivot in scalar registers a partition is two compares, four lane counts, one u16 store / load and one pair
 // store per element.  (Rounds 5-6a partitioned all segments of one recursion depth at once: ~10 generations x 6 rounds x 5 passes of
-// per-element segment tables, 9 069 vector instructions per row with ties against ~4 500 now.)
+// per-element segment tables, 9 069 vector instructions per row with ties against ~5 200 now.)
 // The benchmark's random-init fp16 net answers with a near-uniform policy on the fp16 grid (~240 distinct values among 362 priors),
 // so EVERY row of the headline takes this path.  Scratch (all dead outside this function and the window ranks that follow it):
 //   sprob as u32:  [0, 24) the stack of segments that wait (first | last << 9 | depth << 18); [24] number of heap-sort segments,
 //                  [25, 25 + MS) the list of them; from CUT on, one byte per position: "a segment the loop leaves starts here"
-//   skey + scr:    the rank-indexed positions of the partitions (at most n / 2 swaps: 2 (n / 2 + 1) u16)
+//   replay_ud():   the rank-indexed positions of the partitions (at most n / 2 swaps: 2 (n / 2 + 1) u16, + one slot per lane that does
+//                  not swap): 19x19 behind the cut flags in sprob, 9x9 in skey + scr
 template <int N>
 struct SortScratch {
   static constexpr int NE = ExpandLds<N>::NE;
@@ -1337,7 +1357,8 @@ template <int N>
 __device__ __forceinline__ void introsort_segments_wave(ExpandLds<N>& L, const int n, const int lane) {
   using SS = SortScratch<N>;
   constexpr int NE = ExpandLds<N>::NE;
-  static_assert(offsetof(ExpandLds<N>, scr) == offsetof(ExpandLds<N>, skey) + NE * 2, "skey and scr are one array of 2 NE u16");
+  static_assert(ExpandLds<N>::UD_IN_SPROB || offsetof(ExpandLds<N>, scr) == offsetof(ExpandLds<N>, skey) + NE * 2, "skey and scr are one array of 2 NE u16");
+  static_assert(!ExpandLds<N>::UD_IN_SPROB || ExpandLds<N>::UD_OFF == 2 * (SS::CUT + SS::CUTW), "the position arrays start behind the cut flags");
   u32* const w32 = reinterpret_cast<u32*>(L.sprob);
   u32* const stk = w32 + SS::STK;
   u32* const todo = w32 + SS::TODO;
@@ -1415,7 +1436,7 @@ __device__ unsigned long long g_expand_rowmax[65536];     // per block id: longe
 #define EXP_PHASE(k)
 #endif
 
-// 6 waves per SIMD: 80 VGPRs instead of 81 (the allocation granule is 8, so 81 meant 5 waves); the LDS region allows 26 per CU
+// at least 6 waves per SIMD asked for; round 6b: 60 VGPRs and 5.4 KB of LDS (29 waves per CU by LDS: 7.25 per SIMD)
 template <int N>
 __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const RowRec* rowmap, const float* __restrict__ pi,
                                                      int64_t pi_stride, const float* __restrict__ value, const int64_t* __restrict__ rv,
@@ -1460,7 +1481,7 @@ __global__ __launch_bounds__(64, 6) void k_mcts_expand(TreePool<N> tp, const Row
   // that finds another id compares the two priors).  A hit skips the register sort; a miss (no ties, or all of them hidden by
   // collisions) costs ~100 instructions and falls through to the sort and its exact tie test.  Either way the result is the same.
   const bool probe = ELF_EXP_TIE_PROBE && rfl(tp.gs[g].tie_hint) != 0;
-  u16* const ptab = L.skey;                                  // skey + scr: 2 NE u16
+  u16* const ptab = probe_table<N>(L);                       // 19x19: sprob (free until the sort); 9x9: skey + scr
   constexpr int PSH = 2 * ExpandLds<N>::NE >= 512 ? 23 : 25; // 512 / 128 slots
   static_assert((1 << (32 - PSH)) <= 2 * ExpandLds<N>::NE, "the probe's table fits skey + scr");
 #pragma unroll
