@@ -136,7 +136,7 @@ def test_the_line_of_this_rounds_full_report_fits_too():
     """the same bound on the round-5 full report (more sub-results: search_only with two rooflines, leg timings, played data point)"""
     sys.path.insert(0, ROOT)
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r06k_driver_command_bench_full.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06q_driver_command_bench_full.json")))
     line = bench.compact_line(bench._clean(full), "bench_full.json")
     assert len(line) < 4096
     rep = strict_loads(line)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # ONE script regenerates every measured artefact under profiles/ for a round.  Run on a GPU box from the repo root:
-#     gpurun --timeout 2400 -- 'bash tools/profile_all.sh r06j [tests] [bench] [stats] [pmc] [headline]'
+#     gpurun --timeout 2400 -- 'bash tools/profile_all.sh r06p [tests] [bench] [stats] [pmc] [headline]'
 # (no step names = all steps).  Everything lands in gpurun_out/<tag>/ (scratch, merged back by gpurun); afterwards, in the build container:
 #     python tools/update_issue.py gpurun_out/<tag> <tag>; python tools/update_traffic.py gpurun_out/<tag> <tag>     (PMC -> profiles/pmc_*.json)
 #     cp gpurun_out/<tag>/{pytest_gpu.txt,bench_line.json,bench_full.json,summary_*.txt} profiles/ with the <tag>_ prefix

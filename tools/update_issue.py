@@ -40,7 +40,7 @@ for wl, kernel, key, unit, profile in (("board", "k_playout<19>", "k_playout<19>
     if wl == "train" and "mean_replayed_plies" not in cfg:
         # the compact driver line of an older bench.py did not carry the trainer's per-launch figures: they are the same for the same
         # seeds, take them from a stored full report
-        full = json.load(open(os.path.join(root, "profiles", os.environ.get("ELF_FULL_REPORT", "r06j_bench_full.json"))))
+        full = json.load(open(os.path.join(root, "profiles", os.environ.get("ELF_FULL_REPORT", "r06p_bench_full.json"))))
         cfg = dict(full["train_loader"]["config"], **cfg)
     units = cfg["board_steps_per_pass"] if wl.startswith("board") else cfg.get("mean_forwarded_plies", cfg["mean_replayed_plies"]) * cfg.get("samples_per_launch", cfg["batch"])
     res[key] = {"valu_per_unit": c["SQ_INSTS_VALU"][0] / units, "salu_per_unit": c["SQ_INSTS_SALU"][0] / units,
